@@ -1,0 +1,898 @@
+/*
+ * sage_oracle.c -- CPU ORACLE (test infrastructure; see sage_oracle.h header
+ * comment for scope, usage rules and the parity-pinning status).
+ *
+ * Structure deliberately mirrors the reference: every residual's Jacobian row
+ * is materialised (J buffers), then reduced with Jt*J / Jt*r.  The reduction
+ * accumulates in double (the reference uses an fp32 GEMM whose summation order
+ * is library-defined; double accumulation of the same fp32 rows is the
+ * order-free statement of that sum).
+ *
+ * Paths cited are relative to /root/reference/system/sources.
+ */
+#include "sage_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define R_(x) ((REAL)(x))
+
+static inline REAL orc_floor(REAL x) { return (REAL)floor((double)x); }
+static inline REAL orc_round(REAL x) { return (REAL)round((double)x); } /* C round(): half away from zero, as CUDA round() */
+
+/* float -> int conversion used for tap coordinates.  CUDA's conversion
+ * saturates; in C out-of-range is UB, so clamp first.  Any clamped value is
+ * far outside every image and therefore fails WITHIN_BOUNDS exactly like the
+ * saturated CUDA value (photometric_factor_kernels.cpp:16). */
+static inline int orc_to_int(REAL x)
+{
+  if (!(x == x))
+    return -1000000000;
+  if (x > R_(1.0e9))
+    return 1000000000;
+  if (x < R_(-1.0e9))
+    return -1000000000;
+  return (int)x;
+}
+
+static inline int within(int x, int y, int W, int H) { return x >= 0 && x < W && y >= 0 && y < H; }
+
+/* 4-tap zero-padded bilinear sampler.  Tap order and summation order
+ * nw + se + sw + ne follow photometric_factor_kernels.cpp:106-139 and
+ * geometric_factor_kernels.cpp:546-571. */
+typedef struct
+{
+  int ok[4];
+  int off[4];
+  REAL w[4];
+} tap4_t;
+
+static inline void make_taps(tap4_t *tp, REAL u, REAL v, int W, int H)
+{
+  const int xf = orc_to_int(orc_floor(u)), yf = orc_to_int(orc_floor(v));
+  const int xc = xf + 1, yc = yf + 1;
+  const REAL lx = (REAL)xc - u, ly = (REAL)yc - v; /* lower weights */
+  const REAL ux = 1 - lx, uy = 1 - ly;             /* upper weights */
+  tp->w[0] = lx * ly; /* nw: (xf, yf) */
+  tp->w[1] = ux * uy; /* se: (xc, yc) */
+  tp->w[2] = lx * uy; /* sw: (xf, yc) */
+  tp->w[3] = ux * ly; /* ne: (xc, yf) */
+  tp->ok[0] = within(xf, yf, W, H);
+  tp->ok[1] = within(xc, yc, W, H);
+  tp->ok[2] = within(xf, yc, W, H);
+  tp->ok[3] = within(xc, yf, W, H);
+  tp->off[0] = yf * W + xf;
+  tp->off[1] = yc * W + xc;
+  tp->off[2] = yc * W + xf;
+  tp->off[3] = yf * W + xc;
+}
+
+static inline REAL sample(const tap4_t *tp, const REAL *img)
+{
+  return (tp->ok[0] ? img[tp->off[0]] * tp->w[0] : 0) +
+         (tp->ok[1] ? img[tp->off[1]] * tp->w[1] : 0) +
+         (tp->ok[2] ? img[tp->off[2]] * tp->w[2] : 0) +
+         (tp->ok[3] ? img[tp->off[3]] * tp->w[3] : 0);
+}
+
+/* strided variant for texel-major images ([H,W,C], channel c) */
+static inline REAL sample_strided(const tap4_t *tp, const REAL *img, int stride, int c)
+{
+  return (tp->ok[0] ? img[(size_t)tp->off[0] * stride + c] * tp->w[0] : 0) +
+         (tp->ok[1] ? img[(size_t)tp->off[1] * stride + c] * tp->w[1] : 0) +
+         (tp->ok[2] ? img[(size_t)tp->off[2] * stride + c] * tp->w[2] : 0) +
+         (tp->ok[3] ? img[(size_t)tp->off[3] * stride + c] * tp->w[3] : 0);
+}
+
+/* nearest full-resolution mask lookup with C round():
+ * photometric_factor_kernels.cpp:159-166, geometric_factor_kernels.cpp:585-598 */
+static inline REAL mask_lookup(const REAL *mask, REAL p, REAL q, int W, int H)
+{
+  const int xr = orc_to_int(orc_round(p)), yr = orc_to_int(orc_round(q));
+  return within(xr, yr, W, H) ? mask[yr * W + xr] : 0;
+}
+
+void ORC(camera_pyramid)(const ORC(cam_t) * base, int levels, ORC(cam_t) * out)
+{
+  /* common/camera_pyramid.h:18-32: level i = level i-1 resized to
+   * (size_t)(w/2),(size_t)(h/2); ResizeViewport (pinhole_camera_impl.h:120-132)
+   * scales fx,u0 by new_w/w and fy,v0 by new_h/h. */
+  for (int i = 0; i < levels; ++i)
+  {
+    out[i] = (i == 0) ? *base : out[i - 1];
+    if (i != 0)
+    {
+      const size_t nw = (size_t)(out[i - 1].w / 2);
+      const size_t nh = (size_t)(out[i - 1].h / 2);
+      const REAL xr = (REAL)nw / out[i].w;
+      const REAL yr = (REAL)nh / out[i].h;
+      out[i].fx *= xr;
+      out[i].fy *= yr;
+      out[i].cx *= xr;
+      out[i].cy *= yr;
+      out[i].w = (REAL)nw;
+      out[i].h = (REAL)nh;
+    }
+  }
+}
+
+/* -------------------------------------------------------------------------
+ * Jt*W*J reduction of a materialised row buffer.
+ *   AtA[D,D] = scale * sum_rows wrow * J[row,:]^T J[row,:]
+ *   Atb[D]   = scale * sum_rows wrow * J[row,:]^T r[row]
+ * rows are grouped in `groups` equal chunks with weight gw[g] (level weights);
+ * follows photometric_factor_kernels.cpp:1143-1152 / geometric...:936-940.
+ * ------------------------------------------------------------------------- */
+static void reduce_normal_eq(REAL *AtA, REAL *Atb, const REAL *J, const REAL *r,
+                             size_t rows_per_group, int groups, const REAL *gw, int D, double scale)
+{
+  const size_t DD = (size_t)D * D;
+  double *acc = (double *)calloc(DD + D, sizeof(double));
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+    double *loc = (double *)calloc(DD + D, sizeof(double));
+    for (int g = 0; g < groups; ++g)
+    {
+      const double w = gw ? (double)gw[g] : 1.0;
+#ifdef _OPENMP
+#pragma omp for schedule(static) nowait
+#endif
+      for (long long row = 0; row < (long long)rows_per_group; ++row)
+      {
+        const REAL *j = J + ((size_t)g * rows_per_group + (size_t)row) * D;
+        const double rr = (double)r[(size_t)g * rows_per_group + (size_t)row];
+        int nz = 0;
+        for (int a = 0; a < D; ++a)
+          nz |= (j[a] != 0);
+        if (!nz)
+          continue; /* all-zero row contributes nothing */
+        for (int a = 0; a < D; ++a)
+        {
+          const double wa = w * (double)j[a];
+          if (wa == 0.0)
+            continue;
+          double *rowp = loc + (size_t)a * D;
+          for (int b = 0; b < D; ++b)
+            rowp[b] += wa * (double)j[b];
+          loc[DD + a] += wa * rr;
+        }
+      }
+    }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+    {
+      for (size_t i = 0; i < DD + D; ++i)
+        acc[i] += loc[i];
+    }
+    free(loc);
+  }
+  for (size_t i = 0; i < DD; ++i)
+    AtA[i] = (REAL)(scale * acc[i]);
+  for (int i = 0; i < D; ++i)
+    Atb[i] = (REAL)(scale * acc[DD + i]);
+  free(acc);
+}
+
+/* sampled depth: scale0*(bias0[i] + basis0[i,:].code0)
+ * photometric_factor_kernels.cpp:1094-1095 (gather + matmul on host),
+ * geometric_factor_kernels.cpp:514-521 (in-kernel loop). */
+static inline REAL sampled_depth(const REAL *bias0, const REAL *basis0, const REAL *code0,
+                                 long long i, int CS, REAL scale0)
+{
+  REAL d = bias0[i];
+  for (int k = 0; k < CS; ++k)
+    d += basis0[(size_t)i * CS + k] * code0[k];
+  return d * scale0;
+}
+
+/* =========================================================================
+ * a1  photometric_jac_error_calculate  (kernel :33-368, host :1061-1164)
+ * ========================================================================= */
+void ORC(photo_jac_error)(REAL *AtA, REAL *Atb, REAL *error, REAL *num_inliers,
+                          const REAL *R10, const REAL *t10, const REAL *R0, const REAL *t0,
+                          const REAL *R1, const REAL *t1,
+                          const REAL *bias0, const REAL *basis0, const REAL *code0,
+                          const REAL *mask1, const int64_t *loc1d, const REAL *homo,
+                          const REAL *feat0, const REAL *feat1, const REAL *grad1,
+                          const int32_t *level_offsets, REAL scale0,
+                          const ORC(cam_t) * cams, int L, int N, int FS, int CS, int P,
+                          REAL eps, const REAL *weights,
+                          REAL *J_out, REAL *r_out, REAL *err_out, REAL *valid_out)
+{
+  const int D = 13 + CS;
+  const size_t rows = (size_t)L * N * FS;
+  REAL *J = J_out ? J_out : (REAL *)malloc(rows * D * sizeof(REAL));
+  REAL *r = r_out ? r_out : (REAL *)malloc(rows * sizeof(REAL));
+  REAL *serr = err_out ? err_out : (REAL *)malloc((size_t)L * N * sizeof(REAL));
+  REAL *sval = valid_out ? valid_out : (REAL *)malloc((size_t)L * N * sizeof(REAL));
+
+  const int W0 = (int)cams[0].w, H0 = (int)cams[0].h;
+  const REAL fx0 = cams[0].fx, fy0 = cams[0].fy, cx0 = cams[0].cx, cy0 = cams[0].cy;
+
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(static)
+#endif
+  for (int level = 0; level < L; ++level)
+  {
+    for (int idx = 0; idx < N; ++idx)
+    {
+      const int Hl = (int)cams[level].h, Wl = (int)cams[level].w;
+      const REAL fx = cams[level].fx, fy = cams[level].fy;
+      const REAL *hm = homo + (size_t)idx * 3;
+      const long long i1d = (long long)loc1d[idx];
+      const REAL d = sampled_depth(bias0, basis0, code0, i1d, CS, scale0);
+
+      REAL rh[3], X[3];
+      for (int i = 0; i < 3; ++i) /* :78-93 */
+        rh[i] = R10[i * 3 + 0] * hm[0] + R10[i * 3 + 1] * hm[1] + R10[i * 3 + 2] * hm[2];
+      for (int i = 0; i < 3; ++i)
+        X[i] = d * rh[i] + t10[i];
+      const int pos = X[2] > eps; /* :96 */
+
+      /* source coords from homo (:101-103) */
+      const REAL u0 = (hm[0] * fx0 + cx0 + R_(0.5)) * fx / fx0 - R_(0.5);
+      const REAL v0 = (hm[1] * fy0 + cy0 + R_(0.5)) * fy / fy0 - R_(0.5);
+      tap4_t tp0, tp1;
+      make_taps(&tp0, u0, v0, Wl, Hl);
+      /* destination coords (:142-144) */
+      const REAL p = (X[0] / X[2]) * fx0 + cx0;
+      const REAL q = (X[1] / X[2]) * fy0 + cy0;
+      const REAL u1 = (p + R_(0.5)) * fx / fx0 - R_(0.5);
+      const REAL v1 = (q + R_(0.5)) * fy / fy0 - R_(0.5);
+      make_taps(&tp1, u1, v1, Wl, Hl);
+      const REAL m = mask_lookup(mask1, p, q, W0, H0); /* :159-166 */
+
+      const size_t lo = (size_t)level_offsets[level];
+
+      /* Jacobian geometry (:241-335) */
+      const REAL inv_z = 1 / X[2];
+      const REAL x_z = inv_z * X[0], y_z = inv_z * X[1];
+      const REAL Jpi[2][3] = {{fx * inv_z, 0, -fx * x_z * inv_z}, {0, fy * inv_z, -fy * y_z * inv_z}};
+      REAL Xw[3];
+      for (int i = 0; i < 3; ++i) /* :247-255 */
+        Xw[i] = d * (R0[i * 3 + 0] * hm[0] + R0[i * 3 + 1] * hm[1] + R0[i * 3 + 2] * hm[2]) + t0[i];
+      REAL dX1[3][6], dX0[3][6]; /* dX/dT1 (:258-268), dX/dT0 (:283-297) */
+      for (int i = 0; i < 3; ++i)
+      {
+        dX1[i][0] = -R1[0 * 3 + i];
+        dX1[i][1] = -R1[1 * 3 + i];
+        dX1[i][2] = -R1[2 * 3 + i];
+        dX1[i][3] = R1[1 * 3 + i] * Xw[2] - R1[2 * 3 + i] * Xw[1];
+        dX1[i][4] = -R1[0 * 3 + i] * Xw[2] + R1[2 * 3 + i] * Xw[0];
+        dX1[i][5] = R1[0 * 3 + i] * Xw[1] - R1[1 * 3 + i] * Xw[0];
+      }
+      const REAL E[3][6] = {{1, 0, 0, 0, Xw[2], -Xw[1]}, {0, 1, 0, -Xw[2], 0, Xw[0]}, {0, 0, 1, Xw[1], -Xw[0], 0}};
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 6; ++j)
+          dX0[i][j] = R1[0 * 3 + i] * E[0][j] + R1[1 * 3 + i] * E[1][j] + R1[2 * 3 + i] * E[2][j];
+      REAL P0[2][6], P1[2][6];
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 6; ++j)
+        {
+          P1[i][j] = Jpi[i][0] * dX1[0][j] + Jpi[i][1] * dX1[1][j] + Jpi[i][2] * dX1[2][j];
+          P0[i][j] = Jpi[i][0] * dX0[0][j] + Jpi[i][1] * dX0[1][j] + Jpi[i][2] * dX0[2][j];
+        }
+      const REAL qd[2] = {fx * (rh[0] * inv_z - X[0] * rh[2] * inv_z * inv_z), /* :324-325 */
+                          fy * (rh[1] * inv_z - X[1] * rh[2] * inv_z * inv_z)};
+      const REAL qs[2] = {qd[0] * d / scale0, qd[1] * d / scale0}; /* :335 */
+
+      REAL ferr = 0;
+      for (int c = 0; c < FS; ++c)
+      {
+        const REAL f0 = sample(&tp0, feat0 + (size_t)c * P + lo);
+        const REAL f1 = sample(&tp1, feat1 + (size_t)c * P + lo);
+        REAL g[2];
+        for (int j = 0; j < 2; ++j) /* :191-222 */
+          g[j] = pos ? m * sample(&tp1, grad1 + ((size_t)j * FS + c) * P + lo) : 0;
+        const REAL diff = f0 - f1;
+        ferr += pos ? m * (diff * diff) : 0; /* :228 */
+        const size_t row = ((size_t)level * N + idx) * FS + c;
+        r[row] = pos ? m * diff : 0; /* :234 */
+        REAL *jr = J + row * D;
+        for (int j = 0; j < 6; ++j) /* :319-320, :355-356 */
+        {
+          jr[j] = g[0] * P0[0][j] + g[1] * P0[1][j];
+          jr[6 + j] = g[0] * P1[0][j] + g[1] * P1[1][j];
+        }
+        for (int k = 0; k < CS; ++k) /* :331-332, :345, :361 */
+        {
+          const REAL b = basis0[(size_t)i1d * CS + k];
+          jr[12 + k] = g[0] * (qd[0] * scale0 * b) + g[1] * (qd[1] * scale0 * b);
+        }
+        jr[12 + CS] = g[0] * qs[0] + g[1] * qs[1]; /* :347, :363 */
+      }
+      sval[(size_t)level * N + idx] = pos ? m : 0; /* :237 */
+      serr[(size_t)level * N + idx] = ferr;        /* :238 */
+    }
+  }
+
+  /* host reduction (:1139-1161) */
+  double n_in = 0;
+  for (int idx = 0; idx < N; ++idx)
+    n_in += (double)sval[idx]; /* level 0 only (:1139) */
+  if (num_inliers)
+    *num_inliers = (REAL)n_in;
+  if (n_in > 0)
+  {
+    reduce_normal_eq(AtA, Atb, J, r, (size_t)N * FS, L, weights, D, 1.0 / n_in);
+    double e = 0;
+    for (int level = 0; level < L; ++level)
+    {
+      double s = 0;
+      for (int idx = 0; idx < N; ++idx)
+        s += (double)serr[(size_t)level * N + idx];
+      e += (double)weights[level] * s;
+    }
+    *error = (REAL)(e / n_in);
+  }
+  else
+  {
+    double ws = 0;
+    for (int level = 0; level < L; ++level)
+      ws += (double)weights[level];
+    *error = (REAL)(ws * 10.0); /* :1158 */
+    memset(AtA, 0, sizeof(REAL) * D * D);
+    memset(Atb, 0, sizeof(REAL) * D);
+  }
+  if (!J_out)
+    free(J);
+  if (!r_out)
+    free(r);
+  if (!err_out)
+    free(serr);
+  if (!valid_out)
+    free(sval);
+}
+
+/* =========================================================================
+ * a2  photometric_error_calculate (kernel :370-522, host :990-1059)
+ * source coords come from loc2d = (fmod(loc1d,W), floor(loc1d/W)) (:1012-1014, :423-424)
+ * ========================================================================= */
+REAL ORC(photo_error)(const REAL *R10, const REAL *t10,
+                      const REAL *bias0, const REAL *basis0, const REAL *code0,
+                      const REAL *mask1, const int64_t *loc1d, const REAL *homo,
+                      const REAL *feat0, const REAL *feat1,
+                      const int32_t *level_offsets, REAL scale0,
+                      const ORC(cam_t) * cams, int L, int N, int FS, int CS, int P,
+                      REAL eps, const REAL *weights, REAL *num_inliers)
+{
+  const int W0 = (int)cams[0].w, H0 = (int)cams[0].h;
+  const REAL fx0 = cams[0].fx, fy0 = cams[0].fy, cx0 = cams[0].cx, cy0 = cams[0].cy;
+  double e = 0, n_in = 0;
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(static) reduction(+ : e, n_in)
+#endif
+  for (int level = 0; level < L; ++level)
+  {
+    for (int idx = 0; idx < N; ++idx)
+    {
+      const int Hl = (int)cams[level].h, Wl = (int)cams[level].w;
+      const REAL fx = cams[level].fx, fy = cams[level].fy;
+      const REAL *hm = homo + (size_t)idx * 3;
+      const long long i1d = (long long)loc1d[idx];
+      const REAL d = sampled_depth(bias0, basis0, code0, i1d, CS, scale0);
+      REAL rh[3], X[3];
+      for (int i = 0; i < 3; ++i)
+        rh[i] = R10[i * 3 + 0] * hm[0] + R10[i * 3 + 1] * hm[1] + R10[i * 3 + 2] * hm[2];
+      for (int i = 0; i < 3; ++i)
+        X[i] = d * rh[i] + t10[i];
+      const int pos = X[2] > eps;
+      const REAL lx = (REAL)fmod((double)(REAL)i1d, (double)cams[0].w);
+      const REAL ly = orc_floor((REAL)i1d / cams[0].w);
+      const REAL u0 = (lx + R_(0.5)) * fx / fx0 - R_(0.5);
+      const REAL v0 = (ly + R_(0.5)) * fy / fy0 - R_(0.5);
+      tap4_t tp0, tp1;
+      make_taps(&tp0, u0, v0, Wl, Hl);
+      const REAL p = (X[0] / X[2]) * fx0 + cx0;
+      const REAL q = (X[1] / X[2]) * fy0 + cy0;
+      make_taps(&tp1, (p + R_(0.5)) * fx / fx0 - R_(0.5), (q + R_(0.5)) * fy / fy0 - R_(0.5), Wl, Hl);
+      const REAL m = mask_lookup(mask1, p, q, W0, H0);
+      const size_t lo = (size_t)level_offsets[level];
+      REAL ferr = 0;
+      for (int c = 0; c < FS; ++c)
+      {
+        const REAL f0 = sample(&tp0, feat0 + (size_t)c * P + lo);
+        const REAL f1 = sample(&tp1, feat1 + (size_t)c * P + lo);
+        const REAL diff = f1 - f0;
+        ferr += pos ? m * (diff * diff) : 0; /* :514 */
+      }
+      e += (double)weights[level] * (double)ferr;
+      if (level == 0)
+        n_in += pos ? (double)m : 0.0;
+    }
+  }
+  if (num_inliers)
+    *num_inliers = (REAL)n_in;
+  if (n_in > 0)
+    return (REAL)(e / n_in);
+  double ws = 0;
+  for (int level = 0; level < L; ++level)
+    ws += (double)weights[level];
+  return (REAL)(ws * 10.0); /* :1057 */
+}
+
+/* =========================================================================
+ * a3 tracker kernels: relative pose only, pre-sampled source features
+ * 6-dof :524-695, 7-dof :697-873, hosts :1166-1325
+ * ========================================================================= */
+void ORC(tracker_photo_jac_error)(REAL *AtA, REAL *Atb, REAL *error, REAL *num_inliers, int dof,
+                                  const REAL *R, const REAL *t, const REAL *mask1,
+                                  const REAL *dpts0, const REAL *homo, const REAL *feat0s,
+                                  const REAL *feat1, const REAL *grad1,
+                                  const int32_t *level_offsets, const ORC(cam_t) * cams,
+                                  int L, int N, int FS, int P, REAL scale0, REAL eps,
+                                  const REAL *weights, REAL *J_out, REAL *r_out)
+{
+  const int D = dof;
+  const size_t rows = (size_t)L * N * FS;
+  REAL *J = J_out ? J_out : (REAL *)malloc(rows * D * sizeof(REAL));
+  REAL *r = r_out ? r_out : (REAL *)malloc(rows * sizeof(REAL));
+  REAL *serr = (REAL *)malloc((size_t)L * N * sizeof(REAL));
+  REAL *sval = (REAL *)malloc((size_t)L * N * sizeof(REAL));
+  const int W0 = (int)cams[0].w, H0 = (int)cams[0].h;
+  const REAL fx0 = cams[0].fx, fy0 = cams[0].fy, cx0 = cams[0].cx, cy0 = cams[0].cy;
+
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(static)
+#endif
+  for (int level = 0; level < L; ++level)
+  {
+    for (int idx = 0; idx < N; ++idx)
+    {
+      const int Hl = (int)cams[level].h, Wl = (int)cams[level].w;
+      const REAL fx = cams[level].fx, fy = cams[level].fy;
+      const REAL *hm = homo + (size_t)idx * 3;
+      const REAL d = dpts0[idx];
+      REAL rh[3], X[3];
+      for (int i = 0; i < 3; ++i)
+        rh[i] = R[i * 3 + 0] * hm[0] + R[i * 3 + 1] * hm[1] + R[i * 3 + 2] * hm[2];
+      for (int i = 0; i < 3; ++i)
+        X[i] = d * rh[i] + t[i]; /* :560-574 */
+      const int pos = X[2] > eps;
+      const REAL p = (X[0] / X[2]) * fx0 + cx0;
+      const REAL q = (X[1] / X[2]) * fy0 + cy0;
+      tap4_t tp1;
+      make_taps(&tp1, (p + R_(0.5)) * fx / fx0 - R_(0.5), (q + R_(0.5)) * fy / fy0 - R_(0.5), Wl, Hl);
+      const REAL m = mask_lookup(mask1, p, q, W0, H0);
+      const size_t lo = (size_t)level_offsets[level];
+
+      const REAL inv_z = 1 / X[2];
+      const REAL x_z = inv_z * X[0], y_z = inv_z * X[1];
+      /* closed-form 2x6 (:680-681) */
+      const REAL Jp[2][6] = {{fx * inv_z, 0, -fx * x_z * inv_z, -fx * x_z * y_z, fx * (1 + x_z * x_z), -fx * y_z},
+                             {0, fy * inv_z, -fy * y_z * inv_z, -fy * (1 + y_z * y_z), fy * x_z * y_z, fy * x_z}};
+      const REAL qd[2] = {fx * (rh[0] * inv_z - X[0] * rh[2] * inv_z * inv_z), /* :854-855 */
+                          fy * (rh[1] * inv_z - X[1] * rh[2] * inv_z * inv_z)};
+      REAL qs[2] = {0, 0};
+      if (dof == 7)
+      {
+        qs[0] = qd[0] * d / scale0; /* :856 */
+        qs[1] = qd[1] * d / scale0;
+      }
+      REAL ferr = 0;
+      for (int c = 0; c < FS; ++c)
+      {
+        const REAL f0 = feat0s[((size_t)level * N + idx) * FS + c];
+        const REAL f1 = sample(&tp1, feat1 + (size_t)c * P + lo);
+        REAL g[2];
+        for (int j = 0; j < 2; ++j)
+          g[j] = pos ? m * sample(&tp1, grad1 + ((size_t)j * FS + c) * P + lo) : 0;
+        const REAL diff = f0 - f1;
+        ferr += pos ? m * (diff * diff) : 0; /* :665 */
+        const size_t row = ((size_t)level * N + idx) * FS + c;
+        r[row] = pos ? m * diff : 0;
+        REAL *jr = J + row * D;
+        for (int j = 0; j < 6; ++j)
+          jr[j] = g[0] * Jp[0][j] + g[1] * Jp[1][j]; /* :688-689 */
+        if (dof == 7)
+          jr[6] = g[0] * qs[0] + g[1] * qs[1]; /* :867-868 */
+      }
+      sval[(size_t)level * N + idx] = pos ? m : 0;
+      serr[(size_t)level * N + idx] = ferr;
+    }
+  }
+  double n_in = 0;
+  for (int idx = 0; idx < N; ++idx)
+    n_in += (double)sval[idx];
+  if (num_inliers)
+    *num_inliers = (REAL)n_in;
+  if (n_in > 0)
+  {
+    reduce_normal_eq(AtA, Atb, J, r, (size_t)N * FS, L, weights, D, 1.0 / n_in);
+    double e = 0;
+    for (int level = 0; level < L; ++level)
+    {
+      double s = 0;
+      for (int idx = 0; idx < N; ++idx)
+        s += (double)serr[(size_t)level * N + idx];
+      e += (double)weights[level] * s;
+    }
+    *error = (REAL)(e / n_in);
+  }
+  else
+  {
+    double ws = 0;
+    for (int level = 0; level < L; ++level)
+      ws += (double)weights[level];
+    *error = (REAL)(ws * 10.0); /* :1239 */
+    memset(AtA, 0, sizeof(REAL) * D * D);
+    memset(Atb, 0, sizeof(REAL) * D);
+  }
+  if (!J_out)
+    free(J);
+  if (!r_out)
+    free(r);
+  free(serr);
+  free(sval);
+}
+
+REAL ORC(tracker_photo_error)(const REAL *R, const REAL *t, const REAL *mask1,
+                              const REAL *dpts0, const REAL *homo, const REAL *feat0s,
+                              const REAL *feat1, const int32_t *level_offsets,
+                              const ORC(cam_t) * cams, int L, int N, int FS, int P,
+                              REAL eps, const REAL *weights, REAL *num_inliers)
+{
+  const int W0 = (int)cams[0].w, H0 = (int)cams[0].h;
+  const REAL fx0 = cams[0].fx, fy0 = cams[0].fy, cx0 = cams[0].cx, cy0 = cams[0].cy;
+  double e = 0, n_in = 0;
+#ifdef _OPENMP
+#pragma omp parallel for collapse(2) schedule(static) reduction(+ : e, n_in)
+#endif
+  for (int level = 0; level < L; ++level)
+  {
+    for (int idx = 0; idx < N; ++idx)
+    {
+      const int Hl = (int)cams[level].h, Wl = (int)cams[level].w;
+      const REAL fx = cams[level].fx, fy = cams[level].fy;
+      const REAL *hm = homo + (size_t)idx * 3;
+      const REAL d = dpts0[idx];
+      REAL X[3];
+      for (int i = 0; i < 3; ++i)
+        X[i] = d * (R[i * 3 + 0] * hm[0] + R[i * 3 + 1] * hm[1] + R[i * 3 + 2] * hm[2]) + t[i];
+      const int pos = X[2] > eps;
+      const REAL p = (X[0] / X[2]) * fx0 + cx0;
+      const REAL q = (X[1] / X[2]) * fy0 + cy0;
+      tap4_t tp1;
+      make_taps(&tp1, (p + R_(0.5)) * fx / fx0 - R_(0.5), (q + R_(0.5)) * fy / fy0 - R_(0.5), Wl, Hl);
+      const REAL m = mask_lookup(mask1, p, q, W0, H0);
+      const size_t lo = (size_t)level_offsets[level];
+      REAL ferr = 0;
+      for (int c = 0; c < FS; ++c)
+      {
+        const REAL f0 = feat0s[((size_t)level * N + idx) * FS + c];
+        const REAL f1 = sample(&tp1, feat1 + (size_t)c * P + lo);
+        const REAL diff = f0 - f1;
+        ferr += pos ? m * (diff * diff) : 0;
+      }
+      e += (double)weights[level] * (double)ferr;
+      if (level == 0)
+        n_in += pos ? (double)m : 0.0;
+    }
+  }
+  if (num_inliers)
+    *num_inliers = (REAL)n_in;
+  if (n_in > 0)
+    return (REAL)(e / n_in);
+  double ws = 0;
+  for (int level = 0; level < L; ++level)
+    ws += (double)weights[level];
+  return (REAL)(ws * 10.0); /* :1382 */
+}
+
+/* =========================================================================
+ * a4  geometric_jac_error_calculate (kernel :472-720, host :882-950)
+ * level-0 camera only, NO half-pixel shifts.
+ * ========================================================================= */
+void ORC(geo_jac_error)(REAL *AtA, REAL *Atb, REAL *error, REAL *num_inliers,
+                        const REAL *R10, const REAL *t10, const REAL *R0, const REAL *t0,
+                        const REAL *R1, const REAL *t1,
+                        const REAL *bias0, const REAL *basis0, const REAL *code0,
+                        const REAL *dpt1, const REAL *dpt_grad1, const REAL *basis1,
+                        const REAL *mask1, const int32_t *loc1d, const REAL *homo,
+                        REAL scale0, REAL scale1, const ORC(cam_t) * cam, int N, int CS,
+                        REAL eps, REAL loss_param, REAL weight, REAL *J_out, REAL *r_out)
+{
+  const int D = 14 + 2 * CS;
+  REAL *J = J_out ? J_out : (REAL *)malloc((size_t)N * D * sizeof(REAL));
+  REAL *r = r_out ? r_out : (REAL *)malloc((size_t)N * sizeof(REAL));
+  REAL *serr = (REAL *)malloc((size_t)N * sizeof(REAL));
+  REAL *sval = (REAL *)malloc((size_t)N * sizeof(REAL));
+  const REAL fx = cam->fx, fy = cam->fy, cx = cam->cx, cy = cam->cy;
+  const int H = (int)cam->h, W = (int)cam->w;
+  const size_t HW = (size_t)H * W;
+
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+  for (int idx = 0; idx < N; ++idx)
+  {
+    const REAL *hm = homo + (size_t)idx * 3;
+    const long long i1d = (long long)loc1d[idx];
+    const REAL d0 = sampled_depth(bias0, basis0, code0, i1d, CS, scale0); /* :514-521 */
+    REAL rh[3], X[3];
+    for (int i = 0; i < 3; ++i)
+      rh[i] = R10[i * 3 + 0] * hm[0] + R10[i * 3 + 1] * hm[1] + R10[i * 3 + 2] * hm[2];
+    for (int i = 0; i < 3; ++i)
+      X[i] = d0 * rh[i] + t10[i];
+    const int pos = X[2] > eps; /* :541 */
+    const REAL u = (X[0] / X[2]) * fx + cx; /* :543-544 */
+    const REAL v = (X[1] / X[2]) * fy + cy;
+    tap4_t tp;
+    make_taps(&tp, u, v, W, H);
+    const REAL Ds = sample(&tp, dpt1); /* :567-571 */
+    const REAL gD[2] = {sample(&tp, dpt_grad1), sample(&tp, dpt_grad1 + HW)}; /* :575-582 */
+    const REAL m = mask_lookup(mask1, u, v, W, H); /* :585-598 */
+    const REAL rho = Ds - X[2];
+    {
+      const REAL mr = m * rho;
+      serr[idx] = pos ? (REAL)log(1.0 + (double)(mr * mr) / (double)loss_param) : 0; /* :600 */
+    }
+    sval[idx] = pos ? m : 0;
+
+    const REAL inv_z = 1 / X[2];
+    const REAL x_z = inv_z * X[0], y_z = inv_z * X[1];
+    const REAL Jpi[2][3] = {{fx * inv_z, 0, -fx * x_z * inv_z}, {0, fy * inv_z, -fy * y_z * inv_z}};
+    REAL Xw[3];
+    for (int i = 0; i < 3; ++i)
+      Xw[i] = d0 * (R0[i * 3 + 0] * hm[0] + R0[i * 3 + 1] * hm[1] + R0[i * 3 + 2] * hm[2]) + t0[i];
+    REAL dX1[3][6], dX0[3][6];
+    for (int i = 0; i < 3; ++i)
+    {
+      dX1[i][0] = -R1[0 * 3 + i];
+      dX1[i][1] = -R1[1 * 3 + i];
+      dX1[i][2] = -R1[2 * 3 + i];
+      dX1[i][3] = R1[1 * 3 + i] * Xw[2] - R1[2 * 3 + i] * Xw[1];
+      dX1[i][4] = -R1[0 * 3 + i] * Xw[2] + R1[2 * 3 + i] * Xw[0];
+      dX1[i][5] = R1[0 * 3 + i] * Xw[1] - R1[1 * 3 + i] * Xw[0];
+    }
+    const REAL E[3][6] = {{1, 0, 0, 0, Xw[2], -Xw[1]}, {0, 1, 0, -Xw[2], 0, Xw[0]}, {0, 0, 1, Xw[1], -Xw[0], 0}};
+    for (int i = 0; i < 3; ++i)
+      for (int j = 0; j < 6; ++j)
+        dX0[i][j] = R1[0 * 3 + i] * E[0][j] + R1[1 * 3 + i] * E[1][j] + R1[2 * 3 + i] * E[2][j];
+    REAL a0[6], a1[6];
+    for (int j = 0; j < 6; ++j) /* :671-679 */
+    {
+      const REAL P0x = Jpi[0][0] * dX0[0][j] + Jpi[0][1] * dX0[1][j] + Jpi[0][2] * dX0[2][j];
+      const REAL P0y = Jpi[1][0] * dX0[0][j] + Jpi[1][1] * dX0[1][j] + Jpi[1][2] * dX0[2][j];
+      const REAL P1x = Jpi[0][0] * dX1[0][j] + Jpi[0][1] * dX1[1][j] + Jpi[0][2] * dX1[2][j];
+      const REAL P1y = Jpi[1][0] * dX1[0][j] + Jpi[1][1] * dX1[1][j] + Jpi[1][2] * dX1[2][j];
+      a0[j] = dX0[2][j] - (gD[0] * P0x + gD[1] * P0y);
+      a1[j] = dX1[2][j] - (gD[0] * P1x + gD[1] * P1y);
+    }
+    const REAL qd[2] = {fx * (rh[0] * inv_z - X[0] * rh[2] * inv_z * inv_z), /* :681-682 */
+                        fy * (rh[1] * inv_z - X[1] * rh[2] * inv_z * inv_z)};
+    const REAL dD_dd0 = gD[0] * qd[0] + gD[1] * qd[1]; /* :684 */
+    const REAL kappa_s0 = (rh[2] - dD_dd0) * scale0;   /* :685 */
+    const REAL a_s0 = (rh[2] - dD_dd0) * d0 / scale0;  /* :687 */
+    const REAL a_s1 = -Ds / scale1;                    /* :688 */
+    const REAL sw = pos ? m * (REAL)sqrt(1.0 / ((double)(rho * rho) + (double)loss_param)) : 0; /* :690 */
+
+    r[idx] = sw * rho; /* :699 */
+    REAL *jr = J + (size_t)idx * D;
+    for (int j = 0; j < 6; ++j)
+    {
+      jr[j] = sw * a0[j];
+      jr[6 + j] = sw * a1[j];
+    }
+    for (int k = 0; k < CS; ++k) /* :592-595, :695-696, :711-712 */
+    {
+      const REAL beta = sample_strided(&tp, basis1, CS, k);
+      jr[12 + k] = sw * (kappa_s0 * basis0[(size_t)i1d * CS + k]);
+      jr[12 + CS + k] = sw * (-scale1 * beta);
+    }
+    jr[12 + 2 * CS] = sw * a_s0;
+    jr[13 + 2 * CS] = sw * a_s1;
+  }
+
+  double n_in = 0, e = 0;
+  for (int idx = 0; idx < N; ++idx)
+  {
+    n_in += (double)sval[idx];
+    e += (double)serr[idx];
+  }
+  if (num_inliers)
+    *num_inliers = (REAL)n_in;
+  if (n_in > 0)
+  {
+    *error = (REAL)((double)weight / n_in * e); /* :934 */
+    reduce_normal_eq(AtA, Atb, J, r, (size_t)N, 1, NULL, D, (double)weight / n_in);
+  }
+  else
+  {
+    *error = (REAL)((double)weight * 10.0); /* :944 */
+    memset(AtA, 0, sizeof(REAL) * D * D);
+    memset(Atb, 0, sizeof(REAL) * D);
+  }
+  if (!J_out)
+    free(J);
+  if (!r_out)
+    free(r);
+  free(serr);
+  free(sval);
+}
+
+/* a5 geometric_error_calculate (kernel :127-218, host :837-880) */
+REAL ORC(geo_error)(const REAL *R10, const REAL *t10,
+                    const REAL *bias0, const REAL *basis0, const REAL *code0,
+                    const REAL *dpt1, const REAL *mask1, const int32_t *loc1d, const REAL *homo,
+                    REAL scale0, const ORC(cam_t) * cam, int N, int CS,
+                    REAL eps, REAL loss_param, REAL weight, REAL *num_inliers)
+{
+  const REAL fx = cam->fx, fy = cam->fy, cx = cam->cx, cy = cam->cy;
+  const int H = (int)cam->h, W = (int)cam->w;
+  double e = 0, n_in = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) reduction(+ : e, n_in)
+#endif
+  for (int idx = 0; idx < N; ++idx)
+  {
+    const REAL *hm = homo + (size_t)idx * 3;
+    const long long i1d = (long long)loc1d[idx];
+    const REAL d0 = sampled_depth(bias0, basis0, code0, i1d, CS, scale0);
+    REAL X[3];
+    for (int i = 0; i < 3; ++i)
+      X[i] = d0 * (R10[i * 3 + 0] * hm[0] + R10[i * 3 + 1] * hm[1] + R10[i * 3 + 2] * hm[2]) + t10[i];
+    const int pos = X[2] > eps;
+    const REAL u = (X[0] / X[2]) * fx + cx;
+    const REAL v = (X[1] / X[2]) * fy + cy;
+    tap4_t tp;
+    make_taps(&tp, u, v, W, H);
+    const REAL Ds = sample(&tp, dpt1);
+    const REAL m = mask_lookup(mask1, u, v, W, H);
+    const REAL mr = m * (Ds - X[2]);
+    const REAL se = pos ? (REAL)log(1.0 + (double)(mr * mr) / (double)loss_param) : 0; /* :213 */
+    e += (double)se;
+    n_in += pos ? (double)m : 0.0;
+  }
+  if (num_inliers)
+    *num_inliers = (REAL)n_in;
+  if (n_in > 0)
+    return (REAL)((double)weight * e / n_in); /* :874 */
+  return (REAL)((double)weight * 10.0);       /* :878 */
+}
+
+/* =========================================================================
+ * f1 producers
+ * ========================================================================= */
+void ORC(update_depth)(REAL *dpt, const REAL *bias, const REAL *basis, const REAL *code,
+                       REAL scale, int HW, int CS)
+{
+  /* core/mapping/mapping_utils.h:215-222 */
+  for (int i = 0; i < HW; ++i)
+  {
+    REAL s = 0;
+    for (int k = 0; k < CS; ++k)
+      s += basis[(size_t)i * CS + k] * code[k];
+    dpt[i] = scale * (bias[i] + s);
+  }
+}
+
+void ORC(spatial_grad)(REAL *grad, const REAL *img, int C, int H, int W)
+{
+  /* core/mapping/mapping_utils.h:236-252: replicate pad, 0.5*(next - prev), x then y */
+  const size_t HW = (size_t)H * W;
+  for (int c = 0; c < C; ++c)
+  {
+    const REAL *a = img + (size_t)c * HW;
+    REAL *gx = grad + (size_t)c * HW;
+    REAL *gy = grad + ((size_t)C + c) * HW;
+    for (int y = 0; y < H; ++y)
+      for (int x = 0; x < W; ++x)
+      {
+        const int xm = x > 0 ? x - 1 : 0, xp = x < W - 1 ? x + 1 : W - 1;
+        const int ym = y > 0 ? y - 1 : 0, yp = y < H - 1 ? y + 1 : H - 1;
+        gx[(size_t)y * W + x] = R_(0.5) * (a[(size_t)y * W + xp] - a[(size_t)y * W + xm]);
+        gy[(size_t)y * W + x] = R_(0.5) * (a[(size_t)yp * W + x] - a[(size_t)ym * W + x]);
+      }
+  }
+}
+
+void ORC(gaussian_pyramid_with_grad)(REAL *pyr, REAL *grad, const REAL *feat, const REAL *mask,
+                                     int FS, int H, int W, int L, const int32_t *level_offsets, int P)
+{
+  /* core/mapping/mapper.cpp:1384-1426; kernel [1 2 1;2 4 2;1 2 1]/16 (:30-37),
+   * stride 2, zero pad 1; mask pyramid by nearest interpolate to (h/2, w/2)
+   * (mapping_utils.cpp:321-342; torch 'nearest' picks source index 2*i). */
+  static const REAL G[3][3] = {{1, 2, 1}, {2, 4, 2}, {1, 2, 1}};
+  REAL *cur = (REAL *)malloc((size_t)FS * H * W * sizeof(REAL));
+  REAL *curm = (REAL *)malloc((size_t)H * W * sizeof(REAL));
+  memcpy(cur, feat, (size_t)FS * H * W * sizeof(REAL));
+  memcpy(curm, mask, (size_t)H * W * sizeof(REAL));
+  int h = H, w = W;
+  for (int l = 0; l < L; ++l)
+  {
+    const size_t hw = (size_t)h * w;
+    REAL *g = (REAL *)malloc(2 * (size_t)FS * hw * sizeof(REAL));
+    ORC(spatial_grad)(g, cur, FS, h, w);
+    for (int c = 0; c < FS; ++c)
+    {
+      memcpy(pyr + (size_t)c * P + level_offsets[l], cur + (size_t)c * hw, hw * sizeof(REAL));
+      memcpy(grad + ((size_t)0 * FS + c) * P + level_offsets[l], g + (size_t)c * hw, hw * sizeof(REAL));
+      memcpy(grad + ((size_t)1 * FS + c) * P + level_offsets[l], g + ((size_t)FS + c) * hw, hw * sizeof(REAL));
+    }
+    free(g);
+    if (l == L - 1)
+      break;
+    const int nh = h / 2, nw = w / 2;
+    REAL *nxt = (REAL *)malloc((size_t)FS * nh * nw * sizeof(REAL));
+    REAL *nxtm = (REAL *)malloc((size_t)nh * nw * sizeof(REAL));
+    for (int y = 0; y < nh; ++y)
+      for (int x = 0; x < nw; ++x)
+      {
+        REAL rm = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+          for (int dx = -1; dx <= 1; ++dx)
+          {
+            const int yy = 2 * y + dy, xx = 2 * x + dx;
+            if (within(xx, yy, w, h))
+              rm += (G[dy + 1][dx + 1] / R_(16.0)) * curm[(size_t)yy * w + xx];
+          }
+        for (int c = 0; c < FS; ++c)
+        {
+          REAL rf = 0;
+          for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx)
+            {
+              const int yy = 2 * y + dy, xx = 2 * x + dx;
+              if (within(xx, yy, w, h))
+                rf += (G[dy + 1][dx + 1] / R_(16.0)) *
+                      (cur[(size_t)c * hw + (size_t)yy * w + xx] * curm[(size_t)yy * w + xx]);
+            }
+          nxt[((size_t)c * nh + y) * nw + x] = rf / (rm + R_(1.0e-8));
+        }
+        nxtm[(size_t)y * nw + x] = curm[(size_t)(2 * y) * w + 2 * x];
+      }
+    free(cur);
+    free(curm);
+    cur = nxt;
+    curm = nxtm;
+    h = nh;
+    w = nw;
+  }
+  free(cur);
+  free(curm);
+}
+
+/* =========================================================================
+ * se3_exp: core/mapping/mapping_utils.h:316-346
+ * ========================================================================= */
+void ORC(se3_exp)(const REAL *omega, const REAL *v, REAL *R, REAL *t)
+{
+  REAL theta = (REAL)sqrt((double)(omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2]));
+  REAL n[3] = {1, 0, 0};
+  if (theta > 0)
+  {
+    n[0] = omega[0] / theta;
+    n[1] = omega[1] / theta;
+    n[2] = omega[2] / theta;
+  }
+  if (theta < R_(1.0e-14))
+    theta = R_(1.0e-14);
+  const REAL s = (REAL)sin((double)theta), c = (REAL)cos((double)theta);
+  const REAL K[3][3] = {{0, -n[2], n[1]}, {n[2], 0, -n[0]}, {-n[1], n[0], 0}};
+  REAL K2[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      K2[i][j] = K[i][0] * K[0][j] + K[i][1] * K[1][j] + K[i][2] * K[2][j];
+  const REAL a = (1 - c) / theta, b = (theta - s) / theta;
+  for (int i = 0; i < 3; ++i)
+  {
+    REAL acc = 0;
+    for (int j = 0; j < 3; ++j)
+    {
+      const REAL id = (i == j) ? R_(1.0) : R_(0.0);
+      R[i * 3 + j] = id + s * K[i][j] + (1 - c) * K2[i][j];
+      const REAL V = id + a * K[i][j] + b * K2[i][j];
+      acc += V * v[j];
+    }
+    t[i] = acc;
+  }
+}
