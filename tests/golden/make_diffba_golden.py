@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REFERENCE's own Python implementation of the
+photometric / geometric BA terms (``representation/models/diff_ba.py``:
+``photo_term`` :953-1061, ``geometry_term`` :1164-1287).
+
+Runs ONLY in the build container (needs /root/reference); the outputs
+(``tests/golden/diffba_*.npz``: seeded inputs + the reference's outputs) are
+committed and travel, this script's imports of the reference do not.
+
+``diff_ba.py`` imports a few packages that are absent here and unused by the two
+functions called (cv2, torchgeometry, umap, the repo's own ``utils``/``models``
+packages which pull h5py/tensorboardX/...); they are replaced by empty modules for the
+duration of the import.  ``DiffBundleAdjustment.__init__`` calls ``.cuda()`` on a
+constant (:37-38); ``torch.Tensor.cuda`` is made the identity so it constructs on CPU.
+No arithmetic of the reference is touched.
+
+Usage:  python tests/golden/make_diffba_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF = "/root/reference/representation"
+
+
+def import_reference():
+    for name in ["cv2", "torchgeometry", "umap", "utils", "models", "utils.logger"]:
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["utils"].logger = types.SimpleNamespace(debug=lambda *a, **k: None, error=lambda *a, **k: None)
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_diff_ba", os.path.join(REF, "models", "diff_ba.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.DiffBundleAdjustment
+
+
+def smooth(rng, C, H, W, cycles=1.5, waves=3):
+    yy, xx = np.meshgrid(np.arange(H) / H, np.arange(W) / W, indexing="ij")
+    out = np.zeros((C, H, W))
+    for c in range(C):
+        for _ in range(waves):
+            kx, ky = rng.uniform(-cycles, cycles, 2)
+            out[c] += rng.uniform(0.3, 1.0) * np.sin(2 * np.pi * (kx * xx + ky * yy) + rng.uniform(0, 6.28))
+    return out
+
+
+def central_grad(img):
+    p = np.pad(img, ((0, 0), (1, 1), (1, 1)), mode="edge")
+    gx = 0.5 * (p[:, 1:-1, 2:] - p[:, 1:-1, :-2])
+    gy = 0.5 * (p[:, 2:, 1:-1] - p[:, :-2, 1:-1])
+    return gx, gy
+
+
+def rot(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def make_case(seed, H, W, N, FS, CS, with_invalid):
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = 0.9 * W, 0.85 * W, W / 2.0 - 0.3, H / 2.0 + 0.2
+    feat1 = smooth(rng, FS, H, W)
+    gx, gy = central_grad(feat1)
+    mask = np.ones((H, W))
+    if with_invalid:
+        mask[:, : W // 4] = 0            # a masked band so some samples land on mask == 0
+    # sampled source pixels (integer locations), depths from bias + basis*code
+    loc = rng.choice(H * W, N, replace=False)
+    lx, ly = loc % W, loc // W
+    homo = np.stack([(lx - cx) / fx, (ly - cy) / fy, np.ones(N)], 0)      # 3 x N
+    bias = 1.0 + 0.2 * rng.standard_normal(N)
+    basis = 0.05 * rng.standard_normal((N, CS))
+    code = 0.1 * rng.standard_normal(CS)
+    scale = 1.3
+    if with_invalid:
+        bias[:3] = -0.5                  # negative depth -> behind the camera
+    src_feats = rng.uniform(-1, 1, (FS, N))
+    R = rot(np.array([0.02, -0.03, 0.015]))
+    t = np.array([0.05, -0.02, 0.03])
+    # geometric inputs
+    dmap = 1.2 + 0.1 * smooth(rng, 1, H, W)
+    dgx, dgy = central_grad(dmap)
+    return dict(H=H, W=W, N=N, FS=FS, CS=CS, intr=np.array([fx, fy, cx, cy]),
+                feat1=feat1, gx=gx, gy=gy, mask=mask, loc=loc, homo=homo, bias=bias, basis=basis,
+                code=code, scale=scale, src_feats=src_feats, R=R, t=t,
+                dmap=dmap[0], dgx=dgx[0], dgy=dgy[0])
+
+
+def run_case(ba, c):
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    H, W, FS = c["H"], c["W"], c["FS"]
+    A, diff, valid = ba.photo_term(
+        tgt_feature_map=f32(c["feat1"]).reshape(1, FS, H, W),
+        tgt_feature_map_spatial_grad=f32(np.concatenate([c["gx"], c["gy"]], 0)).reshape(1, 2 * FS, H, W),
+        tgt_valid_mask=f32(c["mask"]).reshape(1, 1, H, W),
+        sampled_src_features=f32(c["src_feats"]),
+        sampled_depth_bias=f32(c["bias"]),
+        sampled_depth_jac_code_hierarchy=f32(c["basis"]),
+        sampled_homo_2d_locations=f32(c["homo"]),
+        camera_intrinsics=f32(c["intr"]).reshape(1, 4),
+        guess_rotation=f32(c["R"]), guess_translation=f32(c["t"]),
+        guess_code_hierarchy=f32(c["code"]), guess_scale=torch.tensor(c["scale"], dtype=torch.float32))
+    mean_sq = float(np.mean(c["dmap"] ** 2))
+    Ag, dg, eg, vg = ba.geometry_term(
+        tgt_valid_mask=f32(c["mask"]).reshape(1, 1, H, W),
+        tgt_depth_map=f32(c["dmap"]).reshape(1, 1, H, W),
+        mean_squared_tgt_depth_value=torch.tensor(mean_sq, dtype=torch.float32),
+        tgt_depth_map_spatial_grad=f32(np.stack([c["dgx"], c["dgy"]], 0)).reshape(1, 2, H, W),
+        sampled_depth_bias=f32(c["bias"]),
+        sampled_depth_jac_code_hierarchy=f32(c["basis"]),
+        sampled_homo_2d_locations=f32(c["homo"]),
+        camera_intrinsics=f32(c["intr"]).reshape(1, 4),
+        guess_rotation=f32(c["R"]), guess_translation=f32(c["t"]),
+        guess_code_hierarchy=f32(c["code"]), guess_scale=torch.tensor(c["scale"], dtype=torch.float32))
+    out = {k: np.asarray(v, dtype=np.float32) if isinstance(v, np.ndarray) and v.dtype.kind == "f" else v
+           for k, v in c.items()}
+    out.update(photo_A=A.detach().numpy(), photo_diff=diff.detach().numpy(), photo_valid=valid.detach().numpy(),
+               geo_A=Ag.detach().numpy(), geo_diff=dg.detach().numpy(), geo_err=eg.detach().numpy(),
+               geo_valid=vg.detach().numpy(), geo_mean_sq=np.float32(mean_sq),
+               geo_cauchy_factor=np.float32(GEO_CAUCHY), depth_eps=np.float32(DEPTH_EPS))
+    return out
+
+
+GEO_CAUCHY = 0.03
+DEPTH_EPS = 1.0e-4
+
+
+def main():
+    DBA = import_reference()
+    # ctor args (diff_ba.py:16-18): match_geom_param_factor, match_geom_term_weight, code_term_weight,
+    # geometry_cauchy_param_factor, geometry_term_weight, scale_term_weight, photo_pow_factor,
+    # photo_weight, num_photo_level, depth_eps, num_display_matches
+    ba = DBA(0.1, 0.1, 1.0e-3, GEO_CAUCHY, 0.1, 1.0, 1.0, 1.0, 1, DEPTH_EPS, 0)
+    with torch.no_grad():
+        for name, kw in {
+            "diffba_allvalid": dict(seed=11, H=16, W=20, N=24, FS=16, CS=32, with_invalid=False),
+            "diffba_invalid": dict(seed=12, H=16, W=20, N=24, FS=16, CS=16, with_invalid=True),
+        }.items():
+            c = make_case(**kw)
+            out = run_case(ba, c)
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print(name, "photo_A", out["photo_A"].shape, "valid", out["photo_valid"].sum(),
+                  "geo_A", out["geo_A"].shape, "geo valid", out["geo_valid"].sum())
+
+
+if __name__ == "__main__":
+    main()

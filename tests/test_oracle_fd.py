@@ -1,0 +1,171 @@
+"""Finite-difference checks of the oracle's analytic Jacobians (fp64 build).
+
+These cover the parts the diff_ba fixtures cannot pin: the world-frame
+two-pose blocks dX/dT0 = R1^T E(Xw), dX/dT1 = -R1^T E(Xw) with non-trivial R0, R1
+(photometric_factor_kernels.cpp:258-297), the geometric code1 / scale1 columns
+(geometric_factor_kernels.cpp:688,696) and the per-level half-pixel coordinate mapping
+(:142-144).  This is the relationship the reference's own commented-out checks use
+(core/gtsam/photometric_factor.cpp:124-143): r(x (+) d) = r(x) - J d + O(d^2).
+
+The Jacobians use *sampled gradient images*, not the derivative of the bilinear
+interpolant, so the check uses images that are linear ramps per level (central-difference
+gradient == true gradient, bilinear interpolation exact).
+"""
+import numpy as np
+import pytest
+
+from sage_slam_amd import synth
+
+
+def rot(w):
+    return synth.so3_exp(np.asarray(w, dtype=np.float64))
+
+
+def retract(R, t, d):
+    """T <- exp([v, w]) * T  (left multiplication, [trans, rot] order; gtsam_traits.h:45-70)."""
+    from oracle import oracle as orc
+    dR, dt = orc.se3_exp(d[3:6], d[0:3], prec="f64")
+    return dR @ R, dR @ t + dt
+
+
+def ramp_pyramid(rng, cams, FS):
+    """per level: f_c(x,y) = a*x + b*y + c ; grad = (a, b) constant."""
+    pyr, gx, gy = [], [], []
+    for cam in cams:
+        Wl, Hl = int(cam.w), int(cam.h)
+        yy, xx = np.meshgrid(np.arange(Hl, dtype=np.float64), np.arange(Wl, dtype=np.float64), indexing="ij")
+        a = rng.uniform(-0.05, 0.05, (FS, 1, 1)); b = rng.uniform(-0.05, 0.05, (FS, 1, 1))
+        c = rng.uniform(-0.5, 0.5, (FS, 1, 1))
+        pyr.append((a * xx + b * yy + c).reshape(FS, -1))
+        gx.append(np.broadcast_to(a, (FS, Hl, Wl)).reshape(FS, -1))
+        gy.append(np.broadcast_to(b, (FS, Hl, Wl)).reshape(FS, -1))
+    return np.concatenate(pyr, 1), np.stack([np.concatenate(gx, 1), np.concatenate(gy, 1)], 0)
+
+
+@pytest.fixture(scope="module")
+def scene():
+    rng = np.random.default_rng(3)
+    H, W, L, FS, CS, N = 32, 40, 3, 4, 8, 40
+    cams = synth.camera_pyramid(synth.Camera(36.0, 34.0, 19.6, 16.3, W, H), L)
+    lo, P = synth.level_offsets_of(cams)
+    feat0, _ = ramp_pyramid(rng, cams, FS)
+    feat1, grad1 = ramp_pyramid(rng, cams, FS)
+    # central region samples so every tap at every level stays interior
+    ys = rng.integers(10, H - 10, N); xs = rng.integers(10, W - 10, N)
+    loc = (ys * W + xs).astype(np.int64)
+    homo = np.stack([(xs - cams[0].cx) / cams[0].fx, (ys - cams[0].cy) / cams[0].fy, np.ones(N)], 1)
+    yy, xx = np.meshgrid(np.arange(H, dtype=np.float64), np.arange(W, dtype=np.float64), indexing="ij")
+    def lin():
+        return (rng.uniform(-2e-3, 2e-3) * xx + rng.uniform(-2e-3, 2e-3) * yy).reshape(-1)
+    bias0 = 1.0 + lin(); basis0 = np.stack([0.05 * rng.standard_normal() + lin() for _ in range(CS)], 1)
+    bias1 = 1.0 + lin(); basis1 = np.stack([0.05 * rng.standard_normal() + lin() for _ in range(CS)], 1)
+    x = dict(R0=rot([0.3, -0.2, 0.1]), t0=np.array([0.4, -0.3, 0.2]),
+             code0=0.1 * rng.standard_normal(CS), code1=0.1 * rng.standard_normal(CS), s0=1.3, s1=0.9)
+    # T1 = T0 * small relative motion, so the projections stay interior
+    dR = rot([0.01, -0.015, 0.02]); dt = np.array([0.02, -0.01, 0.015])
+    x["R1"] = x["R0"] @ dR; x["t1"] = x["R0"] @ dt + x["t0"]
+    return dict(H=H, W=W, L=L, FS=FS, CS=CS, N=N, cams=cams, lo=lo, P=P, feat0=feat0, feat1=feat1,
+                grad1=grad1, loc=loc, homo=homo, bias0=bias0, basis0=basis0, bias1=bias1, basis1=basis1,
+                mask=np.ones((H, W)), x=x, w=np.array([10.0, 9.0, 8.0]))
+
+
+def photo_rows(orc, s, x):
+    R10 = x["R1"].T @ x["R0"]; t10 = x["R1"].T @ (x["t0"] - x["t1"])
+    return orc.photo_jac_error(R10, t10, x["R0"], x["t0"], x["R1"], x["t1"], s["bias0"], s["basis0"],
+                               x["code0"], s["mask"], s["loc"], s["homo"], s["feat0"], s["feat1"], s["grad1"],
+                               s["lo"], x["s0"], s["cams"], 1e-4, s["w"], prec="f64", want_rows=True)
+
+
+def geo_rows(orc, s, x, loss=1e12):
+    R10 = x["R1"].T @ x["R0"]; t10 = x["R1"].T @ (x["t0"] - x["t1"])
+    H, W, CS = s["H"], s["W"], s["CS"]
+    un = (s["bias1"] + s["basis1"] @ x["code1"]).reshape(1, H, W)
+    g = orc.spatial_grad(un, prec="f64")[:, 0]
+    # ramps: replicate-pad central differences are wrong on the border only; samples are interior
+    return orc.geo_jac_error(R10, t10, x["R0"], x["t0"], x["R1"], x["t1"], s["bias0"], s["basis0"], x["code0"],
+                             x["s1"] * un[0], x["s1"] * g, s["basis1"].reshape(H, W, CS), s["mask"],
+                             s["loc"], s["homo"], x["s0"], x["s1"], s["cams"][0], 1e-4, loss, 1.0,
+                             prec="f64", want_rows=True)
+
+
+def perturb(x, name, d, CS):
+    y = dict(x)
+    if name == "pose0":
+        y["R0"], y["t0"] = retract(x["R0"], x["t0"], d)
+    elif name == "pose1":
+        y["R1"], y["t1"] = retract(x["R1"], x["t1"], d)
+    elif name in ("code0", "code1"):
+        y[name] = x[name] + d
+    else:
+        y[name] = x[name] + d[0]
+    return y
+
+
+def test_photo_two_pose_code_scale_jacobian_fd(orc, scene):
+    s, x, CS = scene, scene["x"], scene["CS"]
+    base = photo_rows(orc, s, x)
+    assert base["num_inliers"] == s["N"]
+    J = base["J"].reshape(-1, 13 + CS); r0 = base["r"].reshape(-1)
+    cols = {"pose0": slice(0, 6), "pose1": slice(6, 12), "code0": slice(12, 12 + CS), "s0": slice(12 + CS, 13 + CS)}
+    rng = np.random.default_rng(0)
+    for name, sl in cols.items():
+        n = sl.stop - sl.start
+        d = 1e-6 * rng.standard_normal(n)
+        r1 = photo_rows(orc, s, perturb(x, name, d, CS))["r"].reshape(-1)
+        lin = -J[:, sl] @ d                      # r = f0 - f1, J = +df1/dx
+        err = np.linalg.norm((r1 - r0) - lin) / np.linalg.norm(lin)
+        assert err < 1e-4, (name, err)
+
+
+def test_geo_all_columns_jacobian_fd(orc, scene):
+    s, x, CS = scene, scene["x"], scene["CS"]
+    loss = 1e12
+    base = geo_rows(orc, s, x, loss)
+    assert base["num_inliers"] == s["N"]
+    sc = np.sqrt(loss)                           # sqrt_w = 1/sqrt(rho^2 + c) ~= 1/sqrt(c)
+    J = base["J"] * sc; r0 = base["r"] * sc
+    cols = {"pose0": slice(0, 6), "pose1": slice(6, 12), "code0": slice(12, 12 + CS),
+            "code1": slice(12 + CS, 12 + 2 * CS), "s0": slice(12 + 2 * CS, 13 + 2 * CS),
+            "s1": slice(13 + 2 * CS, 14 + 2 * CS)}
+    rng = np.random.default_rng(1)
+    for name, sl in cols.items():
+        n = sl.stop - sl.start
+        d = 1e-6 * rng.standard_normal(n)
+        r1 = geo_rows(orc, s, perturb(x, name, d, CS), loss)["r"] * sc
+        lin = -J[:, sl] @ d                      # row = -d rho/dx, residual = +rho
+        err = np.linalg.norm((r1 - r0) - lin) / np.linalg.norm(lin)
+        assert err < 1e-4, (name, err)
+
+
+def test_photo_error_only_equals_jac_path(orc, scene):
+    s, x = scene, scene["x"]
+    base = photo_rows(orc, s, x)
+    R10 = x["R1"].T @ x["R0"]; t10 = x["R1"].T @ (x["t0"] - x["t1"])
+    e, n = orc.photo_error(R10, t10, s["bias0"], s["basis0"], x["code0"], s["mask"], s["loc"], s["homo"],
+                           s["feat0"], s["feat1"], s["lo"], x["s0"], s["cams"], 1e-4, s["w"], prec="f64")
+    assert n == base["num_inliers"]
+    assert e == pytest.approx(base["error"], rel=1e-9)
+
+
+def test_error_model_matches_reference_relationship(orc, scene):
+    """err(x+d) - err(x) ~= d^T AtA d - 2 Atb^T d  (photometric_factor.cpp:124-143)."""
+    s, x, CS = scene, scene["x"], scene["CS"]
+    base = photo_rows(orc, s, x)
+    rng = np.random.default_rng(2)
+    d = 1e-4 * rng.standard_normal(13 + CS)
+    y = perturb(perturb(perturb(perturb(x, "pose0", d[0:6], CS), "pose1", d[6:12], CS),
+                        "code0", d[12:12 + CS], CS), "s0", d[12 + CS:], CS)
+    e1 = photo_rows(orc, s, y)["error"]
+    pred = d @ base["AtA"] @ d - 2 * base["Atb"] @ d
+    assert (e1 - base["error"]) == pytest.approx(pred, rel=2e-3)
+
+
+def test_zero_overlap_fallback(orc, scene):
+    """no inliers -> error = 10*sum(w), AtA = Atb = 0 (photometric...:1156-1161; geometric...:944)."""
+    s, x, CS = scene, dict(scene["x"]), scene["CS"]
+    x["t1"] = x["t1"] + x["R1"] @ np.array([0, 0, 50.0])     # every point ends up behind camera 1
+    o = photo_rows(orc, s, x)
+    assert o["num_inliers"] == 0 and o["error"] == pytest.approx(10 * s["w"].sum())
+    assert not o["AtA"].any() and not o["Atb"].any()
+    g = geo_rows(orc, s, x, 0.03)
+    assert g["num_inliers"] == 0 and g["error"] == pytest.approx(10.0) and not g["AtA"].any()
