@@ -1,0 +1,315 @@
+/*
+ * sage_ba.h -- C ABI of the MI355X-native dense bundle-adjustment engine.
+ *
+ * This is the drop-in boundary for the hot path of lppllppl920/SAGE-SLAM: the
+ * per-pixel feature-metric (photometric) and geometric residual/Jacobian
+ * evaluation and the Gauss-Newton/LM reduction into the pose x depth-code x
+ * scale normal equations.  It replaces the free functions declared in
+ *     system/sources/cuda/photometric_factor_kernels.h
+ *     system/sources/cuda/geometric_factor_kernels.h
+ * (namespace df, templated on CS/FS) and adds the batched window engine the
+ * reference does not have (one launch over all factor-graph edges, block-sparse
+ * normal equations, edge sharding across GPUs).
+ *
+ * Conventions
+ *   - every `dev` pointer is a plain HIP device pointer (fp32 unless noted);
+ *     layouts are the reference's own: feature pyramids
+ *     [FS,P] channel-major with levels concatenated fine->coarse, gradient
+ *     pyramids [2,FS,P] (x then y), bias [H*W], basis [H*W,CS] row-major,
+ *     mask [H,W] float 0/1, homo [N,3], loc1d [N].
+ *   - poses are world-from-keyframe; a pose buffer is 12 floats: R row-major
+ *     (9) then t (3).  Tangent order [translation(3), rotation(3)], update is a
+ *     LEFT multiplication T <- exp(delta)*T  (core/gtsam/gtsam_traits.h:45-70).
+ *   - no torch types, no exceptions; every function returns 0 on success or a
+ *     negative SAGE_E_* / positive hipError_t code (the reference calls exit()
+ *     on a launch error: photometric_factor_kernels.cpp:18-31).
+ *   - "no inliers" is NOT an error: error = 10*sum(w) (photometric) or
+ *     10*weight (geometric), AtA = Atb = 0 (photometric...cpp:1156-1161,
+ *     geometric...cpp:942-947).
+ *   - all entry points are re-entrant; a SageWorkspace (stream + scratch) must
+ *     not be used from two host threads at once (the reference is called from
+ *     up to 4 host threads: deepfactors.cpp:1497-1505 -> one workspace each).
+ *
+ * The product path has no CPU fallback: without a HIP device every compute
+ * entry point fails with the hipError from the runtime.
+ */
+#ifndef SAGE_BA_H_
+#define SAGE_BA_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAGE_MAX_LEVELS 8
+#define SAGE_POSE_FLOATS 12 /* R (9, row-major) then t (3) */
+
+#define SAGE_OK 0
+#define SAGE_E_INVALID (-1)     /* bad argument (null pointer, unsupported CS/FS/L ...) */
+#define SAGE_E_UNSUPPORTED (-2) /* combination not instantiated */
+#define SAGE_E_NOT_PSD (-3)     /* host solve: matrix not positive definite even after damping */
+#define SAGE_E_STATE (-4)       /* call order violated (e.g. solve before linearize) */
+
+/* ---- cameras: replaces df::PinholeCamera<float> / df::CameraPyramid<float>
+ *      (common/pinhole_camera.h:44-131, common/camera_pyramid.h:18-32) ---- */
+typedef struct SageCamera
+{
+  float fx, fy, cx, cy, w, h;
+} SageCamera;
+
+typedef struct SagePyramid
+{
+  int32_t levels;
+  int32_t P; /* total texels over all levels */
+  int32_t level_offsets[SAGE_MAX_LEVELS];
+  SageCamera cam[SAGE_MAX_LEVELS];
+} SagePyramid;
+
+/* CameraPyramid ctor: level i = level i-1 resized to (size_t)(w/2),(size_t)(h/2). Host only. */
+int sage_camera_pyramid(const SageCamera *base, int levels, SagePyramid *out);
+
+const char *sage_version(void);
+const char *sage_error_string(int code);
+
+/* ---- workspace: one per host thread / stream ---- */
+typedef struct SageWorkspace SageWorkspace;
+/* hip_stream: a hipStream_t (NULL = default stream). */
+int sage_workspace_create(void *hip_stream, SageWorkspace **out);
+void sage_workspace_destroy(SageWorkspace *ws);
+
+/* =====================================================================
+ * Per-edge operator API == the reference's free functions, raw pointers.
+ * AtA/Atb are DEVICE outputs (row-major D x D and D), `error` is a HOST
+ * output (the call synchronises the stream, like the reference's .item()).
+ * ===================================================================== */
+
+/* df::photometric_jac_error_calculate<CS,FS>  (photometric_factor_kernels.h:20-33,
+ * .cpp:1061-1164).  D = 13+CS, column order [pose0(6) pose1(6) code0(CS) scale0].
+ * weights: HOST float[L] (the reference passes a CPU tensor: photometric_factor.cpp:31-32). */
+int sage_photometric_jac_error_calculate(
+    SageWorkspace *ws, float *AtA_dev, float *Atb_dev, float *error_host, float *num_inliers_host,
+    const float *R10_dev, const float *t10_dev, const float *R0_dev, const float *t0_dev,
+    const float *R1_dev, const float *t1_dev,
+    const float *bias0_dev, const float *basis0_dev, const float *code0_dev, const float *mask1_dev,
+    const int64_t *loc1d_dev, const float *homo_dev,
+    const float *feat0_dev, const float *feat1_dev, const float *grad1_dev,
+    float scale0, const SagePyramid *pyr, float eps, const float *weights_host,
+    int N, int FS, int CS);
+
+/* df::photometric_error_calculate<FS>  (photometric_factor_kernels.h:9-18, .cpp:990-1059) */
+int sage_photometric_error_calculate(
+    SageWorkspace *ws, float *error_host, float *num_inliers_host,
+    const float *R10_dev, const float *t10_dev,
+    const float *bias0_dev, const float *basis0_dev, const float *code0_dev, const float *mask1_dev,
+    const int64_t *loc1d_dev, const float *homo_dev,
+    const float *feat0_dev, const float *feat1_dev,
+    float scale0, const SagePyramid *pyr, float eps, const float *weights_host,
+    int N, int FS, int CS);
+
+/* df::tracker_photo_jac_error_calculate<FS> (dof = 6, photometric_factor_kernels.h:35-46, .cpp:1166-1245)
+ * df::tracker_photo_jac_error_calculate_with_scale<FS> (dof = 7, .h:48-59, .cpp:1247-1325).
+ * feat0s = pre-sampled source features [L,N,FS]; weights: DEVICE float[L] (tracker passes a device tensor). */
+int sage_tracker_photo_jac_error_calculate(
+    SageWorkspace *ws, int dof, float *AtA_dev, float *Atb_dev, float *error_host, float *num_inliers_host,
+    const float *R_dev, const float *t_dev, const float *mask1_dev,
+    const float *dpts0_dev, const float *homo_dev, const float *feat0s_dev,
+    const float *feat1_dev, const float *grad1_dev,
+    const SagePyramid *pyr, float scale0, float eps, const float *weights_dev, int N, int FS);
+
+/* df::tracker_photo_error_calculate<FS> (photometric_factor_kernels.h:61-70, .cpp:1327-1384) */
+int sage_tracker_photo_error_calculate(
+    SageWorkspace *ws, float *error_host, float *num_inliers_host,
+    const float *R_dev, const float *t_dev, const float *mask1_dev,
+    const float *dpts0_dev, const float *homo_dev, const float *feat0s_dev, const float *feat1_dev,
+    const SagePyramid *pyr, float eps, const float *weights_dev, int N, int FS);
+
+/* df::geometric_jac_error_calculate<CS> (geometric_factor_kernels.h:38-48, .cpp:882-950).
+ * D = 14+2CS, column order [pose0 pose1 code0 code1 scale0 scale1].  dpt1 = s1*(bias1+basis1*code1) [H,W],
+ * dpt_grad1 [2,H,W], basis1 [H,W,CS]; loc1d is int32 here (geometric_factor.cpp:344). */
+int sage_geometric_jac_error_calculate(
+    SageWorkspace *ws, float *AtA_dev, float *Atb_dev, float *error_host, float *num_inliers_host,
+    const float *R10_dev, const float *t10_dev, const float *R0_dev, const float *t0_dev,
+    const float *R1_dev, const float *t1_dev,
+    const float *bias0_dev, const float *basis0_dev, const float *code0_dev,
+    const float *dpt1_dev, const float *dpt_grad1_dev, const float *basis1_dev, const float *mask1_dev,
+    const int32_t *loc1d_dev, const float *homo_dev,
+    float scale0, float scale1, const SageCamera *cam, float eps, float loss_param, float weight,
+    int N, int CS);
+
+/* df::geometric_error_calculate<CS> (geometric_factor_kernels.h:18-24, .cpp:837-880) */
+int sage_geometric_error_calculate(
+    SageWorkspace *ws, float *error_host, float *num_inliers_host,
+    const float *R10_dev, const float *t10_dev,
+    const float *bias0_dev, const float *basis0_dev, const float *code0_dev,
+    const float *dpt1_dev, const float *mask1_dev, const int32_t *loc1d_dev, const float *homo_dev,
+    float scale0, const SageCamera *cam, float eps, float loss_param, float weight, int N, int CS);
+
+/* ---- input producers ---- */
+/* UpdateDepth + ComputeSpatialGrad (core/mapping/mapping_utils.h:215-252; caller side of the geometric
+ * factor, geometric_factor.cpp:317-347): dpt[H,W] = scale*(bias+basis*code), grad[2,H,W] = scale*centraldiff. */
+int sage_depth_and_grad(SageWorkspace *ws, float *dpt_dev, float *dpt_grad_dev,
+                        const float *bias_dev, const float *basis_dev, const float *code_dev,
+                        float scale, int H, int W, int CS);
+/* GenerateGaussianPyramidWithGrad (core/mapping/mapper.cpp:1384-1426): feat [FS,H,W], mask [H,W]
+ * -> pyr [FS,P], grad [2,FS,P]. */
+int sage_gaussian_pyramid_with_grad(SageWorkspace *ws, float *pyr_dev, float *grad_dev,
+                                    const float *feat_dev, const float *mask_dev,
+                                    const SagePyramid *pyr, int FS);
+
+/* =====================================================================
+ * Host-side helpers (pure CPU, no device needed)
+ * ===================================================================== */
+/* se3_exp (core/mapping/mapping_utils.h:316-346): R[9], t[3] from omega[3], v[3]. */
+void sage_se3_exp(const float *omega, const float *v, float *R, float *t);
+/* left retraction T <- exp([v,w]) T (core/gtsam/gtsam_traits.h:45-70; camera_tracker.cpp:491-512);
+ * pose/out are 12 floats (R then t), delta = [v(3), w(3)]. */
+void sage_pose_retract(const float *pose, const float *delta6, float *out);
+/* Higham nearest-PSD of a symmetric-ish n x n matrix in double (the algorithm
+ * core/mapping/mapping_utils.h:104-128 intends; see DESIGN.md for the reference's V^T S V slip). */
+int sage_nearest_psd(const double *M, int n, double *out);
+/* solve (A + damp*diag(A)) x = b, column-pivoted Householder QR in fp32 (camera_tracker.cpp:1182-1183). */
+int sage_damped_solve_qr_f32(const float *A, const float *b, int n, float damp, float *x);
+
+/* damped solve of the block-sparse normal equations in double (envelope Cholesky):
+ *   (H + diag_add + damp*diag(H + diag_add)) delta = g + g_add
+ * packed = [diag K*B*B | link nlinks*B*B (rows = links[2l], cols = links[2l+1], links[2l] < links[2l+1]) | g K*B | 4]
+ * (host memory, the layout of sage_window_packed_dev); diag_add / g_add (K*B doubles, may be NULL) carry the
+ * diagonal priors.  Returns SAGE_E_NOT_PSD if the damped matrix is not positive definite. */
+int sage_block_solve(const float *packed_host, int K, int nlinks, const int32_t *links, int B, double damp,
+                     const double *diag_add, const double *g_add, double *delta);
+
+/* ---- tracker LM (core/system/camera_tracker.cpp:1034-1310 / 1312-1672) ---- */
+typedef struct SageLmConfig
+{
+  int max_num_iters;         /* tracking_max_num_iters       = 40   */
+  float min_grad_thresh;     /* tracking_min_grad_thresh     = 1e-4 */
+  float min_param_inc_thresh;/* tracking_min_param_inc_thresh= 1e-2 */
+  float init_damp;           /* tracking_init_damp           = 1e-4 */
+  float min_damp, max_damp;  /* tracking_min_max_damp        = 1e-6, 1e-2 */
+  float damp_dec_factor;     /* tracking_damp_dec_inc_factor = 10, 100 */
+  float damp_inc_factor;
+  float jac_update_err_inc_threshold; /* 1e-2 */
+  int max_inner_evals;       /* window LM only: cap on candidate evaluations per iteration (0 = reference policy: retry until accepted or max_damp) */
+} SageLmConfig;
+void sage_lm_config_default(SageLmConfig *cfg);
+
+/* evaluation back-end of the tracker LM: the product wires these to the HIP kernels above; tests may
+ * wire them to anything.  Return 0 on success. */
+typedef int (*SageTrackLinearizeFn)(void *ctx, const float *pose12, float scale, float *AtA, float *Atb, float *error);
+typedef int (*SageTrackErrorFn)(void *ctx, const float *pose12, float scale, float *error);
+
+typedef struct SageLmTraceEntry
+{
+  float damp, error, candidate_error;
+  int accepted, relinearized;
+} SageLmTraceEntry;
+
+/* dof = 6 (TrackNewFrame) or 7 (TrackFrame, + scale).  pose12/scale are in/out.  trace (optional) receives
+ * up to trace_cap entries, *trace_len the number written. */
+int sage_track_lm(const SageLmConfig *cfg, int dof, SageTrackLinearizeFn lin, SageTrackErrorFn err, void *ctx,
+                  float *pose12, float *scale, float *final_error, int *iters,
+                  SageLmTraceEntry *trace, int trace_cap, int *trace_len);
+
+/* product wiring of the two callbacks to the HIP kernels: track a frame against a keyframe on `ws`. */
+typedef struct SageTrackProblem
+{
+  SageWorkspace *ws;
+  const float *mask1_dev, *dpts0_dev, *homo_dev, *feat0s_dev, *feat1_dev, *grad1_dev;
+  const float *weights_dev;
+  SagePyramid pyr;
+  float eps;
+  int N, FS;
+  float unscaled; /* reserved */
+} SageTrackProblem;
+int sage_track_frame(const SageLmConfig *cfg, int dof, const SageTrackProblem *prob,
+                     float *pose12, float *scale, float *final_error, int *iters);
+
+/* =====================================================================
+ * Batched window engine (no reference counterpart; parity = sum of per-edge results)
+ * ===================================================================== */
+typedef struct SageWindow SageWindow;
+
+typedef struct SageKeyframeView /* device pointers, reference layouts (core/mapping/frame.h:17-125) */
+{
+  const float *feat_pyr;  /* [FS,P]   */
+  const float *grad_pyr;  /* [2,FS,P] */
+  const float *bias;      /* [H*W]    */
+  const float *basis;     /* [H*W,CS] */
+  const int64_t *loc1d;   /* [N]      */
+  const float *homo;      /* [N,3]    */
+  int32_t N;
+} SageKeyframeView;
+
+typedef struct SageWindowConfig
+{
+  SagePyramid pyr;
+  int32_t FS, CS;
+  const float *mask_dev;        /* shared video mask [H,W] */
+  float photo_weights[SAGE_MAX_LEVELS];
+  float geo_weight, geo_loss_param, eps;
+  float code_prior_weight;      /* code_factor_weight (slam_run.flags:104) */
+  float scale_prior_weight;     /* init_scale_prior_weight on keyframe 0 */
+  float pose_prior_weight;      /* init_pose_prior_weight on keyframe 0 */
+  int32_t use_photo, use_geo;
+} SageWindowConfig;
+
+int sage_window_create(const SageWindowConfig *cfg, void *hip_stream, SageWindow **out);
+void sage_window_destroy(SageWindow *w);
+/* variables: pose12 (R,t), code[CS], scale -- HOST pointers, copied. Returns keyframe id >= 0. */
+int sage_window_add_keyframe(SageWindow *w, const SageKeyframeView *view, const float *pose12,
+                             const float *code, float scale);
+/* a link contributes both directed edges of every enabled factor type (mapper.cpp:346-374). */
+int sage_window_add_link(SageWindow *w, int kf_a, int kf_b);
+/* edge sharding for multi-GPU: this process evaluates links l with (l % world) == rank. Default (0,1). */
+int sage_window_set_shard(SageWindow *w, int rank, int world);
+/* must be called once after the last add_keyframe/add_link and before linearize/error. */
+int sage_window_finalize(SageWindow *w);
+
+int sage_window_num_keyframes(const SageWindow *w);
+int sage_window_num_links(const SageWindow *w);
+int sage_window_block_size(const SageWindow *w);       /* B = 7 + CS: [pose6, code CS, scale] */
+/* packed normal-equation buffer (device, fp32), the all-reduce payload:
+ *   [ diag blocks K*B*B | link blocks nlinks*B*B (row = older kf, col = newer kf) | g K*B | err_photo err_geo n_photo n_geo ] */
+size_t sage_window_packed_floats(const SageWindow *w);
+float *sage_window_packed_dev(SageWindow *w);
+/* number of residuals one linearize evaluates on this shard (E_photo*L*N*FS + E_geo*N) and its algorithmic bytes */
+double sage_window_residuals_per_linearize(const SageWindow *w);
+double sage_window_bytes_per_linearize(const SageWindow *w);
+
+/* linearize every local edge at the current estimate and assemble the packed buffer (async on the stream). */
+int sage_window_linearize(SageWindow *w);
+/* total error of every local edge at the CANDIDATE (or current, which = 0/1) variables -> packed-like 4-float
+ * device buffer [err_photo err_geo n_photo n_geo]; async. */
+int sage_window_error(SageWindow *w, int which);
+float *sage_window_error_dev(SageWindow *w);
+/* after (optional) all-reduce of the packed buffer: add priors, D2H, damped solve in double on the host,
+ * write the candidate variables (retracted) and upload them.  Returns the predicted step norm. */
+int sage_window_solve(SageWindow *w, double damp, double *step_norm);
+/* total error (photo + geo + priors) from the (all-reduced) buffers; synchronises. */
+int sage_window_total_error(SageWindow *w, int from_linearize, double *err);
+int sage_window_accept(SageWindow *w);   /* candidate -> current */
+/* read back current variables (HOST outputs; any may be NULL) */
+int sage_window_get_keyframe(const SageWindow *w, int kf, float *pose12, float *code, float *scale);
+int sage_window_set_keyframe(SageWindow *w, int kf, const float *pose12, const float *code, float scale);
+/* host copy of the last solve's delta (K*B doubles), for parity tests */
+int sage_window_get_delta(const SageWindow *w, double *delta);
+/* host copy of per-edge results of the last linearize, reference layouts (for parity tests):
+ * type 0 = photometric (D=13+CS), 1 = geometric (D=14+2CS); edge index e in [0, 2*nlinks): link e/2,
+ * direction e%2 (0: a->b, 1: b->a). */
+int sage_window_get_edge(const SageWindow *w, int type, int e, float *AtA, float *Atb, float *err, float *n_in);
+
+/* one full LM iteration on a single GPU: linearize -> solve -> error at candidate -> accept/reject
+ * (policy of camera_tracker.cpp:1156-1279). */
+typedef struct SageLmState
+{
+  double damp, error, candidate_error;
+  int accepted, iters;
+} SageLmState;
+int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmConfig *cfg);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAGE_BA_H_ */

@@ -1,0 +1,591 @@
+"""ctypes binding of the C ABI (``include/sage_ba.h``) + thin torch plumbing.
+
+PyTorch is used only for device memory (``torch.Tensor.data_ptr()``), streams and
+``torch.distributed``; every compute entry point goes through ``libsage_ba.so``.
+There is no CPU fallback: if the library is missing or no HIP device is present the
+calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsage_ba.so")
+SAGE_MAX_LEVELS = 8
+
+
+class SageError(RuntimeError):
+    def __init__(self, code: int, where: str):
+        self.code = code
+        msg = lib().sage_error_string(code).decode() if _lib is not None else "?"
+        super().__init__(f"{where}: {msg} (code {code})")
+
+
+class SageCamera(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("fx", "fy", "cx", "cy", "w", "h")]
+
+
+class SagePyramid(C.Structure):
+    _fields_ = [("levels", C.c_int32), ("P", C.c_int32), ("level_offsets", C.c_int32 * SAGE_MAX_LEVELS),
+                ("cam", SageCamera * SAGE_MAX_LEVELS)]
+
+
+class SageLmConfig(C.Structure):
+    _fields_ = [("max_num_iters", C.c_int), ("min_grad_thresh", C.c_float), ("min_param_inc_thresh", C.c_float),
+                ("init_damp", C.c_float), ("min_damp", C.c_float), ("max_damp", C.c_float),
+                ("damp_dec_factor", C.c_float), ("damp_inc_factor", C.c_float),
+                ("jac_update_err_inc_threshold", C.c_float), ("max_inner_evals", C.c_int)]
+
+
+class SageLmTraceEntry(C.Structure):
+    _fields_ = [("damp", C.c_float), ("error", C.c_float), ("candidate_error", C.c_float),
+                ("accepted", C.c_int), ("relinearized", C.c_int)]
+
+
+class SageTrackProblem(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("mask1_dev", C.c_void_p), ("dpts0_dev", C.c_void_p), ("homo_dev", C.c_void_p),
+                ("feat0s_dev", C.c_void_p), ("feat1_dev", C.c_void_p), ("grad1_dev", C.c_void_p),
+                ("weights_dev", C.c_void_p), ("pyr", SagePyramid), ("eps", C.c_float), ("N", C.c_int),
+                ("FS", C.c_int), ("unscaled", C.c_float)]
+
+
+class SageKeyframeView(C.Structure):
+    _fields_ = [("feat_pyr", C.c_void_p), ("grad_pyr", C.c_void_p), ("bias", C.c_void_p), ("basis", C.c_void_p),
+                ("loc1d", C.c_void_p), ("homo", C.c_void_p), ("N", C.c_int32)]
+
+
+class SageWindowConfig(C.Structure):
+    _fields_ = [("pyr", SagePyramid), ("FS", C.c_int32), ("CS", C.c_int32), ("mask_dev", C.c_void_p),
+                ("photo_weights", C.c_float * SAGE_MAX_LEVELS), ("geo_weight", C.c_float),
+                ("geo_loss_param", C.c_float), ("eps", C.c_float), ("code_prior_weight", C.c_float),
+                ("scale_prior_weight", C.c_float), ("pose_prior_weight", C.c_float),
+                ("use_photo", C.c_int32), ("use_geo", C.c_int32)]
+
+
+class SageLmState(C.Structure):
+    _fields_ = [("damp", C.c_double), ("error", C.c_double), ("candidate_error", C.c_double),
+                ("accepted", C.c_int), ("iters", C.c_int)]
+
+
+TRACK_LIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float),
+                           C.POINTER(C.c_float), C.POINTER(C.c_float))
+TRACK_ERR_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_float), C.c_float, C.POINTER(C.c_float))
+
+_lib = None
+
+# every symbol include/sage_ba.h declares (checked by tests/test_capi_symbols.py against the header)
+SYMBOLS = [
+    "sage_camera_pyramid", "sage_version", "sage_error_string", "sage_workspace_create", "sage_workspace_destroy",
+    "sage_photometric_jac_error_calculate", "sage_photometric_error_calculate",
+    "sage_tracker_photo_jac_error_calculate", "sage_tracker_photo_error_calculate",
+    "sage_geometric_jac_error_calculate", "sage_geometric_error_calculate", "sage_depth_and_grad",
+    "sage_gaussian_pyramid_with_grad", "sage_se3_exp", "sage_pose_retract", "sage_nearest_psd",
+    "sage_damped_solve_qr_f32", "sage_block_solve", "sage_lm_config_default", "sage_track_lm", "sage_track_frame",
+    "sage_window_create", "sage_window_destroy", "sage_window_add_keyframe", "sage_window_add_link",
+    "sage_window_set_shard", "sage_window_finalize", "sage_window_num_keyframes", "sage_window_num_links",
+    "sage_window_block_size", "sage_window_packed_floats", "sage_window_packed_dev",
+    "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
+    "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
+    "sage_window_accept", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
+    "sage_window_get_edge", "sage_window_lm_step",
+]
+
+
+def lib():
+    """Load ``libsage_ba.so`` (built in-tree by ``sage_slam_amd.build``); fails loudly when absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: run `python -m sage_slam_amd.build` "
+                              "(the HIP engine has no fallback path)")
+        L = C.CDLL(LIB_PATH)
+        L.sage_version.restype = C.c_char_p
+        L.sage_error_string.restype = C.c_char_p
+        L.sage_window_packed_floats.restype = C.c_size_t
+        L.sage_window_packed_dev.restype = C.c_void_p
+        L.sage_window_error_dev.restype = C.c_void_p
+        L.sage_window_residuals_per_linearize.restype = C.c_double
+        L.sage_window_bytes_per_linearize.restype = C.c_double
+        for name in ("sage_window_packed_floats", "sage_window_packed_dev", "sage_window_error_dev",
+                     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize",
+                     "sage_window_num_keyframes", "sage_window_num_links", "sage_window_block_size"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _chk(code: int, where: str):
+    if code != 0:
+        raise SageError(code, where)
+
+
+def _f32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def _fp(a: np.ndarray):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def dptr(t) -> C.c_void_p:
+    """device pointer of a torch tensor (must be contiguous)."""
+    if t is None:
+        return C.c_void_p(0)
+    assert t.is_contiguous(), "device buffers handed to the C ABI must be contiguous"
+    return C.c_void_p(t.data_ptr())
+
+
+# --------------------------------------------------------------------------- host helpers
+def make_pyramid(cam, levels: int) -> SagePyramid:
+    """``CameraPyramid`` (``common/camera_pyramid.h:18-32``) through the C ABI."""
+    base = SageCamera(*[float(v) for v in (cam.fx, cam.fy, cam.cx, cam.cy, cam.w, cam.h)])
+    out = SagePyramid()
+    _chk(lib().sage_camera_pyramid(C.byref(base), levels, C.byref(out)), "sage_camera_pyramid")
+    return out
+
+
+def se3_exp(omega, v):
+    omega = _f32(omega); v = _f32(v)
+    R = np.zeros(9, np.float32); t = np.zeros(3, np.float32)
+    lib().sage_se3_exp(_fp(omega), _fp(v), _fp(R), _fp(t))
+    return R.reshape(3, 3), t
+
+
+def pose_retract(pose12, delta6):
+    pose12 = _f32(pose12).reshape(12); delta6 = _f32(delta6)
+    out = np.zeros(12, np.float32)
+    lib().sage_pose_retract(_fp(pose12), _fp(delta6), _fp(out))
+    return out
+
+
+def nearest_psd(M):
+    M = np.ascontiguousarray(M, dtype=np.float64)
+    out = np.zeros_like(M)
+    _chk(lib().sage_nearest_psd(M.ctypes.data_as(C.POINTER(C.c_double)), M.shape[0],
+                                out.ctypes.data_as(C.POINTER(C.c_double))), "sage_nearest_psd")
+    return out
+
+
+def damped_solve_qr_f32(A, b, damp):
+    A = _f32(A); b = _f32(b)
+    x = np.zeros(b.shape[0], np.float32)
+    _chk(lib().sage_damped_solve_qr_f32(_fp(A), _fp(b), b.shape[0], C.c_float(damp), _fp(x)), "sage_damped_solve_qr_f32")
+    return x
+
+
+def block_solve(packed, K, links, B, damp, diag_add=None, g_add=None):
+    packed = _f32(packed)
+    lk = np.ascontiguousarray(np.asarray(links, dtype=np.int32).reshape(-1))
+    delta = np.zeros(K * B, np.float64)
+    dp = lambda a: None if a is None else np.ascontiguousarray(a, np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    da = None if diag_add is None else np.ascontiguousarray(diag_add, np.float64)
+    ga = None if g_add is None else np.ascontiguousarray(g_add, np.float64)
+    _chk(lib().sage_block_solve(_fp(packed), K, len(lk) // 2, lk.ctypes.data_as(C.POINTER(C.c_int32)), B,
+                                C.c_double(damp), dp(da), dp(ga), delta.ctypes.data_as(C.POINTER(C.c_double))),
+         "sage_block_solve")
+    return delta
+
+
+def lm_config_default() -> SageLmConfig:
+    cfg = SageLmConfig()
+    lib().sage_lm_config_default(C.byref(cfg))
+    return cfg
+
+
+def pack_pose(R, t) -> np.ndarray:
+    return np.concatenate([_f32(R).reshape(9), _f32(t).reshape(3)])
+
+
+def track_lm(cfg: SageLmConfig, dof: int, lin_fn, err_fn, pose12, scale: float, trace_cap: int = 256):
+    """Run the tracker LM policy (``camera_tracker.cpp:1156-1279``) with Python evaluation callbacks.
+    ``lin_fn(pose12, scale) -> (AtA, Atb, error)``; ``err_fn(pose12, scale) -> error``."""
+    def _lin(ctx, p, s, AtA, Atb, err):
+        A, b, e = lin_fn(np.ctypeslib.as_array(p, (12,)).copy(), float(s))
+        A = _f32(A).reshape(-1); b = _f32(b).reshape(-1)
+        for i in range(dof * dof):
+            AtA[i] = A[i]
+        for i in range(dof):
+            Atb[i] = b[i]
+        err[0] = e
+        return 0
+
+    def _err(ctx, p, s, err):
+        err[0] = err_fn(np.ctypeslib.as_array(p, (12,)).copy(), float(s))
+        return 0
+
+    pose = _f32(pose12).reshape(12).copy()
+    sc = C.c_float(scale)
+    fe = C.c_float(0); it = C.c_int(0); tl = C.c_int(0)
+    trace = (SageLmTraceEntry * trace_cap)()
+    cb1, cb2 = TRACK_LIN_FN(_lin), TRACK_ERR_FN(_err)
+    _chk(lib().sage_track_lm(C.byref(cfg), dof, cb1, cb2, None, _fp(pose), C.byref(sc), C.byref(fe), C.byref(it),
+                             trace, trace_cap, C.byref(tl)), "sage_track_lm")
+    tr = [dict(damp=trace[i].damp, error=trace[i].error, candidate_error=trace[i].candidate_error,
+               accepted=trace[i].accepted, relinearized=trace[i].relinearized) for i in range(tl.value)]
+    return pose, sc.value, fe.value, it.value, tr
+
+
+# --------------------------------------------------------------------------- device side
+class Workspace:
+    """``SageWorkspace``: stream + scratch of one host thread."""
+
+    def __init__(self, stream=None):
+        self.h = C.c_void_p()
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(0)
+        _chk(lib().sage_workspace_create(sp, C.byref(self.h)), "sage_workspace_create")
+
+    def close(self):
+        if self.h:
+            lib().sage_workspace_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _dev(x, dtype=None):
+    import torch
+    if isinstance(x, torch.Tensor):
+        return x.contiguous()
+    a = np.ascontiguousarray(x, dtype=dtype)
+    return torch.from_numpy(a).cuda()
+
+
+class DeviceKeyframe:
+    """device-resident copy of a synthetic/real keyframe in the reference layouts (a10)."""
+
+    def __init__(self, kf, H, W):
+        import torch
+        self.feat_pyr = _dev(kf.feat_pyr, np.float32)
+        self.grad_pyr = _dev(kf.grad_pyr, np.float32)
+        self.bias = _dev(kf.bias, np.float32)
+        self.basis = _dev(kf.basis, np.float32)
+        self.loc1d = _dev(kf.loc1d, np.int64)
+        self.loc1d_i32 = self.loc1d.to(torch.int32)
+        self.homo = _dev(kf.homo, np.float32)
+        self.N = int(self.homo.shape[0])
+        self.H, self.W = H, W
+
+    def view(self) -> SageKeyframeView:
+        return SageKeyframeView(self.feat_pyr.data_ptr(), self.grad_pyr.data_ptr(), self.bias.data_ptr(),
+                                self.basis.data_ptr(), self.loc1d.data_ptr(), self.homo.data_ptr(), self.N)
+
+
+def photometric_jac_error(ws: Workspace, R10, t10, R0, t0, R1, t1, bias0, basis0, code0, mask1, loc1d, homo,
+                          feat0, feat1, grad1, scale0, pyr: SagePyramid, eps, weights, FS, CS):
+    """``df::photometric_jac_error_calculate<CS,FS>``; poses/code are small host arrays uploaded here (the
+    reference does the same H2D copies in ``PhotometricFactor::ComputeJacobianAndError``)."""
+    import torch
+    D = 13 + CS
+    small = torch.from_numpy(np.concatenate([_f32(x).reshape(-1) for x in (R10, t10, R0, t0, R1, t1, code0)])).cuda()
+    o = [0, 9, 12, 21, 24, 33, 36]
+    AtA = torch.empty((D, D), dtype=torch.float32, device="cuda")
+    Atb = torch.empty((D,), dtype=torch.float32, device="cuda")
+    err = C.c_float(); nin = C.c_float()
+    w = _f32(weights)
+    N = int(homo.shape[0])
+    base = small.data_ptr()
+    p = lambda i: C.c_void_p(base + 4 * o[i])
+    _chk(lib().sage_photometric_jac_error_calculate(
+        ws.h, dptr(AtA), dptr(Atb), C.byref(err), C.byref(nin), p(0), p(1), p(2), p(3), p(4), p(5),
+        dptr(bias0), dptr(basis0), p(6), dptr(mask1), dptr(loc1d), dptr(homo), dptr(feat0), dptr(feat1),
+        dptr(grad1), C.c_float(scale0), C.byref(pyr), C.c_float(eps), _fp(w), N, FS, CS),
+        "sage_photometric_jac_error_calculate")
+    return dict(AtA=AtA.cpu().numpy(), Atb=Atb.cpu().numpy(), error=err.value, num_inliers=nin.value)
+
+
+def photometric_error(ws: Workspace, R10, t10, bias0, basis0, code0, mask1, loc1d, homo, feat0, feat1, scale0,
+                      pyr: SagePyramid, eps, weights, FS, CS):
+    import torch
+    small = torch.from_numpy(np.concatenate([_f32(x).reshape(-1) for x in (R10, t10, code0)])).cuda()
+    base = small.data_ptr()
+    err = C.c_float(); nin = C.c_float()
+    w = _f32(weights)
+    N = int(homo.shape[0])
+    _chk(lib().sage_photometric_error_calculate(
+        ws.h, C.byref(err), C.byref(nin), C.c_void_p(base), C.c_void_p(base + 36), dptr(bias0), dptr(basis0),
+        C.c_void_p(base + 48), dptr(mask1), dptr(loc1d), dptr(homo), dptr(feat0), dptr(feat1), C.c_float(scale0),
+        C.byref(pyr), C.c_float(eps), _fp(w), N, FS, CS), "sage_photometric_error_calculate")
+    return err.value, nin.value
+
+
+def tracker_photo_jac_error(ws: Workspace, dof, R, t, mask1, dpts0, homo, feat0s, feat1, grad1, pyr, scale0, eps,
+                            weights_dev, FS):
+    import torch
+    small = torch.from_numpy(np.concatenate([_f32(R).reshape(-1), _f32(t).reshape(-1)])).cuda()
+    base = small.data_ptr()
+    AtA = torch.empty((dof, dof), dtype=torch.float32, device="cuda")
+    Atb = torch.empty((dof,), dtype=torch.float32, device="cuda")
+    err = C.c_float(); nin = C.c_float()
+    N = int(homo.shape[0])
+    _chk(lib().sage_tracker_photo_jac_error_calculate(
+        ws.h, dof, dptr(AtA), dptr(Atb), C.byref(err), C.byref(nin), C.c_void_p(base), C.c_void_p(base + 36),
+        dptr(mask1), dptr(dpts0), dptr(homo), dptr(feat0s), dptr(feat1), dptr(grad1), C.byref(pyr),
+        C.c_float(scale0), C.c_float(eps), dptr(weights_dev), N, FS), "sage_tracker_photo_jac_error_calculate")
+    return dict(AtA=AtA.cpu().numpy(), Atb=Atb.cpu().numpy(), error=err.value, num_inliers=nin.value)
+
+
+def tracker_photo_error(ws: Workspace, R, t, mask1, dpts0, homo, feat0s, feat1, pyr, eps, weights_dev, FS):
+    import torch
+    small = torch.from_numpy(np.concatenate([_f32(R).reshape(-1), _f32(t).reshape(-1)])).cuda()
+    base = small.data_ptr()
+    err = C.c_float(); nin = C.c_float()
+    N = int(homo.shape[0])
+    _chk(lib().sage_tracker_photo_error_calculate(
+        ws.h, C.byref(err), C.byref(nin), C.c_void_p(base), C.c_void_p(base + 36), dptr(mask1), dptr(dpts0),
+        dptr(homo), dptr(feat0s), dptr(feat1), C.byref(pyr), C.c_float(eps), dptr(weights_dev), N, FS),
+        "sage_tracker_photo_error_calculate")
+    return err.value, nin.value
+
+
+def geometric_jac_error(ws: Workspace, R10, t10, R0, t0, R1, t1, bias0, basis0, code0, dpt1, dgrad1, basis1, mask1,
+                        loc1d_i32, homo, scale0, scale1, cam: SageCamera, eps, loss_param, weight, CS):
+    import torch
+    D = 14 + 2 * CS
+    small = torch.from_numpy(np.concatenate([_f32(x).reshape(-1) for x in (R10, t10, R0, t0, R1, t1, code0)])).cuda()
+    o = [0, 9, 12, 21, 24, 33, 36]
+    base = small.data_ptr()
+    p = lambda i: C.c_void_p(base + 4 * o[i])
+    AtA = torch.empty((D, D), dtype=torch.float32, device="cuda")
+    Atb = torch.empty((D,), dtype=torch.float32, device="cuda")
+    err = C.c_float(); nin = C.c_float()
+    N = int(homo.shape[0])
+    _chk(lib().sage_geometric_jac_error_calculate(
+        ws.h, dptr(AtA), dptr(Atb), C.byref(err), C.byref(nin), p(0), p(1), p(2), p(3), p(4), p(5),
+        dptr(bias0), dptr(basis0), p(6), dptr(dpt1), dptr(dgrad1), dptr(basis1), dptr(mask1), dptr(loc1d_i32),
+        dptr(homo), C.c_float(scale0), C.c_float(scale1), C.byref(cam), C.c_float(eps), C.c_float(loss_param),
+        C.c_float(weight), N, CS), "sage_geometric_jac_error_calculate")
+    return dict(AtA=AtA.cpu().numpy(), Atb=Atb.cpu().numpy(), error=err.value, num_inliers=nin.value)
+
+
+def geometric_error(ws: Workspace, R10, t10, bias0, basis0, code0, dpt1, mask1, loc1d_i32, homo, scale0,
+                    cam: SageCamera, eps, loss_param, weight, CS):
+    import torch
+    small = torch.from_numpy(np.concatenate([_f32(x).reshape(-1) for x in (R10, t10, code0)])).cuda()
+    base = small.data_ptr()
+    err = C.c_float(); nin = C.c_float()
+    N = int(homo.shape[0])
+    _chk(lib().sage_geometric_error_calculate(
+        ws.h, C.byref(err), C.byref(nin), C.c_void_p(base), C.c_void_p(base + 36), dptr(bias0), dptr(basis0),
+        C.c_void_p(base + 48), dptr(dpt1), dptr(mask1), dptr(loc1d_i32), dptr(homo), C.c_float(scale0),
+        C.byref(cam), C.c_float(eps), C.c_float(loss_param), C.c_float(weight), N, CS),
+        "sage_geometric_error_calculate")
+    return err.value, nin.value
+
+
+def depth_and_grad(ws: Workspace, bias, basis, code, scale, H, W, CS):
+    import torch
+    dpt = torch.empty((H, W), dtype=torch.float32, device="cuda")
+    grad = torch.empty((2, H, W), dtype=torch.float32, device="cuda")
+    code_d = _dev(code, np.float32)
+    _chk(lib().sage_depth_and_grad(ws.h, dptr(dpt), dptr(grad), dptr(bias), dptr(basis), dptr(code_d),
+                                   C.c_float(scale), H, W, CS), "sage_depth_and_grad")
+    return dpt, grad
+
+
+def gaussian_pyramid_with_grad(ws: Workspace, feat, mask, pyr: SagePyramid, FS):
+    import torch
+    out = torch.empty((FS, pyr.P), dtype=torch.float32, device="cuda")
+    grad = torch.empty((2, FS, pyr.P), dtype=torch.float32, device="cuda")
+    _chk(lib().sage_gaussian_pyramid_with_grad(ws.h, dptr(out), dptr(grad), dptr(feat), dptr(mask), C.byref(pyr), FS),
+         "sage_gaussian_pyramid_with_grad")
+    return out, grad
+
+
+class Window:
+    """``SageWindow``: batched K-keyframe BA window on one GPU (one shard of the edge set)."""
+
+    def __init__(self, win, rank: int = 0, world: int = 1, stream=None, use_photo=True, use_geo=True,
+                 code_prior_weight=1.0e-3, scale_prior_weight=1.0e4, pose_prior_weight=1.0e4):
+        import torch
+        self.win = win
+        self.pyr = make_pyramid(win.cams[0], win.L)
+        assert self.pyr.P == win.P
+        self.mask = _dev(win.mask, np.float32)
+        self.kfs = [DeviceKeyframe(kf, win.H, win.W) for kf in win.keyframes]
+        cfg = SageWindowConfig()
+        cfg.pyr = self.pyr
+        cfg.FS, cfg.CS = win.FS, win.CS
+        cfg.mask_dev = self.mask.data_ptr()
+        for l in range(win.L):
+            cfg.photo_weights[l] = float(win.photo_weights[l])
+        cfg.geo_weight, cfg.geo_loss_param, cfg.eps = win.geo_weight, win.geo_loss_param, win.eps
+        cfg.code_prior_weight, cfg.scale_prior_weight, cfg.pose_prior_weight = (
+            code_prior_weight, scale_prior_weight, pose_prior_weight)
+        cfg.use_photo, cfg.use_geo = int(use_photo), int(use_geo)
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        sp = C.c_void_p(stream.cuda_stream) if stream is not None else C.c_void_p(0)
+        L = lib()
+        _chk(L.sage_window_create(C.byref(cfg), sp, C.byref(self.h)), "sage_window_create")
+        for kf, dk in zip(win.keyframes, self.kfs):
+            v = dk.view()
+            pose = pack_pose(kf.R, kf.t)
+            code = _f32(kf.code)
+            r = L.sage_window_add_keyframe(self.h, C.byref(v), _fp(pose), _fp(code), C.c_float(kf.scale))
+            if r < 0:
+                raise SageError(r, "sage_window_add_keyframe")
+        for a, b in win.links:
+            r = L.sage_window_add_link(self.h, a, b)
+            if r < 0:
+                raise SageError(r, "sage_window_add_link")
+        _chk(L.sage_window_set_shard(self.h, rank, world), "sage_window_set_shard")
+        _chk(L.sage_window_finalize(self.h), "sage_window_finalize")
+        self.K = L.sage_window_num_keyframes(self.h)
+        self.B = L.sage_window_block_size(self.h)
+        self.nlinks = L.sage_window_num_links(self.h)
+        self.packed_floats = L.sage_window_packed_floats(self.h)
+        self.residuals_per_linearize = L.sage_window_residuals_per_linearize(self.h)
+        self.bytes_per_linearize = L.sage_window_bytes_per_linearize(self.h)
+
+    # raw-pointer views for torch.distributed (plumbing only)
+    def packed_tensor(self):
+        return _tensor_from_ptr(lib().sage_window_packed_dev(self.h), self.packed_floats)
+
+    def error_tensor(self):
+        return _tensor_from_ptr(lib().sage_window_error_dev(self.h), 4)
+
+    def linearize(self):
+        _chk(lib().sage_window_linearize(self.h), "sage_window_linearize")
+
+    def error(self, which=1):
+        _chk(lib().sage_window_error(self.h, which), "sage_window_error")
+
+    def solve(self, damp):
+        sn = C.c_double()
+        _chk(lib().sage_window_solve(self.h, C.c_double(damp), C.byref(sn)), "sage_window_solve")
+        return sn.value
+
+    def total_error(self, from_linearize: bool):
+        e = C.c_double()
+        _chk(lib().sage_window_total_error(self.h, int(from_linearize), C.byref(e)), "sage_window_total_error")
+        return e.value
+
+    def accept(self):
+        _chk(lib().sage_window_accept(self.h), "sage_window_accept")
+
+    def lm_step(self, state: SageLmState, cfg: SageLmConfig):
+        _chk(lib().sage_window_lm_step(self.h, C.byref(state), C.byref(cfg)), "sage_window_lm_step")
+        return state
+
+    def delta(self):
+        d = np.zeros(self.K * self.B, np.float64)
+        _chk(lib().sage_window_get_delta(self.h, d.ctypes.data_as(C.POINTER(C.c_double))), "sage_window_get_delta")
+        return d
+
+    def get_keyframe(self, k):
+        pose = np.zeros(12, np.float32); code = np.zeros(self.win.CS, np.float32); s = C.c_float()
+        _chk(lib().sage_window_get_keyframe(self.h, k, _fp(pose), _fp(code), C.byref(s)), "sage_window_get_keyframe")
+        return pose, code, s.value
+
+    def set_keyframe(self, k, pose12, code, scale):
+        pose12 = _f32(pose12); code = _f32(code)
+        _chk(lib().sage_window_set_keyframe(self.h, k, _fp(pose12), _fp(code), C.c_float(scale)),
+             "sage_window_set_keyframe")
+
+    def get_edge(self, type_, e):
+        D = 13 + self.win.CS if type_ == 0 else 14 + 2 * self.win.CS
+        A = np.zeros((D, D), np.float32); b = np.zeros(D, np.float32)
+        err = C.c_float(); nin = C.c_float()
+        _chk(lib().sage_window_get_edge(self.h, type_, e, _fp(A), _fp(b), C.byref(err), C.byref(nin)),
+             "sage_window_get_edge")
+        return dict(AtA=A, Atb=b, error=err.value, num_inliers=nin.value)
+
+    def packed_host(self):
+        return self.packed_tensor().cpu().numpy()
+
+    def close(self):
+        if self.h:
+            lib().sage_window_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _tensor_from_ptr(ptr: int, n: int):
+    """wrap engine-owned device memory as a torch tensor (zero-copy) so torch.distributed can all-reduce it."""
+    import torch
+
+    class _Holder:
+        pass
+
+    h = _Holder()
+    h.__cuda_array_interface__ = dict(shape=(int(n),), typestr="<f4", data=(int(ptr), False), version=2)
+    return torch.as_tensor(h, device="cuda")
+
+
+# --------------------------------------------------------------------------- host-side window algebra
+# (pure numpy; used by the multi-process CPU tests of the sharded reduction and by parity tests)
+def shard_links(nlinks: int, rank: int, world: int) -> List[int]:
+    """link ownership rule of ``sage_window_set_shard``: link l belongs to rank l % world."""
+    return [l for l in range(nlinks) if l % world == rank]
+
+
+def edge_col(type_: int, role: int, bi: int, CS: int) -> int:
+    """B-index (pose 6, code CS, scale) -> column of the per-edge system (mirror of the assemble kernel)."""
+    if bi < 6:
+        return role * 6 + bi
+    if type_ == 0:
+        if role == 1:
+            return -1
+        return 12 + (bi - 6) if bi < 6 + CS else 12 + CS
+    if bi < 6 + CS:
+        return 12 + role * CS + (bi - 6)
+    return 12 + 2 * CS + role
+
+
+def assemble_packed(K: int, links: Sequence, CS: int, edge_results: dict) -> np.ndarray:
+    """Sum per-edge normal equations into the packed block layout.
+    ``edge_results[(type, link, dir)] = dict(AtA, Atb, error, num_inliers)`` for the edges present."""
+    B = 7 + CS
+    BB = B * B
+    diag = np.zeros((K, B, B), np.float64)
+    lnk = np.zeros((len(links), B, B), np.float64)
+    g = np.zeros((K, B), np.float64)
+    tail = np.zeros(4, np.float64)
+    cols = {(t, r): np.array([edge_col(t, r, bi, CS) for bi in range(B)]) for t in (0, 1) for r in (0, 1)}
+    for (t, l, d), res in edge_results.items():
+        a, b = links[l]
+        k0, k1 = (a, b) if d == 0 else (b, a)
+        A = np.asarray(res["AtA"], np.float64); v = np.asarray(res["Atb"], np.float64)
+        for kf, role in ((k0, 0), (k1, 1)):
+            c = cols[(t, role)]
+            m = c >= 0
+            diag[kf][np.ix_(m, m)] += A[np.ix_(c[m], c[m])]
+            g[kf][m] += v[c[m]]
+        # link block rows = older keyframe a, cols = newer keyframe b
+        ra, rb = (0, 1) if d == 0 else (1, 0)
+        ca, cb = cols[(t, ra)], cols[(t, rb)]
+        ma, mb = ca >= 0, cb >= 0
+        lnk[l][np.ix_(ma, mb)] += A[np.ix_(ca[ma], cb[mb])]
+        tail[t] += res["error"]
+        tail[2 + t] += res["num_inliers"]
+    return np.concatenate([diag.reshape(-1), lnk.reshape(-1), g.reshape(-1), tail])
+
+
+def unpack_dense(packed: np.ndarray, K: int, links: Sequence, CS: int):
+    """packed block layout -> dense (K*B x K*B) H, g, tail."""
+    B = 7 + CS
+    BB = B * B
+    n = K * B
+    H = np.zeros((n, n), np.float64)
+    diag = packed[:K * BB].reshape(K, B, B)
+    lnk = packed[K * BB:(K + len(links)) * BB].reshape(len(links), B, B)
+    g = packed[(K + len(links)) * BB:(K + len(links)) * BB + n].astype(np.float64)
+    for k in range(K):
+        H[k * B:(k + 1) * B, k * B:(k + 1) * B] = 0.5 * (diag[k] + diag[k].T)
+    for l, (a, b) in enumerate(links):
+        H[a * B:(a + 1) * B, b * B:(b + 1) * B] += lnk[l]
+        H[b * B:(b + 1) * B, a * B:(a + 1) * B] += lnk[l].T
+    return H, g, packed[-4:]

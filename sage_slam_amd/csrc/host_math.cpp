@@ -1,0 +1,619 @@
+// host_math.cpp -- pure-CPU host helpers of the C ABI (no device needed).
+//
+//   sage_camera_pyramid      common/camera_pyramid.h:18-32 + pinhole_camera_impl.h:120-132
+//   sage_se3_exp             core/mapping/mapping_utils.h:316-346
+//   sage_pose_retract        core/gtsam/gtsam_traits.h:45-70, core/system/camera_tracker.cpp:491-512
+//   sage_nearest_psd         the Higham algorithm core/mapping/mapping_utils.h:104-128 intends
+//   sage_damped_solve_qr_f32 core/system/camera_tracker.cpp:1182-1183 (colPivHouseholderQr in fp32)
+//   sage_track_lm            core/system/camera_tracker.cpp:1156-1279 (+ LMConvergence :527-573)
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "host_math.h"
+#include "sage_ba.h"
+
+extern "C" const char *sage_version(void) { return "sage-ba-mi355x 0.1 (gfx950)"; }
+
+extern "C" const char *sage_error_string(int code)
+{
+  switch (code)
+  {
+  case SAGE_OK:
+    return "ok";
+  case SAGE_E_INVALID:
+    return "invalid argument";
+  case SAGE_E_UNSUPPORTED:
+    return "unsupported CS/FS/levels combination";
+  case SAGE_E_NOT_PSD:
+    return "normal equations not positive definite";
+  case SAGE_E_STATE:
+    return "call order violated";
+  default:
+    return code > 0 ? "HIP runtime error (hipError_t)" : "unknown error";
+  }
+}
+
+extern "C" int sage_camera_pyramid(const SageCamera *base, int levels, SagePyramid *out)
+{
+  if (!base || !out || levels < 1 || levels > SAGE_MAX_LEVELS)
+    return SAGE_E_INVALID;
+  std::memset(out, 0, sizeof(*out));
+  out->levels = levels;
+  int off = 0;
+  for (int i = 0; i < levels; ++i)
+  {
+    SageCamera c = (i == 0) ? *base : out->cam[i - 1];
+    if (i != 0)
+    {
+      // new size = (size_t)(w/2), (size_t)(h/2); fx,u0 *= new_w/w ; fy,v0 *= new_h/h   (all fp32)
+      const size_t nw = (size_t)(c.w / 2), nh = (size_t)(c.h / 2);
+      const float xr = (float)nw / c.w, yr = (float)nh / c.h;
+      c.fx *= xr;
+      c.fy *= yr;
+      c.cx *= xr;
+      c.cy *= yr;
+      c.w = (float)nw;
+      c.h = (float)nh;
+    }
+    out->cam[i] = c;
+    out->level_offsets[i] = off;
+    off += (int)c.w * (int)c.h;
+  }
+  out->P = off;
+  return SAGE_OK;
+}
+
+extern "C" void sage_se3_exp(const float *omega, const float *v, float *R, float *t)
+{
+  float theta = std::sqrt(omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2]);
+  float n[3] = {1.f, 0.f, 0.f}; // "a casual rotation direction vector" when theta == 0
+  if (theta > 0)
+  {
+    n[0] = omega[0] / theta;
+    n[1] = omega[1] / theta;
+    n[2] = omega[2] / theta;
+  }
+  theta = std::max(theta, 1.0e-14f);
+  const float s = std::sin(theta), c = std::cos(theta);
+  const float K[3][3] = {{0, -n[2], n[1]}, {n[2], 0, -n[0]}, {-n[1], n[0], 0}};
+  float K2[3][3];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      K2[i][j] = K[i][0] * K[0][j] + K[i][1] * K[1][j] + K[i][2] * K[2][j];
+  const float a = (1.0f - c) / theta, b = (theta - s) / theta;
+  for (int i = 0; i < 3; ++i)
+  {
+    float acc = 0.f;
+    for (int j = 0; j < 3; ++j)
+    {
+      const float id = (i == j) ? 1.f : 0.f;
+      R[i * 3 + j] = id + s * K[i][j] + (1.0f - c) * K2[i][j];
+      acc += (id + a * K[i][j] + b * K2[i][j]) * v[j];
+    }
+    t[i] = acc;
+  }
+}
+
+extern "C" void sage_pose_retract(const float *pose, const float *d, float *out)
+{
+  float dR[9], dt[3];
+  sage_se3_exp(d + 3, d, dR, dt); // delta = [v, omega]
+  float R[9], t[3];
+  for (int i = 0; i < 3; ++i)
+  {
+    for (int j = 0; j < 3; ++j)
+      R[i * 3 + j] = dR[i * 3 + 0] * pose[0 * 3 + j] + dR[i * 3 + 1] * pose[1 * 3 + j] + dR[i * 3 + 2] * pose[2 * 3 + j];
+    t[i] = dR[i * 3 + 0] * pose[9] + dR[i * 3 + 1] * pose[10] + dR[i * 3 + 2] * pose[11] + dt[i];
+  }
+  std::memcpy(out, R, sizeof(R));
+  std::memcpy(out + 9, t, sizeof(t));
+}
+
+// ---------------------------------------------------------------- dense helpers (double)
+namespace sage
+{
+
+// cyclic Jacobi eigen-decomposition of a symmetric matrix: A = V diag(w) V^T (columns of V)
+void sym_eig(std::vector<double> &A, int n, std::vector<double> &w, std::vector<double> &V)
+{
+  V.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i)
+    V[(size_t)i * n + i] = 1.0;
+  for (int sweep = 0; sweep < 100; ++sweep)
+  {
+    double off = 0.0, diag = 0.0;
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j)
+        (i == j ? diag : off) += A[(size_t)i * n + j] * A[(size_t)i * n + j];
+    if (off <= 1e-30 * (diag + 1e-300))
+      break;
+    for (int p = 0; p < n - 1; ++p)
+      for (int q = p + 1; q < n; ++q)
+      {
+        const double apq = A[(size_t)p * n + q];
+        if (std::fabs(apq) < 1e-300)
+          continue;
+        const double app = A[(size_t)p * n + p], aqq = A[(size_t)q * n + q];
+        const double tau = (aqq - app) / (2.0 * apq);
+        const double t = (tau >= 0 ? 1.0 : -1.0) / (std::fabs(tau) + std::sqrt(1.0 + tau * tau));
+        const double c = 1.0 / std::sqrt(1.0 + t * t), s = t * c;
+        for (int k = 0; k < n; ++k)
+        {
+          const double akp = A[(size_t)k * n + p], akq = A[(size_t)k * n + q];
+          A[(size_t)k * n + p] = c * akp - s * akq;
+          A[(size_t)k * n + q] = s * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k)
+        {
+          const double apk = A[(size_t)p * n + k], aqk = A[(size_t)q * n + k];
+          A[(size_t)p * n + k] = c * apk - s * aqk;
+          A[(size_t)q * n + k] = s * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k)
+        {
+          const double vkp = V[(size_t)k * n + p], vkq = V[(size_t)k * n + q];
+          V[(size_t)k * n + p] = c * vkp - s * vkq;
+          V[(size_t)k * n + q] = s * vkp + c * vkq;
+        }
+      }
+  }
+  w.resize(n);
+  for (int i = 0; i < n; ++i)
+    w[i] = A[(size_t)i * n + i];
+}
+
+// LDLT-style positive (semi-)definiteness test (Eigen::LDLT::isPositive): all pivots >= 0.
+static bool is_psd(const std::vector<double> &M, int n)
+{
+  std::vector<double> L(M);
+  for (int j = 0; j < n; ++j)
+  {
+    double d = L[(size_t)j * n + j];
+    for (int k = 0; k < j; ++k)
+      d -= L[(size_t)j * n + k] * L[(size_t)j * n + k] * L[(size_t)k * n + k];
+    if (d < 0.0)
+      return false;
+    L[(size_t)j * n + j] = d;
+    for (int i = j + 1; i < n; ++i)
+    {
+      double s = L[(size_t)i * n + j];
+      for (int k = 0; k < j; ++k)
+        s -= L[(size_t)i * n + k] * L[(size_t)j * n + k] * L[(size_t)k * n + k];
+      L[(size_t)i * n + j] = (d != 0.0) ? s / d : 0.0;
+    }
+  }
+  return true;
+}
+
+} // namespace sage
+
+extern "C" int sage_nearest_psd(const double *M, int n, double *out)
+{
+  if (!M || !out || n < 1)
+    return SAGE_E_INVALID;
+  // B = (M + M^T)/2 ; H = polar factor of B = V |Lambda| V^T ; A2 = (B+H)/2 ; A3 = sym(A2)
+  std::vector<double> B((size_t)n * n), w, V;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      B[(size_t)i * n + j] = 0.5 * (M[(size_t)i * n + j] + M[(size_t)j * n + i]);
+  std::vector<double> tmp(B);
+  sage::sym_eig(tmp, n, w, V);
+  std::vector<double> A3((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+    {
+      double h = 0.0;
+      for (int k = 0; k < n; ++k)
+        h += V[(size_t)i * n + k] * std::fabs(w[k]) * V[(size_t)j * n + k];
+      A3[(size_t)i * n + j] = 0.5 * (B[(size_t)i * n + j] + h);
+    }
+  for (int i = 0; i < n; ++i)
+    for (int j = i + 1; j < n; ++j)
+    {
+      const double s = 0.5 * (A3[(size_t)i * n + j] + A3[(size_t)j * n + i]);
+      A3[(size_t)i * n + j] = A3[(size_t)j * n + i] = s;
+    }
+  // bump by (-min_eig*k + spacing) until LDLT-positive (mapping_utils.h:119-126)
+  int k = 1;
+  const double spacing = 1e-15;
+  for (int it = 0; it < 60 && !sage::is_psd(A3, n); ++it)
+  {
+    std::vector<double> t2(A3), w2, V2;
+    sage::sym_eig(t2, n, w2, V2);
+    const double mn = *std::min_element(w2.begin(), w2.end());
+    for (int i = 0; i < n; ++i)
+      A3[(size_t)i * n + i] += -mn * k + spacing;
+    k *= 2;
+  }
+  std::memcpy(out, A3.data(), sizeof(double) * n * n);
+  return SAGE_OK;
+}
+
+extern "C" int sage_damped_solve_qr_f32(const float *A, const float *b, int n, float damp, float *x)
+{
+  if (!A || !b || !x || n < 1 || n > 64)
+    return SAGE_E_INVALID;
+  // M = A + damp*diag(A); column-pivoted Householder QR, all in fp32
+  std::vector<float> M((size_t)n * n), rhs(b, b + n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      M[(size_t)i * n + j] = A[(size_t)i * n + j] + (i == j ? damp * A[(size_t)i * n + i] : 0.f);
+  std::vector<int> perm(n);
+  for (int i = 0; i < n; ++i)
+    perm[i] = i;
+  for (int k = 0; k < n; ++k)
+  {
+    int best = k;
+    float bn = -1.f;
+    for (int j = k; j < n; ++j)
+    {
+      float s = 0.f;
+      for (int i = k; i < n; ++i)
+        s += M[(size_t)i * n + j] * M[(size_t)i * n + j];
+      if (s > bn)
+      {
+        bn = s;
+        best = j;
+      }
+    }
+    if (best != k)
+    {
+      for (int i = 0; i < n; ++i)
+        std::swap(M[(size_t)i * n + k], M[(size_t)i * n + best]);
+      std::swap(perm[k], perm[best]);
+    }
+    float norm = std::sqrt(bn);
+    if (norm == 0.f)
+      continue;
+    const float akk = M[(size_t)k * n + k];
+    const float alpha = akk > 0 ? -norm : norm;
+    std::vector<float> v(n, 0.f);
+    v[k] = akk - alpha;
+    for (int i = k + 1; i < n; ++i)
+      v[i] = M[(size_t)i * n + k];
+    float vv = 0.f;
+    for (int i = k; i < n; ++i)
+      vv += v[i] * v[i];
+    if (vv == 0.f)
+      continue;
+    for (int j = k; j < n; ++j)
+    {
+      float s = 0.f;
+      for (int i = k; i < n; ++i)
+        s += v[i] * M[(size_t)i * n + j];
+      s = 2.f * s / vv;
+      for (int i = k; i < n; ++i)
+        M[(size_t)i * n + j] -= s * v[i];
+    }
+    float s = 0.f;
+    for (int i = k; i < n; ++i)
+      s += v[i] * rhs[i];
+    s = 2.f * s / vv;
+    for (int i = k; i < n; ++i)
+      rhs[i] -= s * v[i];
+  }
+  std::vector<float> y(n, 0.f);
+  for (int i = n - 1; i >= 0; --i)
+  {
+    float s = rhs[i];
+    for (int j = i + 1; j < n; ++j)
+      s -= M[(size_t)i * n + j] * y[j];
+    const float d = M[(size_t)i * n + i];
+    y[i] = (d != 0.f) ? s / d : 0.f; // rank-deficient column -> minimum-norm-like zero (Eigen zeroes it)
+  }
+  for (int i = 0; i < n; ++i)
+    x[perm[i]] = y[i];
+  return SAGE_OK;
+}
+
+// ---------------------------------------------------------------- tracker LM policy
+extern "C" void sage_lm_config_default(SageLmConfig *c)
+{
+  // system/configs/slam_run.flags:17-23
+  c->max_num_iters = 40;
+  c->min_grad_thresh = 1.0e-4f;
+  c->min_param_inc_thresh = 1.0e-2f;
+  c->init_damp = 1.0e-4f;
+  c->min_damp = 1.0e-6f;
+  c->max_damp = 1.0e-2f;
+  c->damp_dec_factor = 10.f;
+  c->damp_inc_factor = 100.f;
+  c->jac_update_err_inc_threshold = 1.0e-2f;
+  c->max_inner_evals = 0;
+}
+
+namespace sage
+{
+
+// RotationToAngleAxis(R, 1e-6) as written in core/mapping/mapping_utils.h:143-212, including its quirks:
+// the returned vector uses the HALF angle atan2(sin, cos) (the "2.0 *" of the torchgeometry original is
+// missing) and case c0 divides by sqrt(0).  Only used by the convergence test.
+void rotation_to_angle_axis_as_reference(const float *R, float eps, float *out)
+{
+  // rmat_t = R^T
+  auto rt = [&](int i, int j) { return R[j * 3 + i]; };
+  const bool d2 = rt(2, 2) < eps;
+  const bool d0_d1 = rt(0, 0) > rt(1, 1);
+  const bool d0_nd1 = rt(0, 0) < -rt(1, 1);
+  const float t0 = 1.0f + rt(0, 0) - rt(1, 1) - rt(2, 2);
+  const float t1 = 1.0f - rt(0, 0) + rt(1, 1) - rt(2, 2);
+  const float t2 = 1.0f - rt(0, 0) - rt(1, 1) + rt(2, 2);
+  const float t3 = 1.0f + rt(0, 0) + rt(1, 1) + rt(2, 2);
+  float q[4], den;
+  if (d2 && d0_d1)
+  {
+    q[0] = rt(1, 2) - rt(2, 1); q[1] = t0; q[2] = rt(0, 1) + rt(1, 0); q[3] = rt(2, 0) + rt(0, 2);
+    den = 0.f; // t0*mask_c1 (sic) -> 0 in case c0
+  }
+  else if (d2)
+  {
+    q[0] = rt(2, 0) - rt(0, 2); q[1] = rt(0, 1) + rt(1, 0); q[2] = t1; q[3] = rt(1, 2) + rt(2, 1);
+    den = t0 + t1; // t0*mask_c1 + t1*mask_c1 (sic)
+  }
+  else if (d0_nd1)
+  {
+    q[0] = rt(0, 1) - rt(1, 0); q[1] = rt(2, 0) + rt(0, 2); q[2] = rt(1, 2) + rt(2, 1); q[3] = t2;
+    den = t2;
+  }
+  else
+  {
+    q[0] = t3; q[1] = rt(1, 2) - rt(2, 1); q[2] = rt(2, 0) - rt(0, 2); q[3] = rt(0, 1) - rt(1, 0);
+    den = t3;
+  }
+  const float sq = std::sqrt(den);
+  for (int i = 0; i < 4; ++i)
+    q[i] = 0.5f * q[i] / sq;
+  const float ss = q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  const float sn = std::sqrt(ss), cs = q[0];
+  const float two_theta = cs < 0.0f ? std::atan2(-sn, -cs) : std::atan2(sn, cs);
+  const float k = ss > 0.0f ? two_theta / sn : 2.0f;
+  out[0] = k * q[1];
+  out[1] = k * q[2];
+  out[2] = k * q[3];
+}
+
+static bool lm_converged(const SageLmConfig &cfg, int dof, const float *pose, float scale, const float *Atb,
+                         const float *sol)
+{
+  float rv[3];
+  rotation_to_angle_axis_as_reference(pose, 1.0e-6f, rv);
+  float max_grad = 0.f;
+  for (int i = 0; i < dof; ++i)
+    max_grad = std::max(max_grad, std::fabs(Atb[i]));
+  // max( solution / (|[t, rotvec, scale]| + 1e-8) ) -- signed numerator, as written (:531-536)
+  const float den[7] = {std::fabs(pose[9]), std::fabs(pose[10]), std::fabs(pose[11]),
+                        std::fabs(rv[0]), std::fabs(rv[1]), std::fabs(rv[2]), std::fabs(scale)};
+  float max_inc = -INFINITY;
+  bool nan = false;
+  for (int i = 0; i < dof; ++i)
+  {
+    const float r = sol[i] / (den[i] + 1.0e-8f);
+    if (r != r)
+      nan = true;
+    max_inc = std::max(max_inc, r);
+  }
+  if (nan)
+    max_inc = NAN;
+  return max_grad < cfg.min_grad_thresh || max_inc < cfg.min_param_inc_thresh;
+}
+
+} // namespace sage
+
+extern "C" int sage_track_lm(const SageLmConfig *cfgp, int dof, SageTrackLinearizeFn lin, SageTrackErrorFn errf,
+                             void *ctx, float *pose12, float *scale, float *final_error, int *iters,
+                             SageLmTraceEntry *trace, int trace_cap, int *trace_len)
+{
+  if (!cfgp || !lin || !errf || !pose12 || (dof != 6 && dof != 7) || (dof == 7 && !scale))
+    return SAGE_E_INVALID;
+  const SageLmConfig cfg = *cfgp;
+  float AtA[49], Atb[7], sol[7] = {0, 0, 0, 0, 0, 0, 0};
+  float guess[12], cand[12];
+  std::memcpy(guess, pose12, sizeof(guess));
+  float guess_scale = scale ? *scale : 1.0f, cand_scale = guess_scale;
+  bool update_jac = true;
+  float prev_error = 0.f, curr_error = 1.f, cand_error = 0.f;
+  long curr_iter = 0;
+  float damp = cfg.init_damp;
+  int ntrace = 0;
+  auto clampd = [&](float d) { return std::min(std::max(cfg.min_damp, d), cfg.max_damp); };
+  int rc = 0;
+  while (true)
+  {
+    // skip the Jacobian when the last step changed the error too little (:1159)
+    if (std::fabs(curr_error - prev_error) / prev_error > cfg.jac_update_err_inc_threshold)
+    {
+      if ((rc = lin(ctx, guess, guess_scale, AtA, Atb, &curr_error)) != 0)
+        return rc;
+      update_jac = true;
+    }
+    else
+      update_jac = false;
+    curr_iter += 1;
+    if ((rc = sage_damped_solve_qr_f32(AtA, Atb, dof, damp, sol)) != 0)
+      return rc;
+    if (sage::lm_converged(cfg, dof, guess, guess_scale, Atb, sol))
+      break;
+    bool accepted = false;
+    while (true)
+    {
+      sage_pose_retract(guess, sol, cand); // UpdateVariables (:467-512)
+      cand_scale = dof == 7 ? guess_scale + sol[6] : guess_scale;
+      if ((rc = errf(ctx, cand, cand_scale, &cand_error)) != 0)
+        return rc;
+      if (cand_error < curr_error)
+      {
+        accepted = true;
+        break;
+      }
+      else if (damp < cfg.max_damp)
+      {
+        damp = clampd(damp * cfg.damp_inc_factor);
+        if ((rc = sage_damped_solve_qr_f32(AtA, Atb, dof, damp, sol)) != 0)
+          return rc;
+      }
+      else
+        break;
+    }
+    if (trace && ntrace < trace_cap)
+      trace[ntrace++] = SageLmTraceEntry{damp, curr_error, cand_error, accepted ? 1 : 0, update_jac ? 1 : 0};
+    if (cand_error >= curr_error && damp >= cfg.max_damp)
+      break;
+    std::memcpy(guess, cand, sizeof(guess));
+    guess_scale = cand_scale;
+    if (update_jac)
+      prev_error = curr_error;
+    curr_error = cand_error;
+    damp = clampd(damp / cfg.damp_dec_factor);
+    if (curr_iter >= cfg.max_num_iters)
+      break;
+  }
+  std::memcpy(pose12, guess, sizeof(guess));
+  if (scale)
+    *scale = guess_scale;
+  if (final_error)
+    *final_error = curr_error;
+  if (iters)
+    *iters = (int)curr_iter;
+  if (trace_len)
+    *trace_len = ntrace;
+  return SAGE_OK;
+}
+
+// ---------------------------------------------------------------- envelope Cholesky (window solve)
+namespace sage
+{
+
+void EnvelopeMatrix::init(int n_, const std::vector<int> &first_)
+{
+  n = n_;
+  first = first_;
+  rowptr.resize(n + 1);
+  size_t off = 0;
+  for (int r = 0; r < n; ++r)
+  {
+    rowptr[r] = off;
+    off += (size_t)(r - first[r] + 1);
+  }
+  rowptr[n] = off;
+  data.assign(off, 0.0);
+}
+
+bool EnvelopeMatrix::cholesky_inplace()
+{
+  for (int r = 0; r < n; ++r)
+  {
+    double *Lr = &data[rowptr[r]];
+    const int fr = first[r];
+    for (int c = fr; c <= r; ++c)
+    {
+      const double *Lc = &data[rowptr[c]];
+      const int fc = first[c];
+      const int k0 = fr > fc ? fr : fc;
+      double s = Lr[c - fr];
+      const double *a = Lr + (k0 - fr), *b = Lc + (k0 - fc);
+      const int len = c - k0;
+      double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+      int k = 0;
+      for (; k + 4 <= len; k += 4)
+      {
+        acc0 += a[k] * b[k];
+        acc1 += a[k + 1] * b[k + 1];
+        acc2 += a[k + 2] * b[k + 2];
+        acc3 += a[k + 3] * b[k + 3];
+      }
+      for (; k < len; ++k)
+        acc0 += a[k] * b[k];
+      s -= (acc0 + acc1) + (acc2 + acc3);
+      if (c < r)
+        Lr[c - fr] = s / Lc[c - fc];
+      else
+      {
+        if (!(s > 0.0))
+          return false;
+        Lr[c - fr] = std::sqrt(s);
+      }
+    }
+  }
+  return true;
+}
+
+void EnvelopeMatrix::solve_inplace(std::vector<double> &b) const
+{
+  // L y = b
+  for (int r = 0; r < n; ++r)
+  {
+    const double *Lr = &data[rowptr[r]];
+    const int fr = first[r];
+    double s = b[r];
+    for (int c = fr; c < r; ++c)
+      s -= Lr[c - fr] * b[c];
+    b[r] = s / Lr[r - fr];
+  }
+  // L^T x = y
+  for (int r = n - 1; r >= 0; --r)
+  {
+    const double *Lr = &data[rowptr[r]];
+    const int fr = first[r];
+    const double x = b[r] / Lr[r - fr];
+    b[r] = x;
+    for (int c = fr; c < r; ++c)
+      b[c] -= Lr[c - fr] * x;
+  }
+}
+
+} // namespace sage
+
+extern "C" int sage_block_solve(const float *packed, int K, int nlinks, const int32_t *links, int B, double damp,
+                                const double *diag_add, const double *g_add, double *delta)
+{
+  if (!packed || K < 1 || B < 1 || nlinks < 0 || (nlinks > 0 && !links) || !delta)
+    return SAGE_E_INVALID;
+  const int BB = B * B, n = K * B;
+  const float *diag = packed;
+  const float *lnk = diag + (size_t)K * BB;
+  const float *g = lnk + (size_t)nlinks * BB;
+  // envelope: first non-zero block column of each block row
+  std::vector<int> first_blk(K);
+  for (int k = 0; k < K; ++k)
+    first_blk[k] = k;
+  for (int l = 0; l < nlinks; ++l)
+  {
+    const int a = links[2 * l], b = links[2 * l + 1];
+    if (a < 0 || b <= a || b >= K)
+      return SAGE_E_INVALID;
+    first_blk[b] = std::min(first_blk[b], a);
+  }
+  std::vector<int> first(n);
+  for (int k = 0; k < K; ++k)
+    for (int i = 0; i < B; ++i)
+      first[k * B + i] = first_blk[k] * B;
+  sage::EnvelopeMatrix M;
+  M.init(n, first);
+  std::vector<double> rhs(n);
+  for (int k = 0; k < K; ++k)
+    for (int i = 0; i < B; ++i)
+    {
+      for (int j = 0; j <= i; ++j)
+        M.at(k * B + i, k * B + j) =
+            0.5 * ((double)diag[(size_t)k * BB + i * B + j] + (double)diag[(size_t)k * BB + j * B + i]);
+      rhs[k * B + i] = (double)g[(size_t)k * B + i] + (g_add ? g_add[k * B + i] : 0.0);
+      if (diag_add)
+        M.at(k * B + i, k * B + i) += diag_add[k * B + i];
+    }
+  for (int l = 0; l < nlinks; ++l)
+  {
+    const int a = links[2 * l], b = links[2 * l + 1]; // block (a,b) -> lower-triangle rows of b
+    for (int i = 0; i < B; ++i)
+      for (int j = 0; j < B; ++j)
+        M.at(b * B + j, a * B + i) += (double)lnk[(size_t)l * BB + i * B + j];
+  }
+  for (int r = 0; r < n; ++r) // LM damping H + damp*diag(H) (camera_tracker.cpp:1182)
+    M.at(r, r) *= (1.0 + damp);
+  if (!M.cholesky_inplace())
+    return SAGE_E_NOT_PSD;
+  M.solve_inplace(rhs);
+  std::memcpy(delta, rhs.data(), sizeof(double) * n);
+  return SAGE_OK;
+}

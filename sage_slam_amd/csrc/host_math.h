@@ -1,0 +1,23 @@
+// host_math.h -- internal host-side dense helpers (double precision).
+#pragma once
+#include <vector>
+
+namespace sage
+{
+void sym_eig(std::vector<double> &A, int n, std::vector<double> &w, std::vector<double> &V);
+void rotation_to_angle_axis_as_reference(const float *R, float eps, float *out);
+
+// Envelope (skyline) Cholesky of a symmetric positive definite matrix given by its lower triangle:
+// row r stores columns first[r]..r contiguously at data[rowptr[r]...].
+struct EnvelopeMatrix
+{
+  int n = 0;
+  std::vector<int> first;      // first stored column of each row
+  std::vector<size_t> rowptr;  // offset of column first[r] in data
+  std::vector<double> data;
+  void init(int n_, const std::vector<int> &first_);
+  inline double &at(int r, int c) { return data[rowptr[r] + (size_t)(c - first[r])]; } // first[r] <= c <= r
+  bool cholesky_inplace();                       // returns false if not positive definite
+  void solve_inplace(std::vector<double> &b) const; // after cholesky_inplace: b <- A^-1 b
+};
+} // namespace sage

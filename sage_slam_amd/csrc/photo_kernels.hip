@@ -1,0 +1,603 @@
+// photo_kernels.hip -- fused feature-metric (photometric) linearize / error kernels for gfx950.
+//
+// Replaces cuda/photometric_factor_kernels.cpp:33-368 (+ host reduction :1061-1164) and :370-522
+// (+ :990-1059) of the reference.  The reference writes every residual's Jacobian row to global memory
+// ([L,N,FS,13+CS], 236 MB per dense 128x160 edge) and reduces it with two GEMMs; here nothing per-residual
+// ever leaves the CU:
+//
+//   per source pixel n (one lane):   G = sum_l w_l sum_c h h^T (2x2),  v = sum_l w_l sum_c h r,  e
+//        with h = (fx_l gx, fy_l gy) the level-scaled sampled gradient, r = m (f0 - f1)
+//   J_c = h^T P_unit,  P_unit = Q M_n,  Q = [A | q] (2x7): A = Jpi_unit R1^T [I | -[Xw]x],  q = dpi/dd
+//        M_n = [[I6, -I6, 0, 0], [0, 0, s0 b_n^T, d_n/s0]]            (P_pose1 = -P_pose0)
+//   => per pixel S = Q^T G Q (7x7), u = Q^T v (7); 37 scalars are summed with wave64 DPP reductions,
+//      the code blocks  sum_n S66 b_n b_n^T  and  sum_n [S(0:6,6); S66 d; u6] b_n^T  are f32 MFMA
+//      (v_mfma_f32_16x16x4_f32, K = 4 pixels) contractions fed from the LDS basis tile.
+//
+// Algorithmic bytes per source pixel: 4*[4*FS*rho + CS + 6].
+#include "sage_device.h"
+#include "sage_internal.h"
+
+namespace sage
+{
+
+struct PhotoParams
+{
+  PhotoEdge single;
+  const PhotoEdge *table;
+  const WorkItem *work;
+  float *partials;
+  SagePyramid pyr;
+  float w[SAGE_MAX_LEVELS];
+  float eps;
+  int tiles_per_block; // consecutive kTile-pixel sub-tiles one workgroup accumulates before writing its partial
+};
+
+__device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
+{
+  return is64 ? (int)reinterpret_cast<const long long *>(loc)[n] : reinterpret_cast<const int *>(loc)[n];
+}
+
+__device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i <= j < 6
+{
+  return i * 6 - (i * (i - 1)) / 2 + (j - i);
+}
+
+template <int CS, int FS, bool JAC>
+__global__ __launch_bounds__(kBlock) void photo_kernel(const PhotoParams prm)
+{
+  constexpr int LD = CS + 1;
+  constexpr int NT = photo_tiles(CS);
+  __shared__ float s_basis[kTile * LD];
+  __shared__ int s_loc[kTile];
+  __shared__ float s_stash[JAC ? kTile * 9 : 1];
+  __shared__ float s_red[kWaves * kPhotoScalars];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const WorkItem wi = prm.work[blockIdx.x];
+  const PhotoEdge &E = prm.table ? prm.table[wi.edge] : prm.single;
+  const int N = E.N;
+  const float scale0 = E.scale0 ? *E.scale0 : E.scale0_val;
+
+  // ---- poses (wave-uniform) ----
+  const Pose p0 = JAC ? load_pose2(E.R0, E.t0) : Pose{};
+  const Pose p1 = JAC ? load_pose2(E.R1, E.t1) : Pose{};
+  Pose p10;
+  if (E.R10)
+    p10 = load_pose2(E.R10, E.t10);
+  else
+    p10 = relative_pose(load_pose2(E.R0, E.t0), load_pose2(E.R1, E.t1));
+
+  const SagePyramid &pyr = prm.pyr;
+  const float fx0 = pyr.cam[0].fx, fy0 = pyr.cam[0].fy, cx0 = pyr.cam[0].cx, cy0 = pyr.cam[0].cy;
+  const int W0 = (int)pyr.cam[0].w, H0 = (int)pyr.cam[0].h;
+  const uint32_t pyr_bytes = (uint32_t)FS * (uint32_t)pyr.P * 4u;
+  const __amdgpu_buffer_rsrc_t r_f0 = make_rsrc(E.feat0, pyr_bytes);
+  const __amdgpu_buffer_rsrc_t r_f1 = make_rsrc(E.feat1, pyr_bytes);
+  const __amdgpu_buffer_rsrc_t r_g1 = make_rsrc(JAC ? E.grad1 : E.feat1, JAC ? 2u * pyr_bytes : pyr_bytes);
+  const uint32_t plane = (uint32_t)pyr.P * 4u;
+
+  for (int k = tid; k < kWaves * kPhotoScalars; k += kBlock)
+    s_red[k] = 0.f;
+  f32x4 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+    acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float err_acc = 0.f, vm_acc = 0.f; // error-only path: lane-local sums over the sub-tiles
+
+  for (int sub = 0; sub < prm.tiles_per_block; ++sub)
+  {
+  const int tile = wi.tile + sub;
+  if (tile * kTile >= N)
+    break;
+  const int n = tile * kTile + tid;
+  const bool in_range = n < N;
+  const int tile_rows = min(kTile, N - tile * kTile);
+  const int my_loc = in_range ? load_loc(E.loc, E.loc_is_i64, n) : 0;
+  const float d = stage_basis_and_depth<CS>(s_basis, s_loc, E.basis0, E.bias0, E.code0, scale0, my_loc, in_range,
+                                            tile_rows);
+
+  float hm[3] = {0.f, 0.f, 1.f};
+  if (in_range)
+  {
+    hm[0] = E.homo[3 * n + 0];
+    hm[1] = E.homo[3 * n + 1];
+    hm[2] = E.homo[3 * n + 2];
+  }
+  float rh[3], X[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+  {
+    rh[i] = p10.R[i * 3 + 0] * hm[0] + p10.R[i * 3 + 1] * hm[1] + p10.R[i * 3 + 2] * hm[2];
+    X[i] = d * rh[i] + p10.t[i];
+  }
+  const bool pos = X[2] > prm.eps; // photometric_factor_kernels.cpp:96
+  const float inv_z = 1.0f / X[2];
+  const float p = X[0] * inv_z * fx0 + cx0; // :142-144 (level-0 pixel coordinates)
+  const float q = X[1] * inv_z * fy0 + cy0;
+  const float m = mask_lookup(E.mask1, p, q, W0, H0);
+  const float vm = (pos && in_range) ? m : 0.0f; // sampled_valid_mask_1 (:237)
+
+  // source coordinates at level 0 (+0.5): from homo in the Jacobian kernel (:101-103), from loc1d in the
+  // error-only kernel (:423-424, :1012-1014)
+  float su, sv;
+  if (JAC)
+  {
+    su = hm[0] * fx0 + cx0 + 0.5f;
+    sv = hm[1] * fy0 + cy0 + 0.5f;
+  }
+  else
+  {
+    su = (float)(my_loc % W0) + 0.5f;
+    sv = (float)(my_loc / W0) + 0.5f;
+  }
+
+  float G00 = 0.f, G01 = 0.f, G11 = 0.f, v0 = 0.f, v1 = 0.f, err = 0.f;
+  for (int l = 0; l < pyr.levels; ++l)
+  {
+    const float fxl = pyr.cam[l].fx, fyl = pyr.cam[l].fy;
+    const int Wl = (int)pyr.cam[l].w, Hl = (int)pyr.cam[l].h;
+    const float rx = fxl / fx0, ry = fyl / fy0;
+    Taps ts, td;
+    make_taps(ts, su * rx - 0.5f, sv * ry - 0.5f, Wl, Hl);
+    make_taps(td, (p + 0.5f) * rx - 0.5f, (q + 0.5f) * ry - 0.5f, Wl, Hl);
+    const uint32_t lo = (uint32_t)pyr.level_offsets[l];
+    uint32_t so[4], dof[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+    {
+      so[k] = (lo + (uint32_t)ts.off[k]) * 4u;
+      dof[k] = (lo + (uint32_t)td.off[k]) * 4u;
+    }
+    float g00 = 0.f, g01 = 0.f, g11 = 0.f, a0 = 0.f, a1 = 0.f, ee = 0.f;
+#pragma unroll 4
+    for (int c = 0; c < FS; ++c)
+    {
+      const uint32_t soff = (uint32_t)c * plane;
+      float f0 = 0.f, f1 = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+      {
+        f0 += ts.w[k] * buf_load(r_f0, so[k], soff);
+        f1 += td.w[k] * buf_load(r_f1, dof[k], soff);
+      }
+      const float diff = f0 - f1;
+      ee += diff * diff;
+      if (JAC)
+      {
+        const uint32_t soff_y = (uint32_t)(FS + c) * plane;
+        float gx = 0.f, gy = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+          gx += td.w[k] * buf_load(r_g1, dof[k], soff);
+          gy += td.w[k] * buf_load(r_g1, dof[k], soff_y);
+        }
+        const float hx = fxl * gx, hy = fyl * gy;
+        g00 += hx * hx;
+        g01 += hx * hy;
+        g11 += hy * hy;
+        a0 += hx * diff;
+        a1 += hy * diff;
+      }
+    }
+    const float wl = prm.w[l];
+    err += wl * ee;
+    if (JAC)
+    {
+      G00 += wl * g00;
+      G01 += wl * g01;
+      G11 += wl * g11;
+      v0 += wl * a0;
+      v1 += wl * a1;
+    }
+  }
+  err *= vm; // within_mask * pow(diff,2)  (:228)
+
+  if (!JAC)
+  {
+    err_acc += err;
+    vm_acc += vm;
+    __syncthreads(); // s_basis / s_loc are restaged by the next sub-tile
+    continue;
+  }
+
+  // ---- per-pixel 7x7 reduced system ----
+  const bool live = vm != 0.0f;
+  const float vm2 = vm * vm; // gradient and residual both carry m (:200, :234)
+  G00 *= vm2;
+  G01 *= vm2;
+  G11 *= vm2;
+  v0 *= vm2;
+  v1 *= vm2;
+  float Q[2][7];
+  {
+    float Xw[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      Xw[i] = d * (p0.R[i * 3 + 0] * hm[0] + p0.R[i * 3 + 1] * hm[1] + p0.R[i * 3 + 2] * hm[2]) + p0.t[i];
+    float dX[3][6];
+    dX_dT0(p1, Xw, dX);
+    const float jx = -X[0] * inv_z * inv_z, jy = -X[1] * inv_z * inv_z;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+    {
+      Q[0][j] = inv_z * dX[0][j] + jx * dX[2][j];
+      Q[1][j] = inv_z * dX[1][j] + jy * dX[2][j];
+    }
+    Q[0][6] = rh[0] * inv_z - X[0] * rh[2] * inv_z * inv_z; // :324-325 without fx, fy
+    Q[1][6] = rh[1] * inv_z - X[1] * rh[2] * inv_z * inv_z;
+  }
+  float sc[kPhotoScalars];
+  float S6[7], u6;
+  {
+    float GQ0[7], GQ1[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+    {
+      GQ0[j] = G00 * Q[0][j] + G01 * Q[1][j];
+      GQ1[j] = G01 * Q[0][j] + G11 * Q[1][j];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+      for (int j = i; j < 6; ++j)
+        sc[sidx6(i, j)] = live ? Q[0][i] * GQ0[j] + Q[1][i] * GQ1[j] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 7; ++i)
+      S6[i] = live ? Q[0][i] * GQ0[6] + Q[1][i] * GQ1[6] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+    {
+      sc[21 + j] = S6[j] * d;
+      sc[28 + j] = live ? Q[0][j] * v0 + Q[1][j] * v1 : 0.f;
+    }
+    u6 = live ? Q[0][6] * v0 + Q[1][6] * v1 : 0.f;
+    sc[27] = S6[6] * d * d;
+    sc[34] = u6 * d;
+    sc[35] = err;
+    sc[36] = vm;
+  }
+  // stash the rows that multiply b_n: c (6), sigma*d, u6, and sigma itself
+  {
+    float *st = s_stash + tid * 9;
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+      st[j] = S6[j];
+    st[6] = S6[6] * d;
+    st[7] = u6;
+    st[8] = S6[6];
+  }
+#pragma unroll
+  for (int k = 0; k < 37; ++k)
+  {
+    const float s = wave_sum(sc[k]);
+    if (lane == 63)
+      s_red[wave * kPhotoScalars + k] += s; // only this lane ever touches this slot
+  }
+  __syncthreads(); // stash visible to the wave's other lanes
+
+  // ---- MFMA contractions over this wave's 64 pixels, 4 pixels (K) per instruction ----
+  {
+    const int i = lane & 15, k = lane >> 4;
+#pragma unroll 4
+    for (int g = 0; g < 16; ++g)
+    {
+      const int px = wave * 64 + g * 4 + k;
+      const float *br = s_basis + px * LD;
+      const float *st = s_stash + px * 9;
+      const float sg = st[8];
+      const float ai = (i < 8) ? st[i & 7] : 0.f;
+      const float bl = br[i];
+      if (CS == 32)
+      {
+        const float bh = br[16 + i];
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg * bl, bl, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg * bl, bh, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg * bh, bh, acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, bl, acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, bh, acc[4], 0, 0, 0);
+      }
+      else
+      {
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg * bl, bl, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, bl, acc[1], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads(); // everyone is done reading s_basis / s_stash before they are restaged or reused
+  } // sub-tile loop
+
+  if (!JAC)
+  {
+    const float se = wave_sum(err_acc), sn = wave_sum(vm_acc);
+    if (lane == 63)
+    {
+      s_red[wave * 2 + 0] = se;
+      s_red[wave * 2 + 1] = sn;
+    }
+    __syncthreads();
+    if (tid < 2)
+    {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w)
+        a += s_red[w * 2 + tid];
+      prm.partials[(size_t)blockIdx.x * 2 + tid] = a;
+    }
+    return;
+  }
+
+  {
+    float *sw = s_basis + wave * (NT * 256);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        sw[t * 256 + r * 64 + lane] = acc[t][r];
+  }
+  __syncthreads();
+  float *out = prm.partials + (size_t)blockIdx.x * photo_partial_floats(CS);
+  if (tid < kPhotoScalars)
+  {
+    float a = 0.f;
+    if (tid < 37)
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w)
+        a += s_red[w * kPhotoScalars + tid];
+    out[tid] = a;
+  }
+  for (int idx = tid; idx < NT * 256; idx += kBlock)
+  {
+    float a = 0.f;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w)
+      a += s_basis[w * (NT * 256) + idx];
+    out[kPhotoScalars + idx] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: sum the workgroup partials of an edge in a fixed order (deterministic), expand the reduced
+// blocks into the reference layout [pose0 pose1 code0 scale0] (photometric_factor_kernels.cpp:350-364),
+// apply 1/num_inliers and the zero-overlap fallback (:1139-1161).
+// ------------------------------------------------------------------------------------------------
+struct PhotoFinalizeParams
+{
+  PhotoEdge single;
+  const PhotoEdge *table;
+  const int32_t *edge_first;
+  const int32_t *edge_tiles;
+  const float *partials;
+  float *AtA, *Atb, *stats;
+  float wsum;
+};
+
+__device__ __forceinline__ float tile_elem(const float *s, int base, int tile, int row, int col)
+{
+  return s[base + tile * 256 + (row & 3) * 64 + ((row >> 2) * 16 + col)];
+}
+
+template <int CS>
+__global__ __launch_bounds__(kBlock) void photo_finalize_kernel(const PhotoFinalizeParams prm)
+{
+  constexpr int PP = photo_partial_floats(CS);
+  constexpr int D = 13 + CS;
+  __shared__ float s[PP];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const PhotoEdge &E = prm.table ? prm.table[e] : prm.single;
+  const float s0 = E.scale0 ? *E.scale0 : E.scale0_val;
+  const int first = prm.edge_first[e], nt = prm.edge_tiles[e];
+  for (int idx = tid; idx < PP; idx += kBlock)
+  {
+    float a = 0.f;
+    for (int t = 0; t < nt; ++t)
+      a += prm.partials[(size_t)(first + t) * PP + idx];
+    s[idx] = a;
+  }
+  __syncthreads();
+  const float n_in = s[36];
+  const bool ok = n_in > 0.f;
+  const float inv_n = ok ? 1.0f / n_in : 0.f;
+  float *AtA = prm.AtA + (size_t)e * D * D;
+  float *Atb = prm.Atb + (size_t)e * D;
+  if (tid == 0)
+  {
+    prm.stats[2 * e + 0] = ok ? s[35] * inv_n : 10.0f * prm.wsum;
+    prm.stats[2 * e + 1] = n_in;
+  }
+  auto X = [&](int row, int col) -> float { // sum_n a_n[row] * b_n[col]
+    if (CS == 32)
+      return tile_elem(s, kPhotoScalars, col < 16 ? 3 : 4, row, col & 15);
+    return tile_elem(s, kPhotoScalars, 1, row, col);
+  };
+  auto CC = [&](int i, int j) -> float { // sum_n sigma_n b_n[i] b_n[j]
+    if (CS == 32)
+    {
+      const int ti = i >> 4, tj = j >> 4;
+      if (ti <= tj)
+        return tile_elem(s, kPhotoScalars, ti + tj, i & 15, j & 15); // (0,0)->0 (0,1)->1 (1,1)->2
+      return tile_elem(s, kPhotoScalars, 1, j & 15, i & 15);
+    }
+    return tile_elem(s, kPhotoScalars, 0, i, j);
+  };
+  for (int idx = tid; idx < D * D + D; idx += kBlock)
+  {
+    float val = 0.f;
+    if (ok)
+    {
+      if (idx < D * D)
+      {
+        int i = idx / D, j = idx % D;
+        if (i > j)
+        {
+          const int t = i;
+          i = j;
+          j = t;
+        }
+        // classes: pose (0..11), code (12..12+CS-1), scale (12+CS)
+        if (j < 12)
+        {
+          const float sg = ((i >= 6) != (j >= 6)) ? -1.f : 1.f;
+          const int a = i % 6, b = j % 6;
+          val = sg * s[a <= b ? sidx6(a, b) : sidx6(b, a)];
+        }
+        else if (i < 12)
+        {
+          const float sg = (i >= 6) ? -1.f : 1.f;
+          if (j < 12 + CS)
+            val = sg * s0 * X(i % 6, j - 12);
+          else
+            val = sg * s[21 + i % 6] / s0;
+        }
+        else if (i < 12 + CS)
+        {
+          if (j < 12 + CS)
+            val = s0 * s0 * CC(i - 12, j - 12);
+          else
+            val = X(6, i - 12);
+        }
+        else
+          val = s[27] / (s0 * s0);
+        val *= inv_n;
+      }
+      else
+      {
+        const int i = idx - D * D;
+        if (i < 12)
+          val = ((i >= 6) ? -1.f : 1.f) * s[28 + i % 6];
+        else if (i < 12 + CS)
+          val = s0 * X(7, i - 12);
+        else
+          val = s[34] / s0;
+        val *= inv_n;
+      }
+    }
+    if (idx < D * D)
+      AtA[idx] = val;
+    else
+      Atb[idx - D * D] = val;
+  }
+}
+
+// error-only finalize: stats[e] = {sum(err)/n_in or 10*wsum, n_in}   (:1049-1058)
+struct StatsFinalizeParams
+{
+  const int32_t *edge_first;
+  const int32_t *edge_tiles;
+  const float *partials; // [n_work][2]
+  float *stats;
+  float fallback; // 10*sum(w) or 10*weight
+  float scale;    // 1 (photometric) or weight (geometric)
+  int n_edges;
+};
+
+__global__ void stats_finalize_kernel(const StatsFinalizeParams prm)
+{
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= prm.n_edges)
+    return;
+  const int first = prm.edge_first[e], nt = prm.edge_tiles[e];
+  float se = 0.f, sn = 0.f;
+  for (int t = 0; t < nt; ++t)
+  {
+    se += prm.partials[(size_t)(first + t) * 2 + 0];
+    sn += prm.partials[(size_t)(first + t) * 2 + 1];
+  }
+  prm.stats[2 * e + 0] = sn > 0.f ? prm.scale * se / sn : prm.fallback;
+  prm.stats[2 * e + 1] = sn;
+}
+
+hipError_t launch_stats_finalize(hipStream_t s, const LaunchCommon &lc, float *stats, float fallback, float scale)
+{
+  StatsFinalizeParams fp{lc.edge_first, lc.edge_tiles, lc.partials, stats, fallback, scale, lc.n_edges};
+  hipLaunchKernelGGL(stats_finalize_kernel, dim3((lc.n_edges + 63) / 64), dim3(64), 0, s, fp);
+  return hipGetLastError();
+}
+
+static PhotoParams make_params(const PhotoEdge *single, const PhotoEdge *table, const LaunchCommon &lc,
+                               const SagePyramid &pyr, const float *weights_host, float eps, float *wsum)
+{
+  PhotoParams p{};
+  if (single)
+    p.single = *single;
+  p.table = table;
+  p.work = lc.work;
+  p.partials = lc.partials;
+  p.pyr = pyr;
+  float ws = 0.f;
+  for (int l = 0; l < pyr.levels; ++l)
+  {
+    p.w[l] = weights_host[l];
+    ws += weights_host[l];
+  }
+  p.eps = eps;
+  p.tiles_per_block = lc.tiles_per_block;
+  *wsum = ws;
+  return p;
+}
+
+template <int CS, int FS>
+static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const PhotoEdge *table,
+                                 const LaunchCommon &lc, const SagePyramid &pyr, const float *wh, float eps,
+                                 const EdgeOut &out)
+{
+  float wsum;
+  PhotoParams p = make_params(single, table, lc, pyr, wh, eps, &wsum);
+  hipLaunchKernelGGL((photo_kernel<CS, FS, true>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  PhotoFinalizeParams f{};
+  if (single)
+    f.single = *single;
+  f.table = table;
+  f.edge_first = lc.edge_first;
+  f.edge_tiles = lc.edge_tiles;
+  f.partials = lc.partials;
+  f.AtA = out.AtA;
+  f.Atb = out.Atb;
+  f.stats = out.stats;
+  f.wsum = wsum;
+  hipLaunchKernelGGL((photo_finalize_kernel<CS>), dim3(lc.n_edges), dim3(kBlock), 0, s, f);
+  return hipGetLastError();
+}
+
+template <int CS, int FS>
+static hipError_t photo_err_impl(hipStream_t s, const PhotoEdge *single, const PhotoEdge *table,
+                                 const LaunchCommon &lc, const SagePyramid &pyr, const float *wh, float eps,
+                                 float *stats)
+{
+  float wsum;
+  PhotoParams p = make_params(single, table, lc, pyr, wh, eps, &wsum);
+  hipLaunchKernelGGL((photo_kernel<CS, FS, false>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  return launch_stats_finalize(s, lc, stats, 10.0f * wsum, 1.0f);
+}
+
+hipError_t launch_photo_linearize(hipStream_t s, int CS, int FS, const PhotoEdge *single, const PhotoEdge *table,
+                                  const LaunchCommon &lc, const SagePyramid &pyr, const float *weights_host,
+                                  float eps, const EdgeOut &out)
+{
+  if (CS == 32 && FS == 16)
+    return photo_lin_impl<32, 16>(s, single, table, lc, pyr, weights_host, eps, out);
+  if (CS == 16 && FS == 16)
+    return photo_lin_impl<16, 16>(s, single, table, lc, pyr, weights_host, eps, out);
+  if (CS == 32 && FS == 32)
+    return photo_lin_impl<32, 32>(s, single, table, lc, pyr, weights_host, eps, out);
+  if (CS == 16 && FS == 32)
+    return photo_lin_impl<16, 32>(s, single, table, lc, pyr, weights_host, eps, out);
+  return hipErrorInvalidValue;
+}
+
+hipError_t launch_photo_error(hipStream_t s, int CS, int FS, const PhotoEdge *single, const PhotoEdge *table,
+                              const LaunchCommon &lc, const SagePyramid &pyr, const float *weights_host,
+                              float eps, float *stats)
+{
+  if (CS == 32 && FS == 16)
+    return photo_err_impl<32, 16>(s, single, table, lc, pyr, weights_host, eps, stats);
+  if (CS == 16 && FS == 16)
+    return photo_err_impl<16, 16>(s, single, table, lc, pyr, weights_host, eps, stats);
+  if (CS == 32 && FS == 32)
+    return photo_err_impl<32, 32>(s, single, table, lc, pyr, weights_host, eps, stats);
+  if (CS == 16 && FS == 32)
+    return photo_err_impl<16, 32>(s, single, table, lc, pyr, weights_host, eps, stats);
+  return hipErrorInvalidValue;
+}
+
+} // namespace sage

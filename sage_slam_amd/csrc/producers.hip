@@ -1,0 +1,197 @@
+// producers.hip -- keyframe input producers feeding the hot path.
+//   depth_and_grad : UpdateDepth (core/mapping/mapping_utils.h:215-222) + ComputeSpatialGrad (:236-252), the
+//                    caller-side precompute of the geometric factor (core/gtsam/geometric_factor.cpp:317-347)
+//   gaussian_pyramid_with_grad : Mapper::GenerateGaussianPyramidWithGrad (core/mapping/mapper.cpp:1384-1426)
+// Plain HBM-bound image ops: one thread per output texel, coalesced along x.
+#include "sage_device.h"
+#include "sage_internal.h"
+
+namespace sage
+{
+
+// dpt[i] = scale * (bias[i] + basis[i,:] . code) for a batch of keyframes (blockIdx.y = keyframe)
+struct DepthBatch
+{
+  float *const *dpt;          // [K] -> [H*W]
+  const float *const *bias;   // [K]
+  const float *const *basis;  // [K]
+  const float *const *code;   // [K] -> [CS]
+  const float *const *scale;  // [K] -> 1
+};
+
+template <int CS>
+__global__ __launch_bounds__(256) void depth_kernel(float *dpt, const float *__restrict__ bias,
+                                                    const float *__restrict__ basis,
+                                                    const float *__restrict__ code, const float *scale_dev,
+                                                    float scale, int HW)
+{
+  // 8 (CS=32) or 4 (CS=16) lanes cooperate on one texel so the basis row is read as coalesced float4
+  constexpr int F4 = CS / 4;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int px = gid / F4, c4 = gid % F4;
+  const float s = scale_dev ? *scale_dev : scale;
+  float part = 0.f;
+  if (px < HW)
+  {
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(basis + (size_t)px * CS + c4 * 4);
+    part = b[0] * code[c4 * 4 + 0] + b[1] * code[c4 * 4 + 1] + b[2] * code[c4 * 4 + 2] + b[3] * code[c4 * 4 + 3];
+  }
+#pragma unroll
+  for (int o = F4 / 2; o > 0; o >>= 1)
+    part += __shfl_xor(part, o, 64);
+  if (px < HW && c4 == 0)
+    dpt[px] = s * (bias[px] + part);
+}
+
+// batched variant over keyframes (blockIdx.y = keyframe): one launch per LM pass for the whole window
+template <int CS>
+__global__ __launch_bounds__(256) void depth_batch_kernel(const DepthItem *__restrict__ items, int HW)
+{
+  constexpr int F4 = CS / 4;
+  const DepthItem it = items[blockIdx.y];
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int px = gid / F4, c4 = gid % F4;
+  float part = 0.f;
+  if (px < HW)
+  {
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(it.basis + (size_t)px * CS + c4 * 4);
+    part = b[0] * it.code[c4 * 4 + 0] + b[1] * it.code[c4 * 4 + 1] + b[2] * it.code[c4 * 4 + 2] +
+           b[3] * it.code[c4 * 4 + 3];
+  }
+#pragma unroll
+  for (int o = F4 / 2; o > 0; o >>= 1)
+    part += __shfl_xor(part, o, 64);
+  if (px < HW && c4 == 0)
+    it.dpt[px] = it.scale[0] * (it.bias[px] + part);
+}
+
+__global__ void depth_grad_batch_kernel(const DepthItem *__restrict__ items, int H, int W)
+{
+  const DepthItem it = items[blockIdx.z];
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  if (x >= W)
+    return;
+  const float *a = it.dpt;
+  const int xm = max(x - 1, 0), xp = min(x + 1, W - 1), ym = max(y - 1, 0), yp = min(y + 1, H - 1);
+  it.grad[(size_t)y * W + x] = 0.5f * (a[(size_t)y * W + xp] - a[(size_t)y * W + xm]);
+  it.grad[((size_t)H + y) * W + x] = 0.5f * (a[(size_t)yp * W + x] - a[(size_t)ym * W + x]);
+}
+
+hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev, int K, int H, int W)
+{
+  const int HW = H * W;
+  if (CS == 32)
+    hipLaunchKernelGGL((depth_batch_kernel<32>), dim3((HW * 8 + 255) / 256, K), dim3(256), 0, s, items_dev, HW);
+  else if (CS == 16)
+    hipLaunchKernelGGL((depth_batch_kernel<16>), dim3((HW * 4 + 255) / 256, K), dim3(256), 0, s, items_dev, HW);
+  else
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL(depth_grad_batch_kernel, dim3((W + 63) / 64, H, K), dim3(64), 0, s, items_dev, H, W);
+  return hipGetLastError();
+}
+
+// central differences with replicate padding (x then y) on [C,H,W]; out [2,C,H,W]
+__global__ void spatial_grad_kernel(float *grad, const float *__restrict__ img, int C, int H, int W)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y;
+  const int c = blockIdx.z;
+  if (x >= W)
+    return;
+  const float *a = img + (size_t)c * H * W;
+  const int xm = max(x - 1, 0), xp = min(x + 1, W - 1), ym = max(y - 1, 0), yp = min(y + 1, H - 1);
+  grad[((size_t)c * H + y) * W + x] = 0.5f * (a[(size_t)y * W + xp] - a[(size_t)y * W + xm]);
+  grad[(((size_t)C + c) * H + y) * W + x] = 0.5f * (a[(size_t)yp * W + x] - a[(size_t)ym * W + x]);
+}
+
+hipError_t launch_depth_and_grad(hipStream_t s, int CS, float *dpt, float *grad, const float *bias,
+                                 const float *basis, const float *code, const float *scale_dev, float scale,
+                                 int H, int W)
+{
+  const int HW = H * W;
+  if (CS == 32)
+    hipLaunchKernelGGL((depth_kernel<32>), dim3((HW * 8 + 255) / 256), dim3(256), 0, s, dpt, bias, basis, code,
+                       scale_dev, scale, HW);
+  else if (CS == 16)
+    hipLaunchKernelGGL((depth_kernel<16>), dim3((HW * 4 + 255) / 256), dim3(256), 0, s, dpt, bias, basis, code,
+                       scale_dev, scale, HW);
+  else
+    return hipErrorInvalidValue;
+  if (grad)
+    hipLaunchKernelGGL(spatial_grad_kernel, dim3((W + 63) / 64, H, 1), dim3(64), 0, s, grad, dpt, 1, H, W);
+  return hipGetLastError();
+}
+
+// one pyramid level: copy level image + its gradients into the concatenated [FS,P] / [2,FS,P] arrays
+__global__ void store_level_kernel(float *pyr, float *grad, const float *__restrict__ img, int FS, int H, int W,
+                                   int P, int lo)
+{
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, c = blockIdx.z;
+  if (x >= W)
+    return;
+  const float *a = img + (size_t)c * H * W;
+  const int xm = max(x - 1, 0), xp = min(x + 1, W - 1), ym = max(y - 1, 0), yp = min(y + 1, H - 1);
+  const size_t o = (size_t)lo + (size_t)y * W + x;
+  pyr[(size_t)c * P + o] = a[(size_t)y * W + x];
+  grad[(size_t)c * P + o] = 0.5f * (a[(size_t)y * W + xp] - a[(size_t)y * W + xm]);
+  grad[((size_t)FS + c) * P + o] = 0.5f * (a[(size_t)yp * W + x] - a[(size_t)ym * W + x]);
+}
+
+// next level = conv3x3s2(img*mask)/(conv3x3s2(mask)+1e-8); next mask = mask[2y,2x]  (mapper.cpp:1407-1419)
+__global__ void downsample_kernel(float *nxt, float *nmask, const float *__restrict__ img,
+                                  const float *__restrict__ mask, int FS, int H, int W)
+{
+  const int nw = W / 2, nh = H / 2;
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  const int y = blockIdx.y, c = blockIdx.z;
+  if (x >= nw)
+    return;
+  const float G[3] = {1.f, 2.f, 1.f};
+  float rf = 0.f, rm = 0.f;
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx)
+    {
+      const int yy = 2 * y + dy, xx = 2 * x + dx;
+      if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+      {
+        const float g = G[dy + 1] * G[dx + 1] / 16.0f;
+        const float mk = mask[(size_t)yy * W + xx];
+        rm += g * mk;
+        rf += g * (img[((size_t)c * H + yy) * W + xx] * mk);
+      }
+    }
+  nxt[((size_t)c * nh + y) * nw + x] = rf / (rm + 1.0e-8f);
+  if (c == 0)
+    nmask[(size_t)y * nw + x] = mask[(size_t)(2 * y) * W + 2 * x];
+}
+
+// scratch: FS*H*W/4*2 + H*W/4*2 floats (two ping-pong level images + masks)
+hipError_t launch_gaussian_pyramid_with_grad(hipStream_t s, float *pyr, float *grad, const float *feat,
+                                             const float *mask, const SagePyramid &p, int FS, float *scratch)
+{
+  const int H0 = (int)p.cam[0].h, W0 = (int)p.cam[0].w;
+  const size_t img_sz = (size_t)FS * (H0 / 2) * (W0 / 2), m_sz = (size_t)(H0 / 2) * (W0 / 2);
+  float *imgs[2] = {scratch, scratch + img_sz};
+  float *masks[2] = {scratch + 2 * img_sz, scratch + 2 * img_sz + m_sz};
+  const float *cur = feat, *curm = mask;
+  for (int l = 0; l < p.levels; ++l)
+  {
+    const int H = (int)p.cam[l].h, W = (int)p.cam[l].w;
+    hipLaunchKernelGGL(store_level_kernel, dim3((W + 63) / 64, H, FS), dim3(64), 0, s, pyr, grad, cur, FS, H, W,
+                       p.P, p.level_offsets[l]);
+    if (l == p.levels - 1)
+      break;
+    float *n = imgs[l & 1], *nm = masks[l & 1];
+    hipLaunchKernelGGL(downsample_kernel, dim3((W / 2 + 63) / 64, H / 2, FS), dim3(64), 0, s, n, nm, cur, curm, FS,
+                       H, W);
+    cur = n;
+    curm = nm;
+  }
+  return hipGetLastError();
+}
+
+} // namespace sage

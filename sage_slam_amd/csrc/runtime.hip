@@ -1,0 +1,1245 @@
+// runtime.hip -- host runtime behind the C ABI (include/sage_ba.h): workspaces, the per-edge operator API
+// that mirrors the reference's df::*_calculate free functions, the tracker wiring and the batched window
+// engine (edge tables, work lists, deterministic assembly into block-sparse normal equations, host solve).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "host_math.h"
+#include "sage_ba.h"
+#include "sage_internal.h"
+
+using namespace sage;
+
+#define SAGE_HIP(expr)                \
+  do                                  \
+  {                                   \
+    hipError_t _e = (expr);           \
+    if (_e != hipSuccess)             \
+      return (int)_e;                 \
+  } while (0)
+
+namespace
+{
+
+struct DevBuf
+{
+  void *p = nullptr;
+  size_t cap = 0;
+  int reserve(size_t bytes)
+  {
+    if (bytes <= cap)
+      return 0;
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess)
+      return (int)e;
+    cap = bytes;
+    return 0;
+  }
+  void release()
+  {
+    if (p)
+      (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T>
+  T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+int pick_tiles_per_block(long long total_tiles)
+{
+  // keep >= ~4 workgroups per CU in flight while amortising the partial write (one per workgroup)
+  if (total_tiles >= 8192)
+    return 4;
+  if (total_tiles >= 4096)
+    return 2;
+  return 1;
+}
+
+// host-built work list for a set of edges with per-edge pixel counts
+struct WorkList
+{
+  std::vector<WorkItem> work;
+  std::vector<int32_t> edge_first, edge_tiles;
+  int tiles_per_block = 1;
+  void build(const std::vector<int> &N)
+  {
+    long long total = 0;
+    for (int n : N)
+      total += (n + kTile - 1) / kTile;
+    tiles_per_block = pick_tiles_per_block(total);
+    work.clear();
+    edge_first.assign(N.size(), 0);
+    edge_tiles.assign(N.size(), 0);
+    for (size_t e = 0; e < N.size(); ++e)
+    {
+      const int tiles = (N[e] + kTile - 1) / kTile;
+      edge_first[e] = (int32_t)work.size();
+      for (int t = 0; t < tiles; t += tiles_per_block)
+        work.push_back(WorkItem{(int32_t)e, t});
+      edge_tiles[e] = (int32_t)work.size() - edge_first[e];
+    }
+  }
+};
+
+} // namespace
+
+// =====================================================================================================
+// workspace
+// =====================================================================================================
+struct SageWorkspace
+{
+  hipStream_t stream = nullptr;
+  DevBuf work, edge_first, edge_tiles, partials, stats, misc;
+  float *host_stats = nullptr; // pinned, 2 floats
+  int cached_N = -1;
+  int n_work = 0;
+  int tiles_per_block = 1;
+};
+
+extern "C" int sage_workspace_create(void *hip_stream, SageWorkspace **out)
+{
+  if (!out)
+    return SAGE_E_INVALID;
+  int ndev = 0;
+  SAGE_HIP(hipGetDeviceCount(&ndev));
+  if (ndev < 1)
+    return (int)hipErrorNoDevice;
+  SageWorkspace *ws = new SageWorkspace();
+  ws->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  hipError_t e = hipHostMalloc((void **)&ws->host_stats, 16 * sizeof(float), hipHostMallocDefault);
+  if (e != hipSuccess)
+  {
+    delete ws;
+    return (int)e;
+  }
+  *out = ws;
+  return SAGE_OK;
+}
+
+extern "C" void sage_workspace_destroy(SageWorkspace *ws)
+{
+  if (!ws)
+    return;
+  ws->work.release();
+  ws->edge_first.release();
+  ws->edge_tiles.release();
+  ws->partials.release();
+  ws->stats.release();
+  ws->misc.release();
+  if (ws->host_stats)
+    (void)hipHostFree(ws->host_stats);
+  delete ws;
+}
+
+static int ws_prepare(SageWorkspace *ws, int N, size_t partial_floats, LaunchCommon *lc)
+{
+  if (!ws || N < 0)
+    return SAGE_E_INVALID;
+  if (ws->cached_N != N)
+  {
+    WorkList wl;
+    wl.build(std::vector<int>{N});
+    if (wl.work.empty())
+      wl.work.push_back(WorkItem{0, 0}); // N == 0: one empty workgroup so the finalize sees zeros
+    if (wl.edge_tiles[0] == 0)
+      wl.edge_tiles[0] = 1;
+    int rc;
+    if ((rc = ws->work.reserve(wl.work.size() * sizeof(WorkItem))))
+      return rc;
+    if ((rc = ws->edge_first.reserve(sizeof(int32_t))))
+      return rc;
+    if ((rc = ws->edge_tiles.reserve(sizeof(int32_t))))
+      return rc;
+    if ((rc = ws->stats.reserve(4 * sizeof(float))))
+      return rc;
+    SAGE_HIP(hipMemcpyAsync(ws->work.p, wl.work.data(), wl.work.size() * sizeof(WorkItem), hipMemcpyHostToDevice,
+                            ws->stream));
+    SAGE_HIP(hipMemcpyAsync(ws->edge_first.p, wl.edge_first.data(), sizeof(int32_t), hipMemcpyHostToDevice,
+                            ws->stream));
+    SAGE_HIP(hipMemcpyAsync(ws->edge_tiles.p, wl.edge_tiles.data(), sizeof(int32_t), hipMemcpyHostToDevice,
+                            ws->stream));
+    SAGE_HIP(hipStreamSynchronize(ws->stream)); // wl goes out of scope
+    ws->cached_N = N;
+    ws->n_work = (int)wl.work.size();
+    ws->tiles_per_block = wl.tiles_per_block;
+  }
+  int rc;
+  if ((rc = ws->partials.reserve((size_t)ws->n_work * partial_floats * sizeof(float))))
+    return rc;
+  lc->work = ws->work.as<WorkItem>();
+  lc->edge_first = ws->edge_first.as<int32_t>();
+  lc->edge_tiles = ws->edge_tiles.as<int32_t>();
+  lc->n_work = ws->n_work;
+  lc->n_edges = 1;
+  lc->partials = ws->partials.as<float>();
+  lc->tiles_per_block = ws->tiles_per_block;
+  return SAGE_OK;
+}
+
+static int ws_fetch_stats(SageWorkspace *ws, float *error_host, float *num_inliers_host)
+{
+  SAGE_HIP(hipMemcpyAsync(ws->host_stats, ws->stats.p, 2 * sizeof(float), hipMemcpyDeviceToHost, ws->stream));
+  SAGE_HIP(hipStreamSynchronize(ws->stream));
+  if (error_host)
+    *error_host = ws->host_stats[0];
+  if (num_inliers_host)
+    *num_inliers_host = ws->host_stats[1];
+  return SAGE_OK;
+}
+
+static bool supported(int CS, int FS)
+{
+  return (CS == 16 || CS == 32) && (FS == 16 || FS == 32);
+}
+
+// =====================================================================================================
+// per-edge operator API
+// =====================================================================================================
+extern "C" int sage_photometric_jac_error_calculate(
+    SageWorkspace *ws, float *AtA_dev, float *Atb_dev, float *error_host, float *num_inliers_host,
+    const float *R10, const float *t10, const float *R0, const float *t0, const float *R1, const float *t1,
+    const float *bias0, const float *basis0, const float *code0, const float *mask1, const int64_t *loc1d,
+    const float *homo, const float *feat0, const float *feat1, const float *grad1, float scale0,
+    const SagePyramid *pyr, float eps, const float *weights_host, int N, int FS, int CS)
+{
+  if (!ws || !AtA_dev || !Atb_dev || !pyr || !weights_host || !R0 || !t0 || !R1 || !t1 || !bias0 || !basis0 ||
+      !code0 || !mask1 || !loc1d || !homo || !feat0 || !feat1 || !grad1)
+    return SAGE_E_INVALID;
+  if (!supported(CS, FS) || pyr->levels < 1 || pyr->levels > SAGE_MAX_LEVELS)
+    return SAGE_E_UNSUPPORTED;
+  LaunchCommon lc;
+  int rc = ws_prepare(ws, N, photo_partial_floats(CS), &lc);
+  if (rc)
+    return rc;
+  PhotoEdge e{};
+  e.feat0 = feat0; e.feat1 = feat1; e.grad1 = grad1; e.bias0 = bias0; e.basis0 = basis0; e.mask1 = mask1;
+  e.homo = homo; e.loc = loc1d; e.loc_is_i64 = 1;
+  e.R0 = R0; e.t0 = t0; e.R1 = R1; e.t1 = t1; e.R10 = R10; e.t10 = R10 ? t10 : nullptr;
+  e.code0 = code0; e.scale0 = nullptr; e.scale0_val = scale0; e.N = N;
+  EdgeOut out{AtA_dev, Atb_dev, ws->stats.as<float>()};
+  SAGE_HIP(launch_photo_linearize(ws->stream, CS, FS, &e, nullptr, lc, *pyr, weights_host, eps, out));
+  return ws_fetch_stats(ws, error_host, num_inliers_host);
+}
+
+extern "C" int sage_photometric_error_calculate(
+    SageWorkspace *ws, float *error_host, float *num_inliers_host, const float *R10, const float *t10,
+    const float *bias0, const float *basis0, const float *code0, const float *mask1, const int64_t *loc1d,
+    const float *homo, const float *feat0, const float *feat1, float scale0, const SagePyramid *pyr, float eps,
+    const float *weights_host, int N, int FS, int CS)
+{
+  if (!ws || !pyr || !weights_host || !R10 || !t10 || !bias0 || !basis0 || !code0 || !mask1 || !loc1d || !homo ||
+      !feat0 || !feat1)
+    return SAGE_E_INVALID;
+  if (!supported(CS, FS) || pyr->levels < 1 || pyr->levels > SAGE_MAX_LEVELS)
+    return SAGE_E_UNSUPPORTED;
+  LaunchCommon lc;
+  int rc = ws_prepare(ws, N, 2, &lc);
+  if (rc)
+    return rc;
+  PhotoEdge e{};
+  e.feat0 = feat0; e.feat1 = feat1; e.grad1 = nullptr; e.bias0 = bias0; e.basis0 = basis0; e.mask1 = mask1;
+  e.homo = homo; e.loc = loc1d; e.loc_is_i64 = 1;
+  e.R10 = R10; e.t10 = t10; e.code0 = code0; e.scale0 = nullptr; e.scale0_val = scale0; e.N = N;
+  SAGE_HIP(launch_photo_error(ws->stream, CS, FS, &e, nullptr, lc, *pyr, weights_host, eps, ws->stats.as<float>()));
+  return ws_fetch_stats(ws, error_host, num_inliers_host);
+}
+
+static int track_common(SageWorkspace *ws, bool jac, int dof, float *AtA, float *Atb, float *error_host,
+                        float *num_inliers_host, const float *R, const float *t, const float *mask1,
+                        const float *dpts0, const float *homo, const float *feat0s, const float *feat1,
+                        const float *grad1, const SagePyramid *pyr, float scale0, float eps,
+                        const float *weights_dev, int N, int FS)
+{
+  if (!ws || !pyr || !R || !t || !mask1 || !dpts0 || !homo || !feat0s || !feat1 || !weights_dev ||
+      (jac && (!grad1 || !AtA || !Atb)))
+    return SAGE_E_INVALID;
+  if ((FS != 16 && FS != 32) || pyr->levels < 1 || pyr->levels > SAGE_MAX_LEVELS)
+    return SAGE_E_UNSUPPORTED;
+  // tracker kernels process exactly one kTile per workgroup
+  if (ws->cached_N != -(N + 2))
+  {
+    std::vector<WorkItem> work;
+    for (int tl = 0; tl < std::max(1, (N + kTile - 1) / kTile); ++tl)
+      work.push_back(WorkItem{0, tl});
+    int rc;
+    if ((rc = ws->work.reserve(work.size() * sizeof(WorkItem))))
+      return rc;
+    if ((rc = ws->stats.reserve(4 * sizeof(float))))
+      return rc;
+    SAGE_HIP(hipMemcpyAsync(ws->work.p, work.data(), work.size() * sizeof(WorkItem), hipMemcpyHostToDevice,
+                            ws->stream));
+    SAGE_HIP(hipStreamSynchronize(ws->stream));
+    ws->cached_N = -(N + 2);
+    ws->n_work = (int)work.size();
+  }
+  int rc;
+  if ((rc = ws->partials.reserve((size_t)ws->n_work * kTrackScalars * sizeof(float))))
+    return rc;
+  LaunchCommon lc{};
+  lc.work = ws->work.as<WorkItem>();
+  lc.n_work = ws->n_work;
+  lc.n_edges = 1;
+  lc.partials = ws->partials.as<float>();
+  lc.tiles_per_block = 1;
+  TrackEdge e{};
+  e.feat0s = feat0s; e.feat1 = feat1; e.grad1 = grad1; e.mask1 = mask1; e.homo = homo; e.dpts0 = dpts0;
+  e.R = R; e.t = t; e.weights = weights_dev; e.scale0 = scale0; e.N = N;
+  if (jac)
+  {
+    EdgeOut out{AtA, Atb, ws->stats.as<float>()};
+    SAGE_HIP(launch_track_linearize(ws->stream, dof, FS, e, lc, *pyr, eps, out));
+  }
+  else
+    SAGE_HIP(launch_track_error(ws->stream, FS, e, lc, *pyr, eps, ws->stats.as<float>()));
+  return ws_fetch_stats(ws, error_host, num_inliers_host);
+}
+
+extern "C" int sage_tracker_photo_jac_error_calculate(
+    SageWorkspace *ws, int dof, float *AtA_dev, float *Atb_dev, float *error_host, float *num_inliers_host,
+    const float *R, const float *t, const float *mask1, const float *dpts0, const float *homo,
+    const float *feat0s, const float *feat1, const float *grad1, const SagePyramid *pyr, float scale0, float eps,
+    const float *weights_dev, int N, int FS)
+{
+  if (dof != 6 && dof != 7)
+    return SAGE_E_INVALID;
+  return track_common(ws, true, dof, AtA_dev, Atb_dev, error_host, num_inliers_host, R, t, mask1, dpts0, homo,
+                      feat0s, feat1, grad1, pyr, scale0, eps, weights_dev, N, FS);
+}
+
+extern "C" int sage_tracker_photo_error_calculate(
+    SageWorkspace *ws, float *error_host, float *num_inliers_host, const float *R, const float *t,
+    const float *mask1, const float *dpts0, const float *homo, const float *feat0s, const float *feat1,
+    const SagePyramid *pyr, float eps, const float *weights_dev, int N, int FS)
+{
+  return track_common(ws, false, 6, nullptr, nullptr, error_host, num_inliers_host, R, t, mask1, dpts0, homo,
+                      feat0s, feat1, nullptr, pyr, 1.0f, eps, weights_dev, N, FS);
+}
+
+extern "C" int sage_geometric_jac_error_calculate(
+    SageWorkspace *ws, float *AtA_dev, float *Atb_dev, float *error_host, float *num_inliers_host,
+    const float *R10, const float *t10, const float *R0, const float *t0, const float *R1, const float *t1,
+    const float *bias0, const float *basis0, const float *code0, const float *dpt1, const float *dgrad1,
+    const float *basis1, const float *mask1, const int32_t *loc1d, const float *homo, float scale0, float scale1,
+    const SageCamera *cam, float eps, float loss_param, float weight, int N, int CS)
+{
+  if (!ws || !AtA_dev || !Atb_dev || !cam || !R0 || !t0 || !R1 || !t1 || !bias0 || !basis0 || !code0 || !dpt1 ||
+      !dgrad1 || !basis1 || !mask1 || !loc1d || !homo)
+    return SAGE_E_INVALID;
+  if (CS != 16 && CS != 32)
+    return SAGE_E_UNSUPPORTED;
+  LaunchCommon lc;
+  int rc = ws_prepare(ws, N, geo_partial_floats(CS), &lc);
+  if (rc)
+    return rc;
+  GeoEdge e{};
+  e.bias0 = bias0; e.basis0 = basis0; e.dpt1 = dpt1; e.dgrad1 = dgrad1; e.basis1 = basis1; e.mask1 = mask1;
+  e.homo = homo; e.loc = loc1d; e.loc_is_i64 = 0;
+  e.R0 = R0; e.t0 = t0; e.R1 = R1; e.t1 = t1; e.R10 = R10; e.t10 = R10 ? t10 : nullptr;
+  e.code0 = code0; e.scale0 = nullptr; e.scale1 = nullptr; e.scale0_val = scale0; e.scale1_val = scale1; e.N = N;
+  EdgeOut out{AtA_dev, Atb_dev, ws->stats.as<float>()};
+  SAGE_HIP(launch_geo_linearize(ws->stream, CS, &e, nullptr, lc, *cam, eps, loss_param, weight, out));
+  return ws_fetch_stats(ws, error_host, num_inliers_host);
+}
+
+extern "C" int sage_geometric_error_calculate(
+    SageWorkspace *ws, float *error_host, float *num_inliers_host, const float *R10, const float *t10,
+    const float *bias0, const float *basis0, const float *code0, const float *dpt1, const float *mask1,
+    const int32_t *loc1d, const float *homo, float scale0, const SageCamera *cam, float eps, float loss_param,
+    float weight, int N, int CS)
+{
+  if (!ws || !cam || !R10 || !t10 || !bias0 || !basis0 || !code0 || !dpt1 || !mask1 || !loc1d || !homo)
+    return SAGE_E_INVALID;
+  if (CS != 16 && CS != 32)
+    return SAGE_E_UNSUPPORTED;
+  LaunchCommon lc;
+  int rc = ws_prepare(ws, N, 2, &lc);
+  if (rc)
+    return rc;
+  GeoEdge e{};
+  e.bias0 = bias0; e.basis0 = basis0; e.dpt1 = dpt1; e.mask1 = mask1; e.homo = homo; e.loc = loc1d;
+  e.loc_is_i64 = 0; e.R10 = R10; e.t10 = t10; e.code0 = code0; e.scale0_val = scale0; e.scale1_val = 1.f; e.N = N;
+  SAGE_HIP(launch_geo_error(ws->stream, CS, &e, nullptr, lc, *cam, eps, loss_param, weight, ws->stats.as<float>()));
+  return ws_fetch_stats(ws, error_host, num_inliers_host);
+}
+
+extern "C" int sage_depth_and_grad(SageWorkspace *ws, float *dpt, float *grad, const float *bias, const float *basis,
+                                   const float *code, float scale, int H, int W, int CS)
+{
+  if (!ws || !dpt || !bias || !basis || !code)
+    return SAGE_E_INVALID;
+  if (CS != 16 && CS != 32)
+    return SAGE_E_UNSUPPORTED;
+  SAGE_HIP(launch_depth_and_grad(ws->stream, CS, dpt, grad, bias, basis, code, nullptr, scale, H, W));
+  return SAGE_OK;
+}
+
+extern "C" int sage_gaussian_pyramid_with_grad(SageWorkspace *ws, float *pyr_dev, float *grad_dev,
+                                               const float *feat, const float *mask, const SagePyramid *pyr, int FS)
+{
+  if (!ws || !pyr_dev || !grad_dev || !feat || !mask || !pyr)
+    return SAGE_E_INVALID;
+  const int H = (int)pyr->cam[0].h, W = (int)pyr->cam[0].w;
+  for (int l = 0; l + 1 < pyr->levels; ++l) // the reference's conv / camera / mask pyramids only agree for even sizes
+    if (((int)pyr->cam[l].h & 1) || ((int)pyr->cam[l].w & 1))
+      return SAGE_E_UNSUPPORTED;
+  const size_t scratch = ((size_t)FS * (H / 2) * (W / 2) + (size_t)(H / 2) * (W / 2)) * 2 * sizeof(float);
+  int rc = ws->misc.reserve(scratch);
+  if (rc)
+    return rc;
+  SAGE_HIP(launch_gaussian_pyramid_with_grad(ws->stream, pyr_dev, grad_dev, feat, mask, *pyr, FS,
+                                             ws->misc.as<float>()));
+  return SAGE_OK;
+}
+
+// =====================================================================================================
+// tracker: product wiring of the LM callbacks to the HIP kernels
+// =====================================================================================================
+namespace
+{
+struct TrackCtx
+{
+  const SageTrackProblem *prob;
+  int dof;
+  DevBuf pose, out; // pose: 12 floats; out: AtA(49)+Atb(7)
+};
+
+int track_lin_cb(void *vctx, const float *pose12, float scale, float *AtA, float *Atb, float *error)
+{
+  TrackCtx *c = static_cast<TrackCtx *>(vctx);
+  const SageTrackProblem *p = c->prob;
+  hipStream_t s = p->ws->stream;
+  SAGE_HIP(hipMemcpyAsync(c->pose.p, pose12, 12 * sizeof(float), hipMemcpyHostToDevice, s));
+  float *dA = c->out.as<float>(), *db = dA + 49;
+  int rc = sage_tracker_photo_jac_error_calculate(p->ws, c->dof, dA, db, error, nullptr, c->pose.as<float>(),
+                                                  c->pose.as<float>() + 9, p->mask1_dev, p->dpts0_dev, p->homo_dev,
+                                                  p->feat0s_dev, p->feat1_dev, p->grad1_dev, &p->pyr, scale, p->eps,
+                                                  p->weights_dev, p->N, p->FS);
+  if (rc)
+    return rc;
+  float host[56];
+  SAGE_HIP(hipMemcpy(host, dA, 56 * sizeof(float), hipMemcpyDeviceToHost));
+  std::memcpy(AtA, host, c->dof * c->dof * sizeof(float));
+  std::memcpy(Atb, host + 49, c->dof * sizeof(float));
+  return 0;
+}
+
+int track_err_cb(void *vctx, const float *pose12, float /*scale*/, float *error)
+{
+  TrackCtx *c = static_cast<TrackCtx *>(vctx);
+  const SageTrackProblem *p = c->prob;
+  SAGE_HIP(hipMemcpyAsync(c->pose.p, pose12, 12 * sizeof(float), hipMemcpyHostToDevice, p->ws->stream));
+  return sage_tracker_photo_error_calculate(p->ws, error, nullptr, c->pose.as<float>(), c->pose.as<float>() + 9,
+                                            p->mask1_dev, p->dpts0_dev, p->homo_dev, p->feat0s_dev, p->feat1_dev,
+                                            &p->pyr, p->eps, p->weights_dev, p->N, p->FS);
+}
+} // namespace
+
+extern "C" int sage_track_frame(const SageLmConfig *cfg, int dof, const SageTrackProblem *prob, float *pose12,
+                                float *scale, float *final_error, int *iters)
+{
+  if (!cfg || !prob || !prob->ws || !pose12)
+    return SAGE_E_INVALID;
+  TrackCtx ctx;
+  ctx.prob = prob;
+  ctx.dof = dof;
+  int rc;
+  if ((rc = ctx.pose.reserve(12 * sizeof(float))) || (rc = ctx.out.reserve(56 * sizeof(float))))
+    return rc;
+  // NOTE: with dof == 7 the reference rescales nothing on the device side: the scale only enters the Jacobian
+  // column (photometric_factor_kernels.cpp:856) and `s <- s + ds` (camera_tracker.cpp:487).
+  rc = sage_track_lm(cfg, dof, track_lin_cb, track_err_cb, &ctx, pose12, scale, final_error, iters, nullptr, 0,
+                     nullptr);
+  ctx.pose.release();
+  ctx.out.release();
+  return rc;
+}
+
+// =====================================================================================================
+// window engine
+// =====================================================================================================
+namespace sage
+{
+
+struct AdjEntry // one (edge, role) incidence of a keyframe
+{
+  int32_t type; // 0 photo, 1 geo
+  int32_t edge; // local edge index
+  int32_t role; // 0: keyframe is the edge's source ("0"), 1: destination ("1")
+};
+
+struct LinkEdges // local edge indices of a link, -1 if the link is not owned by this rank
+{
+  int32_t e_ab, e_ba; // same indices for photo and geo tables
+};
+
+struct AssembleParams
+{
+  const float *AtA_p, *Atb_p, *stats_p; // photo per-edge results
+  const float *AtA_g, *Atb_g, *stats_g;
+  const int32_t *adj_start; // [K+1]
+  const AdjEntry *adj;
+  const LinkEdges *links; // [nlinks]
+  float *packed;
+  int K, nlinks, CS, n_edges_p, n_edges_g;
+};
+
+// B-index (0..6+CS: pose 6, code CS, scale) -> column of the per-edge system, or -1 if absent
+__device__ __forceinline__ int edge_col(int type, int role, int bi, int CS)
+{
+  if (bi < 6)
+    return role * 6 + bi;
+  if (type == 0)
+  {
+    if (role == 1)
+      return -1; // a photometric edge does not touch code1 / scale1
+    return bi < 6 + CS ? 12 + (bi - 6) : 12 + CS;
+  }
+  if (bi < 6 + CS)
+    return 12 + role * CS + (bi - 6);
+  return 12 + 2 * CS + role;
+}
+
+// one workgroup per output block; thread per element; contributions summed in a fixed order (deterministic)
+__global__ __launch_bounds__(256) void assemble_kernel(const AssembleParams p)
+{
+  const int B = 7 + p.CS, BB = B * B;
+  const int Dp = 13 + p.CS, Dg = 14 + 2 * p.CS;
+  const int blk = blockIdx.x;
+  float *diag = p.packed;
+  float *lnk = diag + (size_t)p.K * BB;
+  float *g = lnk + (size_t)p.nlinks * BB;
+  float *tail = g + (size_t)p.K * B;
+  if (blk < p.K)
+  {
+    const int k = blk;
+    const int a0 = p.adj_start[k], a1 = p.adj_start[k + 1];
+    for (int idx = threadIdx.x; idx < BB + B; idx += blockDim.x)
+    {
+      float acc = 0.f;
+      const bool isg = idx >= BB;
+      const int bi = isg ? idx - BB : idx / B, bj = isg ? 0 : idx % B;
+      for (int a = a0; a < a1; ++a)
+      {
+        const AdjEntry ae = p.adj[a];
+        const int D = ae.type == 0 ? Dp : Dg;
+        const int ci = edge_col(ae.type, ae.role, bi, p.CS);
+        if (ci < 0)
+          continue;
+        if (isg)
+          acc += (ae.type == 0 ? p.Atb_p : p.Atb_g)[(size_t)ae.edge * D + ci];
+        else
+        {
+          const int cj = edge_col(ae.type, ae.role, bj, p.CS);
+          if (cj < 0)
+            continue;
+          acc += (ae.type == 0 ? p.AtA_p : p.AtA_g)[(size_t)ae.edge * D * D + (size_t)ci * D + cj];
+        }
+      }
+      if (isg)
+        g[(size_t)k * B + bi] = acc;
+      else
+        diag[(size_t)k * BB + idx] = acc;
+    }
+  }
+  else if (blk < p.K + p.nlinks)
+  {
+    const int l = blk - p.K;
+    const LinkEdges le = p.links[l];
+    for (int idx = threadIdx.x; idx < BB; idx += blockDim.x)
+    {
+      const int bi = idx / B, bj = idx % B; // bi indexes keyframe a (older), bj keyframe b
+      float acc = 0.f;
+      if (le.e_ab >= 0)
+      {
+        for (int type = 0; type < 2; ++type)
+        {
+          if ((type == 0 && !p.AtA_p) || (type == 1 && !p.AtA_g))
+            continue;
+          const int D = type == 0 ? Dp : Dg;
+          const float *A = type == 0 ? p.AtA_p : p.AtA_g;
+          // edge a->b : a has role 0, b has role 1
+          int ci = edge_col(type, 0, bi, p.CS), cj = edge_col(type, 1, bj, p.CS);
+          if (ci >= 0 && cj >= 0)
+            acc += A[(size_t)le.e_ab * D * D + (size_t)ci * D + cj];
+          // edge b->a : b has role 0, a has role 1
+          ci = edge_col(type, 1, bi, p.CS);
+          cj = edge_col(type, 0, bj, p.CS);
+          if (ci >= 0 && cj >= 0)
+            acc += A[(size_t)le.e_ba * D * D + (size_t)ci * D + cj];
+        }
+      }
+      lnk[(size_t)l * BB + idx] = acc;
+    }
+  }
+  else
+  {
+    // tail: total errors / inlier counts of the local edges, summed serially by one wave for determinism
+    if (threadIdx.x < 4)
+    {
+      const bool photo = (threadIdx.x & 1) == 0;
+      const int which = threadIdx.x >> 1; // 0: error, 1: inliers
+      const float *st = photo ? p.stats_p : p.stats_g;
+      const int n = photo ? p.n_edges_p : p.n_edges_g;
+      float acc = 0.f;
+      if (st)
+        for (int e = 0; e < n; ++e)
+          acc += st[2 * e + which];
+      tail[which * 2 + (photo ? 0 : 1)] = acc; // [err_photo err_geo n_photo n_geo]
+    }
+  }
+}
+
+__global__ void sum_stats_kernel(const float *stats_p, int np, const float *stats_g, int ng, float *out)
+{
+  if (threadIdx.x < 4)
+  {
+    const bool photo = (threadIdx.x & 1) == 0;
+    const int which = threadIdx.x >> 1;
+    const float *st = photo ? stats_p : stats_g;
+    const int n = photo ? np : ng;
+    float acc = 0.f;
+    if (st)
+      for (int e = 0; e < n; ++e)
+        acc += st[2 * e + which];
+    out[which * 2 + (photo ? 0 : 1)] = acc;
+  }
+}
+
+} // namespace sage
+
+struct SageWindow
+{
+  SageWindowConfig cfg;
+  hipStream_t stream = nullptr;
+  bool finalized = false;
+  int rank = 0, world = 1;
+  int K = 0, B = 0, VS = 0; // VS: floats per keyframe in the device variable array
+  std::vector<SageKeyframeView> views;
+  // host variables: [set][kf] ; set 0 = current, 1 = candidate
+  std::vector<float> pose[2], code[2], scale[2];
+  std::vector<float> code_init, scale_init, pose_init;
+  std::vector<std::pair<int, int>> links; // (a, b) with a < b
+  std::vector<int> local_links;           // indices into links
+  int n_edges = 0;                        // local directed edges per factor type (= 2 * local links)
+  // device
+  DevBuf vars[2];                       // [K][VS]: pose 12, scale 1, code CS
+  DevBuf dpt, dgrad, depth_items[2];    // per-keyframe depth maps of the set being evaluated
+  DevBuf ptab[2], gtab[2];              // edge tables per variable set
+  DevBuf work_p, first_p, tiles_p, work_g, first_g, tiles_g;
+  DevBuf part_p, part_g;
+  DevBuf AtA_p, Atb_p, stats_p, AtA_g, Atb_g, stats_g;
+  DevBuf adj_start, adj, link_edges, packed, errbuf;
+  int n_work_p = 0, n_work_g = 0, tpb_p = 1, tpb_g = 1;
+  std::vector<float> host_packed;
+  std::vector<double> delta;
+  double residuals_per_lin = 0, bytes_per_lin = 0;
+  bool have_lin = false;
+};
+
+static void upload_vars_host(SageWindow *w, int set, std::vector<float> &buf)
+{
+  buf.assign((size_t)w->K * w->VS, 0.f);
+  const int CS = w->cfg.CS;
+  for (int k = 0; k < w->K; ++k)
+  {
+    float *d = &buf[(size_t)k * w->VS];
+    std::memcpy(d, &w->pose[set][(size_t)k * 12], 12 * sizeof(float));
+    d[12] = w->scale[set][k];
+    std::memcpy(d + 13, &w->code[set][(size_t)k * CS], CS * sizeof(float));
+  }
+}
+
+static int upload_vars(SageWindow *w, int set)
+{
+  std::vector<float> buf;
+  upload_vars_host(w, set, buf);
+  SAGE_HIP(hipMemcpyAsync(w->vars[set].p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, w->stream));
+  SAGE_HIP(hipStreamSynchronize(w->stream)); // buf is a temporary
+  return SAGE_OK;
+}
+
+extern "C" int sage_window_create(const SageWindowConfig *cfg, void *hip_stream, SageWindow **out)
+{
+  if (!cfg || !out || !cfg->mask_dev)
+    return SAGE_E_INVALID;
+  if (!supported(cfg->CS, cfg->FS) || cfg->pyr.levels < 1 || cfg->pyr.levels > SAGE_MAX_LEVELS)
+    return SAGE_E_UNSUPPORTED;
+  int ndev = 0;
+  SAGE_HIP(hipGetDeviceCount(&ndev));
+  if (ndev < 1)
+    return (int)hipErrorNoDevice;
+  SageWindow *w = new SageWindow();
+  w->cfg = *cfg;
+  w->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  w->B = 7 + cfg->CS;
+  w->VS = ((13 + cfg->CS + 3) / 4) * 4;
+  *out = w;
+  return SAGE_OK;
+}
+
+extern "C" void sage_window_destroy(SageWindow *w)
+{
+  if (!w)
+    return;
+  DevBuf *bufs[] = {&w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
+                    &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
+                    &w->work_g, &w->first_g, &w->tiles_g, &w->part_p, &w->part_g, &w->AtA_p, &w->Atb_p,
+                    &w->stats_p, &w->AtA_g, &w->Atb_g, &w->stats_g, &w->adj_start, &w->adj, &w->link_edges,
+                    &w->packed, &w->errbuf};
+  for (DevBuf *b : bufs)
+    b->release();
+  delete w;
+}
+
+extern "C" int sage_window_add_keyframe(SageWindow *w, const SageKeyframeView *v, const float *pose12,
+                                        const float *code, float scale)
+{
+  if (!w || !v || !pose12 || !code || w->finalized)
+    return SAGE_E_INVALID;
+  if (!v->feat_pyr || !v->grad_pyr || !v->bias || !v->basis || !v->loc1d || !v->homo || v->N < 0)
+    return SAGE_E_INVALID;
+  w->views.push_back(*v);
+  for (int s = 0; s < 2; ++s)
+  {
+    w->pose[s].insert(w->pose[s].end(), pose12, pose12 + 12);
+    w->code[s].insert(w->code[s].end(), code, code + w->cfg.CS);
+    w->scale[s].push_back(scale);
+  }
+  w->pose_init.insert(w->pose_init.end(), pose12, pose12 + 12);
+  w->scale_init.push_back(scale);
+  return w->K++;
+}
+
+extern "C" int sage_window_add_link(SageWindow *w, int a, int b)
+{
+  if (!w || w->finalized || a == b || a < 0 || b < 0 || a >= w->K || b >= w->K)
+    return SAGE_E_INVALID;
+  w->links.emplace_back(std::min(a, b), std::max(a, b));
+  return (int)w->links.size() - 1;
+}
+
+extern "C" int sage_window_set_shard(SageWindow *w, int rank, int world)
+{
+  if (!w || w->finalized || world < 1 || rank < 0 || rank >= world)
+    return SAGE_E_INVALID;
+  w->rank = rank;
+  w->world = world;
+  return SAGE_OK;
+}
+
+extern "C" int sage_window_num_keyframes(const SageWindow *w) { return w ? w->K : 0; }
+extern "C" int sage_window_num_links(const SageWindow *w) { return w ? (int)w->links.size() : 0; }
+extern "C" int sage_window_block_size(const SageWindow *w) { return w ? w->B : 0; }
+extern "C" size_t sage_window_packed_floats(const SageWindow *w)
+{
+  if (!w)
+    return 0;
+  const size_t BB = (size_t)w->B * w->B;
+  return (size_t)w->K * BB + w->links.size() * BB + (size_t)w->K * w->B + 4;
+}
+extern "C" float *sage_window_packed_dev(SageWindow *w) { return w ? w->packed.as<float>() : nullptr; }
+extern "C" float *sage_window_error_dev(SageWindow *w) { return w ? w->errbuf.as<float>() : nullptr; }
+extern "C" double sage_window_residuals_per_linearize(const SageWindow *w) { return w ? w->residuals_per_lin : 0; }
+extern "C" double sage_window_bytes_per_linearize(const SageWindow *w) { return w ? w->bytes_per_lin : 0; }
+
+template <class T>
+static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t s)
+{
+  int rc = b.reserve(std::max<size_t>(v.size(), 1) * sizeof(T));
+  if (rc)
+    return rc;
+  if (!v.empty())
+    SAGE_HIP(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
+  return 0;
+}
+
+extern "C" int sage_window_finalize(SageWindow *w)
+{
+  if (!w || w->finalized || w->K < 1)
+    return SAGE_E_INVALID;
+  const SageWindowConfig &c = w->cfg;
+  const int CS = c.CS, FS = c.FS, K = w->K;
+  const int H = (int)c.pyr.cam[0].h, W = (int)c.pyr.cam[0].w, HW = H * W;
+  int rc;
+  // ---- variables & depth buffers
+  for (int s = 0; s < 2; ++s)
+  {
+    if ((rc = w->vars[s].reserve((size_t)K * w->VS * sizeof(float))))
+      return rc;
+    if ((rc = upload_vars(w, s)))
+      return rc;
+  }
+  if ((rc = w->dpt.reserve((size_t)K * HW * sizeof(float))) || (rc = w->dgrad.reserve((size_t)K * 2 * HW * sizeof(float))))
+    return rc;
+  for (int s = 0; s < 2; ++s)
+  {
+    std::vector<DepthItem> items(K);
+    for (int k = 0; k < K; ++k)
+    {
+      const float *vp = w->vars[s].as<float>() + (size_t)k * w->VS;
+      items[k] = DepthItem{w->views[k].bias, w->views[k].basis, vp + 13, vp + 12,
+                           w->dpt.as<float>() + (size_t)k * HW, w->dgrad.as<float>() + (size_t)k * 2 * HW};
+    }
+    if ((rc = upload(w->depth_items[s], items, w->stream)))
+      return rc;
+    SAGE_HIP(hipStreamSynchronize(w->stream));
+  }
+  // ---- local links / edges
+  w->local_links.clear();
+  for (size_t l = 0; l < w->links.size(); ++l)
+    if ((int)(l % w->world) == w->rank)
+      w->local_links.push_back((int)l);
+  w->n_edges = 2 * (int)w->local_links.size();
+  std::vector<LinkEdges> le(w->links.size(), LinkEdges{-1, -1});
+  std::vector<int> Nedge(w->n_edges);
+  std::vector<std::vector<AdjEntry>> adjv(K);
+  double residuals = 0, bytes = 0;
+  const double rho = (double)c.pyr.P / (double)HW;
+  for (int s = 0; s < 2; ++s)
+  {
+    std::vector<PhotoEdge> pt(w->n_edges);
+    std::vector<GeoEdge> gt(w->n_edges);
+    for (size_t li = 0; li < w->local_links.size(); ++li)
+    {
+      const int l = w->local_links[li];
+      const int ab[2] = {w->links[l].first, w->links[l].second};
+      for (int dir = 0; dir < 2; ++dir)
+      {
+        const int e = 2 * (int)li + dir;
+        const int k0 = ab[dir], k1 = ab[1 - dir];
+        const SageKeyframeView &v0 = w->views[k0], &v1 = w->views[k1];
+        const float *x0 = w->vars[s].as<float>() + (size_t)k0 * w->VS;
+        const float *x1 = w->vars[s].as<float>() + (size_t)k1 * w->VS;
+        PhotoEdge pe{};
+        pe.feat0 = v0.feat_pyr; pe.feat1 = v1.feat_pyr; pe.grad1 = v1.grad_pyr; pe.bias0 = v0.bias;
+        pe.basis0 = v0.basis; pe.mask1 = c.mask_dev; pe.homo = v0.homo; pe.loc = v0.loc1d; pe.loc_is_i64 = 1;
+        pe.R0 = x0; pe.t0 = x0 + 9; pe.R1 = x1; pe.t1 = x1 + 9; pe.R10 = nullptr; pe.t10 = nullptr;
+        pe.code0 = x0 + 13; pe.scale0 = x0 + 12; pe.N = v0.N;
+        pt[e] = pe;
+        GeoEdge ge{};
+        ge.bias0 = v0.bias; ge.basis0 = v0.basis; ge.dpt1 = w->dpt.as<float>() + (size_t)k1 * HW;
+        ge.dgrad1 = w->dgrad.as<float>() + (size_t)k1 * 2 * HW; ge.basis1 = v1.basis; ge.mask1 = c.mask_dev;
+        ge.homo = v0.homo; ge.loc = v0.loc1d; ge.loc_is_i64 = 1;
+        ge.R0 = x0; ge.t0 = x0 + 9; ge.R1 = x1; ge.t1 = x1 + 9; ge.R10 = nullptr; ge.t10 = nullptr;
+        ge.code0 = x0 + 13; ge.scale0 = x0 + 12; ge.scale1 = x1 + 12; ge.N = v0.N;
+        gt[e] = ge;
+        if (s == 0)
+        {
+          Nedge[e] = v0.N;
+          if (c.use_photo)
+          {
+            adjv[k0].push_back(AdjEntry{0, e, 0});
+            adjv[k1].push_back(AdjEntry{0, e, 1});
+            residuals += (double)c.pyr.levels * v0.N * FS;
+            bytes += (double)v0.N * 4.0 * (4.0 * FS * rho + CS + 6.0);
+          }
+          if (c.use_geo)
+          {
+            adjv[k0].push_back(AdjEntry{1, e, 0});
+            adjv[k1].push_back(AdjEntry{1, e, 1});
+            residuals += (double)v0.N;
+            bytes += (double)v0.N * 4.0 * (2.0 * CS + 9.0);
+          }
+        }
+      }
+      if (s == 0)
+        le[l] = LinkEdges{2 * (int)li, 2 * (int)li + 1};
+    }
+    if ((rc = upload(w->ptab[s], pt, w->stream)) || (rc = upload(w->gtab[s], gt, w->stream)))
+      return rc;
+    SAGE_HIP(hipStreamSynchronize(w->stream));
+  }
+  w->residuals_per_lin = residuals;
+  w->bytes_per_lin = bytes;
+  // ---- work lists
+  WorkList wl;
+  wl.build(Nedge);
+  w->n_work_p = w->n_work_g = (int)wl.work.size();
+  w->tpb_p = w->tpb_g = wl.tiles_per_block;
+  if ((rc = upload(w->work_p, wl.work, w->stream)) || (rc = upload(w->first_p, wl.edge_first, w->stream)) ||
+      (rc = upload(w->tiles_p, wl.edge_tiles, w->stream)))
+    return rc;
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  const size_t Dp = 13 + CS, Dg = 14 + 2 * CS;
+  const size_t ne = std::max(1, w->n_edges);
+  if ((rc = w->part_p.reserve(std::max<size_t>(1, w->n_work_p) * photo_partial_floats(CS) * sizeof(float))) ||
+      (rc = w->part_g.reserve(std::max<size_t>(1, w->n_work_g) * geo_partial_floats(CS) * sizeof(float))) ||
+      (rc = w->AtA_p.reserve(ne * Dp * Dp * sizeof(float))) || (rc = w->Atb_p.reserve(ne * Dp * sizeof(float))) ||
+      (rc = w->stats_p.reserve(ne * 2 * sizeof(float))) || (rc = w->AtA_g.reserve(ne * Dg * Dg * sizeof(float))) ||
+      (rc = w->Atb_g.reserve(ne * Dg * sizeof(float))) || (rc = w->stats_g.reserve(ne * 2 * sizeof(float))))
+    return rc;
+  // ---- adjacency for the assembly
+  std::vector<int32_t> adj_start(K + 1, 0);
+  std::vector<AdjEntry> adj;
+  for (int k = 0; k < K; ++k)
+  {
+    adj_start[k] = (int32_t)adj.size();
+    adj.insert(adj.end(), adjv[k].begin(), adjv[k].end());
+  }
+  adj_start[K] = (int32_t)adj.size();
+  if ((rc = upload(w->adj_start, adj_start, w->stream)) || (rc = upload(w->adj, adj, w->stream)) ||
+      (rc = upload(w->link_edges, le, w->stream)))
+    return rc;
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  if ((rc = w->packed.reserve(sage_window_packed_floats(w) * sizeof(float))) || (rc = w->errbuf.reserve(4 * sizeof(float))))
+    return rc;
+  SAGE_HIP(hipMemsetAsync(w->packed.p, 0, sage_window_packed_floats(w) * sizeof(float), w->stream));
+  SAGE_HIP(hipMemsetAsync(w->errbuf.p, 0, 4 * sizeof(float), w->stream));
+  w->host_packed.assign(sage_window_packed_floats(w), 0.f);
+  w->delta.assign((size_t)K * w->B, 0.0);
+  w->finalized = true;
+  return SAGE_OK;
+}
+
+static LaunchCommon window_lc(SageWindow *w, bool photo)
+{
+  LaunchCommon lc{};
+  lc.work = w->work_p.as<WorkItem>();
+  lc.edge_first = w->first_p.as<int32_t>();
+  lc.edge_tiles = w->tiles_p.as<int32_t>();
+  lc.n_work = w->n_work_p;
+  lc.n_edges = w->n_edges;
+  lc.partials = photo ? w->part_p.as<float>() : w->part_g.as<float>();
+  lc.tiles_per_block = w->tpb_p;
+  return lc;
+}
+
+extern "C" int sage_window_linearize(SageWindow *w)
+{
+  if (!w || !w->finalized)
+    return SAGE_E_STATE;
+  const SageWindowConfig &c = w->cfg;
+  const int H = (int)c.pyr.cam[0].h, W = (int)c.pyr.cam[0].w;
+  if (w->n_edges > 0)
+  {
+    if (c.use_photo)
+    {
+      EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>()};
+      SAGE_HIP(launch_photo_linearize(w->stream, c.CS, c.FS, nullptr, w->ptab[0].as<PhotoEdge>(), window_lc(w, true),
+                                      c.pyr, c.photo_weights, c.eps, out));
+    }
+    if (c.use_geo)
+    {
+      SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[0].as<DepthItem>(), w->K, H, W));
+      EdgeOut out{w->AtA_g.as<float>(), w->Atb_g.as<float>(), w->stats_g.as<float>()};
+      SAGE_HIP(launch_geo_linearize(w->stream, c.CS, nullptr, w->gtab[0].as<GeoEdge>(), window_lc(w, false),
+                                    c.pyr.cam[0], c.eps, c.geo_loss_param, c.geo_weight, out));
+    }
+  }
+  AssembleParams ap{};
+  const bool has = w->n_edges > 0;
+  ap.AtA_p = (has && c.use_photo) ? w->AtA_p.as<float>() : nullptr;
+  ap.Atb_p = w->Atb_p.as<float>();
+  ap.stats_p = (has && c.use_photo) ? w->stats_p.as<float>() : nullptr;
+  ap.AtA_g = (has && c.use_geo) ? w->AtA_g.as<float>() : nullptr;
+  ap.Atb_g = w->Atb_g.as<float>();
+  ap.stats_g = (has && c.use_geo) ? w->stats_g.as<float>() : nullptr;
+  ap.adj_start = w->adj_start.as<int32_t>();
+  ap.adj = w->adj.as<AdjEntry>();
+  ap.links = w->link_edges.as<LinkEdges>();
+  ap.packed = w->packed.as<float>();
+  ap.K = w->K;
+  ap.nlinks = (int)w->links.size();
+  ap.CS = c.CS;
+  ap.n_edges_p = w->n_edges;
+  ap.n_edges_g = w->n_edges;
+  hipLaunchKernelGGL(assemble_kernel, dim3(w->K + ap.nlinks + 1), dim3(256), 0, w->stream, ap);
+  SAGE_HIP(hipGetLastError());
+  w->have_lin = true;
+  return SAGE_OK;
+}
+
+extern "C" int sage_window_error(SageWindow *w, int which)
+{
+  if (!w || !w->finalized || which < 0 || which > 1)
+    return SAGE_E_STATE;
+  const SageWindowConfig &c = w->cfg;
+  const int H = (int)c.pyr.cam[0].h, W = (int)c.pyr.cam[0].w;
+  const bool has = w->n_edges > 0;
+  if (has && c.use_photo)
+  {
+    LaunchCommon lc = window_lc(w, true);
+    SAGE_HIP(launch_photo_error(w->stream, c.CS, c.FS, nullptr, w->ptab[which].as<PhotoEdge>(), lc, c.pyr,
+                                c.photo_weights, c.eps, w->stats_p.as<float>()));
+  }
+  if (has && c.use_geo)
+  {
+    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[which].as<DepthItem>(), w->K, H, W));
+    LaunchCommon lc = window_lc(w, false);
+    SAGE_HIP(launch_geo_error(w->stream, c.CS, nullptr, w->gtab[which].as<GeoEdge>(), lc, c.pyr.cam[0], c.eps,
+                              c.geo_loss_param, c.geo_weight, w->stats_g.as<float>()));
+  }
+  hipLaunchKernelGGL(sum_stats_kernel, dim3(1), dim3(64), 0, w->stream,
+                     (has && c.use_photo) ? w->stats_p.as<float>() : nullptr, w->n_edges,
+                     (has && c.use_geo) ? w->stats_g.as<float>() : nullptr, w->n_edges, w->errbuf.as<float>());
+  SAGE_HIP(hipGetLastError());
+  return SAGE_OK;
+}
+
+// prior error terms at a variable set (a9): code prior w*||c||^2/CS per keyframe (code_factor.cpp:99-104, zero
+// prior code), scale prior on keyframe 0 w*(ln s0 - ln s)^2 (scale_factor.cpp:102-129), pose prior on kf 0.
+static void pose_local(const float *origin, const float *other, double out[6])
+{
+  // gtsam_traits.h:78-89 : [t1 - R1 R0^T t0, log(R1 R0^T)]
+  double Rr[9];
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j)
+      Rr[i * 3 + j] = (double)other[i * 3 + 0] * origin[j * 3 + 0] + (double)other[i * 3 + 1] * origin[j * 3 + 1] +
+                      (double)other[i * 3 + 2] * origin[j * 3 + 2];
+  for (int i = 0; i < 3; ++i)
+    out[i] = other[9 + i] - (Rr[i * 3 + 0] * origin[9] + Rr[i * 3 + 1] * origin[10] + Rr[i * 3 + 2] * origin[11]);
+  const double tr = Rr[0] + Rr[4] + Rr[8];
+  const double cs = std::min(1.0, std::max(-1.0, 0.5 * (tr - 1.0)));
+  const double th = std::acos(cs);
+  const double k = th < 1e-8 ? 0.5 : th / (2.0 * std::sin(th));
+  out[3] = k * (Rr[7] - Rr[5]);
+  out[4] = k * (Rr[2] - Rr[6]);
+  out[5] = k * (Rr[3] - Rr[1]);
+}
+
+static double prior_error(const SageWindow *w, int set)
+{
+  const SageWindowConfig &c = w->cfg;
+  double e = 0;
+  for (int k = 0; k < w->K; ++k)
+  {
+    double s = 0;
+    for (int i = 0; i < c.CS; ++i)
+      s += (double)w->code[set][(size_t)k * c.CS + i] * w->code[set][(size_t)k * c.CS + i];
+    e += c.code_prior_weight * s / c.CS;
+  }
+  if (c.scale_prior_weight > 0)
+  {
+    const double d = std::log((double)w->scale_init[0]) - std::log((double)w->scale[set][0]);
+    e += c.scale_prior_weight * d * d;
+  }
+  if (c.pose_prior_weight > 0)
+  {
+    double loc[6];
+    pose_local(&w->pose[set][0], &w->pose_init[0], loc);
+    for (int i = 0; i < 6; ++i)
+      e += c.pose_prior_weight * loc[i] * loc[i];
+  }
+  return e;
+}
+
+extern "C" int sage_window_total_error(SageWindow *w, int from_linearize, double *err)
+{
+  if (!w || !w->finalized || !err)
+    return SAGE_E_STATE;
+  float t[4];
+  if (from_linearize)
+  {
+    const size_t off = sage_window_packed_floats(w) - 4;
+    SAGE_HIP(hipMemcpyAsync(t, w->packed.as<float>() + off, 4 * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+  }
+  else
+    SAGE_HIP(hipMemcpyAsync(t, w->errbuf.p, 4 * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  *err = (double)t[0] + (double)t[1] + prior_error(w, from_linearize ? 0 : 1);
+  return SAGE_OK;
+}
+
+extern "C" int sage_window_solve(SageWindow *w, double damp, double *step_norm)
+{
+  if (!w || !w->finalized || !w->have_lin)
+    return SAGE_E_STATE;
+  const SageWindowConfig &c = w->cfg;
+  const int K = w->K, B = w->B, CS = c.CS, BB = B * B, n = K * B;
+  const size_t np = sage_window_packed_floats(w);
+  SAGE_HIP(hipMemcpyAsync(w->host_packed.data(), w->packed.p, np * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  // diagonal priors (a9): code prior on every keyframe, scale / pose priors on keyframe 0
+  std::vector<double> dadd((size_t)n, 0.0), gadd((size_t)n, 0.0);
+  for (int k = 0; k < K; ++k)
+    for (int i = 0; i < CS; ++i)
+    {
+      dadd[k * B + 6 + i] += c.code_prior_weight;
+      gadd[k * B + 6 + i] += c.code_prior_weight * (0.0 - (double)w->code[0][(size_t)k * CS + i]);
+    }
+  if (c.scale_prior_weight > 0)
+  {
+    const double s = w->scale[0][0];
+    dadd[6 + CS] += c.scale_prior_weight / (s * s);
+    gadd[6 + CS] += c.scale_prior_weight / s * (std::log((double)w->scale_init[0]) - std::log(s));
+  }
+  if (c.pose_prior_weight > 0)
+  {
+    double loc[6];
+    pose_local(&w->pose[0][0], &w->pose_init[0], loc);
+    for (int i = 0; i < 6; ++i)
+    {
+      dadd[i] += c.pose_prior_weight;
+      gadd[i] += c.pose_prior_weight * loc[i];
+    }
+  }
+  std::vector<int32_t> lk(2 * w->links.size());
+  for (size_t l = 0; l < w->links.size(); ++l)
+  {
+    lk[2 * l] = w->links[l].first;
+    lk[2 * l + 1] = w->links[l].second;
+  }
+  std::vector<double> rhs((size_t)n);
+  (void)BB;
+  int rcs = sage_block_solve(w->host_packed.data(), K, (int)w->links.size(), lk.data(), B, damp, dadd.data(),
+                             gadd.data(), rhs.data());
+  if (rcs)
+    return rcs;
+  w->delta = rhs;
+  double nrm = 0;
+  for (double v : rhs)
+    nrm += v * v;
+  if (step_norm)
+    *step_norm = std::sqrt(nrm);
+  // candidate = retract(current, delta)
+  for (int k = 0; k < K; ++k)
+  {
+    float d6[6];
+    for (int i = 0; i < 6; ++i)
+      d6[i] = (float)rhs[k * B + i];
+    sage_pose_retract(&w->pose[0][(size_t)k * 12], d6, &w->pose[1][(size_t)k * 12]);
+    for (int i = 0; i < CS; ++i)
+      w->code[1][(size_t)k * CS + i] = w->code[0][(size_t)k * CS + i] + (float)rhs[k * B + 6 + i];
+    w->scale[1][k] = w->scale[0][k] + (float)rhs[k * B + 6 + CS];
+  }
+  return upload_vars(w, 1);
+}
+
+extern "C" int sage_window_accept(SageWindow *w)
+{
+  if (!w || !w->finalized)
+    return SAGE_E_STATE;
+  w->pose[0] = w->pose[1];
+  w->code[0] = w->code[1];
+  w->scale[0] = w->scale[1];
+  SAGE_HIP(hipMemcpyAsync(w->vars[0].p, w->vars[1].p, (size_t)w->K * w->VS * sizeof(float), hipMemcpyDeviceToDevice,
+                          w->stream));
+  return SAGE_OK;
+}
+
+extern "C" int sage_window_get_keyframe(const SageWindow *w, int kf, float *pose12, float *code, float *scale)
+{
+  if (!w || kf < 0 || kf >= w->K)
+    return SAGE_E_INVALID;
+  if (pose12)
+    std::memcpy(pose12, &w->pose[0][(size_t)kf * 12], 12 * sizeof(float));
+  if (code)
+    std::memcpy(code, &w->code[0][(size_t)kf * w->cfg.CS], w->cfg.CS * sizeof(float));
+  if (scale)
+    *scale = w->scale[0][kf];
+  return SAGE_OK;
+}
+
+extern "C" int sage_window_set_keyframe(SageWindow *w, int kf, const float *pose12, const float *code, float scale)
+{
+  if (!w || kf < 0 || kf >= w->K || !pose12 || !code)
+    return SAGE_E_INVALID;
+  for (int s = 0; s < 2; ++s)
+  {
+    std::memcpy(&w->pose[s][(size_t)kf * 12], pose12, 12 * sizeof(float));
+    std::memcpy(&w->code[s][(size_t)kf * w->cfg.CS], code, w->cfg.CS * sizeof(float));
+    w->scale[s][kf] = scale;
+  }
+  if (w->finalized)
+  {
+    int rc;
+    if ((rc = upload_vars(w, 0)) || (rc = upload_vars(w, 1)))
+      return rc;
+  }
+  return SAGE_OK;
+}
+
+extern "C" int sage_window_get_delta(const SageWindow *w, double *delta)
+{
+  if (!w || !delta)
+    return SAGE_E_INVALID;
+  std::memcpy(delta, w->delta.data(), w->delta.size() * sizeof(double));
+  return SAGE_OK;
+}
+
+extern "C" int sage_window_get_edge(const SageWindow *w, int type, int e, float *AtA, float *Atb, float *err,
+                                    float *n_in)
+{
+  if (!w || !w->finalized || (type != 0 && type != 1))
+    return SAGE_E_INVALID;
+  // e is the global directed-edge index: link e/2, direction e%2 ; map to the local index
+  const int l = e / 2, dir = e % 2;
+  int li = -1;
+  for (size_t i = 0; i < w->local_links.size(); ++i)
+    if (w->local_links[i] == l)
+      li = (int)i;
+  if (li < 0)
+    return SAGE_E_INVALID;
+  const int le = 2 * li + dir;
+  const size_t D = type == 0 ? 13 + w->cfg.CS : 14 + 2 * w->cfg.CS;
+  const DevBuf &A = type == 0 ? w->AtA_p : w->AtA_g, &b = type == 0 ? w->Atb_p : w->Atb_g,
+               &st = type == 0 ? w->stats_p : w->stats_g;
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  if (AtA)
+    SAGE_HIP(hipMemcpy(AtA, A.as<float>() + (size_t)le * D * D, D * D * sizeof(float), hipMemcpyDeviceToHost));
+  if (Atb)
+    SAGE_HIP(hipMemcpy(Atb, b.as<float>() + (size_t)le * D, D * sizeof(float), hipMemcpyDeviceToHost));
+  float s2[2];
+  SAGE_HIP(hipMemcpy(s2, st.as<float>() + (size_t)le * 2, 2 * sizeof(float), hipMemcpyDeviceToHost));
+  if (err)
+    *err = s2[0];
+  if (n_in)
+    *n_in = s2[1];
+  return SAGE_OK;
+}
+
+extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmConfig *cfg)
+{
+  if (!w || !st || !cfg)
+    return SAGE_E_INVALID;
+  int rc;
+  if (st->iters == 0 && st->damp <= 0)
+    st->damp = cfg->init_damp;
+  auto clampd = [&](double d) { return std::min(std::max((double)cfg->min_damp, d), (double)cfg->max_damp); };
+  if ((rc = sage_window_linearize(w)))
+    return rc;
+  if ((rc = sage_window_total_error(w, 1, &st->error)))
+    return rc;
+  int evals = 0;
+  st->accepted = 0;
+  while (true)
+  {
+    double step;
+    if ((rc = sage_window_solve(w, st->damp, &step)))
+      return rc;
+    if ((rc = sage_window_error(w, 1)))
+      return rc;
+    if ((rc = sage_window_total_error(w, 0, &st->candidate_error)))
+      return rc;
+    ++evals;
+    if (st->candidate_error < st->error)
+    {
+      st->accepted = 1;
+      break;
+    }
+    if (st->damp >= cfg->max_damp || (cfg->max_inner_evals > 0 && evals >= cfg->max_inner_evals))
+    {
+      st->damp = clampd(st->damp * cfg->damp_inc_factor);
+      break;
+    }
+    st->damp = clampd(st->damp * cfg->damp_inc_factor);
+  }
+  if (st->accepted)
+  {
+    if ((rc = sage_window_accept(w)))
+      return rc;
+    st->damp = clampd(st->damp / cfg->damp_dec_factor);
+  }
+  st->iters += 1;
+  return SAGE_OK;
+}

@@ -1,0 +1,141 @@
+// sage_internal.h -- structs shared by the host runtime and the kernels (not part of the C ABI).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "sage_ba.h"
+
+namespace sage
+{
+
+constexpr int kBlock = 256;          // 4 waves of 64
+constexpr int kWaves = kBlock / 64;
+constexpr int kTile = 256;           // source pixels per sub-tile (one per lane)
+
+// One directed photometric edge kf0 -> kf1 (a1/a2).  All pointers are device pointers.
+struct PhotoEdge
+{
+  const float *feat0;   // [FS,P]  source pyramid
+  const float *feat1;   // [FS,P]  destination pyramid
+  const float *grad1;   // [2,FS,P]
+  const float *bias0;   // [H*W]
+  const float *basis0;  // [H*W,CS]
+  const float *mask1;   // [H,W]
+  const float *homo;    // [N,3]
+  const void *loc;      // [N] int64 or int32
+  const float *R0, *t0; // world-from-kf0 (9 row-major, 3)
+  const float *R1, *t1; // world-from-kf1
+  const float *R10, *t10; // optional relative pose; nullptr -> computed in-kernel from (R0,t0),(R1,t1)
+  const float *code0;   // [CS]
+  const float *scale0;  // 1 float (device) or nullptr -> scale0_val
+  float scale0_val;
+  int32_t N;
+  int32_t loc_is_i64;
+};
+
+// One directed geometric edge kf0 -> kf1 (a4/a5).
+struct GeoEdge
+{
+  const float *bias0;   // [H*W]
+  const float *basis0;  // [H*W,CS]
+  const float *dpt1;    // [H,W]   s1*(bias1+basis1*code1)
+  const float *dgrad1;  // [2,H,W]
+  const float *basis1;  // [H,W,CS]
+  const float *mask1;   // [H,W]
+  const float *homo;    // [N,3]
+  const void *loc;      // [N]
+  const float *R0, *t0, *R1, *t1, *R10, *t10;
+  const float *code0;
+  const float *scale0, *scale1; // device scalars or nullptr -> *_val
+  float scale0_val, scale1_val;
+  int32_t N;
+  int32_t loc_is_i64;
+};
+
+// Tracker edge (a3): relative pose only, pre-sampled source features.
+struct TrackEdge
+{
+  const float *feat0s;  // [L,N,FS]
+  const float *feat1;   // [FS,P]
+  const float *grad1;   // [2,FS,P]
+  const float *mask1;
+  const float *homo;    // [N,3]
+  const float *dpts0;   // [N]
+  const float *R, *t;   // relative pose T10 (device)
+  const float *weights; // [L] device
+  float scale0;
+  int32_t N;
+};
+
+struct WorkItem
+{
+  int32_t edge;
+  int32_t tile;
+};
+
+// partial-sum layouts (floats per workgroup)
+//   photometric: 40 scalars (37 used) + NT tiles of 16x16 MFMA accumulators (raw [tile][reg][lane])
+//     CS=32: tiles {cc00, cc01, cc11, X_lo, X_hi};  CS=16: {cc00, X_lo}
+//   geometric:   48 scalars (48 used) + NT tiles
+//     t = [kappa*b0 (CS) ; beta (CS)] -> n16 = 2CS/16 column blocks; tiles: upper triangle of T (n16*(n16+1)/2)
+//     then n16 cross tiles (rows = y, 16 padded)
+constexpr int kPhotoScalars = 40;
+constexpr int kGeoScalars = 48;
+__host__ __device__ constexpr int photo_tiles(int CS) { return CS == 32 ? 5 : 2; }
+__host__ __device__ constexpr int photo_partial_floats(int CS) { return kPhotoScalars + photo_tiles(CS) * 256; }
+__host__ __device__ constexpr int geo_n16(int CS) { return 2 * CS / 16; }
+__host__ __device__ constexpr int geo_tiles(int CS) { return geo_n16(CS) * (geo_n16(CS) + 1) / 2 + geo_n16(CS); }
+__host__ __device__ constexpr int geo_partial_floats(int CS) { return kGeoScalars + geo_tiles(CS) * 256; }
+constexpr int kTrackScalars = 40; // 28 (7x7 upper) + 7 + err + valid
+
+struct LaunchCommon
+{
+  const WorkItem *work;      // [n_work]
+  const int32_t *edge_first; // [n_edges] first work index of each edge
+  const int32_t *edge_tiles; // [n_edges]
+  int32_t n_work;
+  int32_t n_edges;
+  float *partials;           // [n_work][partial_floats]
+  int32_t tiles_per_block;   // consecutive kTile sub-tiles per work item (work[i].tile = first sub-tile)
+};
+
+// per-edge results, reference layouts
+struct EdgeOut
+{
+  float *AtA;   // [n_edges][D*D]
+  float *Atb;   // [n_edges][D]
+  float *stats; // [n_edges][2] = {error, num_inliers}
+};
+
+// ---- launchers (implemented in the .hip files) ----
+hipError_t launch_photo_linearize(hipStream_t s, int CS, int FS, const PhotoEdge *single, const PhotoEdge *table,
+                                  const LaunchCommon &lc, const SagePyramid &pyr, const float *weights_host,
+                                  float eps, const EdgeOut &out);
+hipError_t launch_photo_error(hipStream_t s, int CS, int FS, const PhotoEdge *single, const PhotoEdge *table,
+                              const LaunchCommon &lc, const SagePyramid &pyr, const float *weights_host,
+                              float eps, float *stats /*[n_edges][2]*/);
+hipError_t launch_geo_linearize(hipStream_t s, int CS, const GeoEdge *single, const GeoEdge *table,
+                                const LaunchCommon &lc, const SageCamera &cam, float eps, float loss_param,
+                                float weight, const EdgeOut &out);
+hipError_t launch_geo_error(hipStream_t s, int CS, const GeoEdge *single, const GeoEdge *table,
+                            const LaunchCommon &lc, const SageCamera &cam, float eps, float loss_param,
+                            float weight, float *stats);
+hipError_t launch_track_linearize(hipStream_t s, int dof, int FS, const TrackEdge &edge, const LaunchCommon &lc,
+                                  const SagePyramid &pyr, float eps, const EdgeOut &out);
+hipError_t launch_track_error(hipStream_t s, int FS, const TrackEdge &edge, const LaunchCommon &lc,
+                              const SagePyramid &pyr, float eps, float *stats);
+hipError_t launch_depth_and_grad(hipStream_t s, int CS, float *dpt, float *grad, const float *bias,
+                                 const float *basis, const float *code, const float *scale_dev, float scale,
+                                 int H, int W);
+struct DepthItem
+{
+  const float *bias, *basis, *code, *scale;
+  float *dpt, *grad;
+};
+hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev, int K, int H, int W);
+hipError_t launch_stats_finalize(hipStream_t s, const LaunchCommon &lc, float *stats, float fallback, float scale);
+hipError_t launch_gaussian_pyramid_with_grad(hipStream_t s, float *pyr, float *grad, const float *feat,
+                                             const float *mask, const SagePyramid &p, int FS, float *scratch_mask);
+
+} // namespace sage

@@ -1,0 +1,293 @@
+"""GPU parity tests: the HIP engine (through the C ABI) against the CPU oracle on identical seeded inputs.
+
+Tolerances (north_star: fp32, pose/code deltas within 1e-4 rel-L2 of the reference):
+  * per-edge AtA / Atb        rel-L2 (Frobenius) <= 2e-5   (fp32 accumulation-order noise is ~1e-6)
+  * error, num_inliers        rel <= 1e-5 / exact
+  * LM-damped deltas          rel-L2 <= 1e-4
+"""
+import numpy as np
+import pytest
+
+from sage_slam_amd import synth
+from tests.helpers import damped_delta, oracle_geo, oracle_photo, presample_source, rel
+
+pytestmark = pytest.mark.gpu
+
+TOL_H = 2e-5
+TOL_DELTA = 1e-4
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from sage_slam_amd import capi as c
+    c.lib()
+    return c
+
+
+@pytest.fixture(scope="module")
+def ws(capi):
+    w = capi.Workspace()
+    yield w
+    w.close()
+
+
+def dev_window(capi, w):
+    import torch
+    pyr = capi.make_pyramid(w.cams[0], w.L)
+    mask = torch.from_numpy(w.mask).cuda()
+    kfs = [capi.DeviceKeyframe(k, w.H, w.W) for k in w.keyframes]
+    return pyr, mask, kfs
+
+
+def hip_photo(capi, ws, w, pyr, mask, kfs, k0, k1, jac=True):
+    a, b = w.keyframes[k0], w.keyframes[k1]
+    R10, t10 = synth.relative_pose(a.R, a.t, b.R, b.t)
+    if jac:
+        return capi.photometric_jac_error(ws, R10, t10, a.R, a.t, b.R, b.t, kfs[k0].bias, kfs[k0].basis, a.code, mask,
+                                          kfs[k0].loc1d, kfs[k0].homo, kfs[k0].feat_pyr, kfs[k1].feat_pyr,
+                                          kfs[k1].grad_pyr, a.scale, pyr, w.eps, w.photo_weights, w.FS, w.CS)
+    e, n = capi.photometric_error(ws, R10, t10, kfs[k0].bias, kfs[k0].basis, a.code, mask, kfs[k0].loc1d,
+                                  kfs[k0].homo, kfs[k0].feat_pyr, kfs[k1].feat_pyr, a.scale, pyr, w.eps,
+                                  w.photo_weights, w.FS, w.CS)
+    return dict(error=e, num_inliers=n)
+
+
+def hip_geo(capi, ws, w, pyr, mask, kfs, k0, k1, jac=True):
+    import torch
+    a, b = w.keyframes[k0], w.keyframes[k1]
+    R10, t10 = synth.relative_pose(a.R, a.t, b.R, b.t)
+    dpt, grad = capi.depth_and_grad(ws, kfs[k1].bias, kfs[k1].basis, b.code, b.scale, w.H, w.W, w.CS)
+    cam = pyr.cam[0]
+    if jac:
+        return capi.geometric_jac_error(ws, R10, t10, a.R, a.t, b.R, b.t, kfs[k0].bias, kfs[k0].basis, a.code, dpt,
+                                        grad, kfs[k1].basis, mask, kfs[k0].loc1d_i32, kfs[k0].homo, a.scale, b.scale,
+                                        cam, w.eps, w.geo_loss_param, w.geo_weight, w.CS)
+    e, n = capi.geometric_error(ws, R10, t10, kfs[k0].bias, kfs[k0].basis, a.code, dpt, mask, kfs[k0].loc1d_i32,
+                                kfs[k0].homo, a.scale, cam, w.eps, w.geo_loss_param, w.geo_weight, w.CS)
+    return dict(error=e, num_inliers=n)
+
+
+CASES = [
+    dict(K=2, H=32, W=40, FS=16, CS=32, L=3, n_samples=0, seed=1),      # dense, N=384 (ragged last tile)
+    dict(K=2, H=64, W=80, FS=16, CS=16, L=4, n_samples=3072, seed=2),   # reference defaults (slam_run.flags)
+    dict(K=2, H=64, W=80, FS=16, CS=32, L=4, n_samples=700, seed=3),    # sampled, N % 256 != 0
+    dict(K=2, H=32, W=40, FS=32, CS=32, L=2, n_samples=50, seed=4),     # N < one wave; FS=32
+    dict(K=2, H=64, W=80, FS=32, CS=16, L=4, n_samples=0, seed=5),      # dense N=2400+
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"{c['H']}x{c['W']}_FS{c['FS']}_CS{c['CS']}_L{c['L']}_N{c['n_samples']}")
+def test_photometric_linearize_and_error(capi, ws, orc, case):
+    w = synth.make_window(**case)
+    pyr, mask, kfs = dev_window(capi, w)
+    for k0, k1 in ((0, 1), (1, 0)):
+        o = oracle_photo(orc, w, k0, k1)
+        h = hip_photo(capi, ws, w, pyr, mask, kfs, k0, k1)
+        assert h["num_inliers"] == o["num_inliers"] and o["num_inliers"] > 0
+        assert h["error"] == pytest.approx(o["error"], rel=1e-5)
+        assert rel(h["AtA"], o["AtA"]) < TOL_H
+        assert rel(h["Atb"], o["Atb"]) < TOL_H
+        # damped GN step of this single edge (gauge fixed by the damping)
+        D = o["AtA"].shape[0]
+        do = damped_delta(o["AtA"].astype(np.float64) + 1e-6 * np.eye(D), o["Atb"].astype(np.float64), 1e-2)
+        dh = damped_delta(h["AtA"].astype(np.float64) + 1e-6 * np.eye(D), h["Atb"].astype(np.float64), 1e-2)
+        assert rel(dh, do) < TOL_DELTA
+        oe = oracle_photo(orc, w, k0, k1, jac=False)
+        he = hip_photo(capi, ws, w, pyr, mask, kfs, k0, k1, jac=False)
+        assert he["num_inliers"] == oe["num_inliers"]
+        assert he["error"] == pytest.approx(oe["error"], rel=1e-5)
+
+
+@pytest.mark.parametrize("case", CASES[:4], ids=lambda c: f"{c['H']}x{c['W']}_CS{c['CS']}_N{c['n_samples']}")
+def test_geometric_linearize_and_error(capi, ws, orc, case):
+    w = synth.make_window(**case)
+    pyr, mask, kfs = dev_window(capi, w)
+    for k0, k1 in ((0, 1), (1, 0)):
+        o = oracle_geo(orc, w, k0, k1)
+        h = hip_geo(capi, ws, w, pyr, mask, kfs, k0, k1)
+        assert h["num_inliers"] == o["num_inliers"] and o["num_inliers"] > 0
+        assert h["error"] == pytest.approx(o["error"], rel=2e-5)
+        assert rel(h["AtA"], o["AtA"]) < TOL_H
+        assert rel(h["Atb"], o["Atb"]) < TOL_H
+        oe = oracle_geo(orc, w, k0, k1, jac=False)
+        he = hip_geo(capi, ws, w, pyr, mask, kfs, k0, k1, jac=False)
+        assert he["num_inliers"] == oe["num_inliers"]
+        assert he["error"] == pytest.approx(oe["error"], rel=2e-5)
+
+
+def test_zero_overlap_fallback(capi, ws, orc):
+    """no inliers -> error = 10*sum(w) / 10*weight, AtA = Atb = 0 (not an error)."""
+    w = synth.make_window(K=2, H=32, W=40, FS=16, CS=32, L=3, seed=7)
+    w.keyframes[1].t = w.keyframes[1].t + (w.keyframes[1].R @ np.array([0, 0, 50.0], np.float32))
+    pyr, mask, kfs = dev_window(capi, w)
+    h = hip_photo(capi, ws, w, pyr, mask, kfs, 0, 1)
+    assert h["num_inliers"] == 0 and h["error"] == pytest.approx(10 * float(w.photo_weights.sum()))
+    assert not h["AtA"].any() and not h["Atb"].any()
+    g = hip_geo(capi, ws, w, pyr, mask, kfs, 0, 1)
+    assert g["num_inliers"] == 0 and g["error"] == pytest.approx(10 * w.geo_weight) and not g["AtA"].any()
+    assert hip_photo(capi, ws, w, pyr, mask, kfs, 0, 1, jac=False)["error"] == pytest.approx(10 * float(w.photo_weights.sum()))
+
+
+def test_partially_masked_and_negative_depth(capi, ws, orc):
+    """destination mask with holes + some samples behind the camera (mixed validity inside a wave)."""
+    w = synth.make_window(K=2, H=64, W=80, FS=16, CS=32, L=4, n_samples=1000, seed=9)
+    rng = np.random.default_rng(0)
+    w.mask = (w.mask * (rng.uniform(size=w.mask.shape) < 0.8)).astype(np.float32)
+    w.keyframes[0].bias[w.keyframes[0].loc1d[::7]] = -0.4        # negative depth for every 7th sample
+    pyr, mask, kfs = dev_window(capi, w)
+    o = oracle_photo(orc, w, 0, 1); h = hip_photo(capi, ws, w, pyr, mask, kfs, 0, 1)
+    assert 0 < o["num_inliers"] < 1000 and h["num_inliers"] == o["num_inliers"]
+    assert rel(h["AtA"], o["AtA"]) < TOL_H and rel(h["Atb"], o["Atb"]) < TOL_H
+    assert h["error"] == pytest.approx(o["error"], rel=1e-5)
+    og = oracle_geo(orc, w, 0, 1); hg = hip_geo(capi, ws, w, pyr, mask, kfs, 0, 1)
+    assert hg["num_inliers"] == og["num_inliers"]
+    assert rel(hg["AtA"], og["AtA"]) < TOL_H and rel(hg["Atb"], og["Atb"]) < TOL_H
+
+
+@pytest.mark.parametrize("dof", [6, 7])
+def test_tracker_linearize_and_error(capi, ws, orc, dof):
+    import torch
+    w = synth.make_window(K=2, H=64, W=80, FS=16, CS=32, L=4, n_samples=3072, seed=11)   # BASELINE config 1
+    pyr, mask, kfs = dev_window(capi, w)
+    a, b = w.keyframes[0], w.keyframes[1]
+    R10, t10 = synth.relative_pose(a.R, a.t, b.R, b.t)
+    feat0s = presample_source(orc, w, a)
+    dpts0 = (np.float32(a.scale) * (a.bias + a.basis @ a.code))[a.loc1d].astype(np.float32)
+    o = orc.tracker_photo_jac_error(dof, R10, t10, w.mask, dpts0, a.homo, feat0s, b.feat_pyr, b.grad_pyr,
+                                    w.level_offsets, w.cams, w.eps, w.photo_weights, scale0=a.scale)
+    wd = torch.from_numpy(w.photo_weights).cuda()
+    f0 = torch.from_numpy(feat0s).cuda(); dp = torch.from_numpy(dpts0).cuda()
+    h = capi.tracker_photo_jac_error(ws, dof, R10, t10, mask, dp, kfs[0].homo, f0, kfs[1].feat_pyr,
+                                     kfs[1].grad_pyr, pyr, a.scale, w.eps, wd, w.FS)
+    assert h["num_inliers"] == o["num_inliers"] > 0
+    assert h["error"] == pytest.approx(o["error"], rel=1e-5)
+    assert rel(h["AtA"], o["AtA"]) < TOL_H and rel(h["Atb"], o["Atb"]) < TOL_H
+    do = damped_delta(o["AtA"].astype(np.float64), o["Atb"].astype(np.float64), 1e-4)
+    dh = damped_delta(h["AtA"].astype(np.float64), h["Atb"].astype(np.float64), 1e-4)
+    assert rel(dh, do) < TOL_DELTA
+    oe, on = orc.tracker_photo_error(R10, t10, w.mask, dpts0, a.homo, feat0s, b.feat_pyr, w.level_offsets, w.cams,
+                                     w.eps, w.photo_weights)
+    he, hn = capi.tracker_photo_error(ws, R10, t10, mask, dp, kfs[0].homo, f0, kfs[1].feat_pyr, pyr, w.eps, wd, w.FS)
+    assert hn == on and he == pytest.approx(oe, rel=1e-5)
+
+
+def test_producers_match_oracle(capi, ws, orc):
+    import torch
+    w = synth.make_window(K=1, H=64, W=80, FS=16, CS=32, L=4, seed=13)
+    kf = w.keyframes[0]
+    pyr = capi.make_pyramid(w.cams[0], w.L)
+    feat = kf.feat_pyr[:, :w.H * w.W].reshape(w.FS, w.H, w.W)
+    op, og = orc.gaussian_pyramid_with_grad(feat, w.mask, w.L, w.level_offsets, w.P)
+    hp, hg = capi.gaussian_pyramid_with_grad(ws, torch.from_numpy(np.ascontiguousarray(feat)).cuda(),
+                                             torch.from_numpy(w.mask).cuda(), pyr, w.FS)
+    assert rel(hp.cpu().numpy(), op) < 1e-6 and rel(hg.cpu().numpy(), og) < 1e-6
+    d, g = capi.depth_and_grad(ws, torch.from_numpy(kf.bias).cuda(), torch.from_numpy(kf.basis).cuda(), kf.code,
+                               kf.scale, w.H, w.W, w.CS)
+    od = orc.update_depth(kf.bias, kf.basis, kf.code, kf.scale).reshape(w.H, w.W)
+    ogd = orc.spatial_grad(od[None])[:, 0]
+    assert rel(d.cpu().numpy(), od) < 1e-6 and rel(g.cpu().numpy(), ogd) < 1e-5
+
+
+@pytest.mark.parametrize("CS", [16, 32])
+def test_window_assembly_and_delta(capi, orc, CS):
+    """batched engine: packed normal equations == sum of per-edge oracle results; LM delta
+    within 1e-4 rel-L2 of the fp64 solve of the oracle-assembled system."""
+    w = synth.make_window(K=5, H=32, W=40, FS=16, CS=CS, L=3, seed=21, back_links=2)
+    win = capi.Window(w)
+    win.linearize()
+    packed = win.packed_host().astype(np.float64)
+    res = {}
+    for l, (a, b) in enumerate(w.links):
+        for d, (k0, k1) in enumerate(((a, b), (b, a))):
+            res[(0, l, d)] = oracle_photo(orc, w, k0, k1)
+            res[(1, l, d)] = oracle_geo(orc, w, k0, k1)
+            for t in (0, 1):
+                he = win.get_edge(t, 2 * l + d)
+                assert rel(he["AtA"], res[(t, l, d)]["AtA"]) < TOL_H
+                assert he["num_inliers"] == res[(t, l, d)]["num_inliers"]
+    ref = capi.assemble_packed(len(w.keyframes), w.links, CS, res)
+    assert rel(packed[:-4], ref[:-4]) < TOL_H
+    assert packed[-4:] == pytest.approx(ref[-4:], rel=2e-5)
+    # solve: same priors as the engine defaults
+    damp = 1e-3
+    win.solve(damp)
+    dh = win.delta()
+    H, g, _ = capi.unpack_dense(ref, len(w.keyframes), w.links, CS)
+    B = 7 + CS
+    for k, kf in enumerate(w.keyframes):
+        idx = np.arange(k * B + 6, k * B + 6 + CS)
+        H[idx, idx] += 1e-3
+        g[idx] += 1e-3 * (0 - kf.code.astype(np.float64))
+    s = w.keyframes[0].scale
+    H[6 + CS, 6 + CS] += 1e4 / (s * s)
+    H[np.arange(6), np.arange(6)] += 1e4
+    do = damped_delta(H, g, damp)
+    assert rel(dh, do) < TOL_DELTA
+    win.close()
+
+
+def test_window_lm_reduces_error(capi):
+    """end-to-end: a few LM iterations on a consistent synthetic scene reduce the total error."""
+    w = synth.make_window(K=6, H=64, W=80, FS=16, CS=32, L=4, seed=5)
+    win = capi.Window(w)
+    cfg = capi.lm_config_default()
+    st = capi.SageLmState()
+    errs = []
+    for _ in range(6):
+        win.lm_step(st, cfg)
+        errs.append((st.error, st.candidate_error, st.accepted))
+    assert errs[0][2] == 1 and min(e[1] for e in errs) < 0.7 * errs[0][0], errs
+    win.close()
+
+
+def test_sharded_window_sums_to_full(capi):
+    """edge sharding (rank, world): the per-rank packed buffers sum to the single-rank buffer."""
+    w = synth.make_window(K=5, H=32, W=40, FS=16, CS=32, L=3, seed=22)
+    full = capi.Window(w); full.linearize(); pf = full.packed_host().astype(np.float64)
+    acc = np.zeros_like(pf)
+    for r in range(3):
+        sh = capi.Window(w, rank=r, world=3); sh.linearize(); acc += sh.packed_host(); sh.close()
+    assert rel(acc, pf) < 1e-6
+    full.close()
+
+
+def test_track_frame_lm(capi, ws, orc):
+    """host LM (a8) wired to the HIP tracker kernels == the same policy driven by the oracle."""
+    import ctypes as C
+    import torch
+    w = synth.make_window(K=2, H=64, W=80, FS=16, CS=32, L=4, n_samples=3072, seed=31, pose_noise=0.0)
+    a, b = w.keyframes[0], w.keyframes[1]
+    pyr, mask, kfs = dev_window(capi, w)
+    feat0s = presample_source(orc, w, a)
+    dpts0 = (np.float32(a.scale_true) * (a.bias + a.basis @ a.code_true))[a.loc1d].astype(np.float32)
+    R10, t10 = synth.relative_pose(a.R_true, a.t_true, b.R_true, b.t_true)
+    pose0 = capi.pack_pose(synth.so3_exp(np.array([0.004, -0.003, 0.002])) @ R10, t10 + np.array([0.004, -0.003, 0.002], np.float32))
+    cfg = capi.lm_config_default()
+    wts = w.photo_weights
+
+    def lin(p, s):
+        o = orc.tracker_photo_jac_error(6, p[:9].reshape(3, 3), p[9:], w.mask, dpts0, a.homo, feat0s, b.feat_pyr,
+                                        b.grad_pyr, w.level_offsets, w.cams, w.eps, wts)
+        return o["AtA"], o["Atb"], o["error"]
+
+    def err(p, s):
+        return orc.tracker_photo_error(p[:9].reshape(3, 3), p[9:], w.mask, dpts0, a.homo, feat0s, b.feat_pyr,
+                                       w.level_offsets, w.cams, w.eps, wts)[0]
+
+    po, _, eo, ito, tro = capi.track_lm(cfg, 6, lin, err, pose0, 1.0)
+    prob = capi.SageTrackProblem()
+    f0 = torch.from_numpy(feat0s).cuda(); dp = torch.from_numpy(dpts0).cuda(); wd = torch.from_numpy(wts).cuda()
+    prob.ws = ws.h; prob.mask1_dev = mask.data_ptr(); prob.dpts0_dev = dp.data_ptr()
+    prob.homo_dev = kfs[0].homo.data_ptr(); prob.feat0s_dev = f0.data_ptr(); prob.feat1_dev = kfs[1].feat_pyr.data_ptr()
+    prob.grad1_dev = kfs[1].grad_pyr.data_ptr(); prob.weights_dev = wd.data_ptr(); prob.pyr = pyr
+    prob.eps = w.eps; prob.N = a.homo.shape[0]; prob.FS = w.FS
+    ph = pose0.copy(); sc = C.c_float(1.0); fe = C.c_float(); it = C.c_int()
+    rc = capi.lib().sage_track_frame(C.byref(cfg), 6, C.byref(prob), ph.ctypes.data_as(C.POINTER(C.c_float)),
+                                     C.byref(sc), C.byref(fe), C.byref(it))
+    assert rc == 0
+    assert it.value == ito
+    assert fe.value == pytest.approx(eo, rel=1e-3)
+    assert rel(ph, po) < 1e-4
+    assert eo < 0.5 * tro[0]["error"]      # the LM actually converged towards the true relative pose

@@ -1,0 +1,167 @@
+"""CPU-only tests of the product's host logic and of the C-ABI library surface (no compute calls on a GPU).
+
+  * libsage_ba.so loads and exports every symbol include/sage_ba.h declares
+  * host helpers: camera pyramid, se3_exp, retraction, nearest-PSD, damped QR solve, block solve
+  * the tracker LM policy (a8) driven by evaluation callbacks
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from sage_slam_amd import capi, synth
+from tests.helpers import presample_source, rel
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.lib()
+    hdr = open(os.path.join(ROOT, "include", "sage_ba.h")).read()
+    declared = sorted(set(re.findall(r"\b(sage_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 40
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/sage_ba.h but not exported"
+    assert sorted(capi.SYMBOLS) == declared
+    assert b"gfx950" in L.sage_version()
+
+
+def test_compute_entry_points_fail_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(capi.SageError):
+        capi.Workspace()
+
+
+def test_camera_pyramid_matches_reference_rule(orc):
+    cam = synth.Camera(144.0, 143.0, 80.5, 63.5, 160, 128)
+    p = capi.make_pyramid(cam, 4)
+    ref = orc.camera_pyramid(cam.as_array(), 4)
+    py = synth.camera_pyramid(cam, 4)
+    offs, P = synth.level_offsets_of(py)
+    assert p.levels == 4 and p.P == P == 128 * 160 + 64 * 80 + 32 * 40 + 16 * 20
+    for l in range(4):
+        c = p.cam[l]
+        got = np.array([c.fx, c.fy, c.cx, c.cy, c.w, c.h], np.float32)
+        assert np.array_equal(got, ref[l]) and np.array_equal(got, py[l].as_array())
+        assert p.level_offsets[l] == offs[l]
+
+
+def test_se3_exp_and_retract(orc):
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        w = rng.normal(0, 0.3, 3); v = rng.normal(0, 0.5, 3)
+        R, t = capi.se3_exp(w, v)
+        Ro, to = orc.se3_exp(w, v, prec="f64")
+        assert rel(R, Ro) < 1e-6 and rel(t, to) < 1e-6
+        assert np.allclose(R @ R.T, np.eye(3), atol=1e-6)
+    R, t = capi.se3_exp(np.zeros(3), np.array([1.0, 2.0, 3.0]))          # theta == 0 branch
+    assert np.allclose(R, np.eye(3)) and np.allclose(t, [1, 2, 3])
+    # left retraction with [trans, rot] order (gtsam_traits.h:45-70)
+    R0 = synth.so3_exp(np.array([0.2, -0.1, 0.3])); t0 = np.array([0.3, 0.1, -0.2])
+    d = np.array([0.01, -0.02, 0.03, 0.02, 0.01, -0.015])
+    out = capi.pose_retract(capi.pack_pose(R0, t0), d)
+    dR, dt = orc.se3_exp(d[3:], d[:3], prec="f64")
+    assert rel(out[:9].reshape(3, 3), dR @ R0) < 1e-6 and rel(out[9:], dR @ t0 + dt) < 1e-6
+
+
+def test_nearest_psd_is_higham():
+    rng = np.random.default_rng(1)
+    A = rng.normal(size=(12, 12)); S = A @ A.T
+    assert rel(capi.nearest_psd(S), S) < 1e-12                      # PSD input is a fixed point
+    M = S + 1e-3 * rng.normal(size=S.shape)                          # slightly asymmetric
+    assert rel(capi.nearest_psd(M), 0.5 * (M + M.T)) < 1e-9
+    Bm = 0.5 * (A + A.T)                                             # indefinite -> negative part clipped
+    w, V = np.linalg.eigh(Bm)
+    ref = V @ np.diag(np.maximum(w, 0)) @ V.T
+    out = capi.nearest_psd(Bm)
+    assert rel(out, ref) < 1e-8 and np.linalg.eigvalsh(out).min() > -1e-9
+
+
+def test_damped_qr_solve():
+    rng = np.random.default_rng(2)
+    for n in (6, 7):
+        J = rng.normal(size=(50, n)); A = (J.T @ J).astype(np.float32); b = rng.normal(size=n).astype(np.float32)
+        x = capi.damped_solve_qr_f32(A, b, 1e-4)
+        ref = np.linalg.solve(A.astype(np.float64) + 1e-4 * np.diag(np.diag(A)), b)
+        assert rel(x, ref) < 1e-4
+
+
+def test_block_solve_matches_dense():
+    rng = np.random.default_rng(3)
+    K, CS = 7, 16
+    B = 7 + CS
+    links = [(j, i) for i in range(K) for j in range(max(0, i - 3), i)] + [(0, 6)]   # band + a loop closure
+    n = K * B
+    J = rng.normal(size=(3 * n, n))
+    # zero the blocks that are not linked so the dense system has the packed sparsity
+    H = J.T @ J
+    mask = np.zeros((K, K), bool)
+    for a, b in links:
+        mask[a, b] = mask[b, a] = True
+    mask[np.arange(K), np.arange(K)] = True
+    Hs = H * np.kron(mask, np.ones((B, B))) + 5 * n * np.eye(n)
+    g = rng.normal(size=n)
+    diag = np.stack([Hs[k * B:(k + 1) * B, k * B:(k + 1) * B] for k in range(K)])
+    lnk = np.stack([Hs[a * B:(a + 1) * B, b * B:(b + 1) * B] for a, b in links])
+    packed = np.concatenate([diag.reshape(-1), lnk.reshape(-1), g, np.zeros(4)])
+    Hd, gd, _ = capi.unpack_dense(packed, K, links, CS)
+    assert rel(Hd, Hs) < 1e-12
+    dadd = rng.uniform(0, 1, n); gadd = rng.normal(size=n)
+    d = capi.block_solve(packed, K, links, B, 1e-3, dadd, gadd)
+    Hf = Hs.astype(np.float32).astype(np.float64) + np.diag(dadd)
+    ref = np.linalg.solve(Hf + 1e-3 * np.diag(np.diag(Hf)), g.astype(np.float32).astype(np.float64) + gadd)
+    assert rel(d, ref) < 1e-9
+    with pytest.raises(capi.SageError):                                 # not positive definite
+        capi.block_solve(-packed, K, links, B, 0.0)
+
+
+def test_tracker_lm_policy_with_oracle_backend(orc):
+    """the product's LM driver (sage_track_lm) with the oracle as evaluation back-end: converges on a
+    consistent scene, and its trace obeys the reference policy (camera_tracker.cpp:1156-1279)."""
+    w = synth.make_window(K=2, H=32, W=40, FS=16, CS=16, L=3, n_samples=300, seed=31, pose_noise=0.0)
+    a, b = w.keyframes[0], w.keyframes[1]
+    feat0s = presample_source(orc, w, a)
+    dpts0 = (np.float32(a.scale_true) * (a.bias + a.basis @ a.code_true))[a.loc1d].astype(np.float32)
+    R10, t10 = synth.relative_pose(a.R_true, a.t_true, b.R_true, b.t_true)
+    pose0 = capi.pack_pose(synth.so3_exp(np.array([0.004, -0.003, 0.002])) @ R10,
+                           t10 + np.array([0.004, -0.003, 0.002], np.float32))
+    cfg = capi.lm_config_default()
+    assert (cfg.max_num_iters, cfg.init_damp, cfg.damp_inc_factor) == (40, pytest.approx(1e-4), 100.0)
+    calls = dict(lin=0, err=0)
+
+    def lin(p, s):
+        calls["lin"] += 1
+        o = orc.tracker_photo_jac_error(6, p[:9].reshape(3, 3), p[9:], w.mask, dpts0, a.homo, feat0s, b.feat_pyr,
+                                        b.grad_pyr, w.level_offsets, w.cams, w.eps, w.photo_weights)
+        return o["AtA"], o["Atb"], o["error"]
+
+    def err(p, s):
+        calls["err"] += 1
+        return orc.tracker_photo_error(p[:9].reshape(3, 3), p[9:], w.mask, dpts0, a.homo, feat0s, b.feat_pyr,
+                                       w.level_offsets, w.cams, w.eps, w.photo_weights)[0]
+
+    e_start = err(pose0, 1.0)
+    pose, _, e_final, iters, trace = capi.track_lm(cfg, 6, lin, err, pose0, 1.0)
+    assert e_final < 0.5 * e_start and 1 <= iters <= cfg.max_num_iters
+    truth = capi.pack_pose(R10, t10)
+    assert np.linalg.norm(pose - truth) < 0.5 * np.linalg.norm(pose0 - truth)
+    assert trace[0]["relinearized"] == 1 and trace[0]["error"] == pytest.approx(e_start, rel=1e-6)
+    for tr in trace:
+        assert cfg.min_damp <= tr["damp"] <= cfg.max_damp
+        if tr["accepted"]:
+            assert tr["candidate_error"] < tr["error"]
+    assert calls["lin"] <= iters and calls["err"] >= len(trace)
+
+
+def test_synth_producers_match_oracle(orc):
+    w = synth.make_window(K=1, H=32, W=40, FS=16, CS=16, L=3, seed=4)
+    kf = w.keyframes[0]
+    feat = kf.feat_pyr[:, :w.H * w.W].reshape(w.FS, w.H, w.W)
+    op, og = orc.gaussian_pyramid_with_grad(feat, w.mask, w.L, w.level_offsets, w.P)
+    assert rel(kf.feat_pyr, op) < 1e-6 and rel(kf.grad_pyr, og) < 1e-6
+    D1, g1 = synth.depth_and_grad(kf, w.H, w.W)
+    od = orc.update_depth(kf.bias, kf.basis, kf.code, kf.scale).reshape(w.H, w.W)
+    assert rel(D1, od) < 1e-6
