@@ -177,7 +177,7 @@ int sage_damped_solve_qr_f32(const float *A, const float *b, int n, float damp, 
  * packed = [diag K*B*B | link nlinks*B*B (rows = links[2l], cols = links[2l+1], links[2l] < links[2l+1]) | g K*B | 4]
  * (host memory, the layout of sage_window_packed_dev); diag_add / g_add (K*B doubles, may be NULL) carry the
  * diagonal priors.  Returns SAGE_E_NOT_PSD if the damped matrix is not positive definite. */
-int sage_block_solve(const float *packed_host, int K, int nlinks, const int32_t *links, int B, double damp,
+int sage_block_solve(const double *packed_host, int K, int nlinks, const int32_t *links, int B, double damp,
                      const double *diag_add, const double *g_add, double *delta);
 
 /* ---- tracker LM (core/system/camera_tracker.cpp:1034-1310 / 1312-1672) ---- */
@@ -270,20 +270,23 @@ int sage_window_finalize(SageWindow *w);
 int sage_window_num_keyframes(const SageWindow *w);
 int sage_window_num_links(const SageWindow *w);
 int sage_window_block_size(const SageWindow *w);       /* B = 7 + CS: [pose6, code CS, scale] */
-/* packed normal-equation buffer (device, fp32), the all-reduce payload:
- *   [ diag blocks K*B*B | link blocks nlinks*B*B (row = older kf, col = newer kf) | g K*B | err_photo err_geo n_photo n_geo ] */
-size_t sage_window_packed_floats(const SageWindow *w);
-float *sage_window_packed_dev(SageWindow *w);
+/* packed normal-equation buffer (device, DOUBLE), the all-reduce payload:
+ *   [ diag blocks K*B*B | link blocks nlinks*B*B (row = older kf, col = newer kf) | g K*B | err_photo err_geo n_photo n_geo ]
+ * fp32 per-edge results are summed in double, like the reference widens AtA/Atb to double before gtsam adds
+ * the factors (core/gtsam/photometric_factor.cpp:305-306); keeping the payload in double keeps the sum exact
+ * across ranks too. */
+size_t sage_window_packed_count(const SageWindow *w);
+double *sage_window_packed_dev(SageWindow *w);
 /* number of residuals one linearize evaluates on this shard (E_photo*L*N*FS + E_geo*N) and its algorithmic bytes */
 double sage_window_residuals_per_linearize(const SageWindow *w);
 double sage_window_bytes_per_linearize(const SageWindow *w);
 
 /* linearize every local edge at the current estimate and assemble the packed buffer (async on the stream). */
 int sage_window_linearize(SageWindow *w);
-/* total error of every local edge at the CANDIDATE (or current, which = 0/1) variables -> packed-like 4-float
- * device buffer [err_photo err_geo n_photo n_geo]; async. */
+/* total error of every local edge at the CANDIDATE (or current, which = 0/1) variables -> 4-double device
+ * buffer [err_photo err_geo n_photo n_geo]; async. */
 int sage_window_error(SageWindow *w, int which);
-float *sage_window_error_dev(SageWindow *w);
+double *sage_window_error_dev(SageWindow *w);
 /* after (optional) all-reduce of the packed buffer: add priors, D2H, damped solve in double on the host,
  * write the candidate variables (retracted) and upload them.  Returns the predicted step norm. */
 int sage_window_solve(SageWindow *w, double damp, double *step_norm);

@@ -87,7 +87,7 @@ SYMBOLS = [
     "sage_damped_solve_qr_f32", "sage_block_solve", "sage_lm_config_default", "sage_track_lm", "sage_track_frame",
     "sage_window_create", "sage_window_destroy", "sage_window_add_keyframe", "sage_window_add_link",
     "sage_window_set_shard", "sage_window_finalize", "sage_window_num_keyframes", "sage_window_num_links",
-    "sage_window_block_size", "sage_window_packed_floats", "sage_window_packed_dev",
+    "sage_window_block_size", "sage_window_packed_count", "sage_window_packed_dev",
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
@@ -105,12 +105,12 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.sage_version.restype = C.c_char_p
         L.sage_error_string.restype = C.c_char_p
-        L.sage_window_packed_floats.restype = C.c_size_t
+        L.sage_window_packed_count.restype = C.c_size_t
         L.sage_window_packed_dev.restype = C.c_void_p
         L.sage_window_error_dev.restype = C.c_void_p
         L.sage_window_residuals_per_linearize.restype = C.c_double
         L.sage_window_bytes_per_linearize.restype = C.c_double
-        for name in ("sage_window_packed_floats", "sage_window_packed_dev", "sage_window_error_dev",
+        for name in ("sage_window_packed_count", "sage_window_packed_dev", "sage_window_error_dev",
                      "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize",
                      "sage_window_num_keyframes", "sage_window_num_links", "sage_window_block_size"):
             getattr(L, name).argtypes = [C.c_void_p]
@@ -178,13 +178,13 @@ def damped_solve_qr_f32(A, b, damp):
 
 
 def block_solve(packed, K, links, B, damp, diag_add=None, g_add=None):
-    packed = _f32(packed)
+    packed = np.ascontiguousarray(packed, dtype=np.float64)
     lk = np.ascontiguousarray(np.asarray(links, dtype=np.int32).reshape(-1))
     delta = np.zeros(K * B, np.float64)
     dp = lambda a: None if a is None else np.ascontiguousarray(a, np.float64).ctypes.data_as(C.POINTER(C.c_double))
     da = None if diag_add is None else np.ascontiguousarray(diag_add, np.float64)
     ga = None if g_add is None else np.ascontiguousarray(g_add, np.float64)
-    _chk(lib().sage_block_solve(_fp(packed), K, len(lk) // 2, lk.ctypes.data_as(C.POINTER(C.c_int32)), B,
+    _chk(lib().sage_block_solve(packed.ctypes.data_as(C.POINTER(C.c_double)), K, len(lk) // 2, lk.ctypes.data_as(C.POINTER(C.c_int32)), B,
                                 C.c_double(damp), dp(da), dp(ga), delta.ctypes.data_as(C.POINTER(C.c_double))),
          "sage_block_solve")
     return delta
@@ -441,13 +441,13 @@ class Window:
         self.K = L.sage_window_num_keyframes(self.h)
         self.B = L.sage_window_block_size(self.h)
         self.nlinks = L.sage_window_num_links(self.h)
-        self.packed_floats = L.sage_window_packed_floats(self.h)
+        self.packed_count = L.sage_window_packed_count(self.h)
         self.residuals_per_linearize = L.sage_window_residuals_per_linearize(self.h)
         self.bytes_per_linearize = L.sage_window_bytes_per_linearize(self.h)
 
     # raw-pointer views for torch.distributed (plumbing only)
     def packed_tensor(self):
-        return _tensor_from_ptr(lib().sage_window_packed_dev(self.h), self.packed_floats)
+        return _tensor_from_ptr(lib().sage_window_packed_dev(self.h), self.packed_count)
 
     def error_tensor(self):
         return _tensor_from_ptr(lib().sage_window_error_dev(self.h), 4)
@@ -521,7 +521,7 @@ def _tensor_from_ptr(ptr: int, n: int):
         pass
 
     h = _Holder()
-    h.__cuda_array_interface__ = dict(shape=(int(n),), typestr="<f4", data=(int(ptr), False), version=2)
+    h.__cuda_array_interface__ = dict(shape=(int(n),), typestr="<f8", data=(int(ptr), False), version=2)
     return torch.as_tensor(h, device="cuda")
 
 

@@ -102,8 +102,8 @@ __global__ __launch_bounds__(kBlock) void geo_kernel(const GeoParams prm)
   }
   const bool pos = X[2] > prm.eps; // geometric_factor_kernels.cpp:541
   const float inv_z = 1.0f / X[2];
-  const float u = X[0] * inv_z * fx + cx; // :543-544 (no half-pixel shift at level 0)
-  const float v = X[1] * inv_z * fy + cy;
+  const float u = (X[0] / X[2]) * fx + cx; // :543-544 (no half-pixel shift at level 0); true divisions
+  const float v = (X[1] / X[2]) * fy + cy;
   Taps tp;
   make_taps(tp, u, v, W, H);
   float Ds = 0.f;
@@ -324,7 +324,7 @@ __global__ __launch_bounds__(kBlock) void geo_finalize_kernel(const GeoFinalizeP
   constexpr int D = 14 + 2 * CS;
   constexpr int N16 = geo_n16(CS);
   constexpr int NTT = N16 * (N16 + 1) / 2;
-  __shared__ float s[PP];
+  __shared__ double s[PP]; // partial sums and every derived product stay in double until the single final rounding
   const int e = blockIdx.x, tid = threadIdx.x;
   const GeoEdge &E = prm.table ? prm.table[e] : prm.single;
   const float s0 = E.scale0 ? *E.scale0 : E.scale0_val;
@@ -332,24 +332,25 @@ __global__ __launch_bounds__(kBlock) void geo_finalize_kernel(const GeoFinalizeP
   const int first = prm.edge_first[e], nt = prm.edge_tiles[e];
   for (int idx = tid; idx < PP; idx += kBlock)
   {
-    float a = 0.f;
+    double a = 0.0; // the per-workgroup partials are summed in double: free (a few dozen adds), and it keeps the
+                    // engine's accumulation noise below the reference's own fp32 floor
     for (int t = 0; t < nt; ++t)
-      a += prm.partials[(size_t)(first + t) * PP + idx];
+      a += (double)prm.partials[(size_t)(first + t) * PP + idx];
     s[idx] = a;
   }
   __syncthreads();
-  const float n_in = s[45];
-  const bool ok = n_in > 0.f;
-  const float wn = ok ? prm.weight / n_in : 0.f;
+  const double n_in = s[45];
+  const bool ok = n_in > 0.0;
+  const double wn = ok ? (double)prm.weight / n_in : 0.0;
   if (tid == 0)
   {
-    prm.stats[2 * e + 0] = ok ? wn * s[44] : 10.0f * prm.weight; // geometric_factor_kernels.cpp:934,944
-    prm.stats[2 * e + 1] = n_in;
+    prm.stats[2 * e + 0] = ok ? (float)(wn * s[44]) : 10.0f * prm.weight; // geometric_factor_kernels.cpp:934,944
+    prm.stats[2 * e + 1] = (float)n_in;
   }
-  auto telem = [&](int tile, int row, int col) -> float {
+  auto telem = [&](int tile, int row, int col) -> double {
     return s[kGeoScalars + tile * 256 + (row & 3) * 64 + ((row >> 2) * 16 + col)];
   };
-  auto TT = [&](int a, int b) -> float { // sum w t_a t_b
+  auto TT = [&](int a, int b) -> double { // sum w t_a t_b
     int bi = a >> 4, bj = b >> 4, ra = a & 15, rb = b & 15;
     if (bi > bj)
     {
@@ -359,8 +360,8 @@ __global__ __launch_bounds__(kBlock) void geo_finalize_kernel(const GeoFinalizeP
     const int tile = bi * N16 - (bi * (bi - 1)) / 2 + (bj - bi);
     return telem(tile, ra, rb);
   };
-  auto YT = [&](int r, int col) -> float { return telem(NTT + (col >> 4), r, col & 15); }; // sum w y_r t_col
-  auto YY = [&](int a, int b) -> float { // sum w y_a y_b, a,b in 0..8 (never both 8)
+  auto YT = [&](int r, int col) -> double { return telem(NTT + (col >> 4), r, col & 15); }; // sum w y_r t_col
+  auto YY = [&](int a, int b) -> double { // sum w y_a y_b, a,b in 0..8 (never both 8)
     if (a > b)
     {
       const int t = a; a = b; b = t;
@@ -374,28 +375,28 @@ __global__ __launch_bounds__(kBlock) void geo_finalize_kernel(const GeoFinalizeP
     return a < 6 ? s[36 + a] : (a == 6 ? s[42] : s[43]); // b == 8 (rho)
   };
   // column j -> (kind, index, coef): kind 0 = y entry, kind 1 = t entry
-  auto column = [&](int j, int &kind, int &idx, float &coef) {
-    if (j < 6) { kind = 0; idx = j; coef = 1.f; }
-    else if (j < 12) { kind = 0; idx = j - 6; coef = -1.f; }
-    else if (j < 12 + CS) { kind = 1; idx = j - 12; coef = s0; }
-    else if (j < 12 + 2 * CS) { kind = 1; idx = j - 12; coef = -s1; }
-    else if (j == 12 + 2 * CS) { kind = 0; idx = 6; coef = 1.f / s0; }
-    else { kind = 0; idx = 7; coef = -1.f / s1; }
+  auto column = [&](int j, int &kind, int &idx, double &coef) {
+    if (j < 6) { kind = 0; idx = j; coef = 1.0; }
+    else if (j < 12) { kind = 0; idx = j - 6; coef = -1.0; }
+    else if (j < 12 + CS) { kind = 1; idx = j - 12; coef = (double)s0; }
+    else if (j < 12 + 2 * CS) { kind = 1; idx = j - 12; coef = -(double)s1; }
+    else if (j == 12 + 2 * CS) { kind = 0; idx = 6; coef = 1.0 / (double)s0; }
+    else { kind = 0; idx = 7; coef = -1.0 / (double)s1; }
   };
   float *AtA = prm.AtA + (size_t)e * D * D;
   float *Atb = prm.Atb + (size_t)e * D;
   for (int q = tid; q < D * D + D; q += kBlock)
   {
-    float val = 0.f;
+    double val = 0.0;
     if (ok)
     {
       if (q < D * D)
       {
         int ki, ii, kj, ij;
-        float ci, cj;
+        double ci, cj;
         column(q / D, ki, ii, ci);
         column(q % D, kj, ij, cj);
-        float mv;
+        double mv;
         if (ki == 0 && kj == 0)
           mv = YY(ii, ij);
         else if (ki == 1 && kj == 1)
@@ -407,15 +408,15 @@ __global__ __launch_bounds__(kBlock) void geo_finalize_kernel(const GeoFinalizeP
       else
       {
         int k, ii;
-        float c;
+        double c;
         column(q - D * D, k, ii, c);
         val = wn * c * (k == 0 ? YY(ii, 8) : YT(8, ii));
       }
     }
     if (q < D * D)
-      AtA[q] = val;
+      AtA[q] = (float)val;
     else
-      Atb[q - D * D] = val;
+      Atb[q - D * D] = (float)val;
   }
 }
 

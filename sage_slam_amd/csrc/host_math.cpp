@@ -565,15 +565,15 @@ void EnvelopeMatrix::solve_inplace(std::vector<double> &b) const
 
 } // namespace sage
 
-extern "C" int sage_block_solve(const float *packed, int K, int nlinks, const int32_t *links, int B, double damp,
+extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const int32_t *links, int B, double damp,
                                 const double *diag_add, const double *g_add, double *delta)
 {
   if (!packed || K < 1 || B < 1 || nlinks < 0 || (nlinks > 0 && !links) || !delta)
     return SAGE_E_INVALID;
   const int BB = B * B, n = K * B;
-  const float *diag = packed;
-  const float *lnk = diag + (size_t)K * BB;
-  const float *g = lnk + (size_t)nlinks * BB;
+  const double *diag = packed;
+  const double *lnk = diag + (size_t)K * BB;
+  const double *g = lnk + (size_t)nlinks * BB;
   // envelope: first non-zero block column of each block row
   std::vector<int> first_blk(K);
   for (int k = 0; k < K; ++k)

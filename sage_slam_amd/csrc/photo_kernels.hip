@@ -112,8 +112,10 @@ __global__ __launch_bounds__(kBlock) void photo_kernel(const PhotoParams prm)
   }
   const bool pos = X[2] > prm.eps; // photometric_factor_kernels.cpp:96
   const float inv_z = 1.0f / X[2];
-  const float p = X[0] * inv_z * fx0 + cx0; // :142-144 (level-0 pixel coordinates)
-  const float q = X[1] * inv_z * fy0 + cy0;
+  // true divisions, like the reference: the coordinate chain's fp32 rounding is the dominant noise term of
+  // the whole linearisation (every residual of the pixel inherits it), so no reciprocal shortcut here.
+  const float p = (X[0] / X[2]) * fx0 + cx0; // :142-144 (level-0 pixel coordinates)
+  const float q = (X[1] / X[2]) * fy0 + cy0;
   const float m = mask_lookup(E.mask1, p, q, W0, H0);
   const float vm = (pos && in_range) ? m : 0.0f; // sampled_valid_mask_1 (:237)
 
@@ -372,7 +374,7 @@ struct PhotoFinalizeParams
   float wsum;
 };
 
-__device__ __forceinline__ float tile_elem(const float *s, int base, int tile, int row, int col)
+__device__ __forceinline__ double tile_elem(const double *s, int base, int tile, int row, int col)
 {
   return s[base + tile * 256 + (row & 3) * 64 + ((row >> 2) * 16 + col)];
 }
@@ -382,35 +384,37 @@ __global__ __launch_bounds__(kBlock) void photo_finalize_kernel(const PhotoFinal
 {
   constexpr int PP = photo_partial_floats(CS);
   constexpr int D = 13 + CS;
-  __shared__ float s[PP];
+  __shared__ double s[PP]; // partial sums and every derived product stay in double until the single final rounding
   const int e = blockIdx.x, tid = threadIdx.x;
   const PhotoEdge &E = prm.table ? prm.table[e] : prm.single;
   const float s0 = E.scale0 ? *E.scale0 : E.scale0_val;
   const int first = prm.edge_first[e], nt = prm.edge_tiles[e];
   for (int idx = tid; idx < PP; idx += kBlock)
   {
-    float a = 0.f;
+    double a = 0.0; // the per-workgroup partials are summed in double: free (a few dozen adds), and it keeps the
+                    // engine's accumulation noise below the reference's own fp32 floor
     for (int t = 0; t < nt; ++t)
-      a += prm.partials[(size_t)(first + t) * PP + idx];
+      a += (double)prm.partials[(size_t)(first + t) * PP + idx];
     s[idx] = a;
   }
   __syncthreads();
-  const float n_in = s[36];
-  const bool ok = n_in > 0.f;
-  const float inv_n = ok ? 1.0f / n_in : 0.f;
+  const double s0d = (double)s0;
+  const double n_in = s[36];
+  const bool ok = n_in > 0.0;
+  const double inv_n = ok ? 1.0 / n_in : 0.0;
   float *AtA = prm.AtA + (size_t)e * D * D;
   float *Atb = prm.Atb + (size_t)e * D;
   if (tid == 0)
   {
-    prm.stats[2 * e + 0] = ok ? s[35] * inv_n : 10.0f * prm.wsum;
-    prm.stats[2 * e + 1] = n_in;
+    prm.stats[2 * e + 0] = ok ? (float)(s[35] * inv_n) : 10.0f * prm.wsum;
+    prm.stats[2 * e + 1] = (float)n_in;
   }
-  auto X = [&](int row, int col) -> float { // sum_n a_n[row] * b_n[col]
+  auto X = [&](int row, int col) -> double { // sum_n a_n[row] * b_n[col]
     if (CS == 32)
       return tile_elem(s, kPhotoScalars, col < 16 ? 3 : 4, row, col & 15);
     return tile_elem(s, kPhotoScalars, 1, row, col);
   };
-  auto CC = [&](int i, int j) -> float { // sum_n sigma_n b_n[i] b_n[j]
+  auto CC = [&](int i, int j) -> double { // sum_n sigma_n b_n[i] b_n[j]
     if (CS == 32)
     {
       const int ti = i >> 4, tj = j >> 4;
@@ -422,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void photo_finalize_kernel(const PhotoFinal
   };
   for (int idx = tid; idx < D * D + D; idx += kBlock)
   {
-    float val = 0.f;
+    double val = 0.0;
     if (ok)
     {
       if (idx < D * D)
@@ -437,45 +441,45 @@ __global__ __launch_bounds__(kBlock) void photo_finalize_kernel(const PhotoFinal
         // classes: pose (0..11), code (12..12+CS-1), scale (12+CS)
         if (j < 12)
         {
-          const float sg = ((i >= 6) != (j >= 6)) ? -1.f : 1.f;
+          const double sg = ((i >= 6) != (j >= 6)) ? -1.0 : 1.0;
           const int a = i % 6, b = j % 6;
           val = sg * s[a <= b ? sidx6(a, b) : sidx6(b, a)];
         }
         else if (i < 12)
         {
-          const float sg = (i >= 6) ? -1.f : 1.f;
+          const double sg = (i >= 6) ? -1.0 : 1.0;
           if (j < 12 + CS)
-            val = sg * s0 * X(i % 6, j - 12);
+            val = sg * s0d * X(i % 6, j - 12);
           else
-            val = sg * s[21 + i % 6] / s0;
+            val = sg * s[21 + i % 6] / s0d;
         }
         else if (i < 12 + CS)
         {
           if (j < 12 + CS)
-            val = s0 * s0 * CC(i - 12, j - 12);
+            val = s0d * s0d * CC(i - 12, j - 12);
           else
             val = X(6, i - 12);
         }
         else
-          val = s[27] / (s0 * s0);
+          val = s[27] / (s0d * s0d);
         val *= inv_n;
       }
       else
       {
         const int i = idx - D * D;
         if (i < 12)
-          val = ((i >= 6) ? -1.f : 1.f) * s[28 + i % 6];
+          val = ((i >= 6) ? -1.0 : 1.0) * s[28 + i % 6];
         else if (i < 12 + CS)
-          val = s0 * X(7, i - 12);
+          val = s0d * X(7, i - 12);
         else
-          val = s[34] / s0;
+          val = s[34] / s0d;
         val *= inv_n;
       }
     }
     if (idx < D * D)
-      AtA[idx] = val;
+      AtA[idx] = (float)val;
     else
-      Atb[idx - D * D] = val;
+      Atb[idx - D * D] = (float)val;
   }
 }
 

@@ -489,7 +489,7 @@ struct AssembleParams
   const int32_t *adj_start; // [K+1]
   const AdjEntry *adj;
   const LinkEdges *links; // [nlinks]
-  float *packed;
+  double *packed;
   int K, nlinks, CS, n_edges_p, n_edges_g;
 };
 
@@ -515,17 +515,17 @@ __global__ __launch_bounds__(256) void assemble_kernel(const AssembleParams p)
   const int B = 7 + p.CS, BB = B * B;
   const int Dp = 13 + p.CS, Dg = 14 + 2 * p.CS;
   const int blk = blockIdx.x;
-  float *diag = p.packed;
-  float *lnk = diag + (size_t)p.K * BB;
-  float *g = lnk + (size_t)p.nlinks * BB;
-  float *tail = g + (size_t)p.K * B;
+  double *diag = p.packed;
+  double *lnk = diag + (size_t)p.K * BB;
+  double *g = lnk + (size_t)p.nlinks * BB;
+  double *tail = g + (size_t)p.K * B;
   if (blk < p.K)
   {
     const int k = blk;
     const int a0 = p.adj_start[k], a1 = p.adj_start[k + 1];
     for (int idx = threadIdx.x; idx < BB + B; idx += blockDim.x)
     {
-      float acc = 0.f;
+      double acc = 0.0; // fp64 accumulation of the fp32 per-edge results (the reference widens to double before gtsam sums them: photometric_factor.cpp:305-306)
       const bool isg = idx >= BB;
       const int bi = isg ? idx - BB : idx / B, bj = isg ? 0 : idx % B;
       for (int a = a0; a < a1; ++a)
@@ -536,13 +536,13 @@ __global__ __launch_bounds__(256) void assemble_kernel(const AssembleParams p)
         if (ci < 0)
           continue;
         if (isg)
-          acc += (ae.type == 0 ? p.Atb_p : p.Atb_g)[(size_t)ae.edge * D + ci];
+          acc += (double)(ae.type == 0 ? p.Atb_p : p.Atb_g)[(size_t)ae.edge * D + ci];
         else
         {
           const int cj = edge_col(ae.type, ae.role, bj, p.CS);
           if (cj < 0)
             continue;
-          acc += (ae.type == 0 ? p.AtA_p : p.AtA_g)[(size_t)ae.edge * D * D + (size_t)ci * D + cj];
+          acc += (double)(ae.type == 0 ? p.AtA_p : p.AtA_g)[(size_t)ae.edge * D * D + (size_t)ci * D + cj];
         }
       }
       if (isg)
@@ -558,7 +558,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(const AssembleParams p)
     for (int idx = threadIdx.x; idx < BB; idx += blockDim.x)
     {
       const int bi = idx / B, bj = idx % B; // bi indexes keyframe a (older), bj keyframe b
-      float acc = 0.f;
+      double acc = 0.0;
       if (le.e_ab >= 0)
       {
         for (int type = 0; type < 2; ++type)
@@ -570,12 +570,12 @@ __global__ __launch_bounds__(256) void assemble_kernel(const AssembleParams p)
           // edge a->b : a has role 0, b has role 1
           int ci = edge_col(type, 0, bi, p.CS), cj = edge_col(type, 1, bj, p.CS);
           if (ci >= 0 && cj >= 0)
-            acc += A[(size_t)le.e_ab * D * D + (size_t)ci * D + cj];
+            acc += (double)A[(size_t)le.e_ab * D * D + (size_t)ci * D + cj];
           // edge b->a : b has role 0, a has role 1
           ci = edge_col(type, 1, bi, p.CS);
           cj = edge_col(type, 0, bj, p.CS);
           if (ci >= 0 && cj >= 0)
-            acc += A[(size_t)le.e_ba * D * D + (size_t)ci * D + cj];
+            acc += (double)A[(size_t)le.e_ba * D * D + (size_t)ci * D + cj];
         }
       }
       lnk[(size_t)l * BB + idx] = acc;
@@ -590,16 +590,16 @@ __global__ __launch_bounds__(256) void assemble_kernel(const AssembleParams p)
       const int which = threadIdx.x >> 1; // 0: error, 1: inliers
       const float *st = photo ? p.stats_p : p.stats_g;
       const int n = photo ? p.n_edges_p : p.n_edges_g;
-      float acc = 0.f;
+      double acc = 0.0;
       if (st)
         for (int e = 0; e < n; ++e)
-          acc += st[2 * e + which];
+          acc += (double)st[2 * e + which];
       tail[which * 2 + (photo ? 0 : 1)] = acc; // [err_photo err_geo n_photo n_geo]
     }
   }
 }
 
-__global__ void sum_stats_kernel(const float *stats_p, int np, const float *stats_g, int ng, float *out)
+__global__ void sum_stats_kernel(const float *stats_p, int np, const float *stats_g, int ng, double *out)
 {
   if (threadIdx.x < 4)
   {
@@ -607,10 +607,10 @@ __global__ void sum_stats_kernel(const float *stats_p, int np, const float *stat
     const int which = threadIdx.x >> 1;
     const float *st = photo ? stats_p : stats_g;
     const int n = photo ? np : ng;
-    float acc = 0.f;
+    double acc = 0.0;
     if (st)
       for (int e = 0; e < n; ++e)
-        acc += st[2 * e + which];
+        acc += (double)st[2 * e + which];
     out[which * 2 + (photo ? 0 : 1)] = acc;
   }
 }
@@ -640,7 +640,7 @@ struct SageWindow
   DevBuf AtA_p, Atb_p, stats_p, AtA_g, Atb_g, stats_g;
   DevBuf adj_start, adj, link_edges, packed, errbuf;
   int n_work_p = 0, n_work_g = 0, tpb_p = 1, tpb_g = 1;
-  std::vector<float> host_packed;
+  std::vector<double> host_packed;
   std::vector<double> delta;
   double residuals_per_lin = 0, bytes_per_lin = 0;
   bool have_lin = false;
@@ -740,15 +740,15 @@ extern "C" int sage_window_set_shard(SageWindow *w, int rank, int world)
 extern "C" int sage_window_num_keyframes(const SageWindow *w) { return w ? w->K : 0; }
 extern "C" int sage_window_num_links(const SageWindow *w) { return w ? (int)w->links.size() : 0; }
 extern "C" int sage_window_block_size(const SageWindow *w) { return w ? w->B : 0; }
-extern "C" size_t sage_window_packed_floats(const SageWindow *w)
+extern "C" size_t sage_window_packed_count(const SageWindow *w)
 {
   if (!w)
     return 0;
   const size_t BB = (size_t)w->B * w->B;
   return (size_t)w->K * BB + w->links.size() * BB + (size_t)w->K * w->B + 4;
 }
-extern "C" float *sage_window_packed_dev(SageWindow *w) { return w ? w->packed.as<float>() : nullptr; }
-extern "C" float *sage_window_error_dev(SageWindow *w) { return w ? w->errbuf.as<float>() : nullptr; }
+extern "C" double *sage_window_packed_dev(SageWindow *w) { return w ? w->packed.as<double>() : nullptr; }
+extern "C" double *sage_window_error_dev(SageWindow *w) { return w ? w->errbuf.as<double>() : nullptr; }
 extern "C" double sage_window_residuals_per_linearize(const SageWindow *w) { return w ? w->residuals_per_lin : 0; }
 extern "C" double sage_window_bytes_per_linearize(const SageWindow *w) { return w ? w->bytes_per_lin : 0; }
 
@@ -891,11 +891,11 @@ extern "C" int sage_window_finalize(SageWindow *w)
       (rc = upload(w->link_edges, le, w->stream)))
     return rc;
   SAGE_HIP(hipStreamSynchronize(w->stream));
-  if ((rc = w->packed.reserve(sage_window_packed_floats(w) * sizeof(float))) || (rc = w->errbuf.reserve(4 * sizeof(float))))
+  if ((rc = w->packed.reserve(sage_window_packed_count(w) * sizeof(double))) || (rc = w->errbuf.reserve(4 * sizeof(double))))
     return rc;
-  SAGE_HIP(hipMemsetAsync(w->packed.p, 0, sage_window_packed_floats(w) * sizeof(float), w->stream));
-  SAGE_HIP(hipMemsetAsync(w->errbuf.p, 0, 4 * sizeof(float), w->stream));
-  w->host_packed.assign(sage_window_packed_floats(w), 0.f);
+  SAGE_HIP(hipMemsetAsync(w->packed.p, 0, sage_window_packed_count(w) * sizeof(double), w->stream));
+  SAGE_HIP(hipMemsetAsync(w->errbuf.p, 0, 4 * sizeof(double), w->stream));
+  w->host_packed.assign(sage_window_packed_count(w), 0.0);
   w->delta.assign((size_t)K * w->B, 0.0);
   w->finalized = true;
   return SAGE_OK;
@@ -947,7 +947,7 @@ extern "C" int sage_window_linearize(SageWindow *w)
   ap.adj_start = w->adj_start.as<int32_t>();
   ap.adj = w->adj.as<AdjEntry>();
   ap.links = w->link_edges.as<LinkEdges>();
-  ap.packed = w->packed.as<float>();
+  ap.packed = w->packed.as<double>();
   ap.K = w->K;
   ap.nlinks = (int)w->links.size();
   ap.CS = c.CS;
@@ -981,7 +981,7 @@ extern "C" int sage_window_error(SageWindow *w, int which)
   }
   hipLaunchKernelGGL(sum_stats_kernel, dim3(1), dim3(64), 0, w->stream,
                      (has && c.use_photo) ? w->stats_p.as<float>() : nullptr, w->n_edges,
-                     (has && c.use_geo) ? w->stats_g.as<float>() : nullptr, w->n_edges, w->errbuf.as<float>());
+                     (has && c.use_geo) ? w->stats_g.as<float>() : nullptr, w->n_edges, w->errbuf.as<double>());
   SAGE_HIP(hipGetLastError());
   return SAGE_OK;
 }
@@ -1037,16 +1037,16 @@ extern "C" int sage_window_total_error(SageWindow *w, int from_linearize, double
 {
   if (!w || !w->finalized || !err)
     return SAGE_E_STATE;
-  float t[4];
+  double t[4];
   if (from_linearize)
   {
-    const size_t off = sage_window_packed_floats(w) - 4;
-    SAGE_HIP(hipMemcpyAsync(t, w->packed.as<float>() + off, 4 * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+    const size_t off = sage_window_packed_count(w) - 4;
+    SAGE_HIP(hipMemcpyAsync(t, w->packed.as<double>() + off, 4 * sizeof(double), hipMemcpyDeviceToHost, w->stream));
   }
   else
-    SAGE_HIP(hipMemcpyAsync(t, w->errbuf.p, 4 * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+    SAGE_HIP(hipMemcpyAsync(t, w->errbuf.p, 4 * sizeof(double), hipMemcpyDeviceToHost, w->stream));
   SAGE_HIP(hipStreamSynchronize(w->stream));
-  *err = (double)t[0] + (double)t[1] + prior_error(w, from_linearize ? 0 : 1);
+  *err = t[0] + t[1] + prior_error(w, from_linearize ? 0 : 1);
   return SAGE_OK;
 }
 
@@ -1056,8 +1056,8 @@ extern "C" int sage_window_solve(SageWindow *w, double damp, double *step_norm)
     return SAGE_E_STATE;
   const SageWindowConfig &c = w->cfg;
   const int K = w->K, B = w->B, CS = c.CS, BB = B * B, n = K * B;
-  const size_t np = sage_window_packed_floats(w);
-  SAGE_HIP(hipMemcpyAsync(w->host_packed.data(), w->packed.p, np * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+  const size_t np = sage_window_packed_count(w);
+  SAGE_HIP(hipMemcpyAsync(w->host_packed.data(), w->packed.p, np * sizeof(double), hipMemcpyDeviceToHost, w->stream));
   SAGE_HIP(hipStreamSynchronize(w->stream));
   // diagonal priors (a9): code prior on every keyframe, scale / pose priors on keyframe 0
   std::vector<double> dadd((size_t)n, 0.0), gadd((size_t)n, 0.0);

@@ -49,8 +49,8 @@ __global__ __launch_bounds__(kBlock) void track_kernel(const TrackParams prm)
   }
   const bool pos = X[2] > prm.eps;
   const float inv_z = 1.0f / X[2];
-  const float p = X[0] * inv_z * fx0 + cx0;
-  const float q = X[1] * inv_z * fy0 + cy0;
+  const float p = (X[0] / X[2]) * fx0 + cx0;
+  const float q = (X[1] / X[2]) * fy0 + cy0;
   const float m = mask_lookup(E.mask1, p, q, W0, H0);
   const float vm = (pos && in_range) ? m : 0.f;
 

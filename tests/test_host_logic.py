@@ -111,8 +111,8 @@ def test_block_solve_matches_dense():
     assert rel(Hd, Hs) < 1e-12
     dadd = rng.uniform(0, 1, n); gadd = rng.normal(size=n)
     d = capi.block_solve(packed, K, links, B, 1e-3, dadd, gadd)
-    Hf = Hs.astype(np.float32).astype(np.float64) + np.diag(dadd)
-    ref = np.linalg.solve(Hf + 1e-3 * np.diag(np.diag(Hf)), g.astype(np.float32).astype(np.float64) + gadd)
+    Hf = Hs + np.diag(dadd)
+    ref = np.linalg.solve(Hf + 1e-3 * np.diag(np.diag(Hf)), g + gadd)
     assert rel(d, ref) < 1e-9
     with pytest.raises(capi.SageError):                                 # not positive definite
         capi.block_solve(-packed, K, links, B, 0.0)
