@@ -303,6 +303,13 @@ int sage_window_get_delta(const SageWindow *w, double *delta);
  * direction e%2 (0: a->b, 1: b->a). */
 int sage_window_get_edge(const SageWindow *w, int type, int e, float *AtA, float *Atb, float *err, float *n_in);
 
+/* kernel timing with HIP events on the engine's own stream (bench.py's roofline): when enabled every launch of
+ * the four hot kernels is bracketed by an event pair.  which: 0 photometric linearize, 1 geometric linearize,
+ * 2 photometric error, 3 geometric error.  get_kernel_time synchronises, returns the accumulated milliseconds and
+ * launch count since the last reset, and resets them. */
+int sage_window_set_profiling(SageWindow *w, int on);
+int sage_window_get_kernel_time(SageWindow *w, int which, double *total_ms, int *launches);
+
 /* one full LM iteration on a single GPU: linearize -> solve -> error at candidate -> accept/reject
  * (policy of camera_tracker.cpp:1156-1279). */
 typedef struct SageLmState

@@ -91,7 +91,7 @@ SYMBOLS = [
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_lm_step",
+    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step",
 ]
 
 
@@ -497,6 +497,15 @@ class Window:
         _chk(lib().sage_window_get_edge(self.h, type_, e, _fp(A), _fp(b), C.byref(err), C.byref(nin)),
              "sage_window_get_edge")
         return dict(AtA=A, Atb=b, error=err.value, num_inliers=nin.value)
+
+    def set_profiling(self, on: bool):
+        _chk(lib().sage_window_set_profiling(self.h, int(on)), "sage_window_set_profiling")
+
+    def kernel_time(self, which: int):
+        """(total_ms, launches) of hot kernel `which` since the last call (0 photo lin, 1 geo lin, 2 photo err, 3 geo err)."""
+        ms = C.c_double(); n = C.c_int()
+        _chk(lib().sage_window_get_kernel_time(self.h, which, C.byref(ms), C.byref(n)), "sage_window_get_kernel_time")
+        return ms.value, n.value
 
     def packed_host(self):
         return self.packed_tensor().cpu().numpy()

@@ -436,7 +436,11 @@ static hipError_t geo_lin_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   p.eps = eps;
   p.loss_param = loss_param;
   p.tiles_per_block = lc.tiles_per_block;
+  if (lc.ev_start)
+    (void)hipEventRecord(lc.ev_start, s);
   hipLaunchKernelGGL((geo_kernel<CS, true>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  if (lc.ev_stop)
+    (void)hipEventRecord(lc.ev_stop, s);
   GeoFinalizeParams f{};
   if (single)
     f.single = *single;
@@ -466,7 +470,11 @@ static hipError_t geo_err_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   p.eps = eps;
   p.loss_param = loss_param;
   p.tiles_per_block = lc.tiles_per_block;
+  if (lc.ev_start)
+    (void)hipEventRecord(lc.ev_start, s);
   hipLaunchKernelGGL((geo_kernel<CS, false>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  if (lc.ev_stop)
+    (void)hipEventRecord(lc.ev_stop, s);
   return launch_stats_finalize(s, lc, stats, 10.0f * weight, weight);
 }
 

@@ -547,7 +547,11 @@ static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const P
 {
   float wsum;
   PhotoParams p = make_params(single, table, lc, pyr, wh, eps, &wsum);
+  if (lc.ev_start)
+    (void)hipEventRecord(lc.ev_start, s);
   hipLaunchKernelGGL((photo_kernel<CS, FS, true>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  if (lc.ev_stop)
+    (void)hipEventRecord(lc.ev_stop, s);
   PhotoFinalizeParams f{};
   if (single)
     f.single = *single;
@@ -570,7 +574,11 @@ static hipError_t photo_err_impl(hipStream_t s, const PhotoEdge *single, const P
 {
   float wsum;
   PhotoParams p = make_params(single, table, lc, pyr, wh, eps, &wsum);
+  if (lc.ev_start)
+    (void)hipEventRecord(lc.ev_start, s);
   hipLaunchKernelGGL((photo_kernel<CS, FS, false>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  if (lc.ev_stop)
+    (void)hipEventRecord(lc.ev_stop, s);
   return launch_stats_finalize(s, lc, stats, 10.0f * wsum, 1.0f);
 }
 

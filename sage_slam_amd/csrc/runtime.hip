@@ -644,7 +644,58 @@ struct SageWindow
   std::vector<double> delta;
   double residuals_per_lin = 0, bytes_per_lin = 0;
   bool have_lin = false;
+  // optional kernel timing (HIP events on `stream`)
+  bool profiling = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[4];
+  double prof_ms[4] = {0, 0, 0, 0};
+  int prof_n[4] = {0, 0, 0, 0};
 };
+
+static void prof_attach(SageWindow *w, int which, LaunchCommon &lc)
+{
+  if (!w->profiling)
+    return;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+    return;
+  lc.ev_start = a;
+  lc.ev_stop = b;
+  w->pending[which].emplace_back(a, b);
+}
+
+extern "C" int sage_window_set_profiling(SageWindow *w, int on)
+{
+  if (!w)
+    return SAGE_E_INVALID;
+  w->profiling = on != 0;
+  return SAGE_OK;
+}
+
+extern "C" int sage_window_get_kernel_time(SageWindow *w, int which, double *total_ms, int *launches)
+{
+  if (!w || which < 0 || which > 3)
+    return SAGE_E_INVALID;
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  for (auto &pr : w->pending[which])
+  {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess)
+    {
+      w->prof_ms[which] += ms;
+      w->prof_n[which] += 1;
+    }
+    (void)hipEventDestroy(pr.first);
+    (void)hipEventDestroy(pr.second);
+  }
+  w->pending[which].clear();
+  if (total_ms)
+    *total_ms = w->prof_ms[which];
+  if (launches)
+    *launches = w->prof_n[which];
+  w->prof_ms[which] = 0;
+  w->prof_n[which] = 0;
+  return SAGE_OK;
+}
 
 static void upload_vars_host(SageWindow *w, int set, std::vector<float> &buf)
 {
@@ -925,15 +976,19 @@ extern "C" int sage_window_linearize(SageWindow *w)
     if (c.use_photo)
     {
       EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>()};
-      SAGE_HIP(launch_photo_linearize(w->stream, c.CS, c.FS, nullptr, w->ptab[0].as<PhotoEdge>(), window_lc(w, true),
-                                      c.pyr, c.photo_weights, c.eps, out));
+      LaunchCommon lc = window_lc(w, true);
+      prof_attach(w, 0, lc);
+      SAGE_HIP(launch_photo_linearize(w->stream, c.CS, c.FS, nullptr, w->ptab[0].as<PhotoEdge>(), lc, c.pyr,
+                                      c.photo_weights, c.eps, out));
     }
     if (c.use_geo)
     {
       SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[0].as<DepthItem>(), w->K, H, W));
       EdgeOut out{w->AtA_g.as<float>(), w->Atb_g.as<float>(), w->stats_g.as<float>()};
-      SAGE_HIP(launch_geo_linearize(w->stream, c.CS, nullptr, w->gtab[0].as<GeoEdge>(), window_lc(w, false),
-                                    c.pyr.cam[0], c.eps, c.geo_loss_param, c.geo_weight, out));
+      LaunchCommon lc = window_lc(w, false);
+      prof_attach(w, 1, lc);
+      SAGE_HIP(launch_geo_linearize(w->stream, c.CS, nullptr, w->gtab[0].as<GeoEdge>(), lc, c.pyr.cam[0], c.eps,
+                                    c.geo_loss_param, c.geo_weight, out));
     }
   }
   AssembleParams ap{};
@@ -969,6 +1024,7 @@ extern "C" int sage_window_error(SageWindow *w, int which)
   if (has && c.use_photo)
   {
     LaunchCommon lc = window_lc(w, true);
+    prof_attach(w, 2, lc);
     SAGE_HIP(launch_photo_error(w->stream, c.CS, c.FS, nullptr, w->ptab[which].as<PhotoEdge>(), lc, c.pyr,
                                 c.photo_weights, c.eps, w->stats_p.as<float>()));
   }
@@ -976,6 +1032,7 @@ extern "C" int sage_window_error(SageWindow *w, int which)
   {
     SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[which].as<DepthItem>(), w->K, H, W));
     LaunchCommon lc = window_lc(w, false);
+    prof_attach(w, 3, lc);
     SAGE_HIP(launch_geo_error(w->stream, c.CS, nullptr, w->gtab[which].as<GeoEdge>(), lc, c.pyr.cam[0], c.eps,
                               c.geo_loss_param, c.geo_weight, w->stats_g.as<float>()));
   }

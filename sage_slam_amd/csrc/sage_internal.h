@@ -98,6 +98,7 @@ struct LaunchCommon
   int32_t n_edges;
   float *partials;           // [n_work][partial_floats]
   int32_t tiles_per_block;   // consecutive kTile sub-tiles per work item (work[i].tile = first sub-tile)
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr; // optional: recorded around the main kernel only
 };
 
 // per-edge results, reference layouts
