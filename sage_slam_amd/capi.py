@@ -102,6 +102,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `python -m sage_slam_amd.build` "
                               "(the HIP engine has no fallback path)")
+        # torch first: it bundles its own libamdhip64 (same SONAME); loading it before our library makes both
+        # share ONE HIP runtime, so torch device pointers are valid in our launches.  (A C++ host without torch
+        # simply binds /opt/rocm's runtime.)
+        import torch  # noqa: F401
         L = C.CDLL(LIB_PATH)
         L.sage_version.restype = C.c_char_p
         L.sage_error_string.restype = C.c_char_p
