@@ -50,8 +50,16 @@ __global__ __launch_bounds__(kBlock) void geo_kernel(const GeoParams prm)
   __shared__ float s_red[kWaves * kGeoScalars];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const WorkItem wi = prm.work[blockIdx.x];
-  const GeoEdge &E = prm.table ? prm.table[wi.edge] : prm.single;
+  WorkItem wi = prm.work[blockIdx.x];
+  wi.edge = uni(wi.edge);
+  wi.tile = uni(wi.tile);
+  GeoEdge E = prm.table ? prm.table[wi.edge] : prm.single;
+  E.bias0 = uni(E.bias0); E.basis0 = uni(E.basis0); E.dpt1 = uni(E.dpt1); E.dgrad1 = uni(E.dgrad1);
+  E.basis1 = uni(E.basis1); E.mask1 = uni(E.mask1); E.homo = uni(E.homo); E.loc = uni(E.loc);
+  E.R0 = uni(E.R0); E.t0 = uni(E.t0); E.R1 = uni(E.R1); E.t1 = uni(E.t1); E.R10 = uni(E.R10); E.t10 = uni(E.t10);
+  E.code0 = uni(E.code0); E.scale0 = uni(E.scale0); E.scale1 = uni(E.scale1);
+  E.scale0_val = uni(E.scale0_val); E.scale1_val = uni(E.scale1_val);
+  E.N = uni(E.N); E.loc_is_i64 = uni(E.loc_is_i64);
   const int N = E.N;
   const float s0 = E.scale0 ? *E.scale0 : E.scale0_val;
 

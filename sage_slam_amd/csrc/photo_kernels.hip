@@ -53,8 +53,15 @@ __global__ __launch_bounds__(kBlock) void photo_kernel(const PhotoParams prm)
   __shared__ float s_red[kWaves * kPhotoScalars];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const WorkItem wi = prm.work[blockIdx.x];
-  const PhotoEdge &E = prm.table ? prm.table[wi.edge] : prm.single;
+  WorkItem wi = prm.work[blockIdx.x];
+  wi.edge = uni(wi.edge);
+  wi.tile = uni(wi.tile);
+  PhotoEdge E = prm.table ? prm.table[wi.edge] : prm.single;
+  E.feat0 = uni(E.feat0); E.feat1 = uni(E.feat1); E.grad1 = uni(E.grad1); E.bias0 = uni(E.bias0);
+  E.basis0 = uni(E.basis0); E.mask1 = uni(E.mask1); E.homo = uni(E.homo); E.loc = uni(E.loc);
+  E.R0 = uni(E.R0); E.t0 = uni(E.t0); E.R1 = uni(E.R1); E.t1 = uni(E.t1); E.R10 = uni(E.R10); E.t10 = uni(E.t10);
+  E.code0 = uni(E.code0); E.scale0 = uni(E.scale0); E.scale0_val = uni(E.scale0_val);
+  E.N = uni(E.N); E.loc_is_i64 = uni(E.loc_is_i64);
   const int N = E.N;
   const float scale0 = E.scale0 ? *E.scale0 : E.scale0_val;
 

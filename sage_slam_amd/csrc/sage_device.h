@@ -13,6 +13,25 @@ namespace sage
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// ---------------------------------------------------------------- wave-uniform values
+// Everything derived from blockIdx (work item, edge descriptor, base pointers) is wave-uniform, but hipcc cannot
+// prove it once it went through memory; an unproven-uniform buffer descriptor makes it wrap EVERY buffer_load in
+// a waterfall loop (CDNA guide T20).  Passing the scalars through readfirstlane makes the uniformity provable:
+// descriptors and base pointers then live in SGPRs and loads use the saddr / s_load forms.
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float uni(float v)
+{
+  return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v)));
+}
+template <class T>
+__device__ __forceinline__ T *uni(T *p)
+{
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
+}
+
 // ---------------------------------------------------------------- buffer loads
 // Raw buffer descriptors (T8 in the CDNA guide): one SGPR quad per array, the per-lane
 // tap offset in a VGPR, the per-channel plane offset in an SGPR (soffset).  Out-of-image

@@ -27,8 +27,9 @@ __global__ __launch_bounds__(kBlock) void track_kernel(const TrackParams prm)
 {
   __shared__ float s_red[kWaves * kTrackScalars];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const WorkItem wi = prm.work[blockIdx.x];
-  const TrackEdge &E = prm.E;
+  WorkItem wi = prm.work[blockIdx.x];
+  wi.tile = uni(wi.tile);
+  const TrackEdge &E = prm.E; // kernel argument: already in SGPRs
   const int N = E.N;
   const int n = wi.tile * kTile + tid;
   const bool in_range = n < N;
