@@ -19,6 +19,7 @@ SOURCES = ["photo_kernels.hip", "geo_kernels.hip", "track_kernels.hip", "produce
            "host_math.cpp"]
 HEADERS = ["sage_device.h", "sage_internal.h", "host_math.h", os.path.join(ROOT, "include", "sage_ba.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HOSTCXX = os.environ.get("HOSTCXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
@@ -32,7 +33,11 @@ def _compile(src):
     deps = [os.path.join(CSRC, src)] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
     if _mtime(obj) >= max(_mtime(d) for d in deps):
         return obj, False
-    cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".hip") else []) + ["-c", os.path.join(CSRC, src), "-o", obj]
+    if src.endswith(".hip"):
+        cmd = [HIPCC] + FLAGS + ["-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
+    else:   # pure host translation unit: ROCm's clang++ without offload (function multiversioning for AVX2/AVX-512)
+        cmd = [HOSTCXX, "-O3", "-std=c++17", "-fPIC", "-Wall", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC,
+               "-c", os.path.join(CSRC, src), "-o", obj]
     subprocess.check_call(cmd)
     return obj, True
 
@@ -46,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         res = list(ex.map(_compile, SOURCES))
     objs = [o for o, _ in res]
     if any(ch for _, ch in res) or not os.path.exists(LIB):
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-lpthread"])
         if verbose:
             print("built", LIB)
     return LIB

@@ -7,7 +7,12 @@
 //   sage_damped_solve_qr_f32 core/system/camera_tracker.cpp:1182-1183 (colPivHouseholderQr in fp32)
 //   sage_track_lm            core/system/camera_tracker.cpp:1156-1279 (+ LMConvergence :527-573)
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <thread>
 #include <cstring>
 #include <vector>
 
@@ -500,43 +505,268 @@ void EnvelopeMatrix::init(int n_, const std::vector<int> &first_)
   data.assign(off, 0.0);
 }
 
-bool EnvelopeMatrix::cholesky_inplace()
+// dot product with reassociation allowed (SIMD + several accumulators); runtime-dispatched to the widest ISA
+// of the host (the LM step is host-bound on this solve once the kernels are fast).
+__attribute__((target_clones("avx512f", "avx2", "default"))) static double env_dot(const double *a, const double *b,
+                                                                                   int len)
 {
-  for (int r = 0; r < n; ++r)
+#pragma clang fp reassociate(on)
+  double acc = 0.0;
+#pragma clang loop vectorize(enable) interleave_count(4)
+  for (int k = 0; k < len; ++k)
+    acc += a[k] * b[k];
+  return acc;
+}
+
+__attribute__((target_clones("avx512f", "avx2", "default"))) static void env_axpy(double *y, const double *x, double a,
+                                                                                  int len)
+{
+#pragma clang loop vectorize(enable) interleave_count(4)
+  for (int k = 0; k < len; ++k)
+    y[k] -= a * x[k];
+}
+
+namespace
+{
+struct SpinBarrier
+{
+  std::atomic<int> count{0};
+  std::atomic<int> gen{0};
+  int n;
+  explicit SpinBarrier(int n_) : n(n_) {}
+  void wait()
   {
-    double *Lr = &data[rowptr[r]];
-    const int fr = first[r];
-    for (int c = fr; c <= r; ++c)
+    if (n <= 1)
+      return;
+    const int g = gen.load(std::memory_order_acquire);
+    if (count.fetch_add(1, std::memory_order_acq_rel) == n - 1)
     {
-      const double *Lc = &data[rowptr[c]];
-      const int fc = first[c];
-      const int k0 = fr > fc ? fr : fc;
-      double s = Lr[c - fr];
-      const double *a = Lr + (k0 - fr), *b = Lc + (k0 - fc);
-      const int len = c - k0;
-      double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+      count.store(0, std::memory_order_relaxed);
+      gen.fetch_add(1, std::memory_order_release);
+    }
+    else
+      while (gen.load(std::memory_order_acquire) == g)
+        __builtin_ia32_pause();
+  }
+};
+
+typedef double v8d __attribute__((vector_size(64), aligned(8)));
+
+// (macros, not functions: a v8d crossing a function boundary would need the AVX-512 ABI in every clone)
+#define SAGE_LOADU(dst, p) __builtin_memcpy(&(dst), (p), sizeof(v8d))
+#define SAGE_HSUM(v) ((((v)[0] + (v)[4]) + ((v)[2] + (v)[6])) + (((v)[1] + (v)[5]) + ((v)[3] + (v)[7])))
+
+// C_i[j] -= dot(A_i[0:len], B_j[0:len]) for i < ni, j < nj with a 4x4 register-blocked micro-kernel, k vectorised
+// (8 doubles: one zmm, two ymm or four xmm depending on the clone the resolver picks).
+__attribute__((target_clones("avx512f", "avx2", "default"))) static void gemm_nt_sub(double *const *C, int coff,
+                                                                                     const double *const *A,
+                                                                                     const double *const *B, int ni,
+                                                                                     int nj, int len)
+{
+  for (int i0 = 0; i0 < ni; i0 += 4)
+  {
+    const int mi = ni - i0 < 4 ? ni - i0 : 4;
+    for (int j0 = 0; j0 < nj; j0 += 4)
+    {
+      const int mj = nj - j0 < 4 ? nj - j0 : 4;
+      const double *a[4], *b[4];
+      for (int t = 0; t < 4; ++t)
+      {
+        a[t] = A[i0 + (t < mi ? t : 0)];
+        b[t] = B[j0 + (t < mj ? t : 0)];
+      }
+      v8d acc[4][4];
+      for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+          acc[i][j] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
       int k = 0;
-      for (; k + 4 <= len; k += 4)
+      for (; k + 8 <= len; k += 8)
       {
-        acc0 += a[k] * b[k];
-        acc1 += a[k + 1] * b[k + 1];
-        acc2 += a[k + 2] * b[k + 2];
-        acc3 += a[k + 3] * b[k + 3];
+        v8d a0, a1, a2, a3, b0, b1, b2, b3;
+        SAGE_LOADU(a0, a[0] + k); SAGE_LOADU(a1, a[1] + k); SAGE_LOADU(a2, a[2] + k); SAGE_LOADU(a3, a[3] + k);
+        SAGE_LOADU(b0, b[0] + k); SAGE_LOADU(b1, b[1] + k); SAGE_LOADU(b2, b[2] + k); SAGE_LOADU(b3, b[3] + k);
+        acc[0][0] += a0 * b0; acc[0][1] += a0 * b1; acc[0][2] += a0 * b2; acc[0][3] += a0 * b3;
+        acc[1][0] += a1 * b0; acc[1][1] += a1 * b1; acc[1][2] += a1 * b2; acc[1][3] += a1 * b3;
+        acc[2][0] += a2 * b0; acc[2][1] += a2 * b1; acc[2][2] += a2 * b2; acc[2][3] += a2 * b3;
+        acc[3][0] += a3 * b0; acc[3][1] += a3 * b1; acc[3][2] += a3 * b2; acc[3][3] += a3 * b3;
       }
+      double tail[4][4] = {{0}};
       for (; k < len; ++k)
-        acc0 += a[k] * b[k];
-      s -= (acc0 + acc1) + (acc2 + acc3);
-      if (c < r)
-        Lr[c - fr] = s / Lc[c - fc];
-      else
-      {
-        if (!(s > 0.0))
-          return false;
-        Lr[c - fr] = std::sqrt(s);
-      }
+        for (int i = 0; i < 4; ++i)
+          for (int j = 0; j < 4; ++j)
+            tail[i][j] += a[i][k] * b[j][k];
+      for (int i = 0; i < mi; ++i)
+        for (int j = 0; j < mj; ++j)
+          C[i0 + i][coff + j0 + j] -= SAGE_HSUM(acc[i][j]) + tail[i][j];
     }
   }
-  return true;
+}
+} // namespace
+
+// Blocked left-looking Cholesky on the row-contiguous envelope.  With block > 1 the rows come in aligned groups
+// of `block` rows sharing `first` (the window's keyframe blocks); then for block row I and block column J < I
+//     S    = A_IJ - L_I[:, k0:cJ] * L_J[:, k0:cJ]^T          (GEMM, k contiguous in both operands)
+//     L_IJ = S * inv(L_JJ)^T                                   (GEMM against the cached inverse of the diagonal factor)
+// and the diagonal block is a dense block x block Cholesky of A_II - L_I[:, f:r0] L_I[:, f:r0]^T.
+// The GEMMs are split over `threads` by rows of the block row.
+bool EnvelopeMatrix::cholesky_inplace(int block, int threads)
+{
+  bool uniform = block > 1 && n % block == 0;
+  if (uniform)
+    for (int r = 0; r < n && uniform; ++r)
+      uniform = first[r] == first[(r / block) * block] && first[r] % block == 0;
+  if (!uniform)
+  {
+    // generic envelope: plain row-wise left-looking factorisation
+    for (int r = 0; r < n; ++r)
+    {
+      double *Lr = &data[rowptr[r]];
+      const int fr = first[r];
+      for (int c = fr; c <= r; ++c)
+      {
+        const double *Lc = &data[rowptr[c]];
+        const int fc = first[c];
+        const int k0 = fr > fc ? fr : fc;
+        const double s = Lr[c - fr] - env_dot(Lr + (k0 - fr), Lc + (k0 - fc), c - k0);
+        if (c < r)
+          Lr[c - fr] = s / Lc[c - fc];
+        else
+        {
+          if (!(s > 0.0))
+            return false;
+          Lr[c - fr] = std::sqrt(s);
+        }
+      }
+    }
+    return true;
+  }
+  const int nb = block, NB = n / nb;
+  threads = std::max(1, std::min(threads, nb / 4));
+  std::vector<double> winv((size_t)NB * nb * nb, 0.0); // inverse of every diagonal factor block (lower triangular)
+  std::atomic<bool> ok{true};
+  SpinBarrier bar(threads);
+  auto worker = [&](int tid) {
+    std::vector<double> tmp((size_t)nb * nb);
+    std::vector<double *> crow(nb);
+    std::vector<const double *> arow(nb), brow(nb), trow(nb);
+    // this thread's slice of the block row
+    const int per = (nb + threads - 1) / threads;
+    const int i_lo = std::min(nb, tid * per), i_hi = std::min(nb, i_lo + per), ni = i_hi - i_lo;
+    for (int I = 0; I < NB; ++I)
+    {
+      const int r0 = I * nb, f = first[r0];
+      for (int J = f / nb; J < I; ++J)
+      {
+        const int c0 = J * nb, fJ = first[c0], k0 = f > fJ ? f : fJ, len = c0 - k0;
+        if (ni > 0)
+        {
+          for (int i = 0; i < ni; ++i)
+          {
+            double *row = &data[rowptr[r0 + i_lo + i]];
+            crow[i] = row;          // column c is at row[c - f]
+            arow[i] = row + (k0 - f);
+          }
+          for (int j = 0; j < nb; ++j)
+            brow[j] = &data[rowptr[c0 + j]] + (k0 - fJ);
+          gemm_nt_sub(crow.data(), c0 - f, arow.data(), brow.data(), ni, nb, len);
+          // L_IJ = S * Winv_J^T : copy S, clear the destination, accumulate with the (negated) GEMM
+          const double *W = &winv[(size_t)J * nb * nb];
+          for (int i = 0; i < ni; ++i)
+          {
+            double *dst = crow[i] + (c0 - f);
+            for (int j = 0; j < nb; ++j)
+            {
+              tmp[(size_t)i * nb + j] = -dst[j];
+              dst[j] = 0.0;
+            }
+            trow[i] = &tmp[(size_t)i * nb];
+          }
+          for (int j = 0; j < nb; ++j)
+            brow[j] = W + (size_t)j * nb;
+          gemm_nt_sub(crow.data(), c0 - f, trow.data(), brow.data(), ni, nb, nb);
+        }
+        // no barrier needed between block columns: thread t only touches its own rows of block row I,
+        // and block rows < I are final
+      }
+      // diagonal block: subtract the left part (own rows x all rows of the block -> needs everyone's left parts)
+      bar.wait();
+      if (ni > 0)
+      {
+        for (int i = 0; i < ni; ++i)
+        {
+          double *row = &data[rowptr[r0 + i_lo + i]];
+          crow[i] = row;
+          arow[i] = row;
+        }
+        for (int j = 0; j < nb; ++j)
+          brow[j] = &data[rowptr[r0 + j]];
+        // only columns j <= i are stored; compute the full slice into tmp-free in-place form row by row
+        for (int i = 0; i < ni; ++i)
+        {
+          double *ci[1] = {crow[i]};
+          const double *ai[1] = {arow[i]};
+          gemm_nt_sub(ci, r0 - f, ai, brow.data(), 1, i_lo + i + 1, r0 - f);
+        }
+      }
+      bar.wait();
+      if (tid == 0)
+      {
+        // dense Cholesky of the nb x nb diagonal block (lower part, in place) + its inverse
+        for (int i = 0; i < nb && ok.load(std::memory_order_relaxed); ++i)
+        {
+          double *Li = &data[rowptr[r0 + i]] + (r0 - f);
+          for (int j = 0; j <= i; ++j)
+          {
+            const double *Lj = &data[rowptr[r0 + j]] + (r0 - f);
+            double sacc = Li[j];
+            for (int k = 0; k < j; ++k)
+              sacc -= Li[k] * Lj[k];
+            if (j < i)
+              Li[j] = sacc / Lj[j];
+            else
+            {
+              if (!(sacc > 0.0))
+              {
+                ok.store(false);
+                break;
+              }
+              Li[j] = std::sqrt(sacc);
+            }
+          }
+        }
+        if (ok.load())
+        {
+          double *W = &winv[(size_t)I * nb * nb]; // W = inv(L_II): solve L_II W = Id, row by row
+          for (int i = 0; i < nb; ++i)
+          {
+            const double *Li = &data[rowptr[r0 + i]] + (r0 - f);
+            for (int j = 0; j <= i; ++j)
+            {
+              double sacc = (i == j) ? 1.0 : 0.0;
+              for (int k = j; k < i; ++k)
+                sacc -= Li[k] * W[(size_t)k * nb + j];
+              W[(size_t)i * nb + j] = sacc / Li[i];
+            }
+          }
+        }
+      }
+      bar.wait();
+      if (!ok.load())
+        return;
+    }
+  };
+  if (threads == 1)
+    worker(0);
+  else
+  {
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t)
+      pool.emplace_back(worker, t);
+    worker(0);
+    for (auto &th : pool)
+      th.join();
+  }
+  return ok.load();
 }
 
 void EnvelopeMatrix::solve_inplace(std::vector<double> &b) const
@@ -546,10 +776,7 @@ void EnvelopeMatrix::solve_inplace(std::vector<double> &b) const
   {
     const double *Lr = &data[rowptr[r]];
     const int fr = first[r];
-    double s = b[r];
-    for (int c = fr; c < r; ++c)
-      s -= Lr[c - fr] * b[c];
-    b[r] = s / Lr[r - fr];
+    b[r] = (b[r] - env_dot(Lr, &b[fr], r - fr)) / Lr[r - fr];
   }
   // L^T x = y
   for (int r = n - 1; r >= 0; --r)
@@ -558,8 +785,7 @@ void EnvelopeMatrix::solve_inplace(std::vector<double> &b) const
     const int fr = first[r];
     const double x = b[r] / Lr[r - fr];
     b[r] = x;
-    for (int c = fr; c < r; ++c)
-      b[c] -= Lr[c - fr] * x;
+    env_axpy(&b[fr], Lr, x, r - fr);
   }
 }
 
@@ -589,6 +815,9 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
   for (int k = 0; k < K; ++k)
     for (int i = 0; i < B; ++i)
       first[k * B + i] = first_blk[k] * B;
+  static const bool dbg = getenv("SAGE_DEBUG_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_a = tnow();
   sage::EnvelopeMatrix M;
   M.init(n, first);
   std::vector<double> rhs(n);
@@ -611,9 +840,21 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
   }
   for (int r = 0; r < n; ++r) // LM damping H + damp*diag(H) (camera_tracker.cpp:1182)
     M.at(r, r) *= (1.0 + damp);
-  if (!M.cholesky_inplace())
+  static const int n_threads = getenv("SAGE_SOLVE_THREADS")
+                                   ? std::max(1, atoi(getenv("SAGE_SOLVE_THREADS")))
+                                   : 1; // measured on the EPYC 9575F host: the spin-barrier thread split LOSES to one thread at n = 2496
+  auto t_b = tnow();
+  if (!M.cholesky_inplace(B, n_threads))
     return SAGE_E_NOT_PSD;
+  auto t_c = tnow();
   M.solve_inplace(rhs);
+  if (dbg)
+  {
+    auto t_d = tnow();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "[sage block_solve] n %d threads %d: assemble %.3f cholesky %.3f substitution %.3f ms\n", n,
+            n_threads, ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d));
+  }
   std::memcpy(delta, rhs.data(), sizeof(double) * n);
   return SAGE_OK;
 }

@@ -17,7 +17,9 @@ struct EnvelopeMatrix
   std::vector<double> data;
   void init(int n_, const std::vector<int> &first_);
   inline double &at(int r, int c) { return data[rowptr[r] + (size_t)(c - first[r])]; } // first[r] <= c <= r
-  bool cholesky_inplace();                       // returns false if not positive definite
+  // returns false if not positive definite.  block > 1: rows come in aligned groups of `block` rows that share
+  // `first` (the window's keyframe blocks) -> the rows of a group are factorised in parallel on `threads` threads.
+  bool cholesky_inplace(int block = 1, int threads = 1);
   void solve_inplace(std::vector<double> &b) const; // after cholesky_inplace: b <- A^-1 b
 };
 } // namespace sage

@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -1114,8 +1116,14 @@ extern "C" int sage_window_solve(SageWindow *w, double damp, double *step_norm)
   const SageWindowConfig &c = w->cfg;
   const int K = w->K, B = w->B, CS = c.CS, BB = B * B, n = K * B;
   const size_t np = sage_window_packed_count(w);
+  static const bool dbg = getenv("SAGE_DEBUG_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  auto t_a = tnow();
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  auto t_b = tnow();
   SAGE_HIP(hipMemcpyAsync(w->host_packed.data(), w->packed.p, np * sizeof(double), hipMemcpyDeviceToHost, w->stream));
   SAGE_HIP(hipStreamSynchronize(w->stream));
+  auto t_c = tnow();
   // diagonal priors (a9): code prior on every keyframe, scale / pose priors on keyframe 0
   std::vector<double> dadd((size_t)n, 0.0), gadd((size_t)n, 0.0);
   for (int k = 0; k < K; ++k)
@@ -1152,6 +1160,7 @@ extern "C" int sage_window_solve(SageWindow *w, double damp, double *step_norm)
                              gadd.data(), rhs.data());
   if (rcs)
     return rcs;
+  auto t_d = tnow();
   w->delta = rhs;
   double nrm = 0;
   for (double v : rhs)
@@ -1169,7 +1178,15 @@ extern "C" int sage_window_solve(SageWindow *w, double damp, double *step_norm)
       w->code[1][(size_t)k * CS + i] = w->code[0][(size_t)k * CS + i] + (float)rhs[k * B + 6 + i];
     w->scale[1][k] = w->scale[0][k] + (float)rhs[k * B + 6 + CS];
   }
-  return upload_vars(w, 1);
+  const int rcu = upload_vars(w, 1);
+  if (dbg)
+  {
+    auto t_e = tnow();
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "[sage solve] wait-kernels %.3f d2h %.3f block_solve %.3f retract+h2d %.3f ms\n", ms(t_a, t_b),
+            ms(t_b, t_c), ms(t_c, t_d), ms(t_d, t_e));
+  }
+  return rcu;
 }
 
 extern "C" int sage_window_accept(SageWindow *w)
