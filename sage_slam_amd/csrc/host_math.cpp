@@ -603,6 +603,55 @@ __attribute__((target_clones("avx512f", "avx2", "default"))) static void gemm_nt
 }
 } // namespace
 
+// In-place Cholesky of an nb x nb diagonal block given by row pointers (row i holds columns 0..i) and the inverse
+// W of its factor (dense nb x nb row-major, lower triangular).  One multiversioned function so the short inner loops
+// are compiled for the widest host ISA without a per-call dispatch.  Returns false if not positive definite.
+__attribute__((target_clones("avx512f", "avx2", "default"))) static bool diag_factor(double *const *L, int nb, double *W,
+                                                                                 double *col)
+{
+  for (int j = 0; j < nb; ++j)
+  {
+    const double d = L[j][j];
+    if (!(d > 0.0))
+      return false;
+    const double sj = std::sqrt(d), inv = 1.0 / sj;
+    L[j][j] = sj;
+    for (int i = j + 1; i < nb; ++i)
+    {
+      L[i][j] *= inv;
+      col[i] = L[i][j];
+    }
+    for (int i = j + 1; i < nb; ++i) // right-looking update of the trailing rows, contiguous in k
+    {
+      const double lij = col[i];
+      double *Li = L[i];
+#pragma clang loop vectorize(enable)
+      for (int k = j + 1; k <= i; ++k)
+        Li[k] -= lij * col[k];
+    }
+  }
+  for (int i = 0; i < nb; ++i) // W = inv(L): row i = (e_i - sum_{k<i} L[i][k] W[k][:]) / L[i][i]
+  {
+    double *Wi = W + (size_t)i * nb;
+    for (int j = 0; j < nb; ++j)
+      Wi[j] = 0.0;
+    Wi[i] = 1.0;
+    for (int k = 0; k < i; ++k)
+    {
+      const double lik = L[i][k];
+      const double *Wk = W + (size_t)k * nb;
+#pragma clang loop vectorize(enable)
+      for (int j = 0; j <= k; ++j)
+        Wi[j] -= lik * Wk[j];
+    }
+    const double inv = 1.0 / L[i][i];
+#pragma clang loop vectorize(enable)
+    for (int j = 0; j <= i; ++j)
+      Wi[j] *= inv;
+  }
+  return true;
+}
+
 // Blocked left-looking Cholesky on the row-contiguous envelope.  With block > 1 the rows come in aligned groups
 // of `block` rows sharing `first` (the window's keyframe blocks); then for block row I and block column J < I
 //     S    = A_IJ - L_I[:, k0:cJ] * L_J[:, k0:cJ]^T          (GEMM, k contiguous in both operands)
@@ -642,9 +691,14 @@ bool EnvelopeMatrix::cholesky_inplace(int block, int threads)
   }
   const int nb = block, NB = n / nb;
   threads = std::max(1, std::min(threads, nb / 4));
+  if (nb < 16)
+    threads = 1;
   std::vector<double> winv((size_t)NB * nb * nb, 0.0); // inverse of every diagonal factor block (lower triangular)
   std::atomic<bool> ok{true};
   SpinBarrier bar(threads);
+  double t_gemm1 = 0, t_gemm2 = 0, t_diag = 0, t_scalar = 0;
+  auto tk = [] { return std::chrono::steady_clock::now(); };
+  auto dtm = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
   auto worker = [&](int tid) {
     std::vector<double> tmp((size_t)nb * nb);
     std::vector<double *> crow(nb);
@@ -668,7 +722,10 @@ bool EnvelopeMatrix::cholesky_inplace(int block, int threads)
           }
           for (int j = 0; j < nb; ++j)
             brow[j] = &data[rowptr[c0 + j]] + (k0 - fJ);
+          auto q0 = tk();
           gemm_nt_sub(crow.data(), c0 - f, arow.data(), brow.data(), ni, nb, len);
+          if (tid == 0) t_gemm1 += dtm(q0, tk());
+          auto q1 = tk();
           // L_IJ = S * Winv_J^T : copy S, clear the destination, accumulate with the (negated) GEMM
           const double *W = &winv[(size_t)J * nb * nb];
           for (int i = 0; i < ni; ++i)
@@ -684,12 +741,14 @@ bool EnvelopeMatrix::cholesky_inplace(int block, int threads)
           for (int j = 0; j < nb; ++j)
             brow[j] = W + (size_t)j * nb;
           gemm_nt_sub(crow.data(), c0 - f, trow.data(), brow.data(), ni, nb, nb);
+          if (tid == 0) t_gemm2 += dtm(q1, tk());
         }
         // no barrier needed between block columns: thread t only touches its own rows of block row I,
         // and block rows < I are final
       }
       // diagonal block: subtract the left part (own rows x all rows of the block -> needs everyone's left parts)
       bar.wait();
+      auto q2 = tk();
       if (ni > 0)
       {
         for (int i = 0; i < ni; ++i)
@@ -700,57 +759,36 @@ bool EnvelopeMatrix::cholesky_inplace(int block, int threads)
         }
         for (int j = 0; j < nb; ++j)
           brow[j] = &data[rowptr[r0 + j]];
-        // only columns j <= i are stored; compute the full slice into tmp-free in-place form row by row
+        // only columns j <= i are stored: accumulate the full ni x nb slice into tmp, then fold the lower part back
         for (int i = 0; i < ni; ++i)
         {
-          double *ci[1] = {crow[i]};
-          const double *ai[1] = {arow[i]};
-          gemm_nt_sub(ci, r0 - f, ai, brow.data(), 1, i_lo + i + 1, r0 - f);
+          for (int j = 0; j < nb; ++j)
+            tmp[(size_t)i * nb + j] = 0.0;
+          crow[i] = &tmp[(size_t)i * nb];
+        }
+        gemm_nt_sub(crow.data(), 0, arow.data(), brow.data(), ni, std::min(nb, i_hi), r0 - f);
+        for (int i = 0; i < ni; ++i)
+        {
+          double *dst = &data[rowptr[r0 + i_lo + i]] + (r0 - f);
+          for (int j = 0; j <= i_lo + i; ++j)
+            dst[j] += tmp[(size_t)i * nb + j];
         }
       }
       bar.wait();
+      if (tid == 0) t_diag += dtm(q2, tk());
+      auto q3 = tk();
       if (tid == 0)
       {
-        // dense Cholesky of the nb x nb diagonal block (lower part, in place) + its inverse
-        for (int i = 0; i < nb && ok.load(std::memory_order_relaxed); ++i)
-        {
-          double *Li = &data[rowptr[r0 + i]] + (r0 - f);
-          for (int j = 0; j <= i; ++j)
-          {
-            const double *Lj = &data[rowptr[r0 + j]] + (r0 - f);
-            double sacc = Li[j];
-            for (int k = 0; k < j; ++k)
-              sacc -= Li[k] * Lj[k];
-            if (j < i)
-              Li[j] = sacc / Lj[j];
-            else
-            {
-              if (!(sacc > 0.0))
-              {
-                ok.store(false);
-                break;
-              }
-              Li[j] = std::sqrt(sacc);
-            }
-          }
-        }
-        if (ok.load())
-        {
-          double *W = &winv[(size_t)I * nb * nb]; // W = inv(L_II): solve L_II W = Id, row by row
-          for (int i = 0; i < nb; ++i)
-          {
-            const double *Li = &data[rowptr[r0 + i]] + (r0 - f);
-            for (int j = 0; j <= i; ++j)
-            {
-              double sacc = (i == j) ? 1.0 : 0.0;
-              for (int k = j; k < i; ++k)
-                sacc -= Li[k] * W[(size_t)k * nb + j];
-              W[(size_t)i * nb + j] = sacc / Li[i];
-            }
-          }
-        }
+        // dense Cholesky of the nb x nb diagonal block (lower part, in place) + the inverse of its factor
+        std::vector<double *> drow(nb);
+        std::vector<double> colbuf(nb);
+        for (int i = 0; i < nb; ++i)
+          drow[i] = &data[rowptr[r0 + i]] + (r0 - f);
+        if (!diag_factor(drow.data(), nb, &winv[(size_t)I * nb * nb], colbuf.data()))
+          ok.store(false);
       }
       bar.wait();
+      if (tid == 0) t_scalar += dtm(q3, tk());
       if (!ok.load())
         return;
     }
@@ -766,6 +804,9 @@ bool EnvelopeMatrix::cholesky_inplace(int block, int threads)
     for (auto &th : pool)
       th.join();
   }
+  if (getenv("SAGE_DEBUG_TIMING"))
+    fprintf(stderr, "[sage cholesky] gemm(S) %.3f gemm(trsm) %.3f diag-gemm %.3f diag-chol+inv %.3f ms\n", t_gemm1,
+            t_gemm2, t_diag, t_scalar);
   return ok.load();
 }
 
@@ -796,7 +837,10 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
 {
   if (!packed || K < 1 || B < 1 || nlinks < 0 || (nlinks > 0 && !links) || !delta)
     return SAGE_E_INVALID;
-  const int BB = B * B, n = K * B;
+  // the factorisation works on blocks padded to a multiple of 8 rows (identity on the padding) so that every
+  // GEMM inner length is a whole number of 8-double vectors
+  const int Bp = (B + 7) / 8 * 8;
+  const int BB = B * B, n = K * Bp, n_out = K * B;
   const double *diag = packed;
   const double *lnk = diag + (size_t)K * BB;
   const double *g = lnk + (size_t)nlinks * BB;
@@ -813,38 +857,40 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
   }
   std::vector<int> first(n);
   for (int k = 0; k < K; ++k)
-    for (int i = 0; i < B; ++i)
-      first[k * B + i] = first_blk[k] * B;
+    for (int i = 0; i < Bp; ++i)
+      first[k * Bp + i] = first_blk[k] * Bp;
   static const bool dbg = getenv("SAGE_DEBUG_TIMING") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto t_a = tnow();
   sage::EnvelopeMatrix M;
   M.init(n, first);
-  std::vector<double> rhs(n);
+  std::vector<double> rhs(n, 0.0);
   for (int k = 0; k < K; ++k)
+  {
     for (int i = 0; i < B; ++i)
     {
       for (int j = 0; j <= i; ++j)
-        M.at(k * B + i, k * B + j) =
-            0.5 * ((double)diag[(size_t)k * BB + i * B + j] + (double)diag[(size_t)k * BB + j * B + i]);
-      rhs[k * B + i] = (double)g[(size_t)k * B + i] + (g_add ? g_add[k * B + i] : 0.0);
+        M.at(k * Bp + i, k * Bp + j) = 0.5 * (diag[(size_t)k * BB + i * B + j] + diag[(size_t)k * BB + j * B + i]);
+      rhs[k * Bp + i] = g[(size_t)k * B + i] + (g_add ? g_add[k * B + i] : 0.0);
       if (diag_add)
-        M.at(k * B + i, k * B + i) += diag_add[k * B + i];
+        M.at(k * Bp + i, k * Bp + i) += diag_add[k * B + i];
     }
+    for (int i = B; i < Bp; ++i)
+      M.at(k * Bp + i, k * Bp + i) = 1.0; // padding rows: identity, rhs 0 -> delta 0
+  }
   for (int l = 0; l < nlinks; ++l)
   {
     const int a = links[2 * l], b = links[2 * l + 1]; // block (a,b) -> lower-triangle rows of b
     for (int i = 0; i < B; ++i)
       for (int j = 0; j < B; ++j)
-        M.at(b * B + j, a * B + i) += (double)lnk[(size_t)l * BB + i * B + j];
+        M.at(b * Bp + j, a * Bp + i) += lnk[(size_t)l * BB + i * B + j];
   }
   for (int r = 0; r < n; ++r) // LM damping H + damp*diag(H) (camera_tracker.cpp:1182)
     M.at(r, r) *= (1.0 + damp);
-  static const int n_threads = getenv("SAGE_SOLVE_THREADS")
-                                   ? std::max(1, atoi(getenv("SAGE_SOLVE_THREADS")))
-                                   : 1; // measured on the EPYC 9575F host: the spin-barrier thread split LOSES to one thread at n = 2496
+  static const int n_threads = getenv("SAGE_SOLVE_THREADS") ? std::max(1, atoi(getenv("SAGE_SOLVE_THREADS")))
+                                                            : 1; // EPYC 9575F: the thread split loses at n ~ 2.5k
   auto t_b = tnow();
-  if (!M.cholesky_inplace(B, n_threads))
+  if (!M.cholesky_inplace(Bp, n_threads))
     return SAGE_E_NOT_PSD;
   auto t_c = tnow();
   M.solve_inplace(rhs);
@@ -855,6 +901,8 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
     fprintf(stderr, "[sage block_solve] n %d threads %d: assemble %.3f cholesky %.3f substitution %.3f ms\n", n,
             n_threads, ms(t_a, t_b), ms(t_b, t_c), ms(t_c, t_d));
   }
-  std::memcpy(delta, rhs.data(), sizeof(double) * n);
+  for (int k = 0; k < K; ++k)
+    std::memcpy(delta + (size_t)k * B, rhs.data() + (size_t)k * Bp, sizeof(double) * B);
+  (void)n_out;
   return SAGE_OK;
 }
