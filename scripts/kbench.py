@@ -1,0 +1,25 @@
+"""Kernel-only micro-bench on the headline window: N linearize + N error passes, HIP-event kernel times (dev tool;
+also the workload for the rocprofv3 --pmc passes)."""
+import sys, json
+sys.path.insert(0, ".")
+import torch
+from sage_slam_amd import capi, synth
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+w = synth.make_window(K=K, H=128, W=160, FS=16, CS=32, L=4, seed=0)
+win = capi.Window(w)
+win.linearize(); win.error(1); torch.cuda.synchronize()
+win.set_profiling(True)
+for _ in range(n):
+    win.linearize(); win.error(1)
+names = ["photo_lin", "geo_lin", "photo_err", "geo_err"]
+res = {}
+for i, nm in enumerate(names):
+    ms, c = win.kernel_time(i)
+    res[nm] = round(ms / max(1, c), 4)
+N = w.keyframes[0].homo.shape[0]; E = 2 * len(w.links)
+rho = w.P / (w.H * w.W)
+bp = 4 * (4 * w.FS * rho + w.CS + 6) * N * E; bg = 4 * (2 * w.CS + 9) * N * E
+res["photo_GBs"] = round(bp / res["photo_lin"] / 1e6, 1); res["geo_GBs"] = round(bg / res["geo_lin"] / 1e6, 1)
+res["photo_frac"] = round(res["photo_GBs"] / 8000, 4)
+print(json.dumps(res))
