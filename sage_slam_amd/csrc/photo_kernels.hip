@@ -42,7 +42,7 @@ __device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i 
   return i * 6 - (i * (i - 1)) / 2 + (j - i);
 }
 
-template <int CS, int FS, bool JAC>
+template <int CS, int FS, bool JAC, bool PACKED>
 __global__ __launch_bounds__(kBlock) void photo_kernel(const PhotoParams prm)
 {
   constexpr int LD = CS + 1;
@@ -58,6 +58,7 @@ __global__ __launch_bounds__(kBlock) void photo_kernel(const PhotoParams prm)
   wi.tile = uni(wi.tile);
   PhotoEdge E = prm.table ? prm.table[wi.edge] : prm.single;
   E.feat0 = uni(E.feat0); E.feat1 = uni(E.feat1); E.grad1 = uni(E.grad1); E.bias0 = uni(E.bias0);
+  E.feat0_pk = uni(E.feat0_pk); E.feat1_pk = uni(E.feat1_pk); E.gx1_pk = uni(E.gx1_pk); E.gy1_pk = uni(E.gy1_pk);
   E.basis0 = uni(E.basis0); E.mask1 = uni(E.mask1); E.homo = uni(E.homo); E.loc = uni(E.loc);
   E.R0 = uni(E.R0); E.t0 = uni(E.t0); E.R1 = uni(E.R1); E.t1 = uni(E.t1); E.R10 = uni(E.R10); E.t10 = uni(E.t10);
   E.code0 = uni(E.code0); E.scale0 = uni(E.scale0); E.scale0_val = uni(E.scale0_val);
@@ -78,9 +79,11 @@ __global__ __launch_bounds__(kBlock) void photo_kernel(const PhotoParams prm)
   const float fx0 = pyr.cam[0].fx, fy0 = pyr.cam[0].fy, cx0 = pyr.cam[0].cx, cy0 = pyr.cam[0].cy;
   const int W0 = (int)pyr.cam[0].w, H0 = (int)pyr.cam[0].h;
   const uint32_t pyr_bytes = (uint32_t)FS * (uint32_t)pyr.P * 4u;
-  const __amdgpu_buffer_rsrc_t r_f0 = make_rsrc(E.feat0, pyr_bytes);
-  const __amdgpu_buffer_rsrc_t r_f1 = make_rsrc(E.feat1, pyr_bytes);
-  const __amdgpu_buffer_rsrc_t r_g1 = make_rsrc(JAC ? E.grad1 : E.feat1, JAC ? 2u * pyr_bytes : pyr_bytes);
+  const __amdgpu_buffer_rsrc_t r_f0 = make_rsrc(PACKED ? E.feat0_pk : E.feat0, pyr_bytes);
+  const __amdgpu_buffer_rsrc_t r_f1 = make_rsrc(PACKED ? E.feat1_pk : E.feat1, pyr_bytes);
+  const __amdgpu_buffer_rsrc_t r_g1 =
+      make_rsrc(PACKED ? (JAC ? E.gx1_pk : E.feat1_pk) : (JAC ? E.grad1 : E.feat1), (JAC && !PACKED) ? 2u * pyr_bytes : pyr_bytes);
+  const __amdgpu_buffer_rsrc_t r_g1y = make_rsrc((PACKED && JAC) ? E.gy1_pk : E.feat1, pyr_bytes);
   const uint32_t plane = (uint32_t)pyr.P * 4u;
 
   for (int k = tid; k < kWaves * kPhotoScalars; k += kBlock)
@@ -158,6 +161,58 @@ __global__ __launch_bounds__(kBlock) void photo_kernel(const PhotoParams prm)
       dof[k] = (lo + (uint32_t)td.off[k]) * 4u;
     }
     float g00 = 0.f, g01 = 0.f, g11 = 0.f, a0 = 0.f, a1 = 0.f, ee = 0.f;
+    if (PACKED)
+    {
+      // channel-group layout: one dwordx4 per tap and group of 4 channels (16 B per lane, 1 KiB contiguous per wave)
+      for (int g = 0; g < FS / 4; ++g)
+      {
+        const uint32_t soff = (uint32_t)g * plane * 4u;
+        // issue every tap load of the group first (16 independent dwordx4 in flight), then consume: without the
+        // scheduling barrier hipcc serialises load->wait->use through one register quad
+        f32x4 t0[4], t1[4], tx[JAC ? 4 : 1], ty[JAC ? 4 : 1];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+          t0[k] = buf_load4(r_f0, so[k] * 4u, soff);
+          t1[k] = buf_load4(r_f1, dof[k] * 4u, soff);
+          if (JAC)
+          {
+            tx[k] = buf_load4(r_g1, dof[k] * 4u, soff);
+            ty[k] = buf_load4(r_g1y, dof[k] * 4u, soff);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = f0, gx = f0, gy = f0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+          f0 += ts.w[k] * t0[k];
+          f1 += td.w[k] * t1[k];
+          if (JAC)
+          {
+            gx += td.w[k] * tx[k];
+            gy += td.w[k] * ty[k];
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+        {
+          const float diff = f0[c] - f1[c];
+          ee += diff * diff;
+          if (JAC)
+          {
+            const float hx = fxl * gx[c], hy = fyl * gy[c];
+            g00 += hx * hx;
+            g01 += hx * hy;
+            g11 += hy * hy;
+            a0 += hx * diff;
+            a1 += hy * diff;
+          }
+        }
+      }
+    }
+    else
+    {
 #pragma unroll 4
     for (int c = 0; c < FS; ++c)
     {
@@ -188,6 +243,7 @@ __global__ __launch_bounds__(kBlock) void photo_kernel(const PhotoParams prm)
         a0 += hx * diff;
         a1 += hy * diff;
       }
+    }
     }
     const float wl = prm.w[l];
     err += wl * ee;
@@ -556,7 +612,10 @@ static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const P
   PhotoParams p = make_params(single, table, lc, pyr, wh, eps, &wsum);
   if (lc.ev_start)
     (void)hipEventRecord(lc.ev_start, s);
-  hipLaunchKernelGGL((photo_kernel<CS, FS, true>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  if (lc.packed)
+    hipLaunchKernelGGL((photo_kernel<CS, FS, true, true>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  else
+    hipLaunchKernelGGL((photo_kernel<CS, FS, true, false>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   if (lc.ev_stop)
     (void)hipEventRecord(lc.ev_stop, s);
   PhotoFinalizeParams f{};
@@ -583,7 +642,10 @@ static hipError_t photo_err_impl(hipStream_t s, const PhotoEdge *single, const P
   PhotoParams p = make_params(single, table, lc, pyr, wh, eps, &wsum);
   if (lc.ev_start)
     (void)hipEventRecord(lc.ev_start, s);
-  hipLaunchKernelGGL((photo_kernel<CS, FS, false>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  if (lc.packed)
+    hipLaunchKernelGGL((photo_kernel<CS, FS, false, true>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  else
+    hipLaunchKernelGGL((photo_kernel<CS, FS, false, false>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   if (lc.ev_stop)
     (void)hipEventRecord(lc.ev_stop, s);
   return launch_stats_finalize(s, lc, stats, 10.0f * wsum, 1.0f);

@@ -91,6 +91,27 @@ hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev,
   return hipGetLastError();
 }
 
+// [C][P] channel-major -> [C/4][P][4] channel-group layout (engine-internal, once per keyframe)
+__global__ void repack_groups_kernel(float *__restrict__ dst, const float *__restrict__ src, int C, int P)
+{
+  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y;
+  if (p >= P)
+    return;
+  f32x4 v;
+  v[0] = src[(size_t)(4 * g + 0) * P + p];
+  v[1] = src[(size_t)(4 * g + 1) * P + p];
+  v[2] = src[(size_t)(4 * g + 2) * P + p];
+  v[3] = src[(size_t)(4 * g + 3) * P + p];
+  *reinterpret_cast<f32x4 *>(dst + ((size_t)g * P + p) * 4) = v;
+}
+
+hipError_t launch_repack_groups(hipStream_t s, float *dst, const float *src, int C, int P)
+{
+  hipLaunchKernelGGL(repack_groups_kernel, dim3((P + 255) / 256, C / 4), dim3(256), 0, s, dst, src, C, P);
+  return hipGetLastError();
+}
+
 // central differences with replicate padding (x then y) on [C,H,W]; out [2,C,H,W]
 __global__ void spatial_grad_kernel(float *grad, const float *__restrict__ img, int C, int H, int W)
 {

@@ -636,6 +636,7 @@ struct SageWindow
   // device
   DevBuf vars[2];                       // [K][VS]: pose 12, scale 1, code CS
   DevBuf dpt, dgrad, depth_items[2];    // per-keyframe depth maps of the set being evaluated
+  DevBuf pk;                            // engine-internal channel-group pyramids [K][3 (f,gx,gy)][FS/4][P][4]
   DevBuf ptab[2], gtab[2];              // edge tables per variable set
   DevBuf work_p, first_p, tiles_p, work_g, first_g, tiles_g;
   DevBuf part_p, part_g;
@@ -745,7 +746,7 @@ extern "C" void sage_window_destroy(SageWindow *w)
   if (!w)
     return;
   DevBuf *bufs[] = {&w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
-                    &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
+                    &w->pk, &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
                     &w->work_g, &w->first_g, &w->tiles_g, &w->part_p, &w->part_g, &w->AtA_p, &w->Atb_p,
                     &w->stats_p, &w->AtA_g, &w->Atb_g, &w->stats_g, &w->adj_start, &w->adj, &w->link_edges,
                     &w->packed, &w->errbuf};
@@ -847,6 +848,17 @@ extern "C" int sage_window_finalize(SageWindow *w)
       return rc;
     SAGE_HIP(hipStreamSynchronize(w->stream));
   }
+  // ---- engine-internal relayout, once per keyframe: [FS][P] -> [FS/4][P][4] for feat, grad-x, grad-y
+  const size_t plane_f = (size_t)FS * c.pyr.P;
+  if ((rc = w->pk.reserve((size_t)K * 3 * plane_f * sizeof(float))))
+    return rc;
+  for (int k = 0; k < K; ++k)
+  {
+    float *base = w->pk.as<float>() + (size_t)k * 3 * plane_f;
+    SAGE_HIP(launch_repack_groups(w->stream, base, w->views[k].feat_pyr, FS, c.pyr.P));
+    SAGE_HIP(launch_repack_groups(w->stream, base + plane_f, w->views[k].grad_pyr, FS, c.pyr.P));
+    SAGE_HIP(launch_repack_groups(w->stream, base + 2 * plane_f, w->views[k].grad_pyr + plane_f, FS, c.pyr.P));
+  }
   // ---- local links / edges
   w->local_links.clear();
   for (size_t l = 0; l < w->links.size(); ++l)
@@ -875,6 +887,10 @@ extern "C" int sage_window_finalize(SageWindow *w)
         const float *x1 = w->vars[s].as<float>() + (size_t)k1 * w->VS;
         PhotoEdge pe{};
         pe.feat0 = v0.feat_pyr; pe.feat1 = v1.feat_pyr; pe.grad1 = v1.grad_pyr; pe.bias0 = v0.bias;
+        pe.feat0_pk = w->pk.as<float>() + (size_t)k0 * 3 * plane_f;
+        pe.feat1_pk = w->pk.as<float>() + (size_t)k1 * 3 * plane_f;
+        pe.gx1_pk = pe.feat1_pk + plane_f;
+        pe.gy1_pk = pe.feat1_pk + 2 * plane_f;
         pe.basis0 = v0.basis; pe.mask1 = c.mask_dev; pe.homo = v0.homo; pe.loc = v0.loc1d; pe.loc_is_i64 = 1;
         pe.R0 = x0; pe.t0 = x0 + 9; pe.R1 = x1; pe.t1 = x1 + 9; pe.R10 = nullptr; pe.t10 = nullptr;
         pe.code0 = x0 + 13; pe.scale0 = x0 + 12; pe.N = v0.N;
@@ -964,6 +980,7 @@ static LaunchCommon window_lc(SageWindow *w, bool photo)
   lc.n_edges = w->n_edges;
   lc.partials = photo ? w->part_p.as<float>() : w->part_g.as<float>();
   lc.tiles_per_block = w->tpb_p;
+  lc.packed = photo;
   return lc;
 }
 

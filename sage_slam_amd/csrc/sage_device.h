@@ -135,15 +135,16 @@ __device__ __forceinline__ Pose load_pose(const float *__restrict__ p)
   return o;
 }
 
+// the 12 floats are wave-uniform: pin them to SGPRs so they do not occupy VGPRs across the sampling loop
 __device__ __forceinline__ Pose load_pose2(const float *__restrict__ R, const float *__restrict__ t)
 {
   Pose o;
 #pragma unroll
   for (int i = 0; i < 9; ++i)
-    o.R[i] = R[i];
+    o.R[i] = uni(R[i]);
 #pragma unroll
   for (int i = 0; i < 3; ++i)
-    o.t[i] = t[i];
+    o.t[i] = uni(t[i]);
   return o;
 }
 

@@ -19,6 +19,9 @@ struct PhotoEdge
   const float *feat0;   // [FS,P]  source pyramid
   const float *feat1;   // [FS,P]  destination pyramid
   const float *grad1;   // [2,FS,P]
+  // engine-internal channel-group layout [FS/4][P][4] (float4 per texel per group of 4 channels): one
+  // buffer_load_dwordx4 per tap and group, fully coalesced across the wave.  nullptr -> use the reference layout.
+  const float *feat0_pk, *feat1_pk, *gx1_pk, *gy1_pk;
   const float *bias0;   // [H*W]
   const float *basis0;  // [H*W,CS]
   const float *mask1;   // [H,W]
@@ -99,6 +102,7 @@ struct LaunchCommon
   float *partials;           // [n_work][partial_floats]
   int32_t tiles_per_block;   // consecutive kTile sub-tiles per work item (work[i].tile = first sub-tile)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr; // optional: recorded around the main kernel only
+  bool packed = false;       // edges carry the channel-group (float4) pyramids
 };
 
 // per-edge results, reference layouts
@@ -134,6 +138,7 @@ struct DepthItem
   const float *bias, *basis, *code, *scale;
   float *dpt, *grad;
 };
+hipError_t launch_repack_groups(hipStream_t s, float *dst, const float *src, int C, int P);
 hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev, int K, int H, int W);
 hipError_t launch_stats_finalize(hipStream_t s, const LaunchCommon &lc, float *stats, float fallback, float scale);
 hipError_t launch_gaussian_pyramid_with_grad(hipStream_t s, float *pyr, float *grad, const float *feat,

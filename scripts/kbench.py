@@ -1,7 +1,7 @@
 """Kernel-only micro-bench on the headline window: N linearize + N error passes, HIP-event kernel times (dev tool;
 also the workload for the rocprofv3 --pmc passes)."""
 import sys, json
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from sage_slam_amd import capi, synth
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 64

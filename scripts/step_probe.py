@@ -1,6 +1,6 @@
 """Where does one LM step go?  Python-level timers with device syncs around each phase (dev tool)."""
 import sys, time
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from sage_slam_amd import capi, synth
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 64
