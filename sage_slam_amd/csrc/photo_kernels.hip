@@ -43,7 +43,7 @@ __device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i 
 }
 
 template <int CS, int FS, bool JAC, bool PACKED>
-__global__ __launch_bounds__(kBlock) void photo_kernel(const PhotoParams prm)
+__global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
 {
   constexpr int LD = CS + 1;
   constexpr int NT = photo_tiles(CS);
