@@ -42,15 +42,27 @@ __device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i 
   return i * 6 - (i * (i - 1)) / 2 + (j - i);
 }
 
-template <int CS, int FS, bool JAC, bool PACKED>
+constexpr int kStageCap = 1024; // float4 slots of the LDS patch buffer (16 KiB)
+constexpr int kTileDim = 16;    // 16 x 16 source pixels per tile (= kTile lanes)
+
+// MODE 0: reference layout, direct gathers (per-edge operator API, sparse samplings)
+// MODE 1: channel-group layout, direct dwordx4 gathers
+// MODE 2: channel-group layout + 2-D source tiles + destination patches staged in LDS (window engine, dense sampling)
+template <int CS, int FS, bool JAC, int MODE>
 __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
 {
+  constexpr bool PACKED = MODE >= 1;
+  constexpr bool TILED = MODE == 2;
   constexpr int LD = CS + 1;
   constexpr int NT = photo_tiles(CS);
   __shared__ float s_basis[kTile * LD];
   __shared__ int s_loc[kTile];
-  __shared__ float s_stash[JAC ? kTile * 9 : 1];
+  __shared__ float s_stash_raw[(JAC && !TILED) ? kTile * 9 : 1];
+  __shared__ f32x4 s_stage[TILED ? kStageCap : 1];
+  __shared__ int s_bbox[kWaves * 4];
   __shared__ float s_red[kWaves * kPhotoScalars];
+  // the per-pixel stash (phase C/D) reuses the patch buffer: sampling is over by then
+  float *s_stash = TILED ? reinterpret_cast<float *>(s_stage) : s_stash_raw;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WorkItem wi = prm.work[blockIdx.x];
@@ -63,6 +75,7 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
   E.R0 = uni(E.R0); E.t0 = uni(E.t0); E.R1 = uni(E.R1); E.t1 = uni(E.t1); E.R10 = uni(E.R10); E.t10 = uni(E.t10);
   E.code0 = uni(E.code0); E.scale0 = uni(E.scale0); E.scale0_val = uni(E.scale0_val);
   E.N = uni(E.N); E.loc_is_i64 = uni(E.loc_is_i64);
+  E.index_map0 = uni(E.index_map0); E.tiles0 = uni(E.tiles0); E.n_tiles0 = uni(E.n_tiles0); E.f0s = uni(E.f0s);
   const int N = E.N;
   const float scale0 = E.scale0 ? *E.scale0 : E.scale0_val;
 
@@ -97,12 +110,31 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
   for (int sub = 0; sub < prm.tiles_per_block; ++sub)
   {
   const int tile = wi.tile + sub;
-  if (tile * kTile >= N)
-    break;
-  const int n = tile * kTile + tid;
-  const bool in_range = n < N;
-  const int tile_rows = min(kTile, N - tile * kTile);
-  const int my_loc = in_range ? load_loc(E.loc, E.loc_is_i64, n) : 0;
+  int n, my_loc, tile_rows;
+  bool in_range;
+  if (TILED)
+  {
+    if (tile >= E.n_tiles0)
+      break;
+    const int t = uni(E.tiles0[tile]);
+    const int px = (t & 0xffff) + (tid & (kTileDim - 1)), py = (t >> 16) + (tid >> 4);
+    const bool in_img = px < W0 && py < H0;
+    my_loc = in_img ? py * W0 + px : 0;
+    n = in_img ? E.index_map0[my_loc] : -1;
+    in_range = n >= 0;
+    if (!in_range)
+      n = 0;
+    tile_rows = kTile;
+  }
+  else
+  {
+    if (tile * kTile >= N)
+      break;
+    n = tile * kTile + tid;
+    in_range = n < N;
+    tile_rows = min(kTile, N - tile * kTile);
+    my_loc = in_range ? load_loc(E.loc, E.loc_is_i64, n) : 0;
+  }
   const float d = stage_basis_and_depth<CS>(s_basis, s_loc, E.basis0, E.bias0, E.code0, scale0, my_loc, in_range,
                                             tile_rows);
 
@@ -152,6 +184,15 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
     Taps ts, td;
     make_taps(ts, su * rx - 0.5f, sv * ry - 0.5f, Wl, Hl);
     make_taps(td, (p + 0.5f) * rx - 0.5f, (q + 0.5f) * ry - 0.5f, Wl, Hl);
+    if (TILED && !in_range)
+    {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+      {
+        ts.w[k] = td.w[k] = 0.f;
+        ts.off[k] = td.off[k] = 0;
+      }
+    }
     const uint32_t lo = (uint32_t)pyr.level_offsets[l];
     uint32_t so[4], dof[4];
 #pragma unroll
@@ -161,7 +202,139 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
       dof[k] = (lo + (uint32_t)td.off[k]) * 4u;
     }
     float g00 = 0.f, g01 = 0.f, g11 = 0.f, a0 = 0.f, a1 = 0.f, ee = 0.f;
-    if (PACKED)
+    bool staged = false;
+    if (TILED)
+    {
+      // ---- bounding box (level texels) of the tile's destination taps ----
+      const int BIG = 1 << 28;
+      int bb[4];
+      bb[0] = wave_minmax<true>(in_range ? td.xf : BIG);
+      bb[1] = wave_minmax<false>(in_range ? td.xf + 1 : -BIG);
+      bb[2] = wave_minmax<true>(in_range ? td.yf : BIG);
+      bb[3] = wave_minmax<false>(in_range ? td.yf + 1 : -BIG);
+      if (lane == 63)
+      {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          s_bbox[wave * 4 + k] = bb[k];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+      {
+        int v = s_bbox[k];
+#pragma unroll
+        for (int w = 1; w < kWaves; ++w)
+          v = (k & 1) ? max(v, s_bbox[w * 4 + k]) : min(v, s_bbox[w * 4 + k]);
+        bb[k] = uni(v);
+      }
+      const int dx0 = max(bb[0], 0), dx1 = min(bb[1], Wl - 1), dy0 = max(bb[2], 0), dy1 = min(bb[3], Hl - 1);
+      const int dbw = dx1 - dx0 + 1, dbh = dy1 - dy0 + 1;
+      constexpr int NA = JAC ? 3 : 1; // arrays staged for the destination: f1 (+ gx, gy)
+      staged = dbw > 0 && dbh > 0 && dbw <= 32 && NA * dbw * dbh <= kStageCap;
+      if (staged)
+      {
+        const int dsz = dbw * dbh;
+        int di[4]; // LDS slots of this lane's taps (only meaningful where the tap weight is non-zero)
+        {
+          const int b0 = (td.yf - dy0) * dbw + (td.xf - dx0);
+          di[0] = b0; di[1] = b0 + dbw + 1; di[2] = b0 + dbw; di[3] = b0 + 1;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            di[k] = (td.w[k] != 0.f) ? di[k] : 0;
+        }
+        const int rr = tid >> 5, cc = tid & 31; // 8 patch rows x 32 columns per pass
+        // pre-sampled source features of this keyframe: [L][FS/4][N][4]
+        const f32x4 *f0s = reinterpret_cast<const f32x4 *>(E.f0s) + (size_t)l * (FS / 4) * N + n;
+        for (int g = 0; g < FS / 4; ++g)
+        {
+          const uint32_t soff = (uint32_t)g * plane * 4u;
+          if (g > 0)
+            __syncthreads(); // the previous group's taps have been read
+          if (cc < dbw)
+            for (int r = rr; r < dbh; r += 8)
+            {
+              const uint32_t go = (lo + (uint32_t)((dy0 + r) * Wl + dx0 + cc)) * 16u;
+              s_stage[r * dbw + cc] = buf_load4(r_f1, go, soff);
+              if (JAC)
+              {
+                s_stage[dsz + r * dbw + cc] = buf_load4(r_g1, go, soff);
+                s_stage[2 * dsz + r * dbw + cc] = buf_load4(r_g1y, go, soff);
+              }
+            }
+          const f32x4 f0 = f0s[(size_t)g * N];
+          __syncthreads();
+          f32x4 f1 = {0.f, 0.f, 0.f, 0.f}, gx = f1, gy = f1;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+          {
+            f1 += td.w[k] * s_stage[di[k]];
+            if (JAC)
+            {
+              gx += td.w[k] * s_stage[dsz + di[k]];
+              gy += td.w[k] * s_stage[2 * dsz + di[k]];
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+          {
+            const float diff = f0[c] - f1[c];
+            ee += diff * diff;
+            if (JAC)
+            {
+              const float hx = fxl * gx[c], hy = fyl * gy[c];
+              g00 += hx * hx;
+              g01 += hx * hy;
+              g11 += hy * hy;
+              a0 += hx * diff;
+              a1 += hy * diff;
+            }
+          }
+        }
+        __syncthreads(); // patch buffer is reused by the next level (and by the stash afterwards)
+      }
+      else
+      {
+        // rare: the tile's footprint does not fit the patch buffer (extreme warps) -> plain gathers, one tap at a time
+        const f32x4 *f0s = reinterpret_cast<const f32x4 *>(E.f0s) + (size_t)l * (FS / 4) * N + n;
+        for (int g = 0; g < FS / 4; ++g)
+        {
+          const uint32_t soff = (uint32_t)g * plane * 4u;
+          const f32x4 f0 = f0s[(size_t)g * N];
+          f32x4 f1 = {0.f, 0.f, 0.f, 0.f}, gx = f1, gy = f1;
+          for (int k = 0; k < 4; ++k)
+          {
+            f1 += td.w[k] * buf_load4(r_f1, dof[k] * 4u, soff);
+            if (JAC)
+            {
+              gx += td.w[k] * buf_load4(r_g1, dof[k] * 4u, soff);
+              gy += td.w[k] * buf_load4(r_g1y, dof[k] * 4u, soff);
+            }
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+          {
+            const float diff = f0[c] - f1[c];
+            ee += diff * diff;
+            if (JAC)
+            {
+              const float hx = fxl * gx[c], hy = fyl * gy[c];
+              g00 += hx * hx;
+              g01 += hx * hy;
+              g11 += hy * hy;
+              a0 += hx * diff;
+              a1 += hy * diff;
+            }
+          }
+        }
+        staged = true; // handled
+      }
+    }
+    if (TILED)
+    {
+      (void)staged; // both tiled paths have accumulated this level above
+    }
+    else if (PACKED)
     {
       // channel-group layout: one dwordx4 per tap and group of 4 channels (16 B per lane, 1 KiB contiguous per wave)
       for (int g = 0; g < FS / 4; ++g)
@@ -170,10 +343,12 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
         // issue every tap load of the group first (16 independent dwordx4 in flight), then consume: without the
         // scheduling barrier hipcc serialises load->wait->use through one register quad
         f32x4 t0[4], t1[4], tx[JAC ? 4 : 1], ty[JAC ? 4 : 1];
+        // source features: pose-independent, pre-sampled once per keyframe by the window engine ([L][FS/4][N][4])
+        (void)t0;
+        const f32x4 f0pre = reinterpret_cast<const f32x4 *>(E.f0s)[((size_t)l * (FS / 4) + g) * N + (in_range ? n : 0)];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
         {
-          t0[k] = buf_load4(r_f0, so[k] * 4u, soff);
           t1[k] = buf_load4(r_f1, dof[k] * 4u, soff);
           if (JAC)
           {
@@ -182,11 +357,10 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
           }
         }
         __builtin_amdgcn_sched_barrier(0);
-        f32x4 f0 = {0.f, 0.f, 0.f, 0.f}, f1 = f0, gx = f0, gy = f0;
+        f32x4 f0 = f0pre, f1 = {0.f, 0.f, 0.f, 0.f}, gx = f1, gy = f1;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
         {
-          f0 += ts.w[k] * t0[k];
           f1 += td.w[k] * t1[k];
           if (JAC)
           {
@@ -612,10 +786,12 @@ static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const P
   PhotoParams p = make_params(single, table, lc, pyr, wh, eps, &wsum);
   if (lc.ev_start)
     (void)hipEventRecord(lc.ev_start, s);
-  if (lc.packed)
-    hipLaunchKernelGGL((photo_kernel<CS, FS, true, true>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  if (lc.tiled)
+    hipLaunchKernelGGL((photo_kernel<CS, FS, true, 2>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  else if (lc.packed)
+    hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   else
-    hipLaunchKernelGGL((photo_kernel<CS, FS, true, false>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+    hipLaunchKernelGGL((photo_kernel<CS, FS, true, 0>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   if (lc.ev_stop)
     (void)hipEventRecord(lc.ev_stop, s);
   PhotoFinalizeParams f{};
@@ -642,10 +818,12 @@ static hipError_t photo_err_impl(hipStream_t s, const PhotoEdge *single, const P
   PhotoParams p = make_params(single, table, lc, pyr, wh, eps, &wsum);
   if (lc.ev_start)
     (void)hipEventRecord(lc.ev_start, s);
-  if (lc.packed)
-    hipLaunchKernelGGL((photo_kernel<CS, FS, false, true>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  if (lc.tiled)
+    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 2>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  else if (lc.packed)
+    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 1>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   else
-    hipLaunchKernelGGL((photo_kernel<CS, FS, false, false>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 0>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   if (lc.ev_stop)
     (void)hipEventRecord(lc.ev_stop, s);
   return launch_stats_finalize(s, lc, stats, 10.0f * wsum, 1.0f);

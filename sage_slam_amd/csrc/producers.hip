@@ -91,6 +91,40 @@ hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev,
   return hipGetLastError();
 }
 
+// pre-sampled source features f0s[l][g][n][0:4] = 4-tap bilinear sample of the keyframe's own pyramid at its sampled
+// pixels, with the Jacobian kernel's source coordinates (photometric_factor_kernels.cpp:101-139) -- pose independent,
+// built once per keyframe (the tracker's cat_sampled_features_0, camera_tracker.cpp:1104-1123)
+__global__ void presample_source_kernel(float *__restrict__ f0s, const float *__restrict__ feat_pk,
+                                        const float *__restrict__ homo, int N, int G, const SagePyramid pyr)
+{
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  const int g = blockIdx.y, l = blockIdx.z;
+  if (n >= N)
+    return;
+  const float fx0 = pyr.cam[0].fx, fy0 = pyr.cam[0].fy, cx0 = pyr.cam[0].cx, cy0 = pyr.cam[0].cy;
+  const float fxl = pyr.cam[l].fx, fyl = pyr.cam[l].fy;
+  const int Wl = (int)pyr.cam[l].w, Hl = (int)pyr.cam[l].h;
+  const float su = homo[3 * n + 0] * fx0 + cx0 + 0.5f, sv = homo[3 * n + 1] * fy0 + cy0 + 0.5f;
+  Taps ts;
+  make_taps(ts, su * (fxl / fx0) - 0.5f, sv * (fyl / fy0) - 0.5f, Wl, Hl);
+  const f32x4 *src = reinterpret_cast<const f32x4 *>(feat_pk) + (size_t)g * pyr.P + pyr.level_offsets[l];
+  f32x4 f = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    f += ts.w[k] * src[ts.off[k]];
+  reinterpret_cast<f32x4 *>(f0s)[((size_t)l * G + g) * N + n] = f;
+}
+
+hipError_t launch_presample_source(hipStream_t s, float *f0s, const float *feat_pk, const float *homo, int N, int FS,
+                                   const SagePyramid &pyr)
+{
+  if (N <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL(presample_source_kernel, dim3((N + 255) / 256, FS / 4, pyr.levels), dim3(256), 0, s, f0s, feat_pk,
+                     homo, N, FS / 4, pyr);
+  return hipGetLastError();
+}
+
 // [C][P] channel-major -> [C/4][P][4] channel-group layout (engine-internal, once per keyframe)
 __global__ void repack_groups_kernel(float *__restrict__ dst, const float *__restrict__ src, int C, int P)
 {

@@ -73,6 +73,26 @@ __device__ __forceinline__ float wave_sum(float v)
   return v;
 }
 
+// wave64 integer min / max (same DPP ladder; lanes a masked step does not write keep `identity`)
+template <int CTRL, int ROW_MASK, bool IS_MIN>
+__device__ __forceinline__ int dpp_minmax(int v, int identity)
+{
+  const int x = __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xF, false);
+  return IS_MIN ? min(v, x) : max(v, x);
+}
+template <bool IS_MIN>
+__device__ __forceinline__ int wave_minmax(int v) // result valid in lane 63
+{
+  constexpr int id = IS_MIN ? 0x7fffffff : (int)0x80000000;
+  v = dpp_minmax<0xB1, 0xF, IS_MIN>(v, id);
+  v = dpp_minmax<0x4E, 0xF, IS_MIN>(v, id);
+  v = dpp_minmax<0x141, 0xF, IS_MIN>(v, id);
+  v = dpp_minmax<0x140, 0xF, IS_MIN>(v, id);
+  v = dpp_minmax<0x142, 0xA, IS_MIN>(v, id);
+  v = dpp_minmax<0x143, 0xC, IS_MIN>(v, id);
+  return v;
+}
+
 // ---------------------------------------------------------------- bilinear taps
 // 4-tap zero-padded bilinear sampler of the reference (photometric_factor_kernels.cpp:106-139,
 // geometric_factor_kernels.cpp:546-571): taps (xf,yf) (xc,yc) (xf,yc) (xc,yf), each contributing only
@@ -81,6 +101,7 @@ struct Taps
 {
   int off[4];
   float w[4];
+  int xf, yf; // floor coordinates (clamped to a band around the image) -- used by the LDS-staged sampler
 };
 
 __device__ __forceinline__ void make_taps(Taps &t, float u, float v, int W, int H)
@@ -103,6 +124,8 @@ __device__ __forceinline__ void make_taps(Taps &t, float u, float v, int W, int 
   t.off[1] = ok1 ? yc * W + xc : 0;
   t.off[2] = ok2 ? yc * W + xf : 0;
   t.off[3] = ok3 ? yf * W + xc : 0;
+  t.xf = xf;
+  t.yf = yf;
 }
 
 // nearest full-resolution mask lookup with C round() (half away from zero):
