@@ -35,12 +35,14 @@ __device__ __forceinline__ int gload_loc(const void *loc, int is64, int n)
 
 __device__ __forceinline__ int gsidx6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
 
-constexpr int kGeoStash = 19; // y(9) w kappa off(4) wt(4)
+constexpr int kGeoStash = 11; // y(9) omega kappa
 
 template <int CS, bool JAC>
 __global__ __launch_bounds__(kBlock) void geo_kernel(const GeoParams prm)
 {
-  constexpr int LD = CS + 1;
+  // Jacobian kernel: the LDS tile holds t = [b0 (CS) | beta (CS)] per pixel (row stride 2CS+1, conflict free for the
+  // per-pixel accesses and <= 2-way for the MFMA operand reads); error kernel: only b0
+  constexpr int LD = JAC ? 2 * CS + 1 : CS + 1;
   constexpr int N16 = geo_n16(CS);
   constexpr int NTT = N16 * (N16 + 1) / 2;
   constexpr int NT = NTT + N16;
@@ -91,7 +93,7 @@ __global__ __launch_bounds__(kBlock) void geo_kernel(const GeoParams prm)
   const bool in_range = n < N;
   const int tile_rows = min(kTile, N - tile * kTile);
   const int my_loc = in_range ? gload_loc(E.loc, E.loc_is_i64, n) : 0;
-  const float d0 = stage_basis_and_depth<CS>(s_basis, s_loc, E.basis0, E.bias0, E.code0, s0, my_loc, in_range,
+  const float d0 = stage_basis_and_depth<CS, LD>(s_basis, s_loc, E.basis0, E.bias0, E.code0, s0, my_loc, in_range,
                                              tile_rows);
 
   float hm[3] = {0.f, 0.f, 1.f};
@@ -165,6 +167,38 @@ __global__ __launch_bounds__(kBlock) void geo_kernel(const GeoParams prm)
     y[7] = Ds;
     y[8] = rho;
   }
+  // beta = bilinear sample of basis1 [H,W,CS] at the projection (:592-595), lane = pixel: every tap is one 4*CS-byte
+  // texel read with dwordx4 loads, 16 independent loads in flight per half; the result goes to the LDS tile so the
+  // MFMA loop below touches LDS only
+  {
+    float *trow = s_basis + tid * LD + CS;
+#pragma unroll
+    for (int h = 0; h < CS / 16; ++h)
+    {
+      f32x4 tq[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+      {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(E.basis1 + (size_t)tp.off[k] * CS + h * 16);
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq)
+          tq[k][qq] = src[qq];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq)
+      {
+        f32x4 b = tp.w[0] * tq[0][qq];
+        b += tp.w[1] * tq[1][qq];
+        b += tp.w[2] * tq[2][qq];
+        b += tp.w[3] * tq[3][qq];
+        trow[h * 16 + qq * 4 + 0] = b[0];
+        trow[h * 16 + qq * 4 + 1] = b[1];
+        trow[h * 16 + qq * 4 + 2] = b[2];
+        trow[h * 16 + qq * 4 + 3] = b[3];
+      }
+    }
+  }
   // sqrt_cauchy_weight = m / sqrt(rho^2 + c)  (:690);  omega = its square
   const float om = live ? (m * m) / (rho * rho + prm.loss_param) : 0.f;
   if (!live)
@@ -199,12 +233,6 @@ __global__ __launch_bounds__(kBlock) void geo_kernel(const GeoParams prm)
       st[j] = y[j];
     st[9] = om;
     st[10] = kappa;
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-    {
-      st[11 + k] = __int_as_float(tp.off[k]);
-      st[15 + k] = live ? tp.w[k] : 0.f;
-    }
   }
 #pragma unroll
   for (int k = 0; k < 46; ++k)
@@ -218,39 +246,26 @@ __global__ __launch_bounds__(kBlock) void geo_kernel(const GeoParams prm)
   // ---- MFMA: T += w t t^T (upper-triangular 16x16 tiles), Xc += w y t^T ----
   {
     const int i = lane & 15, k = lane >> 4;
-    const float *b1 = E.basis1;
 #pragma unroll 2
     for (int g = 0; g < 16; ++g)
     {
       const int px = wave * 64 + g * 4 + k;
       const float *st = s_stash + px * kGeoStash;
-      const float *br = s_basis + px * LD;
+      const float *tr = s_basis + px * LD;
       const float om_k = st[9], kap = st[10];
       const float yi = (i < 9) ? st[i < 9 ? i : 0] : 0.f;
       float tv[N16];
 #pragma unroll
       for (int b = 0; b < CS / 16; ++b)
-        tv[b] = kap * br[b * 16 + i];
-#pragma unroll
-      for (int b = 0; b < CS / 16; ++b)
-        tv[CS / 16 + b] = 0.f;
-#pragma unroll
-      for (int tap = 0; tap < 4; ++tap)
       {
-        const int off = __float_as_int(st[11 + tap]);
-        const float wt = st[15 + tap];
-        const float *src = b1 + (size_t)off * CS + i;
-#pragma unroll
-        for (int b = 0; b < CS / 16; ++b)
-          tv[CS / 16 + b] += wt * src[b * 16];
+        tv[b] = kap * tr[b * 16 + i];
+        tv[CS / 16 + b] = tr[CS + b * 16 + i];
       }
 #pragma unroll
       for (int bi = 0; bi < N16; ++bi)
 #pragma unroll
         for (int bj = bi; bj < N16; ++bj)
         {
-          constexpr int dummy = 0;
-          (void)dummy;
           const int t = bi * N16 - (bi * (bi - 1)) / 2 + (bj - bi);
           acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(om_k * tv[bi], tv[bj], acc[t], 0, 0, 0);
         }

@@ -206,13 +206,12 @@ __device__ __forceinline__ void dX_dT0(const Pose &p1, const float Xw[3], float 
 // returns this thread's depth  s0 * (bias0[i] + basis0[i,:] . code0)
 // (photometric_factor_kernels.cpp:1094-1095, geometric_factor_kernels.cpp:514-521).
 // Rows past N are zero-filled so they are inert in the MFMA contractions.
-template <int CS>
+template <int CS, int LD = CS + 1>
 __device__ __forceinline__ float stage_basis_and_depth(float *s_basis, int *s_loc, const float *__restrict__ basis0,
                                                        const float *__restrict__ bias0,
                                                        const float *__restrict__ code0, float scale0,
                                                        int my_loc, bool in_range, int tile_rows)
 {
-  constexpr int LD = CS + 1;
   constexpr int F4 = CS / 4;          // float4 per row
   constexpr int RPP = kBlock / F4;    // rows per pass
   const int tid = threadIdx.x;
