@@ -32,6 +32,13 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
+# HBM bytes per launch of the dominant kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
+# passes, same workload: scripts/pmc_run.sh -> profiles/r01_pmc_summary.txt).  FETCH_SIZE is doubled as
+# MI355X_MICROARCH.md prescribes for 16 B/lane reads on gfx950 (all tap loads are dwordx4).  bench.py cannot collect
+# PMC counters itself; this is the committed measurement for the K=64 headline window (null for any other workload).
+PMC_TRAFFIC_BYTES_K64 = {"fetch_size_kb": 1.2985e6, "write_size_kb": 30690.0,
+                         "hbm_bytes_per_launch": (2 * 1.2985e6 + 30690.0) * 1024.0}
+
 
 def cpu_baseline(win, budget_s: float = 20.0):
     """Reference-style CPU path (oracle/, kind = "port") timed on a bounded sample of the same workload:
@@ -141,14 +148,19 @@ def main():
         torch.cuda.synchronize()
 
     hist = []
-    for _ in range(args.warmup):
+    RESTART = 5   # the LM converges in ~3 steps on this scene: restart from the initial estimate every RESTART steps so
+                  # the timed steps are live descent steps (a restart is one small H2D of the variables, inside the timing)
+    for i in range(args.warmup):
         hist.append(lm_step())
     win.set_profiling(True)
     for which in range(4):
         win.kernel_time(which)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i % RESTART == 0:
+            win.reset()
+            damp = float(cfg.init_damp)
         hist.append(lm_step())
     barrier()
     elapsed = time.perf_counter() - t0
@@ -187,7 +199,9 @@ def main():
                        "error_first_last": [hist[0][0], hist[-1][1]]},
             "roofline": {"bound": "hbm", "kernel": "photo_kernel<CS,FS,true> (fused photometric linearize)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": (PMC_TRAFFIC_BYTES_K64["hbm_bytes_per_launch"]
+                                     if (world == 1 and args.keyframes == 64 and args.height == 128 and args.fs == 16) else None),
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, profiles/r01_pmc_summary.txt",
                          "bytes_per_launch": px_launch * bytes_photo_px, "avg_launch_ms": ms_photo,
                          "geo_kernel": {"achieved": ach_geo, "frac": ach_geo / HBM_PEAK_GBS, "avg_launch_ms": ms_geo,
                                         "bytes_per_launch": px_launch * bytes_geo_px},

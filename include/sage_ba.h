@@ -293,6 +293,7 @@ int sage_window_solve(SageWindow *w, double damp, double *step_norm);
 /* total error (photo + geo + priors) from the (all-reduced) buffers; synchronises. */
 int sage_window_total_error(SageWindow *w, int from_linearize, double *err);
 int sage_window_accept(SageWindow *w);   /* candidate -> current */
+int sage_window_reset(SageWindow *w);    /* restore the variables every keyframe was added with */
 /* read back current variables (HOST outputs; any may be NULL) */
 int sage_window_get_keyframe(const SageWindow *w, int kf, float *pose12, float *code, float *scale);
 int sage_window_set_keyframe(SageWindow *w, int kf, const float *pose12, const float *code, float scale);

@@ -90,7 +90,7 @@ SYMBOLS = [
     "sage_window_block_size", "sage_window_packed_count", "sage_window_packed_dev",
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
-    "sage_window_accept", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
+    "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
     "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step",
 ]
 
@@ -474,6 +474,9 @@ class Window:
 
     def accept(self):
         _chk(lib().sage_window_accept(self.h), "sage_window_accept")
+
+    def reset(self):
+        _chk(lib().sage_window_reset(self.h), "sage_window_reset")
 
     def lm_step(self, state: SageLmState, cfg: SageLmConfig):
         _chk(lib().sage_window_lm_step(self.h, C.byref(state), C.byref(cfg)), "sage_window_lm_step")

@@ -375,7 +375,7 @@ __global__ __launch_bounds__(kBlock) void geo_finalize_kernel(const GeoFinalizeP
   };
   auto TT = [&](int a, int b) -> double { // sum w t_a t_b
     int bi = a >> 4, bj = b >> 4, ra = a & 15, rb = b & 15;
-    if (bi > bj)
+    if (bi > bj || (bi == bj && ra > rb)) // always read the upper triangle: (w t_a) t_b != (w t_b) t_a in fp32
     {
       int t = bi; bi = bj; bj = t;
       t = ra; ra = rb; rb = t;
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(kBlock) void geo_finalize_kernel(const GeoFinalizeP
           mv = TT(ii, ij);
         else
           mv = ki == 0 ? YT(ii, ij) : YT(ij, ii);
-        val = wn * ci * cj * mv;
+        val = wn * (ci * cj) * mv; // (ci*cj) first: exactly symmetric in (i, j)
       }
       else
       {

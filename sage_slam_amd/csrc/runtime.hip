@@ -630,6 +630,7 @@ struct SageWindow
   // host variables: [set][kf] ; set 0 = current, 1 = candidate
   std::vector<float> pose[2], code[2], scale[2];
   std::vector<float> code_init, scale_init, pose_init;
+  std::vector<float> code_added; // codes as added (code_init is the zero prior mean)
   std::vector<std::pair<int, int>> links; // (a, b) with a < b
   std::vector<int> local_links;           // indices into links
   int n_edges = 0;                        // local directed edges per factor type (= 2 * local links)
@@ -773,6 +774,7 @@ extern "C" int sage_window_add_keyframe(SageWindow *w, const SageKeyframeView *v
     w->scale[s].push_back(scale);
   }
   w->pose_init.insert(w->pose_init.end(), pose12, pose12 + 12);
+  w->code_added.insert(w->code_added.end(), code, code + w->cfg.CS);
   w->scale_init.push_back(scale);
   return w->K++;
 }
@@ -1299,6 +1301,23 @@ extern "C" int sage_window_accept(SageWindow *w)
   w->scale[0] = w->scale[1];
   SAGE_HIP(hipMemcpyAsync(w->vars[0].p, w->vars[1].p, (size_t)w->K * w->VS * sizeof(float), hipMemcpyDeviceToDevice,
                           w->stream));
+  return SAGE_OK;
+}
+
+extern "C" int sage_window_reset(SageWindow *w)
+{
+  if (!w || !w->finalized)
+    return SAGE_E_STATE;
+  for (int s = 0; s < 2; ++s)
+  {
+    w->pose[s] = w->pose_init;
+    w->code[s] = w->code_added;
+    w->scale[s] = w->scale_init;
+  }
+  int rc;
+  if ((rc = upload_vars(w, 0)) || (rc = upload_vars(w, 1)))
+    return rc;
+  w->have_lin = false;
   return SAGE_OK;
 }
 

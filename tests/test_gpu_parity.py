@@ -364,3 +364,49 @@ def test_track_frame_lm(capi, ws, orc):
     assert fe.value == pytest.approx(eo, rel=1e-3)
     assert rel(ph, po) < 1e-4
     assert eo < 0.5 * tro[0]["error"]      # the LM actually converged towards the true relative pose
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# full-size configurations (BASELINE.json configs 2 and 4): the oracle would take minutes here, so parity is checked
+# through size-independent properties of the path
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [dict(K=4, H=128, W=160, FS=16, CS=32), dict(K=3, H=256, W=320, FS=32, CS=32)],
+                         ids=["128x160x16", "256x320x32"])
+def test_full_size_properties(capi, orc, cfg):
+    w = synth.make_window(L=4, seed=41, **cfg)
+    CS = cfg["CS"]
+    win = capi.Window(w)
+    win.linearize()
+    p1 = win.packed_host().copy()
+    win.linearize()
+    assert np.array_equal(p1, win.packed_host())                     # deterministic: no atomics, fixed summation order
+    n_dir = 2 * len(w.links)
+    tot = np.zeros(2)
+    for e in range(n_dir):
+        ph = win.get_edge(0, e)
+        A, b = ph["AtA"].astype(np.float64), ph["Atb"].astype(np.float64)
+        assert np.array_equal(A, A.T) and np.linalg.eigvalsh(A).min() > -1e-6 * np.abs(A).max()
+        assert np.array_equal(A[0:6, 6:12], -A[0:6, 0:6]) and np.array_equal(A[6:12, 6:12], A[0:6, 0:6])   # P_pose1 = -P_pose0
+        assert np.array_equal(b[6:12], -b[0:6]) and ph["num_inliers"] > 0.5 * w.keyframes[0].homo.shape[0]
+        ge = win.get_edge(1, e)
+        G = ge["AtA"].astype(np.float64)
+        assert np.array_equal(G, G.T) and np.array_equal(G[0:6, 6:12], -G[0:6, 0:6])
+        tot += [ph["error"], ge["error"]]
+    tail = p1[-4:]
+    assert tail[0] == pytest.approx(tot[0], rel=1e-6) and tail[1] == pytest.approx(tot[1], rel=1e-6)
+    # the error-only pass at the same variables reproduces the linearize pass' error (a2 == a1, a5 == a4)
+    win.error(0)
+    e_lin, e_err = win.total_error(True), None
+    import ctypes as C
+    ed = C.c_double()
+    assert capi.lib().sage_window_total_error(win.h, 0, C.byref(ed)) == 0
+    # total_error(False) adds the CANDIDATE's priors; candidate == current before any solve
+    assert ed.value == pytest.approx(e_lin, rel=2e-6)
+    # one edge against the oracle (the only oracle call at this size: a few seconds)
+    o = oracle_photo(orc, w, 0, 1)
+    h = win.get_edge(0, 0)
+    assert rel(h["AtA"], o["AtA"]) < TOL_H and rel(h["Atb"], o["Atb"]) < TOL_H and h["num_inliers"] == o["num_inliers"]
+    og = oracle_geo(orc, w, 0, 1)
+    hg = win.get_edge(1, 0)
+    assert rel(hg["AtA"], og["AtA"]) < TOL_H and rel(hg["Atb"], og["Atb"]) < TOL_H
+    win.close()
