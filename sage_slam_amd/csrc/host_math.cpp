@@ -561,14 +561,26 @@ typedef double v8d __attribute__((vector_size(64), aligned(8)));
 __attribute__((target_clones("avx512f", "avx2", "default"))) static void gemm_nt_sub(double *const *C, int coff,
                                                                                      const double *const *A,
                                                                                      const double *const *B, int ni,
-                                                                                     int nj, int len)
+                                                                                     int nj, int len_full,
+                                                                                     bool b_lower_tri, int lower_only_row0)
 {
+  // b_lower_tri: row j of B is zero beyond column j (inverse of a Cholesky factor) -> the k range of tile column j0
+  //              stops at j0+4 (rounded up to whole vectors);
+  // lower_only_row0 >= 0: only outputs with j <= lower_only_row0 + i are needed (lower triangle of a diagonal block)
   for (int i0 = 0; i0 < ni; i0 += 4)
   {
     const int mi = ni - i0 < 4 ? ni - i0 : 4;
     for (int j0 = 0; j0 < nj; j0 += 4)
     {
+      if (lower_only_row0 >= 0 && j0 > lower_only_row0 + i0 + 3)
+        break;
       const int mj = nj - j0 < 4 ? nj - j0 : 4;
+      int len = len_full;
+      if (b_lower_tri)
+      {
+        const int need = ((j0 + 4 + 7) / 8) * 8;
+        len = need < len_full ? need : len_full;
+      }
       const double *a[4], *b[4];
       for (int t = 0; t < 4; ++t)
       {
@@ -723,7 +735,7 @@ bool EnvelopeMatrix::cholesky_inplace(int block, int threads)
           for (int j = 0; j < nb; ++j)
             brow[j] = &data[rowptr[c0 + j]] + (k0 - fJ);
           auto q0 = tk();
-          gemm_nt_sub(crow.data(), c0 - f, arow.data(), brow.data(), ni, nb, len);
+          gemm_nt_sub(crow.data(), c0 - f, arow.data(), brow.data(), ni, nb, len, false, -1);
           if (tid == 0) t_gemm1 += dtm(q0, tk());
           auto q1 = tk();
           // L_IJ = S * Winv_J^T : copy S, clear the destination, accumulate with the (negated) GEMM
@@ -740,7 +752,7 @@ bool EnvelopeMatrix::cholesky_inplace(int block, int threads)
           }
           for (int j = 0; j < nb; ++j)
             brow[j] = W + (size_t)j * nb;
-          gemm_nt_sub(crow.data(), c0 - f, trow.data(), brow.data(), ni, nb, nb);
+          gemm_nt_sub(crow.data(), c0 - f, trow.data(), brow.data(), ni, nb, nb, true, -1);
           if (tid == 0) t_gemm2 += dtm(q1, tk());
         }
         // no barrier needed between block columns: thread t only touches its own rows of block row I,
@@ -766,7 +778,7 @@ bool EnvelopeMatrix::cholesky_inplace(int block, int threads)
             tmp[(size_t)i * nb + j] = 0.0;
           crow[i] = &tmp[(size_t)i * nb];
         }
-        gemm_nt_sub(crow.data(), 0, arow.data(), brow.data(), ni, std::min(nb, i_hi), r0 - f);
+        gemm_nt_sub(crow.data(), 0, arow.data(), brow.data(), ni, std::min(nb, i_hi), r0 - f, false, i_lo);
         for (int i = 0; i < ni; ++i)
         {
           double *dst = &data[rowptr[r0 + i_lo + i]] + (r0 - f);
