@@ -129,7 +129,7 @@ def main():
         if dist is not None:
             dist.all_reduce(packed)
         e0 = win.total_error(True)
-        win.solve(damp)
+        win.solve(damp, want_norm=False)
         win.error(1)
         if dist is not None:
             dist.all_reduce(errt)

@@ -462,7 +462,12 @@ class Window:
     def error(self, which=1):
         _chk(lib().sage_window_error(self.h, which), "sage_window_error")
 
-    def solve(self, damp):
+    def solve(self, damp, want_norm=True):
+        """Damped step + candidate variables.  With ``want_norm=False`` the device solver is only enqueued (no
+        synchronisation); a non-positive pivot is then reported by the next ``total_error``/``accept``."""
+        if not want_norm:
+            _chk(lib().sage_window_solve(self.h, C.c_double(damp), None), "sage_window_solve")
+            return None
         sn = C.c_double()
         _chk(lib().sage_window_solve(self.h, C.c_double(damp), C.byref(sn)), "sage_window_solve")
         return sn.value

@@ -844,6 +844,322 @@ void EnvelopeMatrix::solve_inplace(std::vector<double> &b) const
 
 } // namespace sage
 
+// ------------------------------------------------------------------------------------------------
+// Fixed-block-size Cholesky on transposed block storage (the window solve's host leg).
+//
+// Every finished block is kept as T_ij = L_ij^T (row t of T = column t of L), the diagonal factors as U = L^T and
+// X = U^-1.  With that layout every contraction is "broadcast one scalar, multiply a contiguous row":
+//   C_ij^T[c][:]  -= sum_k sum_t T_jk[t][c] * T_ik[t][:]         (trailing update)
+//   T_ij[c][:]     = sum_{t<=c} X_j[t][c] * C_ij^T[t][:]          (L_ij = C_ij L_jj^-T)
+// so the micro-kernel is 4 output rows x NV vectors of accumulators, NV loads + 4 broadcasts + 4*NV FMAs per step,
+// no horizontal sums (the envelope code above pays one per output).
+// ------------------------------------------------------------------------------------------------
+namespace sage
+{
+namespace
+{
+#define SAGE_STOREU(p, v) __builtin_memcpy((p), &(v), sizeof(v8d))
+
+// CT[c][8*V0 ..] -= sum_t Tj[t][c] * Ti[t][8*V0 ..]  for the 4 rows c0..c0+3 ; vectors V0..NV-1 only
+template <int NV, int V0>
+static inline __attribute__((always_inline)) void tn_sub_rows4(double *CT, const double *Tj, const double *Ti, int c0)
+{
+  constexpr int BP = NV * 8;
+  v8d acc[4][NV];
+  for (int u = 0; u < 4; ++u)
+    for (int v = V0; v < NV; ++v)
+      acc[u][v] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
+  for (int t = 0; t < BP; ++t)
+  {
+    const double *ti = Ti + t * BP, *tj = Tj + t * BP + c0;
+    v8d b[NV];
+    for (int v = V0; v < NV; ++v)
+      SAGE_LOADU(b[v], ti + 8 * v);
+    for (int u = 0; u < 4; ++u)
+    {
+      const double sc = tj[u];
+      const v8d s = {sc, sc, sc, sc, sc, sc, sc, sc};
+      for (int v = V0; v < NV; ++v)
+        acc[u][v] += s * b[v];
+    }
+  }
+  for (int u = 0; u < 4; ++u)
+    for (int v = V0; v < NV; ++v)
+    {
+      v8d c;
+      SAGE_LOADU(c, CT + (c0 + u) * BP + 8 * v);
+      c -= acc[u][v];
+      SAGE_STOREU(CT + (c0 + u) * BP + 8 * v, c);
+    }
+}
+
+// CT -= Tj^T-contraction with Ti over the whole block; upper_only: only entries [c][r >= c] are needed (diagonal
+// block, symmetric) -> the vectors left of the diagonal are skipped
+template <int NV>
+static inline __attribute__((always_inline)) void tn_sub(double *CT, const double *Tj, const double *Ti, bool upper_only)
+{
+  constexpr int BP = NV * 8;
+  for (int c0 = 0; c0 < BP; c0 += 4)
+  {
+    const int v0 = upper_only ? c0 / 8 : 0;
+    switch (v0)
+    {
+    case 0: tn_sub_rows4<NV, 0>(CT, Tj, Ti, c0); break;
+    case 1: tn_sub_rows4<NV, (NV > 1 ? 1 : 0)>(CT, Tj, Ti, c0); break;
+    case 2: tn_sub_rows4<NV, (NV > 2 ? 2 : 0)>(CT, Tj, Ti, c0); break;
+    case 3: tn_sub_rows4<NV, (NV > 3 ? 3 : 0)>(CT, Tj, Ti, c0); break;
+    default: tn_sub_rows4<NV, (NV > 4 ? 4 : 0)>(CT, Tj, Ti, c0); break;
+    }
+  }
+}
+
+// in place: CT[c][:] <- sum_{t<=c} X[t][c] * CT[t][:]   (rows in descending groups of 4: a group reads rows <= its own)
+template <int NV>
+static inline __attribute__((always_inline)) void apply_inverse(double *CT, const double *X)
+{
+  constexpr int BP = NV * 8;
+  for (int c0 = BP - 4; c0 >= 0; c0 -= 4)
+  {
+    v8d acc[4][NV];
+    for (int u = 0; u < 4; ++u)
+      for (int v = 0; v < NV; ++v)
+        acc[u][v] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
+    for (int t = 0; t <= c0 + 3; ++t)
+    {
+      const double *ct = CT + t * BP, *xs = X + t * BP + c0; // X[t][c] = 0 for c < t
+      v8d b[NV];
+      for (int v = 0; v < NV; ++v)
+        SAGE_LOADU(b[v], ct + 8 * v);
+      for (int u = 0; u < 4; ++u)
+      {
+        const double sc = xs[u];
+        const v8d s = {sc, sc, sc, sc, sc, sc, sc, sc};
+        for (int v = 0; v < NV; ++v)
+          acc[u][v] += s * b[v];
+      }
+    }
+    for (int u = 0; u < 4; ++u)
+      for (int v = 0; v < NV; ++v)
+        SAGE_STOREU(CT + (c0 + u) * BP + 8 * v, acc[u][v]);
+  }
+}
+
+// S (symmetric, entries [c][r >= c] valid) -> U = L^T in place (A = U^T U), X = U^-1 (upper triangular, zeros below).
+// Blocked by panels of 8 rows: scalar pivots inside the panel, one rank-8 register-accumulated update per trailing row.
+template <int NV>
+static inline __attribute__((always_inline)) bool factor_diag(double *S, double *X)
+{
+  constexpr int BP = NV * 8;
+  for (int p = 0; p < NV; ++p)
+  {
+    for (int c = 8 * p; c < 8 * p + 8; ++c)
+    {
+      double *row = S + c * BP;
+      const double d = row[c];
+      if (!(d > 0.0))
+        return false;
+      const double rs = 1.0 / std::sqrt(d);
+      for (int r = 8 * p; r < c; ++r)
+        row[r] = 0.0;
+      const v8d rsv = {rs, rs, rs, rs, rs, rs, rs, rs};
+      for (int v = p; v < NV; ++v)
+      {
+        v8d x;
+        SAGE_LOADU(x, row + 8 * v);
+        x *= rsv;
+        SAGE_STOREU(row + 8 * v, x);
+      }
+      for (int c2 = c + 1; c2 < 8 * p + 8; ++c2)
+      {
+        const double f = row[c2];
+        const v8d fv = {f, f, f, f, f, f, f, f};
+        double *row2 = S + c2 * BP;
+        for (int v = p; v < NV; ++v)
+        {
+          v8d x, y2;
+          SAGE_LOADU(x, row + 8 * v);
+          SAGE_LOADU(y2, row2 + 8 * v);
+          y2 -= fv * x;
+          SAGE_STOREU(row2 + 8 * v, y2);
+        }
+      }
+    }
+    for (int c2 = 8 * p + 8; c2 < BP; ++c2)
+    {
+      double *row2 = S + c2 * BP;
+      v8d f[8];
+      for (int t = 0; t < 8; ++t)
+      {
+        const double ft = S[(8 * p + t) * BP + c2];
+        f[t] = v8d{ft, ft, ft, ft, ft, ft, ft, ft};
+      }
+      for (int v = c2 / 8; v < NV; ++v)
+      {
+        v8d acc;
+        SAGE_LOADU(acc, row2 + 8 * v);
+        for (int t = 0; t < 8; ++t)
+        {
+          v8d x;
+          SAGE_LOADU(x, S + (8 * p + t) * BP + 8 * v);
+          acc -= f[t] * x;
+        }
+        SAGE_STOREU(row2 + 8 * v, acc);
+      }
+    }
+  }
+  // X = U^-1 by back substitution on rows: X[c][:] = (e_c - sum_{t>c} U[c][t] X[t][:]) / U[c][c]
+  for (int c = BP - 1; c >= 0; --c)
+  {
+    double e[BP];
+    for (int r = 0; r < BP; ++r)
+      e[r] = 0.0;
+    e[c] = 1.0;
+    v8d acc[NV];
+    for (int v = 0; v < NV; ++v)
+      SAGE_LOADU(acc[v], e + 8 * v);
+    const double *u = S + c * BP;
+    for (int t = c + 1; t < BP; ++t)
+    {
+      const double f = u[t];
+      const v8d fv = {f, f, f, f, f, f, f, f};
+      const double *xt = X + t * BP;
+      for (int v = 0; v < NV; ++v)
+      {
+        v8d x;
+        SAGE_LOADU(x, xt + 8 * v);
+        acc[v] -= fv * x;
+      }
+    }
+    const double inv = 1.0 / u[c];
+    const v8d iv = {inv, inv, inv, inv, inv, inv, inv, inv};
+    for (int v = 0; v < NV; ++v)
+    {
+      acc[v] *= iv;
+      SAGE_STOREU(X + c * BP + 8 * v, acc[v]);
+    }
+  }
+  return true;
+}
+
+template <int NV>
+static inline __attribute__((always_inline)) int block_chol_impl(int K, const int32_t *row_first, const int32_t *row_off,
+                                                                 double *T, double *X, double *y)
+{
+  constexpr int BP = NV * 8, BB = BP * BP;
+  auto blk = [&](int i, int j) { return T + (size_t)(row_off[i] + j - row_first[i]) * BB; };
+#ifdef SAGE_CHOL_PROFILE
+  double tp[5] = {0, 0, 0, 0, 0};
+  unsigned long long tlast = __builtin_readcyclecounter();
+  auto lap = [&](int k) { const unsigned long long t = __builtin_readcyclecounter(); tp[k] += (double)(t - tlast); tlast = t; };
+#else
+  auto lap = [](int) {};
+#endif
+  for (int i = 0; i < K; ++i)
+  {
+    const int fi = row_first[i];
+    for (int j = fi; j < i; ++j)
+    {
+      double *CT = blk(i, j);
+      for (int k = std::max(fi, (int)row_first[j]); k < j; ++k)
+        tn_sub<NV>(CT, blk(j, k), blk(i, k), false);
+      lap(0);
+      apply_inverse<NV>(CT, X + (size_t)j * BB);
+      lap(1);
+    }
+    double *S = blk(i, i);
+    for (int k = fi; k < i; ++k)
+      tn_sub<NV>(S, blk(i, k), blk(i, k), true);
+    lap(2);
+    if (!factor_diag<NV>(S, X + (size_t)i * BB))
+      return 1 + i;
+    lap(3);
+    // forward substitution: y_i = L_ii^-1 (g_i - sum_k L_ik y_k)
+    double w[BP];
+    for (int r = 0; r < BP; ++r)
+      w[r] = y[(size_t)i * BP + r];
+    for (int k = fi; k < i; ++k)
+    {
+      const double *Tk = blk(i, k), *yk = y + (size_t)k * BP;
+      for (int t = 0; t < BP; ++t)
+      {
+        const double f = yk[t];
+        for (int r = 0; r < BP; ++r)
+          w[r] -= f * Tk[t * BP + r];
+      }
+    }
+    double yi[BP];
+    for (int c = 0; c < BP; ++c)
+      yi[c] = 0.0;
+    const double *Xi = X + (size_t)i * BB;
+    for (int t = 0; t < BP; ++t)
+    {
+      const double f = w[t];
+      for (int c = 0; c < BP; ++c) // X[t][c] = 0 for c < t
+        yi[c] += f * Xi[t * BP + c];
+    }
+    for (int c = 0; c < BP; ++c)
+      y[(size_t)i * BP + c] = yi[c];
+    lap(4);
+  }
+#ifdef SAGE_CHOL_PROFILE
+  fprintf(stderr, "[chol profile] kcycles(tsc): offdiag-gemm %.1f apply-inverse %.1f diag-gemm %.1f factor+inv %.1f fwd-subst %.1f\n", tp[0] * 1e-3,
+          tp[1] * 1e-3, tp[2] * 1e-3, tp[3] * 1e-3, tp[4] * 1e-3);
+#endif
+  // back substitution: x_i = L_ii^-T (y_i - sum_{m>i, first[m]<=i} L_mi^T x_m)
+  for (int i = K - 1; i >= 0; --i)
+  {
+    double z[BP];
+    for (int t = 0; t < BP; ++t)
+      z[t] = y[(size_t)i * BP + t];
+    for (int m = i + 1; m < K; ++m)
+    {
+      if (row_first[m] > i)
+        continue;
+      const double *Tm = blk(m, i), *xm = y + (size_t)m * BP;
+      for (int t = 0; t < BP; ++t)
+      {
+        double acc = 0.0;
+        for (int r = 0; r < BP; ++r)
+          acc += Tm[t * BP + r] * xm[r];
+        z[t] -= acc;
+      }
+    }
+    const double *Xi = X + (size_t)i * BB;
+    for (int c = 0; c < BP; ++c)
+    {
+      double acc = 0.0;
+      for (int t = c; t < BP; ++t)
+        acc += Xi[c * BP + t] * z[t];
+      y[(size_t)i * BP + c] = acc;
+    }
+  }
+  return 0;
+}
+
+__attribute__((target_clones("avx512f", "avx2", "default"))) static int block_chol_40(int K, const int32_t *row_first,
+                                                                                      const int32_t *row_off, double *T,
+                                                                                      double *X, double *y)
+{
+  return block_chol_impl<5>(K, row_first, row_off, T, X, y);
+}
+__attribute__((target_clones("avx512f", "avx2", "default"))) static int block_chol_24(int K, const int32_t *row_first,
+                                                                                      const int32_t *row_off, double *T,
+                                                                                      double *X, double *y)
+{
+  return block_chol_impl<3>(K, row_first, row_off, T, X, y);
+}
+} // namespace
+
+int block_chol_solve_tr(int K, int Bp, const int32_t *row_first, const int32_t *row_off, double *T, double *X, double *y)
+{
+  if (Bp == 40)
+    return block_chol_40(K, row_first, row_off, T, X, y);
+  if (Bp == 24)
+    return block_chol_24(K, row_first, row_off, T, X, y);
+  return -1;
+}
+} // namespace sage
+
 extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const int32_t *links, int B, double damp,
                                 const double *diag_add, const double *g_add, double *delta)
 {
@@ -866,6 +1182,59 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
     if (a < 0 || b <= a || b >= K)
       return SAGE_E_INVALID;
     first_blk[b] = std::min(first_blk[b], a);
+  }
+  static const bool force_envelope = getenv("SAGE_SOLVE_ENVELOPE") != nullptr;
+  if ((Bp == 40 || Bp == 24) && !force_envelope)
+  {
+    // fixed-size transposed-block path (the one the window engine runs on the device-scattered storage)
+    const int BBp = Bp * Bp;
+    std::vector<int32_t> row_first(first_blk.begin(), first_blk.end()), row_off(K);
+    int nblk = 0;
+    for (int k = 0; k < K; ++k)
+    {
+      row_off[k] = nblk;
+      nblk += k - row_first[k] + 1;
+    }
+    std::vector<double> T((size_t)nblk * BBp, 0.0), X((size_t)K * BBp), y((size_t)K * Bp, 0.0);
+    for (int k = 0; k < K; ++k)
+    {
+      double *D = T.data() + (size_t)(row_off[k] + k - row_first[k]) * BBp;
+      for (int i = 0; i < Bp; ++i)
+        for (int j = 0; j < Bp; ++j)
+        {
+          double v = 0.0;
+          if (i < B && j < B)
+          {
+            v = 0.5 * (diag[(size_t)k * BB + i * B + j] + diag[(size_t)k * BB + j * B + i]);
+            if (i == j)
+              v = (v + (diag_add ? diag_add[k * B + i] : 0.0)) * (1.0 + damp);
+          }
+          else if (i == j)
+            v = 1.0 + damp;
+          D[i * Bp + j] = v;
+        }
+      for (int i = 0; i < B; ++i)
+        y[(size_t)k * Bp + i] = g[(size_t)k * B + i] + (g_add ? g_add[k * B + i] : 0.0);
+    }
+    for (int l = 0; l < nlinks; ++l)
+    {
+      const int a = links[2 * l], b = links[2 * l + 1]; // block (row b, col a), stored transposed: [c in a][r in b]
+      double *D = T.data() + (size_t)(row_off[b] + a - row_first[b]) * BBp;
+      for (int i = 0; i < B; ++i)
+        for (int j = 0; j < B; ++j)
+          D[i * Bp + j] += lnk[(size_t)l * BB + i * B + j];
+    }
+    static const bool dbg2 = getenv("SAGE_DEBUG_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rcf = sage::block_chol_solve_tr(K, Bp, row_first.data(), row_off.data(), T.data(), X.data(), y.data());
+    if (dbg2)
+      fprintf(stderr, "[sage block_solve] fixed-block Cholesky + substitution %.3f ms\n",
+              std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    if (rcf != 0)
+      return SAGE_E_NOT_PSD;
+    for (int k = 0; k < K; ++k)
+      std::memcpy(delta + (size_t)k * B, y.data() + (size_t)k * Bp, sizeof(double) * B);
+    return SAGE_OK;
   }
   std::vector<int> first(n);
   for (int k = 0; k < K; ++k)

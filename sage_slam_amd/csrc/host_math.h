@@ -1,5 +1,7 @@
 // host_math.h -- internal host-side dense helpers (double precision).
 #pragma once
+#include <stdint.h>
+
 #include <vector>
 
 namespace sage
@@ -22,4 +24,12 @@ struct EnvelopeMatrix
   bool cholesky_inplace(int block = 1, int threads = 1);
   void solve_inplace(std::vector<double> &b) const; // after cholesky_inplace: b <- A^-1 b
 };
+
+// Block-envelope Cholesky solve on the storage the device scatter kernel produces (solve_kernels.hip): block (i,j),
+// row_first[i] <= j <= i, lives at T + (row_off[i] + j - row_first[i]) * Bp*Bp and holds the TRANSPOSED block
+// ([c][r] = A[i*Bp + r][j*Bp + c]); Bp is 40 or 24.  In place: T becomes L^T blockwise, X (K*Bp*Bp) receives the
+// inverses of the diagonal factors, y (K*Bp) the right-hand side on entry and the solution on return.
+// Returns 0, or 1 + the block column of the first non-positive pivot.
+int block_chol_solve_tr(int K, int Bp, const int32_t *row_first, const int32_t *row_off, double *T, double *X,
+                        double *y);
 } // namespace sage

@@ -649,6 +649,10 @@ struct SageWindow
   int n_work_p = 0, n_work_g = 0, tpb_p = 1, tpb_g = 1;
   std::vector<double> host_packed;
   std::vector<double> delta;
+  // device solver (solve_kernels.hip); nullptr -> host envelope Cholesky (envelope wider than the LDS panel, or
+  // SAGE_HOST_SOLVE=1).  After a device solve the candidate's host mirrors are refreshed lazily (sync_candidate).
+  sage::DeviceSolver *solver = nullptr;
+  bool cand_pending = false;
   double residuals_per_lin = 0, bytes_per_lin = 0;
   bool have_lin = false;
   // optional kernel timing (HIP events on `stream`)
@@ -756,6 +760,7 @@ extern "C" void sage_window_destroy(SageWindow *w)
                     &w->packed, &w->errbuf};
   for (DevBuf *b : bufs)
     b->release();
+  solver_destroy(w->solver);
   delete w;
 }
 
@@ -1051,6 +1056,12 @@ extern "C" int sage_window_finalize(SageWindow *w)
   SAGE_HIP(hipMemsetAsync(w->errbuf.p, 0, 4 * sizeof(double), w->stream));
   w->host_packed.assign(sage_window_packed_count(w), 0.0);
   w->delta.assign((size_t)K * w->B, 0.0);
+  if (!getenv("SAGE_HOST_SOLVE"))
+  {
+    rc = solver_create(&w->solver, K, w->B, w->VS, w->links, w->stream);
+    if (rc != SAGE_OK && rc != SAGE_E_UNSUPPORTED)
+      return rc;
+  }
   w->finalized = true;
   return SAGE_OK;
 }
@@ -1148,6 +1159,29 @@ extern "C" int sage_window_error(SageWindow *w, int which)
   return SAGE_OK;
 }
 
+// After a device solve the candidate variables / delta live in the solver's pinned buffers until the stream has
+// drained: refresh the host mirrors (set 1) here.  Returns SAGE_E_NOT_PSD when the factorisation hit a non-positive
+// pivot (the candidate is then meaningless).
+static int sync_candidate(SageWindow *w)
+{
+  if (!w->cand_pending)
+    return SAGE_OK;
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  w->cand_pending = false;
+  if (solver_host_status(w->solver) != 0)
+    return SAGE_E_NOT_PSD;
+  const int K = w->K, CS = w->cfg.CS, VS = w->VS;
+  const float *v = solver_host_vars(w->solver);
+  for (int k = 0; k < K; ++k)
+  {
+    std::memcpy(&w->pose[1][(size_t)k * 12], v + (size_t)k * VS, 12 * sizeof(float));
+    w->scale[1][k] = v[(size_t)k * VS + 12];
+    std::memcpy(&w->code[1][(size_t)k * CS], v + (size_t)k * VS + 13, CS * sizeof(float));
+  }
+  std::memcpy(w->delta.data(), solver_host_delta(w->solver), w->delta.size() * sizeof(double));
+  return SAGE_OK;
+}
+
 // prior error terms at a variable set (a9): code prior w*||c||^2/CS per keyframe (code_factor.cpp:99-104, zero
 // prior code), scale prior on keyframe 0 w*(ln s0 - ln s)^2 (scale_factor.cpp:102-129), pose prior on kf 0.
 static void pose_local(const float *origin, const float *other, double out[6])
@@ -1200,6 +1234,9 @@ extern "C" int sage_window_total_error(SageWindow *w, int from_linearize, double
   if (!w || !w->finalized || !err)
     return SAGE_E_STATE;
   double t[4];
+  int rcs = sync_candidate(w);
+  if (rcs)
+    return rcs;
   if (from_linearize)
   {
     const size_t off = sage_window_packed_count(w) - 4;
@@ -1218,6 +1255,27 @@ extern "C" int sage_window_solve(SageWindow *w, double damp, double *step_norm)
     return SAGE_E_STATE;
   const SageWindowConfig &c = w->cfg;
   const int K = w->K, B = w->B, CS = c.CS, BB = B * B, n = K * B;
+  if (w->solver)
+  {
+    // device path: nothing leaves HBM but the candidate's host mirror (pinned, async); no synchronisation here
+    // unless the caller asks for the step norm
+    int rc = sync_candidate(w); // an unconsumed earlier candidate (a re-solve with another damping)
+    if (rc && rc != SAGE_E_NOT_PSD)
+      return rc;
+    rc = solver_run(w->solver, w->stream, w->packed.as<double>(), w->vars[0].as<float>(), w->vars[1].as<float>(), CS,
+                    damp, c.code_prior_weight, c.scale_prior_weight, c.pose_prior_weight, w->scale_init[0],
+                    &w->pose_init[0]);
+    if (rc)
+      return rc;
+    w->cand_pending = true;
+    if (step_norm)
+    {
+      if ((rc = sync_candidate(w)))
+        return rc;
+      *step_norm = std::sqrt(solver_host_step_norm2(w->solver));
+    }
+    return SAGE_OK;
+  }
   const size_t np = sage_window_packed_count(w);
   static const bool dbg = getenv("SAGE_DEBUG_TIMING") != nullptr;
   auto tnow = [] { return std::chrono::steady_clock::now(); };
@@ -1296,6 +1354,9 @@ extern "C" int sage_window_accept(SageWindow *w)
 {
   if (!w || !w->finalized)
     return SAGE_E_STATE;
+  int rcs = sync_candidate(w);
+  if (rcs)
+    return rcs;
   w->pose[0] = w->pose[1];
   w->code[0] = w->code[1];
   w->scale[0] = w->scale[1];
@@ -1308,6 +1369,7 @@ extern "C" int sage_window_reset(SageWindow *w)
 {
   if (!w || !w->finalized)
     return SAGE_E_STATE;
+  (void)sync_candidate(w);
   for (int s = 0; s < 2; ++s)
   {
     w->pose[s] = w->pose_init;
@@ -1338,6 +1400,7 @@ extern "C" int sage_window_set_keyframe(SageWindow *w, int kf, const float *pose
 {
   if (!w || kf < 0 || kf >= w->K || !pose12 || !code)
     return SAGE_E_INVALID;
+  (void)sync_candidate(w);
   for (int s = 0; s < 2; ++s)
   {
     std::memcpy(&w->pose[s][(size_t)kf * 12], pose12, 12 * sizeof(float));
@@ -1357,6 +1420,9 @@ extern "C" int sage_window_get_delta(const SageWindow *w, double *delta)
 {
   if (!w || !delta)
     return SAGE_E_INVALID;
+  int rcs = sync_candidate(const_cast<SageWindow *>(w));
+  if (rcs)
+    return rcs;
   std::memcpy(delta, w->delta.data(), w->delta.size() * sizeof(double));
   return SAGE_OK;
 }

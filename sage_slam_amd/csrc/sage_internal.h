@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <utility>
+#include <vector>
+
 #include "sage_ba.h"
 
 namespace sage
@@ -154,5 +157,20 @@ hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev,
 hipError_t launch_stats_finalize(hipStream_t s, const LaunchCommon &lc, float *stats, float fallback, float scale);
 hipError_t launch_gaussian_pyramid_with_grad(hipStream_t s, float *pyr, float *grad, const float *feat,
                                              const float *mask, const SagePyramid &p, int FS, float *scratch_mask);
+
+
+// ---- device solver of the window's damped normal equations (solve_kernels.hip) ----
+struct DeviceSolver;
+// SAGE_E_UNSUPPORTED when the block envelope is wider than the LDS panel (the caller keeps the host solver)
+int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<std::pair<int, int>> &links,
+                  hipStream_t stream);
+void solver_destroy(DeviceSolver *S);
+int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, const float *vars0, float *vars1, int CS,
+               double damp, double code_w, double scale_w, double pose_w, float scale_init0, const float *pose_init0);
+// valid after the stream has been synchronised
+const float *solver_host_vars(const DeviceSolver *S);
+const double *solver_host_delta(const DeviceSolver *S);
+double solver_host_step_norm2(const DeviceSolver *S);
+int solver_host_status(const DeviceSolver *S);
 
 } // namespace sage

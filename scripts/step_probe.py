@@ -11,7 +11,7 @@ def T(f):
 for it in range(6):
     t_lin = T(win.linearize)
     t_e0 = T(lambda: win.total_error(True))
-    t_solve = T(lambda: win.solve(1e-4))
+    t_solve = T(lambda: win.solve(1e-4, want_norm=False))
     t_err = T(lambda: win.error(1))
     t_e1 = T(lambda: win.total_error(False))
     t_acc = T(win.accept)

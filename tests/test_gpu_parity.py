@@ -410,3 +410,44 @@ def test_full_size_properties(capi, orc, cfg):
     hg = win.get_edge(1, 0)
     assert rel(hg["AtA"], og["AtA"]) < TOL_H and rel(hg["Atb"], og["Atb"]) < TOL_H
     win.close()
+
+
+@pytest.mark.parametrize("CS,K,back,extra", [(32, 6, 2, [(0, 5)]), (16, 7, 3, []), (32, 12, 3, [(0, 11), (2, 9)])])
+def test_device_solver_matches_host_cholesky(capi, CS, K, back, extra):
+    """The one-workgroup block-envelope Cholesky (solve_kernels.hip) against the host envelope Cholesky
+    (sage_block_solve, double) on the SAME packed normal equations, priors and damping: both are fp64 direct
+    solves of a cond ~1e9 system, so they agree to ~cond*eps; also a loop-closure envelope and the padded
+    B = 23 -> 24 case, candidate variables = retract(current, delta), and a second solve with another damping."""
+    w = synth.make_window(K=K, H=32, W=40, FS=16, CS=CS, L=3, seed=5, back_links=back)
+    for lk in extra:
+        if lk not in w.links:
+            w.links.append(lk)
+    win = capi.Window(w)
+    win.linearize()
+    packed = win.packed_host().astype(np.float64)
+    B = 7 + CS
+    dadd = np.zeros(K * B); gadd = np.zeros(K * B)
+    for k, kf in enumerate(w.keyframes):
+        idx = np.arange(k * B + 6, k * B + 6 + CS)
+        dadd[idx] += 1e-3
+        gadd[idx] += 1e-3 * (0 - kf.code.astype(np.float64))
+    s = float(w.keyframes[0].scale)
+    dadd[6 + CS] += 1e4 / (s * s)
+    dadd[:6] += 1e4                      # pose prior: current == initial pose -> zero gradient
+    for damp in (1e-3, 1e-1):
+        nrm = win.solve(damp)
+        dh = win.delta()
+        dref = capi.block_solve(packed[:-4], K, w.links, B, damp, dadd, gadd)
+        print(f"CS {CS} K {K} damp {damp}: device vs host solve rel-L2 {rel(dh, dref):.3e}")
+        assert rel(dh, dref) < 1e-7
+        assert nrm == pytest.approx(np.linalg.norm(dref), rel=1e-6)
+    # candidate = retract(current, delta): the error pass at the candidate and an accepted step must work end to end
+    e0 = win.total_error(True)
+    win.solve(1e-3)
+    win.error(1)
+    e1 = win.total_error(False)
+    assert np.isfinite(e1) and e1 < e0
+    win.accept()
+    pose, code, scale = win.get_keyframe(1)
+    assert np.allclose(code, w.keyframes[1].code + win.delta()[B + 6:B + 6 + CS].astype(np.float32), atol=1e-6)
+    win.close()
