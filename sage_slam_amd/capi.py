@@ -99,6 +99,7 @@ def lib():
     """Load ``libsage_ba.so`` (built in-tree by ``sage_slam_amd.build``); fails loudly when absent."""
     global _lib
     if _lib is None:
+        LIB_PATH = os.environ.get("SAGE_BA_LIB", globals()["LIB_PATH"])   # dev: A/B a variant build
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: run `python -m sage_slam_amd.build` "
                               "(the HIP engine has no fallback path)")

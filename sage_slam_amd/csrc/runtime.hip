@@ -73,12 +73,12 @@ struct WorkList
   std::vector<WorkItem> work;
   std::vector<int32_t> edge_first, edge_tiles;
   int tiles_per_block = 1;
-  void build(const std::vector<int> &N)
+  void build(const std::vector<int> &N, int tpb_override = 0)
   {
     long long total = 0;
     for (int n : N)
       total += (n + kTile - 1) / kTile;
-    tiles_per_block = pick_tiles_per_block(total);
+    tiles_per_block = tpb_override > 0 ? tpb_override : pick_tiles_per_block(total);
     work.clear();
     edge_first.assign(N.size(), 0);
     edge_tiles.assign(N.size(), 0);
@@ -101,7 +101,7 @@ struct WorkList
 struct SageWorkspace
 {
   hipStream_t stream = nullptr;
-  DevBuf work, edge_first, edge_tiles, partials, stats, misc;
+  DevBuf work, edge_first, edge_tiles, partials, stats, misc, dpt0;
   float *host_stats = nullptr; // pinned, 2 floats
   int cached_N = -1;
   int n_work = 0;
@@ -138,6 +138,7 @@ extern "C" void sage_workspace_destroy(SageWorkspace *ws)
   ws->partials.release();
   ws->stats.release();
   ws->misc.release();
+  ws->dpt0.release();
   if (ws->host_stats)
     (void)hipHostFree(ws->host_stats);
   delete ws;
@@ -343,7 +344,14 @@ extern "C" int sage_geometric_jac_error_calculate(
   int rc = ws_prepare(ws, N, geo_partial_floats(CS), &lc);
   if (rc)
     return rc;
+  // depth map of the source keyframe at (code0, scale0): the kernel reads its sample depths from it
+  const int gH = (int)cam->h, gW = (int)cam->w;
+  if ((rc = ws->dpt0.reserve((size_t)gH * gW * sizeof(float))))
+    return rc;
+  SAGE_HIP(launch_depth_and_grad(ws->stream, CS, ws->dpt0.as<float>(), nullptr, bias0, basis0, code0, nullptr, scale0,
+                                 gH, gW));
   GeoEdge e{};
+  e.dpt0 = ws->dpt0.as<float>();
   e.bias0 = bias0; e.basis0 = basis0; e.dpt1 = dpt1; e.dgrad1 = dgrad1; e.basis1 = basis1; e.mask1 = mask1;
   e.homo = homo; e.loc = loc1d; e.loc_is_i64 = 0;
   e.R0 = R0; e.t0 = t0; e.R1 = R1; e.t1 = t1; e.R10 = R10; e.t10 = R10 ? t10 : nullptr;
@@ -367,7 +375,13 @@ extern "C" int sage_geometric_error_calculate(
   int rc = ws_prepare(ws, N, 2, &lc);
   if (rc)
     return rc;
+  const int gH = (int)cam->h, gW = (int)cam->w;
+  if ((rc = ws->dpt0.reserve((size_t)gH * gW * sizeof(float))))
+    return rc;
+  SAGE_HIP(launch_depth_and_grad(ws->stream, CS, ws->dpt0.as<float>(), nullptr, bias0, basis0, code0, nullptr, scale0,
+                                 gH, gW));
   GeoEdge e{};
+  e.dpt0 = ws->dpt0.as<float>();
   e.bias0 = bias0; e.basis0 = basis0; e.dpt1 = dpt1; e.mask1 = mask1; e.homo = homo; e.loc = loc1d;
   e.loc_is_i64 = 0; e.R10 = R10; e.t10 = t10; e.code0 = code0; e.scale0_val = scale0; e.scale1_val = 1.f; e.N = N;
   SAGE_HIP(launch_geo_error(ws->stream, CS, &e, nullptr, lc, *cam, eps, loss_param, weight, ws->stats.as<float>()));
@@ -958,6 +972,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
         pe.code0 = x0 + 13; pe.scale0 = x0 + 12; pe.N = v0.N;
         pt[e] = pe;
         GeoEdge ge{};
+        ge.dpt0 = w->dpt.as<float>() + (size_t)k0 * HW;
         ge.bias0 = v0.bias; ge.basis0 = v0.basis; ge.dpt1 = w->dpt.as<float>() + (size_t)k1 * HW;
         ge.dgrad1 = w->dgrad.as<float>() + (size_t)k1 * 2 * HW; ge.basis1 = v1.basis; ge.mask1 = c.mask_dev;
         ge.homo = v0.homo; ge.loc = v0.loc1d; ge.loc_is_i64 = 1;
@@ -994,7 +1009,17 @@ extern "C" int sage_window_finalize(SageWindow *w)
   w->bytes_per_lin = bytes;
   // ---- work lists
   WorkList wl;
-  wl.build(Nedge);
+  {
+    // geometric linearize: the two wave groups of a workgroup alternate over its sub-tiles (geo_kernels.hip), so a
+    // workgroup wants an even, longish run of them: the pipeline fill/drain costs one half-step per workgroup
+    long long total = 0;
+    for (int n : Nedge)
+      total += (n + kTile - 1) / kTile;
+    int tpb = total >= 8192 ? 16 : (total >= 2048 ? 8 : (total >= 512 ? 4 : 2));
+    if (const char *e = getenv("SAGE_GEO_TPB"))
+      tpb = std::max(1, atoi(e));
+    wl.build(Nedge, tpb);
+  }
   w->n_work_g = (int)wl.work.size();
   w->tpb_g = wl.tiles_per_block;
   if ((rc = upload(w->work_g, wl.work, w->stream)) || (rc = upload(w->first_g, wl.edge_first, w->stream)) ||

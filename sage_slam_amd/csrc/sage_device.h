@@ -46,6 +46,14 @@ __device__ __forceinline__ float buf_load(__amdgpu_buffer_rsrc_t r, uint32_t vof
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)soff, 0));
 }
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
+{
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0);
+  return __builtin_bit_cast(f32x2, v);
+}
+
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff)
 {
   typedef int i32x4 __attribute__((ext_vector_type(4)));

@@ -51,6 +51,7 @@ struct PhotoEdge
 // One directed geometric edge kf0 -> kf1 (a4/a5).
 struct GeoEdge
 {
+  const float *dpt0;    // [H,W]   s0*(bias0+basis0*code0): depth map of the SOURCE keyframe at the evaluated variables
   const float *bias0;   // [H*W]
   const float *basis0;  // [H*W,CS]
   const float *dpt1;    // [H,W]   s1*(bias1+basis1*code1)
