@@ -123,8 +123,17 @@ def main():
     def clamp(d):
         return min(max(float(cfg.min_damp), d), float(cfg.max_damp))
 
+    state = capi.SageLmState()
+    cfg.max_inner_evals = 1          # one linearize + one solve + one error pass per step, as the multi-GPU path
+
     def lm_step():
         nonlocal damp
+        if dist is None:
+            # single GPU: the engine's own LM iteration (sage_window_lm_step), no Python between the launches
+            state.damp = damp
+            win.lm_step(state, cfg)
+            damp = state.damp
+            return state.error, state.candidate_error, bool(state.accepted)
         win.linearize()
         if dist is not None:
             dist.all_reduce(packed)
@@ -161,6 +170,7 @@ def main():
         if i % RESTART == 0:
             win.reset()
             damp = float(cfg.init_damp)
+            state.iters = 0
         hist.append(lm_step())
     barrier()
     elapsed = time.perf_counter() - t0

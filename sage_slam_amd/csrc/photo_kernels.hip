@@ -346,6 +346,18 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
         // source features: pose-independent, pre-sampled once per keyframe by the window engine ([L][FS/4][N][4])
         (void)t0;
         const f32x4 f0pre = reinterpret_cast<const f32x4 *>(E.f0s)[((size_t)l * (FS / 4) + g) * N + (in_range ? n : 0)];
+#ifdef SAGE_EXP_NO_LOADS
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+          t1[k] = f32x4{td.w[k], p, q, (float)dof[k]};
+          if (JAC)
+          {
+            tx[k] = f32x4{p, td.w[k], q, (float)soff};
+            ty[k] = f32x4{q, p, td.w[k], 1.f};
+          }
+        }
+#else
 #pragma unroll
         for (int k = 0; k < 4; ++k)
         {
@@ -356,6 +368,7 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
             ty[k] = buf_load4(r_g1y, dof[k] * 4u, soff);
           }
         }
+#endif
         __builtin_amdgcn_sched_barrier(0);
         f32x4 f0 = f0pre, f1 = {0.f, 0.f, 0.f, 0.f}, gx = f1, gy = f1;
 #pragma unroll

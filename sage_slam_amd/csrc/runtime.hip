@@ -1493,16 +1493,17 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
   auto clampd = [&](double d) { return std::min(std::max((double)cfg->min_damp, d), (double)cfg->max_damp); };
   if ((rc = sage_window_linearize(w)))
     return rc;
-  if ((rc = sage_window_total_error(w, 1, &st->error)))
-    return rc;
   int evals = 0;
   st->accepted = 0;
   while (true)
   {
-    double step;
-    if ((rc = sage_window_solve(w, st->damp, &step)))
+    // everything of one evaluation is enqueued before the host looks at a number: the error at the linearisation
+    // point (tail of the packed buffer) is read together with the candidate's
+    if ((rc = sage_window_solve(w, st->damp, nullptr)))
       return rc;
     if ((rc = sage_window_error(w, 1)))
+      return rc;
+    if (evals == 0 && (rc = sage_window_total_error(w, 1, &st->error)))
       return rc;
     if ((rc = sage_window_total_error(w, 0, &st->candidate_error)))
       return rc;
