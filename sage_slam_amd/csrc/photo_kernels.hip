@@ -30,6 +30,9 @@ struct PhotoParams
   float w[SAGE_MAX_LEVELS];
   float eps;
   int tiles_per_block; // consecutive kTile-pixel sub-tiles one workgroup accumulates before writing its partial
+  int width, height;   // level-0 size as integers (scalar values for the basis descriptor)
+  float rx[SAGE_MAX_LEVELS], ry[SAGE_MAX_LEVELS]; // fx_l/fx_0, fy_l/fy_0 (host-computed: no per-level divisions on the device)
+  int lw[SAGE_MAX_LEVELS], lh[SAGE_MAX_LEVELS];   // level sizes as integers
 };
 
 __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
@@ -42,42 +45,57 @@ __device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i 
   return i * 6 - (i * (i - 1)) / 2 + (j - i);
 }
 
-constexpr int kStageCap = 1024; // float4 slots of the LDS patch buffer (16 KiB)
-constexpr int kTileDim = 16;    // 16 x 16 source pixels per tile (= kTile lanes)
+#ifndef SAGE_PHOTO_WAVES
+#define SAGE_PHOTO_WAVES 3 // workgroups per CU the linearize kernel is register-budgeted for (x4 waves)
+#endif
 
-// MODE 0: reference layout, direct gathers (per-edge operator API, sparse samplings)
-// MODE 1: channel-group layout, direct dwordx4 gathers
-// MODE 2: channel-group layout + 2-D source tiles + destination patches staged in LDS (window engine, dense sampling)
+// per-pixel hand-over from the sampling phase (lane = pixel) to the contraction phase (lane = (channel i, pixel k)):
+//   [0..7] rows of the cross tile: c(6) = S(0:6,6), sigma*d, u6      [8] sigma = S66     [9] loc*CS*4 (int bits)
+constexpr int kPhotoStashLD = 12; // floats per pixel, 16-byte aligned rows
+
+// One (level, channel-group) step of the sampler in the engine's channel-group layout: 4 taps x (f1, gx, gy) dwordx4
+// loads + the pre-sampled source features.
+template <bool JAC>
+struct TapBatch
+{
+  f32x4 t1[4], tx[JAC ? 4 : 1], ty[JAC ? 4 : 1], f0;
+};
+
+// MODE 0: reference layout [FS][P] / [2][FS][P], dword gathers, source features sampled in-kernel (per-edge operator API)
+// MODE 1: engine layout [FS/4][P][4] (one dwordx4 per tap and channel group, 1 KiB contiguous per wave) with the
+//         source features pre-sampled per keyframe; the (level, group) steps are software-pipelined: the 13 loads of
+//         step it+1 are in flight while step it is reduced (two register batches).
+//
+// Phases per 64-pixel wave slice (no workgroup barrier inside the sub-tile loop, the waves only meet for the final sum):
+//   A  warp: depth from the keyframe's depth map, projection, mask                      (lane = pixel)
+//   B  sampling: G, v, e accumulated over levels and channels                           (lane = pixel)
+//   C  per-pixel 7x7 reduced system, 37 scalar sums (DPP), rows for the contraction -> wave-private LDS stash
+//   D  code blocks: f32 MFMA 16x16x4 with the basis rows loaded from global memory directly in operand layout
+//      (lane = (channel pair i, pixel k): 16 lanes x dwordx2 = one 128-byte basis row; CS = 32: operand block 0 = even
+//      channels, block 1 = odd channels)
 template <int CS, int FS, bool JAC, int MODE>
-__global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
+__global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kernel(const PhotoParams prm)
 {
   constexpr bool PACKED = MODE >= 1;
-  constexpr bool TILED = MODE == 2;
-  constexpr int LD = CS + 1;
+  constexpr int NB = CS / 16;
+  constexpr int NG = FS / 4;
   constexpr int NT = photo_tiles(CS);
-  __shared__ float s_basis[kTile * LD];
-  __shared__ int s_loc[kTile];
-  __shared__ float s_stash_raw[(JAC && !TILED) ? kTile * 9 : 1];
-  __shared__ f32x4 s_stage[TILED ? kStageCap : 1];
-  __shared__ int s_bbox[kWaves * 4];
+  constexpr int STASH = JAC ? kWaves * 64 * kPhotoStashLD : 1;
+  constexpr int SUMBUF = JAC ? NT * 256 : 1;
+  __shared__ __attribute__((aligned(16))) float s_mem[STASH > SUMBUF ? STASH : SUMBUF];
   __shared__ float s_red[kWaves * kPhotoScalars];
-  // the per-pixel stash (phase C/D) reuses the patch buffer: sampling is over by then
-  float *s_stash = TILED ? reinterpret_cast<float *>(s_stage) : s_stash_raw;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   WorkItem wi = prm.work[blockIdx.x];
   wi.edge = uni(wi.edge);
   wi.tile = uni(wi.tile);
   PhotoEdge E = prm.table ? prm.table[wi.edge] : prm.single;
-  E.feat0 = uni(E.feat0); E.feat1 = uni(E.feat1); E.grad1 = uni(E.grad1); E.bias0 = uni(E.bias0);
-  E.feat0_pk = uni(E.feat0_pk); E.feat1_pk = uni(E.feat1_pk); E.gx1_pk = uni(E.gx1_pk); E.gy1_pk = uni(E.gy1_pk);
+  E.feat0 = uni(E.feat0); E.feat1 = uni(E.feat1); E.grad1 = uni(E.grad1); E.dpt0 = uni(E.dpt0);
+  E.feat1_pk = uni(E.feat1_pk); E.gx1_pk = uni(E.gx1_pk); E.gy1_pk = uni(E.gy1_pk);
   E.basis0 = uni(E.basis0); E.mask1 = uni(E.mask1); E.homo = uni(E.homo); E.loc = uni(E.loc);
   E.R0 = uni(E.R0); E.t0 = uni(E.t0); E.R1 = uni(E.R1); E.t1 = uni(E.t1); E.R10 = uni(E.R10); E.t10 = uni(E.t10);
-  E.code0 = uni(E.code0); E.scale0 = uni(E.scale0); E.scale0_val = uni(E.scale0_val);
-  E.N = uni(E.N); E.loc_is_i64 = uni(E.loc_is_i64);
-  E.index_map0 = uni(E.index_map0); E.tiles0 = uni(E.tiles0); E.n_tiles0 = uni(E.n_tiles0); E.f0s = uni(E.f0s);
+  E.N = uni(E.N); E.loc_is_i64 = uni(E.loc_is_i64); E.f0s = uni(E.f0s);
   const int N = E.N;
-  const float scale0 = E.scale0 ? *E.scale0 : E.scale0_val;
 
   // ---- poses (wave-uniform) ----
   const Pose p0 = JAC ? load_pose2(E.R0, E.t0) : Pose{};
@@ -90,14 +108,16 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
 
   const SagePyramid &pyr = prm.pyr;
   const float fx0 = pyr.cam[0].fx, fy0 = pyr.cam[0].fy, cx0 = pyr.cam[0].cx, cy0 = pyr.cam[0].cy;
-  const int W0 = (int)pyr.cam[0].w, H0 = (int)pyr.cam[0].h;
+  const int W0 = prm.width, H0 = prm.height;
   const uint32_t pyr_bytes = (uint32_t)FS * (uint32_t)pyr.P * 4u;
-  const __amdgpu_buffer_rsrc_t r_f0 = make_rsrc(PACKED ? E.feat0_pk : E.feat0, pyr_bytes);
+  const __amdgpu_buffer_rsrc_t r_f0 = make_rsrc(E.feat0, pyr_bytes);
   const __amdgpu_buffer_rsrc_t r_f1 = make_rsrc(PACKED ? E.feat1_pk : E.feat1, pyr_bytes);
   const __amdgpu_buffer_rsrc_t r_g1 =
       make_rsrc(PACKED ? (JAC ? E.gx1_pk : E.feat1_pk) : (JAC ? E.grad1 : E.feat1), (JAC && !PACKED) ? 2u * pyr_bytes : pyr_bytes);
   const __amdgpu_buffer_rsrc_t r_g1y = make_rsrc((PACKED && JAC) ? E.gy1_pk : E.feat1, pyr_bytes);
+  const __amdgpu_buffer_rsrc_t r_b0 = make_rsrc(E.basis0, (uint32_t)W0 * (uint32_t)H0 * (uint32_t)(CS * 4));
   const uint32_t plane = (uint32_t)pyr.P * 4u;
+  const int nlev = pyr.levels;
 
   for (int k = tid; k < kWaves * kPhotoScalars; k += kBlock)
     s_red[k] = 0.f;
@@ -106,37 +126,18 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
   for (int t = 0; t < NT; ++t)
     acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float err_acc = 0.f, vm_acc = 0.f; // error-only path: lane-local sums over the sub-tiles
+  float *st_w = s_mem + wave * 64 * kPhotoStashLD; // this wave's stash
+  __syncthreads();                                 // s_red zeroed
 
-  for (int sub = 0; sub < prm.tiles_per_block; ++sub)
+  const int nsub = min(prm.tiles_per_block, (N + kTile - 1) / kTile - wi.tile);
+  for (int sub = 0; sub < nsub; ++sub)
   {
   const int tile = wi.tile + sub;
-  int n, my_loc, tile_rows;
-  bool in_range;
-  if (TILED)
-  {
-    if (tile >= E.n_tiles0)
-      break;
-    const int t = uni(E.tiles0[tile]);
-    const int px = (t & 0xffff) + (tid & (kTileDim - 1)), py = (t >> 16) + (tid >> 4);
-    const bool in_img = px < W0 && py < H0;
-    my_loc = in_img ? py * W0 + px : 0;
-    n = in_img ? E.index_map0[my_loc] : -1;
-    in_range = n >= 0;
-    if (!in_range)
-      n = 0;
-    tile_rows = kTile;
-  }
-  else
-  {
-    if (tile * kTile >= N)
-      break;
-    n = tile * kTile + tid;
-    in_range = n < N;
-    tile_rows = min(kTile, N - tile * kTile);
-    my_loc = in_range ? load_loc(E.loc, E.loc_is_i64, n) : 0;
-  }
-  const float d = stage_basis_and_depth<CS>(s_basis, s_loc, E.basis0, E.bias0, E.code0, scale0, my_loc, in_range,
-                                            tile_rows);
+  const int n = tile * kTile + tid;
+  const bool in_range = n < N;
+  const int my_loc = in_range ? load_loc(E.loc, E.loc_is_i64, n) : 0;
+  // depth of the source pixel: s0*(bias + basis.code), read from the keyframe's depth map (:1094-1095)
+  const float d = in_range ? E.dpt0[my_loc] : 1.0f;
 
   float hm[3] = {0.f, 0.f, 1.f};
   if (in_range)
@@ -161,230 +162,53 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
   const float m = mask_lookup(E.mask1, p, q, W0, H0);
   const float vm = (pos && in_range) ? m : 0.0f; // sampled_valid_mask_1 (:237)
 
-  // source coordinates at level 0 (+0.5): from homo in the Jacobian kernel (:101-103), from loc1d in the
-  // error-only kernel (:423-424, :1012-1014)
-  float su, sv;
-  if (JAC)
-  {
-    su = hm[0] * fx0 + cx0 + 0.5f;
-    sv = hm[1] * fy0 + cy0 + 0.5f;
-  }
-  else
-  {
-    su = (float)(my_loc % W0) + 0.5f;
-    sv = (float)(my_loc / W0) + 0.5f;
-  }
-
   float G00 = 0.f, G01 = 0.f, G11 = 0.f, v0 = 0.f, v1 = 0.f, err = 0.f;
-  for (int l = 0; l < pyr.levels; ++l)
+  if (PACKED)
   {
-    const float fxl = pyr.cam[l].fx, fyl = pyr.cam[l].fy;
-    const int Wl = (int)pyr.cam[l].w, Hl = (int)pyr.cam[l].h;
-    const float rx = fxl / fx0, ry = fyl / fy0;
-    Taps ts, td;
-    make_taps(ts, su * rx - 0.5f, sv * ry - 0.5f, Wl, Hl);
-    make_taps(td, (p + 0.5f) * rx - 0.5f, (q + 0.5f) * ry - 0.5f, Wl, Hl);
-    if (TILED && !in_range)
+    // ---- sampler over (level, channel group): the 13 dwordx4 loads of a step are issued together, then reduced ----
+    const f32x4 *f0s = reinterpret_cast<const f32x4 *>(E.f0s) + (in_range ? n : 0);
+    for (int l = 0; l < nlev; ++l)
     {
+      const float fxl = pyr.cam[l].fx, fyl = pyr.cam[l].fy;
+      Taps td;
+      make_taps(td, (p + 0.5f) * prm.rx[l] - 0.5f, (q + 0.5f) * prm.ry[l] - 0.5f, prm.lw[l], prm.lh[l]);
+      const uint32_t lo = (uint32_t)pyr.level_offsets[l];
+      uint32_t dof[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-      {
-        ts.w[k] = td.w[k] = 0.f;
-        ts.off[k] = td.off[k] = 0;
-      }
-    }
-    const uint32_t lo = (uint32_t)pyr.level_offsets[l];
-    uint32_t so[4], dof[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-    {
-      so[k] = (lo + (uint32_t)ts.off[k]) * 4u;
-      dof[k] = (lo + (uint32_t)td.off[k]) * 4u;
-    }
-    float g00 = 0.f, g01 = 0.f, g11 = 0.f, a0 = 0.f, a1 = 0.f, ee = 0.f;
-    bool staged = false;
-    if (TILED)
-    {
-      // ---- bounding box (level texels) of the tile's destination taps ----
-      const int BIG = 1 << 28;
-      int bb[4];
-      bb[0] = wave_minmax<true>(in_range ? td.xf : BIG);
-      bb[1] = wave_minmax<false>(in_range ? td.xf + 1 : -BIG);
-      bb[2] = wave_minmax<true>(in_range ? td.yf : BIG);
-      bb[3] = wave_minmax<false>(in_range ? td.yf + 1 : -BIG);
-      if (lane == 63)
-      {
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          s_bbox[wave * 4 + k] = bb[k];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-      {
-        int v = s_bbox[k];
-#pragma unroll
-        for (int w = 1; w < kWaves; ++w)
-          v = (k & 1) ? max(v, s_bbox[w * 4 + k]) : min(v, s_bbox[w * 4 + k]);
-        bb[k] = uni(v);
-      }
-      const int dx0 = max(bb[0], 0), dx1 = min(bb[1], Wl - 1), dy0 = max(bb[2], 0), dy1 = min(bb[3], Hl - 1);
-      const int dbw = dx1 - dx0 + 1, dbh = dy1 - dy0 + 1;
-      constexpr int NA = JAC ? 3 : 1; // arrays staged for the destination: f1 (+ gx, gy)
-      staged = dbw > 0 && dbh > 0 && dbw <= 32 && NA * dbw * dbh <= kStageCap;
-      if (staged)
-      {
-        const int dsz = dbw * dbh;
-        int di[4]; // LDS slots of this lane's taps (only meaningful where the tap weight is non-zero)
-        {
-          const int b0 = (td.yf - dy0) * dbw + (td.xf - dx0);
-          di[0] = b0; di[1] = b0 + dbw + 1; di[2] = b0 + dbw; di[3] = b0 + 1;
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            di[k] = (td.w[k] != 0.f) ? di[k] : 0;
-        }
-        const int rr = tid >> 5, cc = tid & 31; // 8 patch rows x 32 columns per pass
-        // pre-sampled source features of this keyframe: [L][FS/4][N][4]
-        const f32x4 *f0s = reinterpret_cast<const f32x4 *>(E.f0s) + (size_t)l * (FS / 4) * N + n;
-        for (int g = 0; g < FS / 4; ++g)
-        {
-          const uint32_t soff = (uint32_t)g * plane * 4u;
-          if (g > 0)
-            __syncthreads(); // the previous group's taps have been read
-          if (cc < dbw)
-            for (int r = rr; r < dbh; r += 8)
-            {
-              const uint32_t go = (lo + (uint32_t)((dy0 + r) * Wl + dx0 + cc)) * 16u;
-              s_stage[r * dbw + cc] = buf_load4(r_f1, go, soff);
-              if (JAC)
-              {
-                s_stage[dsz + r * dbw + cc] = buf_load4(r_g1, go, soff);
-                s_stage[2 * dsz + r * dbw + cc] = buf_load4(r_g1y, go, soff);
-              }
-            }
-          const f32x4 f0 = f0s[(size_t)g * N];
-          __syncthreads();
-          f32x4 f1 = {0.f, 0.f, 0.f, 0.f}, gx = f1, gy = f1;
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-          {
-            f1 += td.w[k] * s_stage[di[k]];
-            if (JAC)
-            {
-              gx += td.w[k] * s_stage[dsz + di[k]];
-              gy += td.w[k] * s_stage[2 * dsz + di[k]];
-            }
-          }
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-          {
-            const float diff = f0[c] - f1[c];
-            ee += diff * diff;
-            if (JAC)
-            {
-              const float hx = fxl * gx[c], hy = fyl * gy[c];
-              g00 += hx * hx;
-              g01 += hx * hy;
-              g11 += hy * hy;
-              a0 += hx * diff;
-              a1 += hy * diff;
-            }
-          }
-        }
-        __syncthreads(); // patch buffer is reused by the next level (and by the stash afterwards)
-      }
-      else
-      {
-        // rare: the tile's footprint does not fit the patch buffer (extreme warps) -> plain gathers, one tap at a time
-        const f32x4 *f0s = reinterpret_cast<const f32x4 *>(E.f0s) + (size_t)l * (FS / 4) * N + n;
-        for (int g = 0; g < FS / 4; ++g)
-        {
-          const uint32_t soff = (uint32_t)g * plane * 4u;
-          const f32x4 f0 = f0s[(size_t)g * N];
-          f32x4 f1 = {0.f, 0.f, 0.f, 0.f}, gx = f1, gy = f1;
-          for (int k = 0; k < 4; ++k)
-          {
-            f1 += td.w[k] * buf_load4(r_f1, dof[k] * 4u, soff);
-            if (JAC)
-            {
-              gx += td.w[k] * buf_load4(r_g1, dof[k] * 4u, soff);
-              gy += td.w[k] * buf_load4(r_g1y, dof[k] * 4u, soff);
-            }
-          }
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-          {
-            const float diff = f0[c] - f1[c];
-            ee += diff * diff;
-            if (JAC)
-            {
-              const float hx = fxl * gx[c], hy = fyl * gy[c];
-              g00 += hx * hx;
-              g01 += hx * hy;
-              g11 += hy * hy;
-              a0 += hx * diff;
-              a1 += hy * diff;
-            }
-          }
-        }
-        staged = true; // handled
-      }
-    }
-    if (TILED)
-    {
-      (void)staged; // both tiled paths have accumulated this level above
-    }
-    else if (PACKED)
-    {
-      // channel-group layout: one dwordx4 per tap and group of 4 channels (16 B per lane, 1 KiB contiguous per wave)
-      for (int g = 0; g < FS / 4; ++g)
+        dof[k] = (lo + (uint32_t)td.off[k]) * 16u;
+      float g00 = 0.f, g01 = 0.f, g11 = 0.f, a0 = 0.f, a1 = 0.f, ee = 0.f; // level accumulators (:200-236)
+      for (int g = 0; g < NG; ++g)
       {
         const uint32_t soff = (uint32_t)g * plane * 4u;
-        // issue every tap load of the group first (16 independent dwordx4 in flight), then consume: without the
-        // scheduling barrier hipcc serialises load->wait->use through one register quad
-        f32x4 t0[4], t1[4], tx[JAC ? 4 : 1], ty[JAC ? 4 : 1];
-        // source features: pose-independent, pre-sampled once per keyframe by the window engine ([L][FS/4][N][4])
-        (void)t0;
-        const f32x4 f0pre = reinterpret_cast<const f32x4 *>(E.f0s)[((size_t)l * (FS / 4) + g) * N + (in_range ? n : 0)];
-#ifdef SAGE_EXP_NO_LOADS
+        TapBatch<JAC> B;
+        B.f0 = f0s[((size_t)l * NG + g) * N];
 #pragma unroll
         for (int k = 0; k < 4; ++k)
         {
-          t1[k] = f32x4{td.w[k], p, q, (float)dof[k]};
+          B.t1[k] = buf_load4(r_f1, dof[k], soff);
           if (JAC)
           {
-            tx[k] = f32x4{p, td.w[k], q, (float)soff};
-            ty[k] = f32x4{q, p, td.w[k], 1.f};
+            B.tx[k] = buf_load4(r_g1, dof[k], soff);
+            B.ty[k] = buf_load4(r_g1y, dof[k], soff);
           }
         }
-#else
+        __builtin_amdgcn_sched_barrier(0); // without it hipcc serialises load->wait->use through one register quad
+        f32x4 f1 = {0.f, 0.f, 0.f, 0.f}, gx = f1, gy = f1;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
         {
-          t1[k] = buf_load4(r_f1, dof[k] * 4u, soff);
+          f1 += td.w[k] * B.t1[k];
           if (JAC)
           {
-            tx[k] = buf_load4(r_g1, dof[k] * 4u, soff);
-            ty[k] = buf_load4(r_g1y, dof[k] * 4u, soff);
-          }
-        }
-#endif
-        __builtin_amdgcn_sched_barrier(0);
-        f32x4 f0 = f0pre, f1 = {0.f, 0.f, 0.f, 0.f}, gx = f1, gy = f1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-        {
-          f1 += td.w[k] * t1[k];
-          if (JAC)
-          {
-            gx += td.w[k] * tx[k];
-            gy += td.w[k] * ty[k];
+            gx += td.w[k] * B.tx[k];
+            gy += td.w[k] * B.ty[k];
           }
         }
 #pragma unroll
         for (int c = 0; c < 4; ++c)
         {
-          const float diff = f0[c] - f1[c];
+          const float diff = B.f0[c] - f1[c];
           ee += diff * diff;
           if (JAC)
           {
@@ -397,61 +221,98 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
           }
         }
       }
+      const float wl = prm.w[l];
+      err += wl * ee;
+      if (JAC)
+      {
+        G00 += wl * g00;
+        G01 += wl * g01;
+        G11 += wl * g11;
+        v0 += wl * a0;
+        v1 += wl * a1;
+      }
+    }
+  }
+  else
+  {
+    // source coordinates at level 0 (+0.5): from homo in the Jacobian kernel (:101-103), from loc1d in the
+    // error-only kernel (:423-424, :1012-1014)
+    float su, sv;
+    if (JAC)
+    {
+      su = hm[0] * fx0 + cx0 + 0.5f;
+      sv = hm[1] * fy0 + cy0 + 0.5f;
     }
     else
     {
-#pragma unroll 4
-    for (int c = 0; c < FS; ++c)
+      su = (float)(my_loc % W0) + 0.5f;
+      sv = (float)(my_loc / W0) + 0.5f;
+    }
+    for (int l = 0; l < nlev; ++l)
     {
-      const uint32_t soff = (uint32_t)c * plane;
-      float f0 = 0.f, f1 = 0.f;
+      const float fxl = pyr.cam[l].fx, fyl = pyr.cam[l].fy;
+      const int Wl = prm.lw[l], Hl = prm.lh[l];
+      const float rx = prm.rx[l], ry = prm.ry[l];
+      Taps ts, td;
+      make_taps(ts, su * rx - 0.5f, sv * ry - 0.5f, Wl, Hl);
+      make_taps(td, (p + 0.5f) * rx - 0.5f, (q + 0.5f) * ry - 0.5f, Wl, Hl);
+      const uint32_t lo = (uint32_t)pyr.level_offsets[l];
+      uint32_t so[4], dof[4];
 #pragma unroll
       for (int k = 0; k < 4; ++k)
       {
-        f0 += ts.w[k] * buf_load(r_f0, so[k], soff);
-        f1 += td.w[k] * buf_load(r_f1, dof[k], soff);
+        so[k] = (lo + (uint32_t)ts.off[k]) * 4u;
+        dof[k] = (lo + (uint32_t)td.off[k]) * 4u;
       }
-      const float diff = f0 - f1;
-      ee += diff * diff;
-      if (JAC)
+      float g00 = 0.f, g01 = 0.f, g11 = 0.f, a0 = 0.f, a1 = 0.f, ee = 0.f;
+#pragma unroll 4
+      for (int c = 0; c < FS; ++c)
       {
-        const uint32_t soff_y = (uint32_t)(FS + c) * plane;
-        float gx = 0.f, gy = 0.f;
+        const uint32_t soff = (uint32_t)c * plane;
+        float f0 = 0.f, f1 = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
         {
-          gx += td.w[k] * buf_load(r_g1, dof[k], soff);
-          gy += td.w[k] * buf_load(r_g1, dof[k], soff_y);
+          f0 += ts.w[k] * buf_load(r_f0, so[k], soff);
+          f1 += td.w[k] * buf_load(r_f1, dof[k], soff);
         }
-        const float hx = fxl * gx, hy = fyl * gy;
-        g00 += hx * hx;
-        g01 += hx * hy;
-        g11 += hy * hy;
-        a0 += hx * diff;
-        a1 += hy * diff;
+        const float diff = f0 - f1;
+        ee += diff * diff;
+        if (JAC)
+        {
+          const uint32_t soff_y = (uint32_t)(FS + c) * plane;
+          float gx = 0.f, gy = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+          {
+            gx += td.w[k] * buf_load(r_g1, dof[k], soff);
+            gy += td.w[k] * buf_load(r_g1, dof[k], soff_y);
+          }
+          const float hx = fxl * gx, hy = fyl * gy;
+          g00 += hx * hx;
+          g01 += hx * hy;
+          g11 += hy * hy;
+          a0 += hx * diff;
+          a1 += hy * diff;
+        }
       }
-    }
-    }
-    const float wl = prm.w[l];
-    err += wl * ee;
-    if (JAC)
-    {
-      G00 += wl * g00;
-      G01 += wl * g01;
-      G11 += wl * g11;
-      v0 += wl * a0;
-      v1 += wl * a1;
+      const float wl = prm.w[l];
+      err += wl * ee;
+      if (JAC)
+      {
+        G00 += wl * g00;
+        G01 += wl * g01;
+        G11 += wl * g11;
+        v0 += wl * a0;
+        v1 += wl * a1;
+      }
     }
   }
   err *= vm; // within_mask * pow(diff,2)  (:228)
-
+  err_acc += err;
+  vm_acc += vm;
   if (!JAC)
-  {
-    err_acc += err;
-    vm_acc += vm;
-    __syncthreads(); // s_basis / s_loc are restaged by the next sub-tile
     continue;
-  }
 
   // ---- per-pixel 7x7 reduced system ----
   const bool live = vm != 0.0f;
@@ -509,15 +370,12 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
     sc[35] = err;
     sc[36] = vm;
   }
-  // stash the rows that multiply b_n: c (6), sigma*d, u6, and sigma itself
+  // stash the rows that multiply b_n: c (6), sigma*d, u6, then sigma itself and the byte offset of the basis row
   {
-    float *st = s_stash + tid * 9;
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      st[j] = S6[j];
-    st[6] = S6[6] * d;
-    st[7] = u6;
-    st[8] = S6[6];
+    f32x4 *st = reinterpret_cast<f32x4 *>(st_w + lane * kPhotoStashLD);
+    st[0] = f32x4{S6[0], S6[1], S6[2], S6[3]};
+    st[1] = f32x4{S6[4], S6[5], S6[6] * d, u6};
+    st[2] = f32x4{S6[6], __int_as_float(my_loc * (CS * 4)), 0.f, 0.f};
   }
 #pragma unroll
   for (int k = 0; k < 37; ++k)
@@ -526,37 +384,70 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
     if (lane == 63)
       s_red[wave * kPhotoScalars + k] += s; // only this lane ever touches this slot
   }
-  __syncthreads(); // stash visible to the wave's other lanes
+  __builtin_amdgcn_wave_barrier(); // same-wave LDS hand-over (in-order LDS pipe): no workgroup barrier needed
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
-  // ---- MFMA contractions over this wave's 64 pixels, 4 pixels (K) per instruction ----
+  // ---- MFMA contractions over this wave's 64 pixels, 4 pixels (K) per instruction; basis rows streamed from
+  //      global memory in operand layout, AHEAD groups in flight ----
   {
     const int i = lane & 15, k = lane >> 4;
-#pragma unroll 4
-    for (int g = 0; g < 16; ++g)
+    const uint32_t lane_off = (uint32_t)i * (NB == 2 ? 8u : 4u);
+    constexpr int G = 16, AHEAD = 3;
+    float bl[G], bh[G], ai[G], sg[G];
+    int locp[G];
+#define SAGE_PHOTO_READ_STASH(g)                                                        \
+  {                                                                                     \
+    const float *p_ = st_w + ((g) * 4 + k) * kPhotoStashLD;                             \
+    ai[g] = p_[i & 7];                                                                  \
+    const f32x2 sl_ = *reinterpret_cast<const f32x2 *>(p_ + 8); /* sigma, loc */        \
+    sg[g] = sl_[0];                                                                     \
+    locp[g] = __float_as_int(sl_[1]);                                                   \
+  }
+#define SAGE_PHOTO_ISSUE(g)                                                             \
+  {                                                                                     \
+    if (NB == 2)                                                                        \
+    {                                                                                   \
+      const f32x2 vb_ = buf_load2(r_b0, (uint32_t)locp[g] + lane_off, 0);               \
+      bl[g] = vb_[0];                                                                   \
+      bh[g] = vb_[1];                                                                   \
+    }                                                                                   \
+    else                                                                                \
+    {                                                                                   \
+      bl[g] = buf_load(r_b0, (uint32_t)locp[g] + lane_off, 0);                          \
+      bh[g] = 0.f;                                                                      \
+    }                                                                                   \
+  }
+#pragma unroll
+    for (int g = 0; g < AHEAD + 1; ++g)
+      SAGE_PHOTO_READ_STASH(g)
+#pragma unroll
+    for (int g = 0; g < AHEAD; ++g)
+      SAGE_PHOTO_ISSUE(g)
+    const float asel = (i < 8) ? 1.f : 0.f; // rows 8..15 of the cross operand are zero
+#pragma unroll
+    for (int g = 0; g < G; ++g)
     {
-      const int px = wave * 64 + g * 4 + k;
-      const float *br = s_basis + px * LD;
-      const float *st = s_stash + px * 9;
-      const float sg = st[8];
-      const float ai = (i < 8) ? st[i & 7] : 0.f;
-      const float bl = br[i];
+      if (g + AHEAD < G)
+        SAGE_PHOTO_ISSUE(g + AHEAD)
+      if (g + AHEAD + 1 < G)
+        SAGE_PHOTO_READ_STASH(g + AHEAD + 1)
+      const float a = asel * ai[g];
       if (CS == 32)
       {
-        const float bh = br[16 + i];
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg * bl, bl, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg * bl, bh, acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg * bh, bh, acc[2], 0, 0, 0);
-        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, bl, acc[3], 0, 0, 0);
-        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, bh, acc[4], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bl[g], bl[g], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bl[g], bh[g], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bh[g], bh[g], acc[2], 0, 0, 0);
+        acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bl[g], acc[3], 0, 0, 0);
+        acc[4] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bh[g], acc[4], 0, 0, 0);
       }
       else
       {
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg * bl, bl, acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(ai, bl, acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bl[g], bl[g], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bl[g], acc[1], 0, 0, 0);
       }
     }
   }
-  __syncthreads(); // everyone is done reading s_basis / s_stash before they are restaged or reused
+  __builtin_amdgcn_wave_barrier(); // the stash is rewritten by the next sub-tile
   } // sub-tile loop
 
   if (!JAC)
@@ -579,13 +470,21 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
     return;
   }
 
+  // ---- cross-wave sum in a fixed order (deterministic), NT*256 floats in the (now idle) stash memory ----
+  for (int w = 0; w < kWaves; ++w)
   {
-    float *sw = s_basis + wave * (NT * 256);
+    __syncthreads();
+    if (wave == w)
+    {
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-        sw[t * 256 + r * 64 + lane] = acc[t][r];
+        for (int r = 0; r < 4; ++r)
+        {
+          float *qd = s_mem + t * 256 + r * 64 + lane;
+          *qd = (w == 0) ? acc[t][r] : *qd + acc[t][r];
+        }
+    }
   }
   __syncthreads();
   float *out = prm.partials + (size_t)blockIdx.x * photo_partial_floats(CS);
@@ -599,13 +498,7 @@ __global__ __launch_bounds__(kBlock, 3) void photo_kernel(const PhotoParams prm)
     out[tid] = a;
   }
   for (int idx = tid; idx < NT * 256; idx += kBlock)
-  {
-    float a = 0.f;
-#pragma unroll
-    for (int w = 0; w < kWaves; ++w)
-      a += s_basis[w * (NT * 256) + idx];
-    out[kPhotoScalars + idx] = a;
-  }
+    out[kPhotoScalars + idx] = s_mem[idx];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -659,18 +552,19 @@ __global__ __launch_bounds__(kBlock) void photo_finalize_kernel(const PhotoFinal
     prm.stats[2 * e + 0] = ok ? (float)(s[35] * inv_n) : 10.0f * prm.wsum;
     prm.stats[2 * e + 1] = (float)n_in;
   }
+  // CS = 32: the contraction loads channel pairs per lane -> operand block = channel parity, row = channel / 2
   auto X = [&](int row, int col) -> double { // sum_n a_n[row] * b_n[col]
     if (CS == 32)
-      return tile_elem(s, kPhotoScalars, col < 16 ? 3 : 4, row, col & 15);
+      return tile_elem(s, kPhotoScalars, (col & 1) ? 4 : 3, row, col >> 1);
     return tile_elem(s, kPhotoScalars, 1, row, col);
   };
-  auto CC = [&](int i, int j) -> double { // sum_n sigma_n b_n[i] b_n[j]
+  auto CC = [&](int i, int j) -> double { // sum_n sigma_n b_n[i] b_n[j], i <= j
     if (CS == 32)
     {
-      const int ti = i >> 4, tj = j >> 4;
+      const int ti = i & 1, tj = j & 1;
       if (ti <= tj)
-        return tile_elem(s, kPhotoScalars, ti + tj, i & 15, j & 15); // (0,0)->0 (0,1)->1 (1,1)->2
-      return tile_elem(s, kPhotoScalars, 1, j & 15, i & 15);
+        return tile_elem(s, kPhotoScalars, ti + tj, i >> 1, j >> 1); // (0,0)->0 (0,1)->1 (1,1)->2
+      return tile_elem(s, kPhotoScalars, 1, j >> 1, i >> 1);
     }
     return tile_elem(s, kPhotoScalars, 0, i, j);
   };
@@ -786,6 +680,15 @@ static PhotoParams make_params(const PhotoEdge *single, const PhotoEdge *table, 
   }
   p.eps = eps;
   p.tiles_per_block = lc.tiles_per_block;
+  p.width = (int)pyr.cam[0].w;
+  p.height = (int)pyr.cam[0].h;
+  for (int l = 0; l < pyr.levels; ++l)
+  {
+    p.rx[l] = pyr.cam[l].fx / pyr.cam[0].fx; // same fp32 quotient the kernels used to form per pixel
+    p.ry[l] = pyr.cam[l].fy / pyr.cam[0].fy;
+    p.lw[l] = (int)pyr.cam[l].w;
+    p.lh[l] = (int)pyr.cam[l].h;
+  }
   *wsum = ws;
   return p;
 }
@@ -799,9 +702,7 @@ static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const P
   PhotoParams p = make_params(single, table, lc, pyr, wh, eps, &wsum);
   if (lc.ev_start)
     (void)hipEventRecord(lc.ev_start, s);
-  if (lc.tiled)
-    hipLaunchKernelGGL((photo_kernel<CS, FS, true, 2>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
-  else if (lc.packed)
+  if (lc.packed)
     hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   else
     hipLaunchKernelGGL((photo_kernel<CS, FS, true, 0>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
@@ -831,9 +732,7 @@ static hipError_t photo_err_impl(hipStream_t s, const PhotoEdge *single, const P
   PhotoParams p = make_params(single, table, lc, pyr, wh, eps, &wsum);
   if (lc.ev_start)
     (void)hipEventRecord(lc.ev_start, s);
-  if (lc.tiled)
-    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 2>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
-  else if (lc.packed)
+  if (lc.packed)
     hipLaunchKernelGGL((photo_kernel<CS, FS, false, 1>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   else
     hipLaunchKernelGGL((photo_kernel<CS, FS, false, 0>), dim3(lc.n_work), dim3(kBlock), 0, s, p);

@@ -224,7 +224,14 @@ extern "C" int sage_photometric_jac_error_calculate(
   int rc = ws_prepare(ws, N, photo_partial_floats(CS), &lc);
   if (rc)
     return rc;
+  // depth map of the source keyframe at (code0, scale0): the kernel reads its sample depths from it
+  const int pH = (int)pyr->cam[0].h, pW = (int)pyr->cam[0].w;
+  if ((rc = ws->dpt0.reserve((size_t)pH * pW * sizeof(float))))
+    return rc;
+  SAGE_HIP(launch_depth_and_grad(ws->stream, CS, ws->dpt0.as<float>(), nullptr, bias0, basis0, code0, nullptr, scale0,
+                                 pH, pW));
   PhotoEdge e{};
+  e.dpt0 = ws->dpt0.as<float>();
   e.feat0 = feat0; e.feat1 = feat1; e.grad1 = grad1; e.bias0 = bias0; e.basis0 = basis0; e.mask1 = mask1;
   e.homo = homo; e.loc = loc1d; e.loc_is_i64 = 1;
   e.R0 = R0; e.t0 = t0; e.R1 = R1; e.t1 = t1; e.R10 = R10; e.t10 = R10 ? t10 : nullptr;
@@ -249,7 +256,14 @@ extern "C" int sage_photometric_error_calculate(
   int rc = ws_prepare(ws, N, 2, &lc);
   if (rc)
     return rc;
+  // depth map of the source keyframe at (code0, scale0): the kernel reads its sample depths from it
+  const int pH = (int)pyr->cam[0].h, pW = (int)pyr->cam[0].w;
+  if ((rc = ws->dpt0.reserve((size_t)pH * pW * sizeof(float))))
+    return rc;
+  SAGE_HIP(launch_depth_and_grad(ws->stream, CS, ws->dpt0.as<float>(), nullptr, bias0, basis0, code0, nullptr, scale0,
+                                 pH, pW));
   PhotoEdge e{};
+  e.dpt0 = ws->dpt0.as<float>();
   e.feat0 = feat0; e.feat1 = feat1; e.grad1 = nullptr; e.bias0 = bias0; e.basis0 = basis0; e.mask1 = mask1;
   e.homo = homo; e.loc = loc1d; e.loc_is_i64 = 1;
   e.R10 = R10; e.t10 = t10; e.code0 = code0; e.scale0 = nullptr; e.scale0_val = scale0; e.N = N;
@@ -967,6 +981,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
         pe.tiles0 = w->tile_list.as<int32_t>() + tile_off[k0];
         pe.n_tiles0 = tile_off[k0 + 1] - tile_off[k0];
         pe.f0s = w->f0s.as<float>() + f0s_off[k0];
+        pe.dpt0 = w->dpt.as<float>() + (size_t)k0 * HW;
         pe.basis0 = v0.basis; pe.mask1 = c.mask_dev; pe.homo = v0.homo; pe.loc = v0.loc1d; pe.loc_is_i64 = 1;
         pe.R0 = x0; pe.t0 = x0 + 9; pe.R1 = x1; pe.t1 = x1 + 9; pe.R10 = nullptr; pe.t10 = nullptr;
         pe.code0 = x0 + 13; pe.scale0 = x0 + 12; pe.N = v0.N;
@@ -1114,6 +1129,8 @@ extern "C" int sage_window_linearize(SageWindow *w)
   const int H = (int)c.pyr.cam[0].h, W = (int)c.pyr.cam[0].w;
   if (w->n_edges > 0)
   {
+    // depth maps of every keyframe at the current variables: both factor types read their sample depths from them
+    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[0].as<DepthItem>(), w->K, H, W));
     if (c.use_photo)
     {
       EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>()};
@@ -1124,7 +1141,6 @@ extern "C" int sage_window_linearize(SageWindow *w)
     }
     if (c.use_geo)
     {
-      SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[0].as<DepthItem>(), w->K, H, W));
       EdgeOut out{w->AtA_g.as<float>(), w->Atb_g.as<float>(), w->stats_g.as<float>()};
       LaunchCommon lc = window_lc(w, false);
       prof_attach(w, 1, lc);
@@ -1162,6 +1178,8 @@ extern "C" int sage_window_error(SageWindow *w, int which)
   const SageWindowConfig &c = w->cfg;
   const int H = (int)c.pyr.cam[0].h, W = (int)c.pyr.cam[0].w;
   const bool has = w->n_edges > 0;
+  if (has)
+    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[which].as<DepthItem>(), w->K, H, W));
   if (has && c.use_photo)
   {
     LaunchCommon lc = window_lc(w, true);
@@ -1171,7 +1189,6 @@ extern "C" int sage_window_error(SageWindow *w, int which)
   }
   if (has && c.use_geo)
   {
-    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[which].as<DepthItem>(), w->K, H, W));
     LaunchCommon lc = window_lc(w, false);
     prof_attach(w, 3, lc);
     SAGE_HIP(launch_geo_error(w->stream, c.CS, nullptr, w->gtab[which].as<GeoEdge>(), lc, c.pyr.cam[0], c.eps,

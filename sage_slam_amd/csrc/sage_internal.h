@@ -33,6 +33,7 @@ struct PhotoEdge
   // pose-independent pre-sampled source features of the source keyframe [L][FS/4][N][4] (what the reference's
   // tracker calls cat_sampled_features_0, camera_tracker.cpp:1104-1123), built once per keyframe
   const float *f0s;
+  const float *dpt0;    // [H,W]   s0*(bias0+basis0*code0): depth map of the SOURCE keyframe at the evaluated variables
   const float *bias0;   // [H*W]
   const float *basis0;  // [H*W,CS]
   const float *mask1;   // [H,W]
