@@ -613,36 +613,40 @@ __global__ __launch_bounds__(256) void assemble_kernel(const AssembleParams p)
   }
   else
   {
-    // tail: total errors / inlier counts of the local edges, summed serially by one wave for determinism
-    if (threadIdx.x < 4)
-    {
-      const bool photo = (threadIdx.x & 1) == 0;
-      const int which = threadIdx.x >> 1; // 0: error, 1: inliers
-      const float *st = photo ? p.stats_p : p.stats_g;
-      const int n = photo ? p.n_edges_p : p.n_edges_g;
-      double acc = 0.0;
-      if (st)
-        for (int e = 0; e < n; ++e)
-          acc += (double)st[2 * e + which];
+    // tail: total errors / inlier counts of the local edges; one wave per sum, fixed lane order (deterministic)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool photo = (wave & 1) == 0;
+    const int which = wave >> 1; // 0: error, 1: inliers
+    const float *st = photo ? p.stats_p : p.stats_g;
+    const int n = photo ? p.n_edges_p : p.n_edges_g;
+    double acc = 0.0;
+    if (st)
+      for (int e = lane; e < n; e += 64)
+        acc += (double)st[2 * e + which];
+    for (int off = 32; off > 0; off >>= 1)
+      acc += __shfl_down(acc, off);
+    if (lane == 0)
       tail[which * 2 + (photo ? 0 : 1)] = acc; // [err_photo err_geo n_photo n_geo]
-    }
   }
 }
 
-__global__ void sum_stats_kernel(const float *stats_p, int np, const float *stats_g, int ng, double *out)
+__global__ __launch_bounds__(256) void sum_stats_kernel(const float *stats_p, int np, const float *stats_g, int ng,
+                                                        double *out)
 {
-  if (threadIdx.x < 4)
-  {
-    const bool photo = (threadIdx.x & 1) == 0;
-    const int which = threadIdx.x >> 1;
-    const float *st = photo ? stats_p : stats_g;
-    const int n = photo ? np : ng;
-    double acc = 0.0;
-    if (st)
-      for (int e = 0; e < n; ++e)
-        acc += (double)st[2 * e + which];
+  // out = {sum err_photo, sum err_geo, sum n_photo, sum n_geo}; wave w sums one of the four in a fixed lane order
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool photo = (wave & 1) == 0;
+  const int which = wave >> 1;
+  const float *st = photo ? stats_p : stats_g;
+  const int n = photo ? np : ng;
+  double acc = 0.0;
+  if (st)
+    for (int e = lane; e < n; e += 64)
+      acc += (double)st[2 * e + which];
+  for (int off = 32; off > 0; off >>= 1)
+    acc += __shfl_down(acc, off);
+  if (lane == 0)
     out[which * 2 + (photo ? 0 : 1)] = acc;
-  }
 }
 
 } // namespace sage
@@ -1194,7 +1198,7 @@ extern "C" int sage_window_error(SageWindow *w, int which)
     SAGE_HIP(launch_geo_error(w->stream, c.CS, nullptr, w->gtab[which].as<GeoEdge>(), lc, c.pyr.cam[0], c.eps,
                               c.geo_loss_param, c.geo_weight, w->stats_g.as<float>()));
   }
-  hipLaunchKernelGGL(sum_stats_kernel, dim3(1), dim3(64), 0, w->stream,
+  hipLaunchKernelGGL(sum_stats_kernel, dim3(1), dim3(256), 0, w->stream,
                      (has && c.use_photo) ? w->stats_p.as<float>() : nullptr, w->n_edges,
                      (has && c.use_geo) ? w->stats_g.as<float>() : nullptr, w->n_edges, w->errbuf.as<double>());
   SAGE_HIP(hipGetLastError());

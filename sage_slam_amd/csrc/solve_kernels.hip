@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <chrono>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
 
 #include "host_math.h"
@@ -452,43 +453,58 @@ __device__ inline void se3_exp_dev(const float *omega, const float *v, float *R,
   }
 }
 
-// out_tail: [0] = |delta|^2
-__global__ void solve_retract_kernel(const double *__restrict__ x, int K, int B, int Bp, int CS, int VS,
-                                     const float *__restrict__ vars0, float *__restrict__ vars1,
-                                     double *__restrict__ delta, double *__restrict__ out_tail)
+// One workgroup.  Besides the candidate variables (device) it writes the host mirror -- candidate variables, delta and
+// |delta|^2 -- straight into pinned host memory (h_*: device-visible), so no copy follows the solve.
+__global__ __launch_bounds__(256) void solve_retract_kernel(const double *__restrict__ x, int K, int B, int Bp, int CS,
+                                                            int VS, const float *__restrict__ vars0,
+                                                            float *__restrict__ vars1, float *__restrict__ h_vars,
+                                                            double *__restrict__ h_delta, double *__restrict__ h_tail)
 {
-  const int k = blockIdx.x, tid = threadIdx.x; // one 64-lane workgroup per keyframe
-  const double *xk = x + (size_t)k * Bp;
-  const float *v0 = vars0 + (size_t)k * VS;
-  float *v1 = vars1 + (size_t)k * VS;
+  const int tid = threadIdx.x;
   double nrm = 0.0;
-  for (int r = tid; r < B; r += 64)
+  for (int idx = tid; idx < K * B; idx += blockDim.x)
   {
-    const double d = xk[r];
-    delta[(size_t)k * B + r] = d;
+    const int k = idx / B, r = idx - k * B;
+    const double d = x[(size_t)k * Bp + r];
+    h_delta[idx] = d;
     nrm += d * d;
-    if (r >= 6 && r < 6 + CS)
-      v1[13 + r - 6] = v0[13 + r - 6] + (float)d;
-    else if (r == 6 + CS)
-      v1[12] = v0[12] + (float)d;
+    const float *v0 = vars0 + (size_t)k * VS;
+    if (r >= 6)
+    {
+      const int slot = r < 6 + CS ? 13 + r - 6 : 12; // code entries, then the scale
+      const float v = v0[slot] + (float)d;
+      vars1[(size_t)k * VS + slot] = v;
+      h_vars[(size_t)k * VS + slot] = v;
+    }
   }
-  if (tid == 0)
+  for (int k = tid; k < K; k += blockDim.x)
   {
-    float d6[6], dR[9], dt[3];
+    const double *xk = x + (size_t)k * Bp;
+    const float *v0 = vars0 + (size_t)k * VS;
+    float d6[6], dR[9], dt[3], o[12];
     for (int i = 0; i < 6; ++i)
       d6[i] = (float)xk[i];
     se3_exp_dev(d6 + 3, d6, dR, dt);
     for (int i = 0; i < 3; ++i)
     {
       for (int j = 0; j < 3; ++j)
-        v1[i * 3 + j] = dR[i * 3 + 0] * v0[0 * 3 + j] + dR[i * 3 + 1] * v0[1 * 3 + j] + dR[i * 3 + 2] * v0[2 * 3 + j];
-      v1[9 + i] = dR[i * 3 + 0] * v0[9] + dR[i * 3 + 1] * v0[10] + dR[i * 3 + 2] * v0[11] + dt[i];
+        o[i * 3 + j] = dR[i * 3 + 0] * v0[0 * 3 + j] + dR[i * 3 + 1] * v0[1 * 3 + j] + dR[i * 3 + 2] * v0[2 * 3 + j];
+      o[9 + i] = dR[i * 3 + 0] * v0[9] + dR[i * 3 + 1] * v0[10] + dR[i * 3 + 2] * v0[11] + dt[i];
+    }
+    for (int i = 0; i < 12; ++i)
+    {
+      vars1[(size_t)k * VS + i] = o[i];
+      h_vars[(size_t)k * VS + i] = o[i];
     }
   }
+  __shared__ double s_n[4];
   for (int off = 32; off > 0; off >>= 1)
     nrm += __shfl_down(nrm, off);
+  if ((tid & 63) == 0)
+    s_n[tid >> 6] = nrm;
+  __syncthreads();
   if (tid == 0)
-    atomicAdd(out_tail, nrm);
+    h_tail[0] = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,13 +515,14 @@ struct DeviceSolver
   int K = 0, B = 0, Bp = 0, nblk = 0, nlinks = 0, max_rows = 0;
   void *d_int = nullptr;   // all int tables in one allocation
   void *d_dbg = nullptr;
-  void *d_L = nullptr, *d_y = nullptr, *d_delta = nullptr, *d_tail = nullptr; // tail: [|delta|^2] ; status int after it
+  void *d_L = nullptr, *d_y = nullptr; // one allocation: block storage, then the right-hand side (d_y = d_L + nblk*Bp*Bp)
+  void *d_tail = nullptr;              // device factorisation only: [unused double | status int]
   void *h_pinned = nullptr; // [K*VS floats | K*B doubles | tail double | status int]
   size_t h_vars_off = 0, h_delta_off = 0, h_tail_off = 0, h_status_off = 0, h_bytes = 0;
   SolvePlan plan{};
   int VS = 0;
   bool device_factor = false;               // SAGE_DEVICE_SOLVE=1
-  void *h_T = nullptr, *h_y = nullptr;       // pinned: block storage / right-hand side -> solution (hybrid path)
+  void *h_T = nullptr, *h_y = nullptr;       // pinned, one allocation like d_L/d_y (hybrid path)
   std::vector<double> h_X;                   // inverses of the diagonal factors
   std::vector<int32_t> h_row_first, h_row_off;
 };
@@ -624,11 +641,11 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
     return fail((int)hipErrorUnknown);
   if (hipStreamSynchronize(stream) != hipSuccess)
     return fail((int)hipErrorUnknown);
-  if (hipMalloc(&S->d_L, (size_t)nblk * Bp * Bp * sizeof(double)) != hipSuccess ||
-      hipMalloc(&S->d_y, (size_t)K * Bp * sizeof(double)) != hipSuccess ||
-      hipMalloc(&S->d_delta, (size_t)K * B * sizeof(double)) != hipSuccess ||
+  const size_t ty_doubles = (size_t)nblk * Bp * Bp + (size_t)K * Bp;
+  if (hipMalloc(&S->d_L, ty_doubles * sizeof(double)) != hipSuccess ||
       hipMalloc(&S->d_tail, 2 * sizeof(double)) != hipSuccess)
     return fail((int)hipErrorOutOfMemory);
+  S->d_y = reinterpret_cast<double *>(S->d_L) + (size_t)nblk * Bp * Bp;
   if (getenv("SAGE_DEBUG_TIMING") && hipMalloc(&S->d_dbg, 8 * sizeof(unsigned long long)) != hipSuccess)
     return fail((int)hipErrorOutOfMemory);
   S->device_factor = getenv("SAGE_DEVICE_SOLVE") != nullptr;
@@ -636,9 +653,9 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   S->h_row_off = row_off;
   if (!S->device_factor)
   {
-    if (hipHostMalloc(&S->h_T, (size_t)nblk * Bp * Bp * sizeof(double), hipHostMallocDefault) != hipSuccess ||
-        hipHostMalloc(&S->h_y, (size_t)K * Bp * sizeof(double), hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc(&S->h_T, ty_doubles * sizeof(double), hipHostMallocDefault) != hipSuccess)
       return fail((int)hipErrorOutOfMemory);
+    S->h_y = reinterpret_cast<double *>(S->h_T) + (size_t)nblk * Bp * Bp;
     S->h_X.assign((size_t)K * Bp * Bp, 0.0);
   }
   S->h_vars_off = 0;
@@ -653,6 +670,7 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   P.row_first = base + o_rf; P.row_off = base + o_ro; P.col_ptr = base + o_cp; P.col_rows = base + o_cr;
   P.job_ptr = base + o_jp; P.jobs = reinterpret_cast<const int2 *>(base + o_jobs);
   P.blk_row = base + o_br; P.blk_col = base + o_bc; P.blk_src = base + o_bs;
+  std::memset(S->h_pinned, 0, S->h_bytes);
   *out = S;
   return SAGE_OK;
 }
@@ -661,11 +679,11 @@ void solver_destroy(DeviceSolver *S)
 {
   if (!S)
     return;
-  void *bufs[] = {S->d_int, S->d_L, S->d_y, S->d_delta, S->d_tail, S->d_dbg};
+  void *bufs[] = {S->d_int, S->d_L, S->d_tail, S->d_dbg};
   for (void *p : bufs)
     if (p)
       (void)hipFree(p);
-  void *hbufs[] = {S->h_pinned, S->h_T, S->h_y};
+  void *hbufs[] = {S->h_pinned, S->h_T};
   for (void *p : hbufs)
     if (p)
       (void)hipHostFree(p);
@@ -684,7 +702,7 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
     pri.pose_init0[i] = pose_init0[i];
   double *tail = reinterpret_cast<double *>(S->d_tail);
   int *status = reinterpret_cast<int *>(tail + 1);
-  if (hipMemsetAsync(S->d_tail, 0, 2 * sizeof(double), stream) != hipSuccess)
+  if (S->device_factor && hipMemsetAsync(S->d_tail, 0, 2 * sizeof(double), stream) != hipSuccess)
     return (int)hipGetLastError();
   double *dL = reinterpret_cast<double *>(S->d_L), *dy = reinterpret_cast<double *>(S->d_y);
   hipLaunchKernelGGL(solve_scatter_kernel, dim3(S->nblk), dim3(256), 0, stream, S->plan, packed_dev, vars0, S->VS, CS,
@@ -713,10 +731,8 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
     static const bool dbgt = getenv("SAGE_DEBUG_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t eh;
-    if ((eh = hipMemcpyAsync(S->h_T, dL, (size_t)S->nblk * S->Bp * S->Bp * sizeof(double), hipMemcpyDeviceToHost,
-                             stream)) != hipSuccess ||
-        (eh = hipMemcpyAsync(S->h_y, dy, (size_t)S->K * S->Bp * sizeof(double), hipMemcpyDeviceToHost, stream)) !=
-            hipSuccess ||
+    if ((eh = hipMemcpyAsync(S->h_T, dL, ((size_t)S->nblk * S->Bp * S->Bp + (size_t)S->K * S->Bp) * sizeof(double),
+                             hipMemcpyDeviceToHost, stream)) != hipSuccess ||
         (eh = hipStreamSynchronize(stream)) != hipSuccess)
       return (int)eh;
     const auto t1 = std::chrono::steady_clock::now();
@@ -734,17 +750,15 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
         hipSuccess)
       return (int)eh;
   }
-  hipLaunchKernelGGL(solve_retract_kernel, dim3(S->K), dim3(64), 0, stream, reinterpret_cast<const double *>(S->d_y),
-                     S->K, S->B, S->Bp, CS, S->VS, vars0, vars1, reinterpret_cast<double *>(S->d_delta), tail);
+  char *h = reinterpret_cast<char *>(S->h_pinned);
+  hipLaunchKernelGGL(solve_retract_kernel, dim3(1), dim3(256), 0, stream, reinterpret_cast<const double *>(S->d_y), S->K,
+                     S->B, S->Bp, CS, S->VS, vars0, vars1, reinterpret_cast<float *>(h + S->h_vars_off),
+                     reinterpret_cast<double *>(h + S->h_delta_off), reinterpret_cast<double *>(h + S->h_tail_off));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess)
     return (int)e;
-  char *h = reinterpret_cast<char *>(S->h_pinned);
-  if ((e = hipMemcpyAsync(h + S->h_vars_off, vars1, (size_t)S->K * S->VS * sizeof(float), hipMemcpyDeviceToHost,
-                          stream)) != hipSuccess ||
-      (e = hipMemcpyAsync(h + S->h_delta_off, S->d_delta, (size_t)S->K * S->B * sizeof(double), hipMemcpyDeviceToHost,
-                          stream)) != hipSuccess ||
-      (e = hipMemcpyAsync(h + S->h_tail_off, S->d_tail, 2 * sizeof(double), hipMemcpyDeviceToHost, stream)) !=
+  if (S->device_factor && // the pivot status of the device factorisation (the hybrid path reports it synchronously)
+      (e = hipMemcpyAsync(h + S->h_tail_off + sizeof(double), status, sizeof(int), hipMemcpyDeviceToHost, stream)) !=
           hipSuccess)
     return (int)e;
   return SAGE_OK;
