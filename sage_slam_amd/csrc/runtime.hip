@@ -540,7 +540,7 @@ __device__ __forceinline__ int edge_col(int type, int role, int bi, int CS)
 }
 
 // one workgroup per output block; thread per element; contributions summed in a fixed order (deterministic)
-__global__ __launch_bounds__(256) void assemble_kernel(const AssembleParams p)
+__global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
 {
   const int B = 7 + p.CS, BB = B * B;
   const int Dp = 13 + p.CS, Dg = 14 + 2 * p.CS;
@@ -551,34 +551,53 @@ __global__ __launch_bounds__(256) void assemble_kernel(const AssembleParams p)
   double *tail = g + (size_t)p.K * B;
   if (blk < p.K)
   {
+    // fp64 accumulation of the fp32 per-edge results (the reference widens to double before gtsam sums them:
+    // photometric_factor.cpp:305-306).  Adjacency loop outside, the lane's (at most two) outputs inside: the gathers of
+    // different adjacency entries are independent, so they overlap instead of forming one chain of ~150 dependent loads
     const int k = blk;
     const int a0 = p.adj_start[k], a1 = p.adj_start[k + 1];
-    for (int idx = threadIdx.x; idx < BB + B; idx += blockDim.x)
+    constexpr int S = 2;
+    double acc[S] = {0.0, 0.0};
+    int bi[S], bj[S];
+    bool isg[S], valid[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s)
     {
-      double acc = 0.0; // fp64 accumulation of the fp32 per-edge results (the reference widens to double before gtsam sums them: photometric_factor.cpp:305-306)
-      const bool isg = idx >= BB;
-      const int bi = isg ? idx - BB : idx / B, bj = isg ? 0 : idx % B;
-      for (int a = a0; a < a1; ++a)
+      const int idx = (int)threadIdx.x + s * (int)blockDim.x;
+      valid[s] = idx < BB + B;
+      isg[s] = idx >= BB;
+      bi[s] = isg[s] ? idx - BB : idx / B;
+      bj[s] = isg[s] ? 0 : idx % B;
+    }
+#pragma unroll 4
+    for (int a = a0; a < a1; ++a)
+    {
+      const AdjEntry ae = p.adj[a];
+      const int D = ae.type == 0 ? Dp : Dg;
+      const float *A = ae.type == 0 ? p.AtA_p : p.AtA_g;
+      const float *b = ae.type == 0 ? p.Atb_p : p.Atb_g;
+#pragma unroll
+      for (int s = 0; s < S; ++s)
       {
-        const AdjEntry ae = p.adj[a];
-        const int D = ae.type == 0 ? Dp : Dg;
-        const int ci = edge_col(ae.type, ae.role, bi, p.CS);
-        if (ci < 0)
+        if (!valid[s])
           continue;
-        if (isg)
-          acc += (double)(ae.type == 0 ? p.Atb_p : p.Atb_g)[(size_t)ae.edge * D + ci];
-        else
-        {
-          const int cj = edge_col(ae.type, ae.role, bj, p.CS);
-          if (cj < 0)
-            continue;
-          acc += (double)(ae.type == 0 ? p.AtA_p : p.AtA_g)[(size_t)ae.edge * D * D + (size_t)ci * D + cj];
-        }
+        const int ci = edge_col(ae.type, ae.role, bi[s], p.CS);
+        const int cj = isg[s] ? 0 : edge_col(ae.type, ae.role, bj[s], p.CS);
+        if (ci < 0 || cj < 0)
+          continue;
+        acc[s] += isg[s] ? (double)b[(size_t)ae.edge * D + ci] : (double)A[(size_t)ae.edge * D * D + (size_t)ci * D + cj];
       }
-      if (isg)
-        g[(size_t)k * B + bi] = acc;
+    }
+#pragma unroll
+    for (int s = 0; s < S; ++s)
+    {
+      const int idx = (int)threadIdx.x + s * (int)blockDim.x;
+      if (!valid[s])
+        continue;
+      if (isg[s])
+        g[(size_t)k * B + bi[s]] = acc[s];
       else
-        diag[(size_t)k * BB + idx] = acc;
+        diag[(size_t)k * BB + idx] = acc[s];
     }
   }
   else if (blk < p.K + p.nlinks)
@@ -620,12 +639,12 @@ __global__ __launch_bounds__(256) void assemble_kernel(const AssembleParams p)
     const float *st = photo ? p.stats_p : p.stats_g;
     const int n = photo ? p.n_edges_p : p.n_edges_g;
     double acc = 0.0;
-    if (st)
+    if (st && wave < 4)
       for (int e = lane; e < n; e += 64)
         acc += (double)st[2 * e + which];
     for (int off = 32; off > 0; off >>= 1)
       acc += __shfl_down(acc, off);
-    if (lane == 0)
+    if (lane == 0 && wave < 4)
       tail[which * 2 + (photo ? 0 : 1)] = acc; // [err_photo err_geo n_photo n_geo]
   }
 }
@@ -1169,7 +1188,7 @@ extern "C" int sage_window_linearize(SageWindow *w)
   ap.CS = c.CS;
   ap.n_edges_p = w->n_edges;
   ap.n_edges_g = w->n_edges;
-  hipLaunchKernelGGL(assemble_kernel, dim3(w->K + ap.nlinks + 1), dim3(256), 0, w->stream, ap);
+  hipLaunchKernelGGL(assemble_kernel, dim3(w->K + ap.nlinks + 1), dim3(1024), 0, w->stream, ap);
   SAGE_HIP(hipGetLastError());
   w->have_lin = true;
   return SAGE_OK;
