@@ -311,6 +311,20 @@ int sage_window_get_edge(const SageWindow *w, int type, int e, float *AtA, float
 int sage_window_set_profiling(SageWindow *w, int on);
 int sage_window_get_kernel_time(SageWindow *w, int which, double *total_ms, int *launches);
 
+/* ---- f1 producers: valid-pixel enumeration and seeded keyframe sampling ------------------------------------
+ * sage_valid_locations: core/mapping/mapping_utils.h:254-287 (GenerateValidLocations): flat indices of mask > 0.5 in
+ *   ascending order and their normalised homogeneous coordinates ((x-u0)/fx, (y-v0)/fy, 1).  Outputs are device
+ *   arrays with room for H*W entries; *n_valid_host receives the count (synchronises the stream).
+ * sage_shuffle_indices (host): the permutation mapper.cpp:1326-1333 draws -- std::iota, std::mt19937 seeded with
+ *   (long)timestamp, std::shuffle -- through the same standard-library calls.
+ * sage_sample_locations: mapper.cpp:1334-1340: the first min(num_samples, n_valid) shuffled indices gathered from the
+ *   valid arrays into the keyframe's sampled_locations_1d / sampled_locations_homo. */
+int sage_valid_locations(SageWorkspace *ws, const float *mask_dev, const SageCamera *cam, int64_t *loc1d_dev,
+                         float *homo_dev, int *n_valid_host);
+int sage_shuffle_indices(int64_t seed, int64_t n, int64_t *idx_host);
+int sage_sample_locations(SageWorkspace *ws, const int64_t *valid_loc1d_dev, const float *valid_homo_dev, int n_valid,
+                          int64_t seed, int num_samples, int64_t *loc1d_dev, float *homo_dev, int *n_out_host);
+
 /* one full LM iteration on a single GPU: linearize -> solve -> error at candidate -> accept/reject
  * (policy of camera_tracker.cpp:1156-1279). */
 typedef struct SageLmState

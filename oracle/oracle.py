@@ -264,3 +264,23 @@ def se3_exp(omega, v, prec="f32"):
     R = np.zeros((3, 3), dtype=dt); t = np.zeros((3,), dtype=dt)
     getattr(lib(), "orc_se3_exp" + sfx)(_p(omega), _p(v), _p(R), _p(t))
     return R, t
+
+
+def valid_locations(mask, cam, prec="f32"):
+    """mapping_utils.h:254-287 -> (loc1d int64 [n], homo [n,3])."""
+    dt, ct, sfx = _dt(prec)
+    mask = _arr(mask, dt)
+    H, W = mask.shape
+    loc = np.zeros(H * W, np.int64); homo = np.zeros((H * W, 3), dt)
+    c = _cams([cam], dt)          # OrcCamera = 6 REALs {fx, fy, cx, cy, w, h}
+    fn = getattr(lib(), "orc_valid_locations" + sfx)
+    fn.restype = C.c_int
+    n = fn(loc.ctypes.data_as(C.c_void_p), _p(homo), _p(mask), _p(c))
+    return loc[:n].copy(), homo[:n].copy()
+
+
+def shuffle_indices(n, seed):
+    """std::iota + std::mt19937(seed) + std::shuffle as libstdc++ 11 does it (mapper.cpp:1326-1333)."""
+    idx = np.zeros(max(n, 1), np.int64)
+    lib().orc_shuffle_indices_f32(idx.ctypes.data_as(C.c_void_p), C.c_longlong(n), C.c_longlong(seed))
+    return idx[:n].copy()

@@ -896,3 +896,120 @@ void ORC(se3_exp)(const REAL *omega, const REAL *v, REAL *R, REAL *t)
     t[i] = acc;
   }
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * f1: valid locations (mapping_utils.h:254-287) and the seeded shuffle (mapper.cpp:1326-1333)
+ * ------------------------------------------------------------------------------------------------ */
+int ORC(valid_locations)(long long *loc1d, REAL *homo, const REAL *mask, const ORC(cam_t) * cam)
+{
+  const int W = (int)cam->w, H = (int)cam->h;
+  int n = 0;
+  for (int i = 0; i < W * H; ++i)
+    if (mask[i] > (REAL)0.5) /* :267 */
+    {
+      const REAL x = (REAL)(i % W), y = (REAL)(i / W); /* fmod / floor of the flat index (:269-270) */
+      loc1d[n] = i;
+      homo[3 * n + 0] = (x - cam->cx) / cam->fx; /* :279-280 */
+      homo[3 * n + 1] = (y - cam->cy) / cam->fy;
+      homo[3 * n + 2] = (REAL)1;
+      ++n;
+    }
+  return n;
+}
+
+typedef struct
+{
+  uint32_t mt[624];
+  int pos;
+} OrcMt19937;
+
+static void orc_mt_seed(OrcMt19937 *g, uint32_t s)
+{
+  g->mt[0] = s;
+  for (int i = 1; i < 624; ++i)
+    g->mt[i] = 1812433253u * (g->mt[i - 1] ^ (g->mt[i - 1] >> 30)) + (uint32_t)i;
+  g->pos = 624;
+}
+
+static uint32_t orc_mt_next(OrcMt19937 *g)
+{
+  if (g->pos >= 624)
+  {
+    for (int i = 0; i < 624; ++i)
+    {
+      const uint32_t yv = (g->mt[i] & 0x80000000u) | (g->mt[(i + 1) % 624] & 0x7fffffffu);
+      g->mt[i] = g->mt[(i + 397) % 624] ^ (yv >> 1) ^ ((yv & 1u) ? 0x9908b0dfu : 0u);
+    }
+    g->pos = 0;
+  }
+  uint32_t yv = g->mt[g->pos++];
+  yv ^= yv >> 11;
+  yv ^= (yv << 7) & 0x9d2c5680u;
+  yv ^= (yv << 15) & 0xefc60000u;
+  yv ^= yv >> 18;
+  return yv;
+}
+
+/* uniform integer in [0, b] from a 32-bit engine: libstdc++ >= 11 uses Lemire's nearly divisionless method */
+static uint64_t orc_uniform(OrcMt19937 *g, uint64_t b)
+{
+  if (b >= 0xffffffffull)
+    return orc_mt_next(g); /* (ranges beyond 32 bits are never requested by the shuffle of < 2^32 elements) */
+  const uint32_t range = (uint32_t)(b + 1);
+  uint64_t product = (uint64_t)orc_mt_next(g) * (uint64_t)range;
+  uint32_t low = (uint32_t)product;
+  if (low < range)
+  {
+    const uint32_t threshold = (uint32_t)(0u - range) % range;
+    while (low < threshold)
+    {
+      product = (uint64_t)orc_mt_next(g) * (uint64_t)range;
+      low = (uint32_t)product;
+    }
+  }
+  return product >> 32;
+}
+
+void ORC(shuffle_indices)(long long *idx, long long n, long long seed)
+{
+  for (long long i = 0; i < n; ++i)
+    idx[i] = i;
+  if (n <= 0)
+    return;
+  OrcMt19937 g;
+  orc_mt_seed(&g, (uint32_t)((uint64_t)seed & 0xffffffffull)); /* mersenne_twister_engine::seed reduces mod 2^32 */
+  const uint64_t urng = 0xffffffffull, un = (uint64_t)n;
+#define ORC_SWAP(a, b)            \
+  {                               \
+    const long long t_ = idx[a];  \
+    idx[a] = idx[b];              \
+    idx[b] = t_;                  \
+  }
+  if (urng / un >= un)
+  {
+    long long i = 1;
+    if ((un % 2) == 0)
+    {
+      const uint64_t pp = orc_uniform(&g, 1);
+      ORC_SWAP(i, (long long)pp)
+      ++i;
+    }
+    while (i != n)
+    {
+      const uint64_t sr = (uint64_t)i + 1; /* two positions from one draw: x in [0, sr*(sr+1)) */
+      const uint64_t x = orc_uniform(&g, sr * (sr + 1) - 1);
+      const uint64_t p1 = x / (sr + 1), p2 = x % (sr + 1);
+      ORC_SWAP(i, (long long)p1)
+      ++i;
+      ORC_SWAP(i, (long long)p2)
+      ++i;
+    }
+    return;
+  }
+  for (long long i = 1; i < n; ++i)
+  {
+    const uint64_t pp = orc_uniform(&g, (uint64_t)i);
+    ORC_SWAP(i, (long long)pp)
+  }
+#undef ORC_SWAP
+}

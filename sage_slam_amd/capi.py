@@ -92,6 +92,7 @@ SYMBOLS = [
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
     "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step",
+    "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
 ]
 
 
@@ -611,3 +612,35 @@ def unpack_dense(packed: np.ndarray, K: int, links: Sequence, CS: int):
         H[a * B:(a + 1) * B, b * B:(b + 1) * B] += lnk[l]
         H[b * B:(b + 1) * B, a * B:(a + 1) * B] += lnk[l].T
     return H, g, packed[-4:]
+
+
+def shuffle_indices(n: int, seed: int) -> np.ndarray:
+    """Host helper: the keyframe sampling permutation (mapper.cpp:1326-1333)."""
+    idx = np.zeros(max(n, 1), np.int64)
+    _chk(lib().sage_shuffle_indices(C.c_int64(seed), C.c_int64(n), idx.ctypes.data_as(C.POINTER(C.c_int64))),
+         "sage_shuffle_indices")
+    return idx[:n].copy()
+
+
+def valid_locations(ws: "Workspace", mask, cam):
+    """mask: [H,W] float cuda tensor; cam: SageCamera -> (loc1d int64 [n], homo [n,3]) cuda tensors."""
+    import torch
+    H, W = mask.shape
+    loc = torch.zeros(H * W, dtype=torch.int64, device="cuda")
+    homo = torch.zeros(H * W, 3, dtype=torch.float32, device="cuda")
+    n = C.c_int()
+    _chk(lib().sage_valid_locations(ws.h, C.c_void_p(mask.data_ptr()), C.byref(cam), C.c_void_p(loc.data_ptr()),
+                                    C.c_void_p(homo.data_ptr()), C.byref(n)), "sage_valid_locations")
+    return loc[:n.value].clone(), homo[:n.value].clone()
+
+
+def sample_locations(ws: "Workspace", vloc, vhomo, seed: int, num_samples: int):
+    import torch
+    nv = int(vloc.shape[0])
+    loc = torch.zeros(max(min(num_samples, nv), 1), dtype=torch.int64, device="cuda")
+    homo = torch.zeros(max(min(num_samples, nv), 1), 3, dtype=torch.float32, device="cuda")
+    n = C.c_int()
+    _chk(lib().sage_sample_locations(ws.h, C.c_void_p(vloc.data_ptr()), C.c_void_p(vhomo.data_ptr()), nv,
+                                     C.c_int64(seed), num_samples, C.c_void_p(loc.data_ptr()),
+                                     C.c_void_p(homo.data_ptr()), C.byref(n)), "sage_sample_locations")
+    return loc[:n.value].clone(), homo[:n.value].clone()

@@ -14,6 +14,8 @@
 #include <cstdlib>
 #include <thread>
 #include <cstring>
+#include <numeric>
+#include <random>
 #include <vector>
 
 #include "host_math.h"
@@ -67,6 +69,21 @@ extern "C" int sage_camera_pyramid(const SageCamera *base, int levels, SagePyram
     off += (int)c.w * (int)c.h;
   }
   out->P = off;
+  return SAGE_OK;
+}
+
+// mapper.cpp:1326-1333: the keyframe's sample permutation (the reference's own standard-library calls)
+extern "C" int sage_shuffle_indices(int64_t seed, int64_t n, int64_t *idx)
+{
+  if (n < 0 || (n > 0 && !idx))
+    return SAGE_E_INVALID;
+  std::vector<long> indices((size_t)n);
+  std::iota(indices.begin(), indices.end(), 0);
+  std::mt19937 g;
+  g.seed((long)seed);
+  std::shuffle(indices.begin(), indices.end(), g);
+  for (int64_t i = 0; i < n; ++i)
+    idx[i] = indices[(size_t)i];
   return SAGE_OK;
 }
 

@@ -249,4 +249,86 @@ hipError_t launch_gaussian_pyramid_with_grad(hipStream_t s, float *pyr, float *g
   return hipGetLastError();
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// f1: valid-pixel enumeration (mapping_utils.h:254-287) -- ordered stream compaction by ONE workgroup (the mask is
+// per video, this runs once): chunks of 1024 pixels, wave ballots + a running offset keep the ascending order.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void valid_locations_kernel(const float *__restrict__ mask, SageCamera cam, int HW,
+                                                               int W, long long *__restrict__ loc1d,
+                                                               float *__restrict__ homo, int *__restrict__ n_out)
+{
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0)
+    s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < HW; c0 += 1024)
+  {
+    const int i = c0 + tid;
+    const bool v = i < HW && mask[i] > 0.5f; // :267
+    const unsigned long long b = __ballot(v);
+    const int before = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0)
+      s_wave[wave] = __popcll(b);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w)
+      off += s_wave[w];
+    if (v)
+    {
+      const int n = off + before;
+      const float x = (float)(i % W), y = (float)(i / W); // :269-270
+      loc1d[n] = i;
+      homo[3 * n + 0] = (x - cam.cx) / cam.fx; // :279-280
+      homo[3 * n + 1] = (y - cam.cy) / cam.fy;
+      homo[3 * n + 2] = 1.0f;
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w)
+        tot += s_wave[w];
+      s_base += tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0)
+    *n_out = s_base;
+}
+
+hipError_t launch_valid_locations(hipStream_t s, const float *mask, const SageCamera &cam, long long *loc1d, float *homo,
+                                  int *n_out_dev)
+{
+  const int W = (int)cam.w, H = (int)cam.h;
+  hipLaunchKernelGGL(valid_locations_kernel, dim3(1), dim3(1024), 0, s, mask, cam, H * W, W, loc1d, homo, n_out_dev);
+  return hipGetLastError();
+}
+
+// mapper.cpp:1334-1340: sampled_locations = valid_locations[indexes]
+__global__ void gather_locations_kernel(const long long *__restrict__ vloc, const float *__restrict__ vhomo,
+                                        const long long *__restrict__ index, int n, long long *__restrict__ loc1d,
+                                        float *__restrict__ homo)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n)
+    return;
+  const long long j = index[i];
+  loc1d[i] = vloc[j];
+  homo[3 * i + 0] = vhomo[3 * j + 0];
+  homo[3 * i + 1] = vhomo[3 * j + 1];
+  homo[3 * i + 2] = vhomo[3 * j + 2];
+}
+
+hipError_t launch_gather_locations(hipStream_t s, const long long *vloc, const float *vhomo, const long long *index_dev,
+                                   int n, long long *loc1d, float *homo)
+{
+  if (n > 0)
+    hipLaunchKernelGGL(gather_locations_kernel, dim3((n + 255) / 256), dim3(256), 0, s, vloc, vhomo, index_dev, n, loc1d,
+                       homo);
+  return hipGetLastError();
+}
+
 } // namespace sage

@@ -413,6 +413,46 @@ extern "C" int sage_depth_and_grad(SageWorkspace *ws, float *dpt, float *grad, c
   return SAGE_OK;
 }
 
+extern "C" int sage_valid_locations(SageWorkspace *ws, const float *mask_dev, const SageCamera *cam,
+                                    int64_t *loc1d_dev, float *homo_dev, int *n_valid_host)
+{
+  if (!ws || !mask_dev || !cam || !loc1d_dev || !homo_dev || !n_valid_host)
+    return SAGE_E_INVALID;
+  int rc = ws->misc.reserve(sizeof(int));
+  if (rc)
+    return rc;
+  SAGE_HIP(launch_valid_locations(ws->stream, mask_dev, *cam, reinterpret_cast<long long *>(loc1d_dev), homo_dev,
+                                  ws->misc.as<int>()));
+  SAGE_HIP(hipMemcpyAsync(n_valid_host, ws->misc.p, sizeof(int), hipMemcpyDeviceToHost, ws->stream));
+  SAGE_HIP(hipStreamSynchronize(ws->stream));
+  return SAGE_OK;
+}
+
+extern "C" int sage_sample_locations(SageWorkspace *ws, const int64_t *valid_loc1d_dev, const float *valid_homo_dev,
+                                     int n_valid, int64_t seed, int num_samples, int64_t *loc1d_dev, float *homo_dev,
+                                     int *n_out_host)
+{
+  if (!ws || !valid_loc1d_dev || !valid_homo_dev || n_valid < 0 || num_samples < 0 || !loc1d_dev || !homo_dev ||
+      !n_out_host)
+    return SAGE_E_INVALID;
+  std::vector<int64_t> idx((size_t)std::max(n_valid, 1));
+  int rc = sage_shuffle_indices(seed, n_valid, idx.data());
+  if (rc)
+    return rc;
+  const int n = std::min(num_samples, n_valid); // mapper.cpp:1336
+  if ((rc = ws->misc.reserve((size_t)std::max(n, 1) * sizeof(int64_t))))
+    return rc;
+  if (n > 0)
+  {
+    SAGE_HIP(hipMemcpyAsync(ws->misc.p, idx.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, ws->stream));
+    SAGE_HIP(launch_gather_locations(ws->stream, reinterpret_cast<const long long *>(valid_loc1d_dev), valid_homo_dev,
+                                     ws->misc.as<long long>(), n, reinterpret_cast<long long *>(loc1d_dev), homo_dev));
+    SAGE_HIP(hipStreamSynchronize(ws->stream)); // idx goes out of scope
+  }
+  *n_out_host = n;
+  return SAGE_OK;
+}
+
 extern "C" int sage_gaussian_pyramid_with_grad(SageWorkspace *ws, float *pyr_dev, float *grad_dev,
                                                const float *feat, const float *mask, const SagePyramid *pyr, int FS)
 {

@@ -157,6 +157,10 @@ hipError_t launch_presample_source(hipStream_t s, float *f0s, const float *feat_
 hipError_t launch_repack_groups(hipStream_t s, float *dst, const float *src, int C, int P);
 hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev, int K, int H, int W);
 hipError_t launch_stats_finalize(hipStream_t s, const LaunchCommon &lc, float *stats, float fallback, float scale);
+hipError_t launch_valid_locations(hipStream_t s, const float *mask, const SageCamera &cam, long long *loc1d, float *homo,
+                                  int *n_out_dev);
+hipError_t launch_gather_locations(hipStream_t s, const long long *vloc, const float *vhomo, const long long *index_dev,
+                                   int n, long long *loc1d, float *homo);
 hipError_t launch_gaussian_pyramid_with_grad(hipStream_t s, float *pyr, float *grad, const float *feat,
                                              const float *mask, const SagePyramid &p, int FS, float *scratch_mask);
 

@@ -451,3 +451,30 @@ def test_device_solver_matches_host_cholesky(capi, CS, K, back, extra):
     pose, code, scale = win.get_keyframe(1)
     assert np.allclose(code, w.keyframes[1].code + win.delta()[B + 6:B + 6 + CS].astype(np.float32), atol=1e-6)
     win.close()
+
+
+def test_valid_locations_and_seeded_sampling(capi, orc):
+    """f1 producers (mapping_utils.h:254-287, mapper.cpp:1326-1340): ordered enumeration of the mask, homogeneous
+    coordinates, and the seeded subsample -- integers bit exact, coordinates exact (same fp32 operations); edge
+    cases: empty mask, num_samples > n_valid, a mask with values around the 0.5 threshold."""
+    import torch
+    ws = capi.Workspace()
+    rng = np.random.default_rng(4)
+    H, W = 64, 80
+    cam = capi.SageCamera(72.0, 70.5, 39.5, 31.5, float(W), float(H))
+    masks = [np.zeros((H, W), np.float32), np.ones((H, W), np.float32),
+             (rng.random((H, W)) > 0.3).astype(np.float32), rng.random((H, W)).astype(np.float32)]
+    masks[3][5, 7] = 0.5                                            # not > 0.5
+    for m in masks:
+        oloc, ohomo = orc.valid_locations(m, cam)
+        hloc, hhomo = capi.valid_locations(ws, torch.from_numpy(m).cuda(), cam)
+        assert np.array_equal(hloc.cpu().numpy(), oloc)
+        assert np.array_equal(hhomo.cpu().numpy(), ohomo)
+        if len(oloc) == 0:
+            continue
+        for seed, ns in ((11, 300), (1699999999, 3072), (5, 10**6)):
+            perm = orc.shuffle_indices(len(oloc), seed)[:min(ns, len(oloc))]
+            sloc, shomo = capi.sample_locations(ws, hloc, hhomo, seed, ns)
+            assert np.array_equal(sloc.cpu().numpy(), oloc[perm])
+            assert np.array_equal(shomo.cpu().numpy(), ohomo[perm])
+    ws.close()

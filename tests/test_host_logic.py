@@ -165,3 +165,12 @@ def test_synth_producers_match_oracle(orc):
     D1, g1 = synth.depth_and_grad(kf, w.H, w.W)
     od = orc.update_depth(kf.bias, kf.basis, kf.code, kf.scale).reshape(w.H, w.W)
     assert rel(D1, od) < 1e-6
+
+
+def test_shuffle_indices_host_helper_matches_oracle(orc):
+    """sage_shuffle_indices (the engine's host helper, std::shuffle) against the oracle restatement: bit exact;
+    empty and single-element inputs."""
+    for seed, n in ((0, 0), (3, 1), (1700000000, 16128), (42, 20480), (2**32 + 5, 4097), (9, 70001)):
+        a = capi.shuffle_indices(n, seed)
+        b = orc.shuffle_indices(n, seed)
+        assert a.dtype == np.int64 and np.array_equal(a, b), (seed, n)

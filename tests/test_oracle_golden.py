@@ -119,3 +119,22 @@ def test_geometric_rows_match_diffba(orc, name, prec):
     assert np.all(J[~valid] == 0)
     assert o["num_inliers"] == pytest.approx(valid.sum())
     assert o["error"] == pytest.approx(float(c["geo_err"].sum()) / valid.sum(), rel=1e-5)
+
+
+def test_shuffle_restatement_matches_std_shuffle_golden(orc):
+    """orc_shuffle_indices (MT19937 + libstdc++ 11 std::shuffle restated in C) against the permutations the literal
+    reference call sequence (std::iota / std::mt19937::seed / std::shuffle, mapper.cpp:1326-1333) produced
+    (tests/golden/make_shuffle_golden.cpp -> shuffle_golden.json): bit exact, incl. seeds >= 2^32 and n > 65535
+    (where libstdc++ switches from two-positions-per-draw to one)."""
+    import json
+    import os
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "shuffle_golden.json")))
+    assert len(g["cases"]) == 55
+    for c in g["cases"]:
+        idx = orc.shuffle_indices(c["n"], c["seed"])
+        assert sorted(idx.tolist()) == list(range(c["n"]))          # a permutation
+        h = 1469598103934665603
+        for v in idx.tolist():
+            h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+        assert str(h) == c["fnv1a"], (c["seed"], c["n"])
+        assert idx[:16].tolist() == c["head"]
