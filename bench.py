@@ -134,14 +134,14 @@ def main():
             win.lm_step(state, cfg)
             damp = state.damp
             return state.error, state.candidate_error, bool(state.accepted)
+        # multi-GPU: the same sequence with the two all-reduces in between; nothing is read back before the candidate's
+        # error pass has been enqueued (the error at the linearisation point is the tail of the reduced packed buffer)
         win.linearize()
-        if dist is not None:
-            dist.all_reduce(packed)
-        e0 = win.total_error(True)
+        dist.all_reduce(packed)
         win.solve(damp, want_norm=False)
         win.error(1)
-        if dist is not None:
-            dist.all_reduce(errt)
+        dist.all_reduce(errt)
+        e0 = win.total_error(True)
         e1 = win.total_error(False)
         if e1 < e0:
             win.accept()
