@@ -96,12 +96,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
-    torch.cuda.set_device(local_rank)
+    # dev knob: SAGE_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 with the gloo backend -- a functional check of the
+    # sharded path on a 1-GPU box (the driver's multi-GPU runs use one GPU per rank and RCCL)
+    one_dev = os.environ.get("SAGE_BENCH_ONE_DEVICE") == "1"
+    dev_index = 0 if one_dev else local_rank
+    torch.cuda.set_device(dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if one_dev:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
 
     from sage_slam_amd import capi, synth
     capi.lib()
