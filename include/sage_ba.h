@@ -311,6 +311,35 @@ int sage_window_get_edge(const SageWindow *w, int type, int e, float *AtA, float
 int sage_window_set_profiling(SageWindow *w, int on);
 int sage_window_get_kernel_time(SageWindow *w, int which, double *total_ms, int *launches);
 
+/* ---- f3 (first part): sparse reprojection factor with the fair loss ----------------------------------------------
+ * Replaces cuda/reprojection_factor_kernels.h:8-46 (reference: reprojection_factor_kernels.cpp):
+ *   sage_reprojection_jac_error_calculate   <- reprojection_jac_error_calculate<CS>   (:468-531; kernel :27-213)
+ *   sage_reprojection_error_calculate       <- reprojection_error_calculate<CS>       (:417-466; kernel :215-286)
+ *   sage_tracker_reproj_jac_error_calculate <- tracker_reproj_jac_error_calculate     (:533-593; kernel :288-366)
+ *   sage_tracker_reproj_error_calculate     <- tracker_reproj_error_calculate         (:595-628; kernel :367-415)
+ * matched_2d [N,2] are the matched keypoint locations in keyframe 1 (pixels); loc1d is int32 as in the reference;
+ * AtA [D,D] / Atb [D] are device arrays, D = 13+CS (mapper: [pose0 pose1 code0 scale0]) or 6 (tracker);
+ * error / num_inliers are host scalars (the call synchronises the stream, like the reference's .item<float>()).
+ * Without a keypoint in front of the camera: error = 10*weight, AtA = Atb = 0. */
+int sage_reprojection_jac_error_calculate(SageWorkspace *ws, float *AtA_dev, float *Atb_dev, float *error_host,
+                                          float *num_inliers_host, const float *R10, const float *t10, const float *R0,
+                                          const float *t0, const float *R1, const float *t1, const float *bias0,
+                                          const float *basis0, const float *code0, const int32_t *loc1d,
+                                          const float *homo, const float *matched_2d, float scale0,
+                                          const SageCamera *cam, float eps, float loss_param, float weight, int N, int CS);
+int sage_reprojection_error_calculate(SageWorkspace *ws, float *error_host, float *num_inliers_host, const float *R10,
+                                      const float *t10, const float *bias0, const float *basis0, const float *code0,
+                                      const int32_t *loc1d, const float *homo, const float *matched_2d, float scale0,
+                                      const SageCamera *cam, float eps, float loss_param, float weight, int N, int CS);
+int sage_tracker_reproj_jac_error_calculate(SageWorkspace *ws, float *AtA_dev, float *Atb_dev, float *error_host,
+                                            float *num_inliers_host, const float *R, const float *t,
+                                            const float *sampled_dpts0, const float *homo, const float *matched_2d,
+                                            const SageCamera *cam, float eps, float loss_param, float weight, int N);
+int sage_tracker_reproj_error_calculate(SageWorkspace *ws, float *error_host, float *num_inliers_host, const float *R,
+                                        const float *t, const float *sampled_dpts0, const float *homo,
+                                        const float *matched_2d, const SageCamera *cam, float eps, float loss_param,
+                                        float weight, int N);
+
 /* ---- f1 producers: valid-pixel enumeration and seeded keyframe sampling ------------------------------------
  * sage_valid_locations: core/mapping/mapping_utils.h:254-287 (GenerateValidLocations): flat indices of mask > 0.5 in
  *   ascending order and their normalised homogeneous coordinates ((x-u0)/fx, (y-v0)/fy, 1).  Outputs are device

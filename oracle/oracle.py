@@ -284,3 +284,57 @@ def shuffle_indices(n, seed):
     idx = np.zeros(max(n, 1), np.int64)
     lib().orc_shuffle_indices_f32(idx.ctypes.data_as(C.c_void_p), C.c_longlong(n), C.c_longlong(seed))
     return idx[:n].copy()
+
+
+def reproj_jac_error(R10, t10, R0, t0, R1, t1, bias0, basis0, code0, loc1d, homo, matched, scale0, cam, eps,
+                     loss_param, weight, prec="f32", want_rows=False):
+    """cuda/reprojection_factor_kernels.cpp:27-213 + :468-531 (mapper factor, D = 13+CS)."""
+    dt, ct, sfx = _dt(prec)
+    basis0 = _arr(basis0, dt); CS = basis0.shape[-1]; D = 13 + CS
+    homo = _arr(homo, dt); N = homo.shape[0]
+    AtA = np.zeros((D, D), dt); Atb = np.zeros(D, dt); err = np.zeros(1, dt); nin = np.zeros(1, dt)
+    J = np.zeros((max(N, 1), 2, D), dt) if want_rows else None
+    r = np.zeros((max(N, 1), 2), dt) if want_rows else None
+    sw = np.zeros((max(N, 1), 2), dt) if want_rows else None
+    getattr(lib(), "orc_reproj_jac_error" + sfx)(
+        _p(AtA), _p(Atb), _p(err), _p(nin), _p(_arr(R10, dt)), _p(_arr(t10, dt)), _p(_arr(R0, dt)), _p(_arr(t0, dt)),
+        _p(_arr(R1, dt)), _p(_arr(t1, dt)), _p(_arr(bias0, dt)), _p(basis0), _p(_arr(code0, dt)),
+        _p(_arr(loc1d, np.int32)), _p(homo), _p(_arr(matched, dt)), ct(scale0), _p(_cams([cam], dt)), C.c_int(N),
+        C.c_int(CS), ct(eps), ct(loss_param), ct(weight), _p(J), _p(r), _p(sw))
+    out = dict(AtA=AtA, Atb=Atb, error=float(err[0]), num_inliers=float(nin[0]))
+    if want_rows:
+        out.update(J=J[:N], r=r[:N], sw=sw[:N])
+    return out
+
+
+def reproj_error(R10, t10, bias0, basis0, code0, loc1d, homo, matched, scale0, cam, eps, loss_param, weight, prec="f32"):
+    dt, ct, sfx = _dt(prec)
+    basis0 = _arr(basis0, dt); CS = basis0.shape[-1]
+    homo = _arr(homo, dt); N = homo.shape[0]
+    nin = np.zeros(1, dt)
+    fn = getattr(lib(), "orc_reproj_error" + sfx); fn.restype = ct
+    e = fn(_p(_arr(R10, dt)), _p(_arr(t10, dt)), _p(_arr(bias0, dt)), _p(basis0), _p(_arr(code0, dt)),
+           _p(_arr(loc1d, np.int32)), _p(homo), _p(_arr(matched, dt)), ct(scale0), _p(_cams([cam], dt)), C.c_int(N),
+           C.c_int(CS), ct(eps), ct(loss_param), ct(weight), _p(nin))
+    return float(e), float(nin[0])
+
+
+def tracker_reproj_jac_error(R, t, dpts0, homo, matched, cam, eps, loss_param, weight, prec="f32"):
+    """cuda/reprojection_factor_kernels.cpp:288-366 + :533-593 (tracker, D = 6)."""
+    dt, ct, sfx = _dt(prec)
+    homo = _arr(homo, dt); N = homo.shape[0]
+    AtA = np.zeros((6, 6), dt); Atb = np.zeros(6, dt); err = np.zeros(1, dt); nin = np.zeros(1, dt)
+    getattr(lib(), "orc_tracker_reproj_jac_error" + sfx)(
+        _p(AtA), _p(Atb), _p(err), _p(nin), _p(_arr(R, dt)), _p(_arr(t, dt)), _p(_arr(dpts0, dt)), _p(homo),
+        _p(_arr(matched, dt)), _p(_cams([cam], dt)), C.c_int(N), ct(eps), ct(loss_param), ct(weight))
+    return dict(AtA=AtA, Atb=Atb, error=float(err[0]), num_inliers=float(nin[0]))
+
+
+def tracker_reproj_error(R, t, dpts0, homo, matched, cam, eps, loss_param, weight, prec="f32"):
+    dt, ct, sfx = _dt(prec)
+    homo = _arr(homo, dt); N = homo.shape[0]
+    nin = np.zeros(1, dt)
+    fn = getattr(lib(), "orc_tracker_reproj_error" + sfx); fn.restype = ct
+    e = fn(_p(_arr(R, dt)), _p(_arr(t, dt)), _p(_arr(dpts0, dt)), _p(homo), _p(_arr(matched, dt)), _p(_cams([cam], dt)),
+           C.c_int(N), ct(eps), ct(loss_param), ct(weight), _p(nin))
+    return float(e), float(nin[0])

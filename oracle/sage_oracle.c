@@ -1013,3 +1013,218 @@ void ORC(shuffle_indices)(long long *idx, long long n, long long seed)
   }
 #undef ORC_SWAP
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * f3: reprojection factor (fair loss), cuda/reprojection_factor_kernels.cpp
+ * ------------------------------------------------------------------------------------------------ */
+/* shared per-keypoint part: projection, normalised differences, error, sqrt fair weights (:76-103 / :321-343) */
+static int reproj_point(const REAL X[3], const REAL *match, const ORC(cam_t) * cam, REAL eps, REAL loss_param,
+                        REAL diff[2], REAL sw[2], REAL *err)
+{
+  const int pos = X[2] > eps;
+  const REAL px = (X[0] / X[2]) * cam->fx + cam->cx, py = (X[1] / X[2]) * cam->fy + cam->cy;
+  const REAL sl = (REAL)sqrt((double)loss_param);
+  diff[0] = match[0] - px;
+  diff[1] = match[1] - py;
+  const REAL nx = (REAL)fabs((double)diff[0]) / sl, ny = (REAL)fabs((double)diff[1]) / sl;
+  sw[0] = pos ? (REAL)sqrt(1.0 / (double)(loss_param * (1 + nx))) : 0;
+  sw[1] = pos ? (REAL)sqrt(1.0 / (double)(loss_param * (1 + ny))) : 0;
+  *err = pos ? 2 * (nx + ny - (REAL)log(1.0 + (double)nx) - (REAL)log(1.0 + (double)ny)) : 0;
+  return pos;
+}
+
+/* AtA = (weight/n) J^T J, Atb = (weight/n) J^T r over the 2N weighted rows; fallback error = 10*weight (:507-528) */
+static void reproj_reduce(REAL *AtA, REAL *Atb, REAL *error, REAL *num_inliers, const REAL *J, const REAL *r,
+                          const REAL *serr, const REAL *sval, int N, int D, REAL weight)
+{
+  double n_in = 0, se = 0;
+  for (int i = 0; i < N; ++i)
+  {
+    n_in += sval[i];
+    se += serr[i];
+  }
+  if (num_inliers)
+    *num_inliers = (REAL)n_in;
+  if (n_in > 0)
+  {
+    const double sc = (double)weight / n_in;
+    *error = (REAL)(sc * se);
+    for (int a = 0; a < D; ++a)
+    {
+      for (int b = 0; b < D; ++b)
+      {
+        double acc = 0;
+        for (int k = 0; k < 2 * N; ++k)
+          acc += (double)J[(size_t)k * D + a] * (double)J[(size_t)k * D + b];
+        AtA[a * D + b] = (REAL)(sc * acc);
+      }
+      double accb = 0;
+      for (int k = 0; k < 2 * N; ++k)
+        accb += (double)J[(size_t)k * D + a] * (double)r[k];
+      Atb[a] = (REAL)(sc * accb);
+    }
+  }
+  else
+  {
+    *error = weight * 10;
+    memset(AtA, 0, sizeof(REAL) * D * D);
+    memset(Atb, 0, sizeof(REAL) * D);
+  }
+}
+
+void ORC(reproj_jac_error)(REAL *AtA, REAL *Atb, REAL *error, REAL *num_inliers,
+                           const REAL *R10, const REAL *t10, const REAL *R0, const REAL *t0, const REAL *R1, const REAL *t1,
+                           const REAL *bias0, const REAL *basis0, const REAL *code0, const int32_t *loc1d, const REAL *homo,
+                           const REAL *matched, REAL scale0, const ORC(cam_t) * cam, int N, int CS, REAL eps,
+                           REAL loss_param, REAL weight, REAL *J_out, REAL *r_out, REAL *sw_out)
+{
+  const int D = 13 + CS;
+  REAL *J = J_out ? J_out : (REAL *)malloc((size_t)(N > 0 ? N : 1) * 2 * D * sizeof(REAL));
+  REAL *r = r_out ? r_out : (REAL *)malloc((size_t)(N > 0 ? N : 1) * 2 * sizeof(REAL));
+  REAL *serr = (REAL *)malloc((size_t)(N > 0 ? N : 1) * sizeof(REAL));
+  REAL *sval = (REAL *)malloc((size_t)(N > 0 ? N : 1) * sizeof(REAL));
+  const REAL fx = cam->fx, fy = cam->fy;
+  for (int idx = 0; idx < N; ++idx)
+  {
+    const REAL *hm = homo + (size_t)idx * 3;
+    const long long i1d = (long long)loc1d[idx];
+    const REAL d0 = sampled_depth(bias0, basis0, code0, i1d, CS, scale0); /* :57-64 */
+    REAL rh[3], X[3];
+    for (int i = 0; i < 3; ++i)
+      rh[i] = R10[i * 3 + 0] * hm[0] + R10[i * 3 + 1] * hm[1] + R10[i * 3 + 2] * hm[2];
+    for (int i = 0; i < 3; ++i)
+      X[i] = d0 * rh[i] + t10[i];
+    REAL diff[2], sw[2], e;
+    const int pos = reproj_point(X, matched + (size_t)idx * 2, cam, eps, loss_param, diff, sw, &e);
+    serr[idx] = e;
+    sval[idx] = pos ? 1 : 0;
+    const REAL inv_z = 1 / X[2];
+    const REAL x_z = inv_z * X[0], y_z = inv_z * X[1];
+    const REAL Jpi[2][3] = {{fx * inv_z, 0, -fx * x_z * inv_z}, {0, fy * inv_z, -fy * y_z * inv_z}}; /* :108-109 */
+    REAL Xw[3];
+    for (int i = 0; i < 3; ++i)
+      Xw[i] = d0 * (R0[i * 3 + 0] * hm[0] + R0[i * 3 + 1] * hm[1] + R0[i * 3 + 2] * hm[2]) + t0[i];
+    REAL dX1[3][6], dX0[3][6];
+    for (int i = 0; i < 3; ++i) /* :124-133 */
+    {
+      dX1[i][0] = -R1[0 * 3 + i];
+      dX1[i][1] = -R1[1 * 3 + i];
+      dX1[i][2] = -R1[2 * 3 + i];
+      dX1[i][3] = R1[1 * 3 + i] * Xw[2] - R1[2 * 3 + i] * Xw[1];
+      dX1[i][4] = -R1[0 * 3 + i] * Xw[2] + R1[2 * 3 + i] * Xw[0];
+      dX1[i][5] = R1[0 * 3 + i] * Xw[1] - R1[1 * 3 + i] * Xw[0];
+    }
+    {
+      const REAL E[3][6] = {{1, 0, 0, 0, Xw[2], -Xw[1]}, {0, 1, 0, -Xw[2], 0, Xw[0]}, {0, 0, 1, Xw[1], -Xw[0], 0}};
+      for (int i = 0; i < 3; ++i) /* :148-161 */
+        for (int j = 0; j < 6; ++j)
+          dX0[i][j] = R1[0 * 3 + i] * E[0][j] + R1[1 * 3 + i] * E[1][j] + R1[2 * 3 + i] * E[2][j];
+    }
+    const REAL jd[2] = {fx * (rh[0] * inv_z - X[0] * rh[2] * inv_z * inv_z), /* :175-176 */
+                        fy * (rh[1] * inv_z - X[1] * rh[2] * inv_z * inv_z)};
+    for (int c = 0; c < 2; ++c)
+    {
+      REAL *row = J + ((size_t)idx * 2 + c) * D;
+      for (int j = 0; j < 6; ++j)
+      {
+        const REAL p0 = Jpi[c][0] * dX0[0][j] + Jpi[c][1] * dX0[1][j] + Jpi[c][2] * dX0[2][j];
+        const REAL p1 = Jpi[c][0] * dX1[0][j] + Jpi[c][1] * dX1[1][j] + Jpi[c][2] * dX1[2][j];
+        row[j] = sw[c] * p0;
+        row[6 + j] = sw[c] * p1;
+      }
+      for (int i = 0; i < CS; ++i)
+        row[12 + i] = sw[c] * (jd[c] * scale0 * basis0[(size_t)i1d * CS + i]); /* :182-183 */
+      row[12 + CS] = sw[c] * (jd[c] * d0 / scale0);                           /* :186 */
+      r[(size_t)idx * 2 + c] = sw[c] * diff[c];                               /* :188-189 */
+      if (sw_out)
+        sw_out[(size_t)idx * 2 + c] = sw[c];
+    }
+  }
+  reproj_reduce(AtA, Atb, error, num_inliers, J, r, serr, sval, N, D, weight);
+  if (!J_out)
+    free(J);
+  if (!r_out)
+    free(r);
+  free(serr);
+  free(sval);
+}
+
+REAL ORC(reproj_error)(const REAL *R10, const REAL *t10, const REAL *bias0, const REAL *basis0, const REAL *code0,
+                       const int32_t *loc1d, const REAL *homo, const REAL *matched, REAL scale0, const ORC(cam_t) * cam,
+                       int N, int CS, REAL eps, REAL loss_param, REAL weight, REAL *num_inliers)
+{
+  double se = 0, n_in = 0;
+  for (int idx = 0; idx < N; ++idx)
+  {
+    const REAL *hm = homo + (size_t)idx * 3;
+    const REAL d0 = sampled_depth(bias0, basis0, code0, (long long)loc1d[idx], CS, scale0);
+    REAL X[3];
+    for (int i = 0; i < 3; ++i)
+      X[i] = d0 * (R10[i * 3 + 0] * hm[0] + R10[i * 3 + 1] * hm[1] + R10[i * 3 + 2] * hm[2]) + t10[i];
+    REAL diff[2], sw[2], e;
+    const int pos = reproj_point(X, matched + (size_t)idx * 2, cam, eps, loss_param, diff, sw, &e);
+    se += e;
+    n_in += pos ? 1 : 0;
+  }
+  if (num_inliers)
+    *num_inliers = (REAL)n_in;
+  return n_in > 0 ? (REAL)((double)weight * se / n_in) : weight * 10; /* :457-464 */
+}
+
+void ORC(tracker_reproj_jac_error)(REAL *AtA, REAL *Atb, REAL *error, REAL *num_inliers, const REAL *R, const REAL *t,
+                                   const REAL *dpts0, const REAL *homo, const REAL *matched, const ORC(cam_t) * cam, int N,
+                                   REAL eps, REAL loss_param, REAL weight)
+{
+  const int D = 6;
+  REAL *J = (REAL *)malloc((size_t)(N > 0 ? N : 1) * 2 * D * sizeof(REAL));
+  REAL *r = (REAL *)malloc((size_t)(N > 0 ? N : 1) * 2 * sizeof(REAL));
+  REAL *serr = (REAL *)malloc((size_t)(N > 0 ? N : 1) * sizeof(REAL));
+  REAL *sval = (REAL *)malloc((size_t)(N > 0 ? N : 1) * sizeof(REAL));
+  const REAL fx = cam->fx, fy = cam->fy;
+  for (int idx = 0; idx < N; ++idx)
+  {
+    const REAL *hm = homo + (size_t)idx * 3;
+    REAL X[3];
+    for (int i = 0; i < 3; ++i)
+      X[i] = dpts0[idx] * (R[i * 3 + 0] * hm[0] + R[i * 3 + 1] * hm[1] + R[i * 3 + 2] * hm[2]) + t[i];
+    REAL diff[2], sw[2], e;
+    const int pos = reproj_point(X, matched + (size_t)idx * 2, cam, eps, loss_param, diff, sw, &e);
+    serr[idx] = e;
+    sval[idx] = pos ? 1 : 0;
+    const REAL inv_z = 1 / X[2];
+    const REAL x_z = inv_z * X[0], y_z = inv_z * X[1];
+    const REAL Jr[2][6] = {{fx * inv_z, 0, -fx * x_z * inv_z, -fx * x_z * y_z, fx * (1 + x_z * x_z), -fx * y_z}, /* :348-349 */
+                           {0, fy * inv_z, -fy * y_z * inv_z, -fy * (1 + y_z * y_z), fy * x_z * y_z, fy * x_z}};
+    for (int c = 0; c < 2; ++c)
+    {
+      for (int j = 0; j < 6; ++j)
+        J[((size_t)idx * 2 + c) * D + j] = sw[c] * Jr[c][j];
+      r[(size_t)idx * 2 + c] = sw[c] * diff[c];
+    }
+  }
+  reproj_reduce(AtA, Atb, error, num_inliers, J, r, serr, sval, N, D, weight);
+  free(J);
+  free(r);
+  free(serr);
+  free(sval);
+}
+
+REAL ORC(tracker_reproj_error)(const REAL *R, const REAL *t, const REAL *dpts0, const REAL *homo, const REAL *matched,
+                               const ORC(cam_t) * cam, int N, REAL eps, REAL loss_param, REAL weight, REAL *num_inliers)
+{
+  double se = 0, n_in = 0;
+  for (int idx = 0; idx < N; ++idx)
+  {
+    const REAL *hm = homo + (size_t)idx * 3;
+    REAL X[3];
+    for (int i = 0; i < 3; ++i)
+      X[i] = dpts0[idx] * (R[i * 3 + 0] * hm[0] + R[i * 3 + 1] * hm[1] + R[i * 3 + 2] * hm[2]) + t[i];
+    REAL diff[2], sw[2], e;
+    const int pos = reproj_point(X, matched + (size_t)idx * 2, cam, eps, loss_param, diff, sw, &e);
+    se += e;
+    n_in += pos ? 1 : 0;
+  }
+  if (num_inliers)
+    *num_inliers = (REAL)n_in;
+  return n_in > 0 ? (REAL)((double)weight * se / n_in) : weight * 10;
+}

@@ -93,6 +93,8 @@ SYMBOLS = [
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
     "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
+    "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
+    "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
 ]
 
 
@@ -644,3 +646,54 @@ def sample_locations(ws: "Workspace", vloc, vhomo, seed: int, num_samples: int):
                                      C.c_int64(seed), num_samples, C.c_void_p(loc.data_ptr()),
                                      C.c_void_p(homo.data_ptr()), C.byref(n)), "sage_sample_locations")
     return loc[:n.value].clone(), homo[:n.value].clone()
+
+
+def _dptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def reprojection_jac_error(ws, R10, t10, R0, t0, R1, t1, bias0, basis0, code0, loc1d_i32, homo, matched, scale0, cam,
+                           eps, loss_param, weight, CS):
+    """All array arguments are cuda tensors (poses 9/3 floats).  Returns dict(AtA [D,D], Atb [D] tensors, error, num_inliers)."""
+    import torch
+    N = int(homo.shape[0]); D = 13 + CS
+    AtA = torch.zeros(D, D, device="cuda"); Atb = torch.zeros(D, device="cuda")
+    e = C.c_float(); n = C.c_float()
+    _chk(lib().sage_reprojection_jac_error_calculate(
+        ws.h, _dptr(AtA), _dptr(Atb), C.byref(e), C.byref(n), _dptr(R10), _dptr(t10), _dptr(R0), _dptr(t0), _dptr(R1),
+        _dptr(t1), _dptr(bias0), _dptr(basis0), _dptr(code0), _dptr(loc1d_i32), _dptr(homo), _dptr(matched),
+        C.c_float(scale0), C.byref(cam), C.c_float(eps), C.c_float(loss_param), C.c_float(weight), N, CS),
+        "sage_reprojection_jac_error_calculate")
+    return dict(AtA=AtA, Atb=Atb, error=e.value, num_inliers=n.value)
+
+
+def reprojection_error(ws, R10, t10, bias0, basis0, code0, loc1d_i32, homo, matched, scale0, cam, eps, loss_param,
+                       weight, CS):
+    N = int(homo.shape[0])
+    e = C.c_float(); n = C.c_float()
+    _chk(lib().sage_reprojection_error_calculate(
+        ws.h, C.byref(e), C.byref(n), _dptr(R10), _dptr(t10), _dptr(bias0), _dptr(basis0), _dptr(code0),
+        _dptr(loc1d_i32), _dptr(homo), _dptr(matched), C.c_float(scale0), C.byref(cam), C.c_float(eps),
+        C.c_float(loss_param), C.c_float(weight), N, CS), "sage_reprojection_error_calculate")
+    return e.value, n.value
+
+
+def tracker_reproj_jac_error(ws, R, t, dpts0, homo, matched, cam, eps, loss_param, weight):
+    import torch
+    N = int(homo.shape[0])
+    AtA = torch.zeros(6, 6, device="cuda"); Atb = torch.zeros(6, device="cuda")
+    e = C.c_float(); n = C.c_float()
+    _chk(lib().sage_tracker_reproj_jac_error_calculate(
+        ws.h, _dptr(AtA), _dptr(Atb), C.byref(e), C.byref(n), _dptr(R), _dptr(t), _dptr(dpts0), _dptr(homo),
+        _dptr(matched), C.byref(cam), C.c_float(eps), C.c_float(loss_param), C.c_float(weight), N),
+        "sage_tracker_reproj_jac_error_calculate")
+    return dict(AtA=AtA, Atb=Atb, error=e.value, num_inliers=n.value)
+
+
+def tracker_reproj_error(ws, R, t, dpts0, homo, matched, cam, eps, loss_param, weight):
+    N = int(homo.shape[0])
+    e = C.c_float(); n = C.c_float()
+    _chk(lib().sage_tracker_reproj_error_calculate(
+        ws.h, C.byref(e), C.byref(n), _dptr(R), _dptr(t), _dptr(dpts0), _dptr(homo), _dptr(matched), C.byref(cam),
+        C.c_float(eps), C.c_float(loss_param), C.c_float(weight), N), "sage_tracker_reproj_error_calculate")
+    return e.value, n.value

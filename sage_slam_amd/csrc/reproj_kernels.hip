@@ -1,0 +1,250 @@
+// reproj_kernels.hip -- sparse reprojection factor (fair loss) for matched keypoints, mapper and tracker variants.
+//
+// Replaces cuda/reprojection_factor_kernels.cpp of the reference: kernels :27-213 / :215-286 (mapper factor,
+// D = 13+CS, [pose0 pose1 code0 scale0]) and :288-366 / :367-415 (tracker, D = 6), hosts :417-628.
+// N is a few hundred keypoints at most (launch-latency, not bandwidth): the weighted rows are written
+// once (2N x (D+1) floats, the residual is the last column) and contracted by D workgroups in double -- two launches
+// per call, nothing clever.  Same conventions as the dense factors: world-frame left-perturbation Jacobians,
+// P_pose1 = -P_pose0, weight/num_inliers normalisation, 10*weight fallback without inliers.
+#include "sage_device.h"
+#include "sage_internal.h"
+
+namespace sage
+{
+
+struct ReprojParams
+{
+  const float *R10, *t10, *R0, *t0, *R1, *t1; // mapper: all six; tracker: R10/t10 = the relative pose
+  const float *bias0, *basis0, *code0;        // mapper
+  const int32_t *loc;                         // mapper
+  const float *dpts0;                         // tracker: sampled depths [N]
+  const float *homo, *matched;                // [N,3], [N,2]
+  float scale0;
+  SageCamera cam;
+  float eps, loss_param, weight;
+  int N;
+  float *rows; // [2N][D+1]
+  float *serr; // [N]
+  float *sval; // [N]
+};
+
+// MODE 0: mapper factor (D = 13+CS), MODE 1: tracker (D = 6)
+template <int CS, int MODE, bool JAC>
+__global__ __launch_bounds__(256) void reproj_rows_kernel(const ReprojParams p)
+{
+  constexpr int D = MODE == 0 ? 13 + CS : 6;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.N)
+    return;
+  const float fx = p.cam.fx, fy = p.cam.fy, cx = p.cam.cx, cy = p.cam.cy;
+  const float hm[3] = {p.homo[3 * idx + 0], p.homo[3 * idx + 1], p.homo[3 * idx + 2]};
+  float d0;
+  int loc = 0;
+  if (MODE == 0)
+  {
+    loc = p.loc[idx];
+    float acc = p.bias0[loc]; // reprojection_factor_kernels.cpp:57-64
+    for (int i = 0; i < CS; ++i)
+      acc += p.basis0[(size_t)loc * CS + i] * p.code0[i];
+    d0 = acc * p.scale0;
+  }
+  else
+    d0 = p.dpts0[idx];
+  float rh[3], X[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+  {
+    rh[i] = p.R10[i * 3 + 0] * hm[0] + p.R10[i * 3 + 1] * hm[1] + p.R10[i * 3 + 2] * hm[2];
+    X[i] = d0 * rh[i] + p.t10[i];
+  }
+  const bool pos = X[2] > p.eps; // :74
+  const float px = (X[0] / X[2]) * fx + cx, py = (X[1] / X[2]) * fy + cy;
+  const float sl = sqrtf(p.loss_param);
+  const float diff[2] = {p.matched[2 * idx + 0] - px, p.matched[2 * idx + 1] - py};
+  const float nx = fabsf(diff[0]) / sl, ny = fabsf(diff[1]) / sl;
+  const float sw[2] = {pos ? sqrtf(1.0f / (p.loss_param * (1.0f + nx))) : 0.f,  // :83-84
+                       pos ? sqrtf(1.0f / (p.loss_param * (1.0f + ny))) : 0.f};
+  p.serr[idx] = pos ? 2.0f * (nx + ny - logf(1.0f + nx) - logf(1.0f + ny)) : 0.f; // :87-90
+  p.sval[idx] = pos ? 1.f : 0.f;
+  if (!JAC)
+    return;
+  const float inv_z = 1.0f / X[2];
+  const float x_z = inv_z * X[0], y_z = inv_z * X[1];
+  float *row0 = p.rows + ((size_t)idx * 2 + 0) * (D + 1), *row1 = p.rows + ((size_t)idx * 2 + 1) * (D + 1);
+  if (MODE == 1)
+  {
+    const float J0[6] = {fx * inv_z, 0.f, -fx * x_z * inv_z, -fx * x_z * y_z, fx * (1.0f + x_z * x_z), -fx * y_z}; // :348
+    const float J1[6] = {0.f, fy * inv_z, -fy * y_z * inv_z, -fy * (1.0f + y_z * y_z), fy * x_z * y_z, fy * x_z};
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+    {
+      row0[j] = sw[0] * J0[j];
+      row1[j] = sw[1] * J1[j];
+    }
+  }
+  else
+  {
+    const float Jpi[2][3] = {{fx * inv_z, 0.f, -fx * x_z * inv_z}, {0.f, fy * inv_z, -fy * y_z * inv_z}}; // :108-109
+    float Xw[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      Xw[i] = d0 * (p.R0[i * 3 + 0] * hm[0] + p.R0[i * 3 + 1] * hm[1] + p.R0[i * 3 + 2] * hm[2]) + p.t0[i];
+    Pose p1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      p1.R[i] = p.R1[i];
+    float dX[3][6];
+    dX_dT0(p1, Xw, dX); // R1^T [I | -[Xw]x]  (:148-161); dX/dT1 = -dX/dT0 (:124-133)
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+    {
+      const float a0 = Jpi[0][0] * dX[0][j] + Jpi[0][1] * dX[1][j] + Jpi[0][2] * dX[2][j];
+      const float a1 = Jpi[1][0] * dX[0][j] + Jpi[1][1] * dX[1][j] + Jpi[1][2] * dX[2][j];
+      row0[j] = sw[0] * a0;
+      row1[j] = sw[1] * a1;
+      row0[6 + j] = sw[0] * (-a0);
+      row1[6 + j] = sw[1] * (-a1);
+    }
+    const float jd0 = fx * (rh[0] * inv_z - X[0] * rh[2] * inv_z * inv_z); // :175-176
+    const float jd1 = fy * (rh[1] * inv_z - X[1] * rh[2] * inv_z * inv_z);
+    for (int i = 0; i < CS; ++i)
+    {
+      const float b = p.basis0[(size_t)loc * CS + i];
+      row0[12 + i] = sw[0] * (jd0 * p.scale0 * b); // :182-183
+      row1[12 + i] = sw[1] * (jd1 * p.scale0 * b);
+    }
+    row0[12 + CS] = sw[0] * (jd0 * d0 / p.scale0); // :186
+    row1[12 + CS] = sw[1] * (jd1 * d0 / p.scale0);
+  }
+  row0[D] = sw[0] * diff[0]; // :188-189
+  row1[D] = sw[1] * diff[1];
+}
+
+// workgroup a: AtA[a][:] and Atb[a] = (weight/n) sum_rows J[row][a] * [J[row][:] | r[row]] in double; workgroup 0 also
+// writes stats = {error, num_inliers}.  D+1 <= 64 columns x 4 row groups per workgroup.
+__global__ __launch_bounds__(256) void reproj_reduce_kernel(const float *__restrict__ rows, const float *__restrict__ serr,
+                                                            const float *__restrict__ sval, int N, int D, float weight,
+                                                            float *__restrict__ AtA, float *__restrict__ Atb,
+                                                            float *__restrict__ stats)
+{
+  __shared__ double s_acc[4][64];
+  __shared__ double s_n[256], s_e[256];
+  const int a = blockIdx.x, tid = threadIdx.x, j = tid & 63, grp = tid >> 6;
+  double n_in = 0.0, se = 0.0;
+  for (int i = tid; i < N; i += 256)
+  {
+    n_in += (double)sval[i];
+    se += (double)serr[i];
+  }
+  s_n[tid] = n_in;
+  s_e[tid] = se;
+  double acc = 0.0;
+  if (j <= D)
+    for (int k = grp; k < 2 * N; k += 4)
+      acc += (double)rows[(size_t)k * (D + 1) + a] * (double)rows[(size_t)k * (D + 1) + j];
+  s_acc[grp][j] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1)
+  {
+    if (tid < off)
+    {
+      s_n[tid] += s_n[tid + off];
+      s_e[tid] += s_e[tid + off];
+    }
+    __syncthreads();
+  }
+  const double ninl = s_n[0];
+  const double sc = ninl > 0.0 ? (double)weight / ninl : 0.0;
+  if (tid <= D)
+  {
+    const double v = sc * ((s_acc[0][tid] + s_acc[1][tid]) + (s_acc[2][tid] + s_acc[3][tid]));
+    if (tid < D)
+      AtA[(size_t)a * D + tid] = (float)v;
+    else
+      Atb[a] = (float)v;
+  }
+  if (a == 0 && tid == 0)
+  {
+    stats[0] = ninl > 0.0 ? (float)(sc * s_e[0]) : weight * 10.0f; // :507, :523
+    stats[1] = (float)ninl;
+  }
+}
+
+__global__ __launch_bounds__(256) void reproj_stats_kernel(const float *__restrict__ serr, const float *__restrict__ sval,
+                                                           int N, float weight, float *__restrict__ stats)
+{
+  __shared__ double s_n[256], s_e[256];
+  const int tid = threadIdx.x;
+  double n_in = 0.0, se = 0.0;
+  for (int i = tid; i < N; i += 256)
+  {
+    n_in += (double)sval[i];
+    se += (double)serr[i];
+  }
+  s_n[tid] = n_in;
+  s_e[tid] = se;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1)
+  {
+    if (tid < off)
+    {
+      s_n[tid] += s_n[tid + off];
+      s_e[tid] += s_e[tid + off];
+    }
+    __syncthreads();
+  }
+  if (tid == 0)
+  {
+    stats[0] = s_n[0] > 0.0 ? (float)((double)weight * s_e[0] / s_n[0]) : weight * 10.0f; // :457-464
+    stats[1] = (float)s_n[0];
+  }
+}
+
+// scratch: rows 2N*(D+1) floats, then serr N, sval N
+size_t reproj_scratch_floats(int N, int D) { return (size_t)2 * N * (D + 1) + (size_t)2 * N + 4; }
+
+template <int CS, int MODE>
+static hipError_t reproj_impl(hipStream_t s, ReprojParams p, bool jac, float *scratch, float *AtA, float *Atb, float *stats)
+{
+  constexpr int D = MODE == 0 ? 13 + CS : 6;
+  const int N = p.N;
+  p.rows = scratch;
+  p.serr = scratch + (size_t)2 * N * (D + 1);
+  p.sval = p.serr + N;
+  const int grid = (N + 255) / 256;
+  if (jac)
+  {
+    if (grid > 0)
+      hipLaunchKernelGGL((reproj_rows_kernel<CS, MODE, true>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(reproj_reduce_kernel, dim3(D), dim3(256), 0, s, p.rows, p.serr, p.sval, N, D, p.weight, AtA, Atb,
+                       stats);
+  }
+  else
+  {
+    if (grid > 0)
+      hipLaunchKernelGGL((reproj_rows_kernel<CS, MODE, false>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(reproj_stats_kernel, dim3(1), dim3(256), 0, s, p.serr, p.sval, N, p.weight, stats);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_reproj(hipStream_t s, int CS, bool tracker, bool jac, const float *R10, const float *t10, const float *R0,
+                         const float *t0, const float *R1, const float *t1, const float *bias0, const float *basis0,
+                         const float *code0, const int32_t *loc, const float *dpts0, const float *homo,
+                         const float *matched, float scale0, const SageCamera &cam, float eps, float loss_param,
+                         float weight, int N, float *scratch, float *AtA, float *Atb, float *stats)
+{
+  ReprojParams p{};
+  p.R10 = R10; p.t10 = t10; p.R0 = R0; p.t0 = t0; p.R1 = R1; p.t1 = t1;
+  p.bias0 = bias0; p.basis0 = basis0; p.code0 = code0; p.loc = loc; p.dpts0 = dpts0; p.homo = homo; p.matched = matched;
+  p.scale0 = scale0; p.cam = cam; p.eps = eps; p.loss_param = loss_param; p.weight = weight; p.N = N;
+  if (tracker)
+    return reproj_impl<16, 1>(s, p, jac, scratch, AtA, Atb, stats);
+  if (CS == 32)
+    return reproj_impl<32, 0>(s, p, jac, scratch, AtA, Atb, stats);
+  if (CS == 16)
+    return reproj_impl<16, 0>(s, p, jac, scratch, AtA, Atb, stats);
+  return hipErrorInvalidValue;
+}
+
+} // namespace sage

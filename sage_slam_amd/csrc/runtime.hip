@@ -413,6 +413,76 @@ extern "C" int sage_depth_and_grad(SageWorkspace *ws, float *dpt, float *grad, c
   return SAGE_OK;
 }
 
+// ---- sparse reprojection factor (reproj_kernels.hip) ----
+static int reproj_common(SageWorkspace *ws, bool tracker, bool jac, float *AtA, float *Atb, float *error_host,
+                         float *num_inliers_host, const float *R10, const float *t10, const float *R0, const float *t0,
+                         const float *R1, const float *t1, const float *bias0, const float *basis0, const float *code0,
+                         const int32_t *loc, const float *dpts0, const float *homo, const float *matched, float scale0,
+                         const SageCamera *cam, float eps, float loss_param, float weight, int N, int CS)
+{
+  if (!ws || !cam || N < 0 || !R10 || !t10 || (N > 0 && (!homo || !matched)) || (jac && (!AtA || !Atb)))
+    return SAGE_E_INVALID;
+  if (!tracker && (!bias0 || !basis0 || !code0 || (N > 0 && !loc) || (jac && (!R0 || !t0 || !R1 || !t1))))
+    return SAGE_E_INVALID;
+  if (tracker && N > 0 && !dpts0)
+    return SAGE_E_INVALID;
+  if (!tracker && CS != 16 && CS != 32)
+    return SAGE_E_UNSUPPORTED;
+  const int D = tracker ? 6 : 13 + CS;
+  int rc;
+  if ((rc = ws->misc.reserve(reproj_scratch_floats(N, D) * sizeof(float))) || (rc = ws->stats.reserve(4 * sizeof(float))))
+    return rc;
+  SAGE_HIP(launch_reproj(ws->stream, CS, tracker, jac, R10, t10, R0, t0, R1, t1, bias0, basis0, code0, loc, dpts0, homo,
+                         matched, scale0, *cam, eps, loss_param, weight, N, ws->misc.as<float>(), AtA, Atb,
+                         ws->stats.as<float>()));
+  return ws_fetch_stats(ws, error_host, num_inliers_host);
+}
+
+extern "C" int sage_reprojection_jac_error_calculate(SageWorkspace *ws, float *AtA_dev, float *Atb_dev, float *error_host,
+                                                     float *num_inliers_host, const float *R10, const float *t10,
+                                                     const float *R0, const float *t0, const float *R1, const float *t1,
+                                                     const float *bias0, const float *basis0, const float *code0,
+                                                     const int32_t *loc1d, const float *homo, const float *matched_2d,
+                                                     float scale0, const SageCamera *cam, float eps, float loss_param,
+                                                     float weight, int N, int CS)
+{
+  return reproj_common(ws, false, true, AtA_dev, Atb_dev, error_host, num_inliers_host, R10, t10, R0, t0, R1, t1, bias0,
+                       basis0, code0, loc1d, nullptr, homo, matched_2d, scale0, cam, eps, loss_param, weight, N, CS);
+}
+
+extern "C" int sage_reprojection_error_calculate(SageWorkspace *ws, float *error_host, float *num_inliers_host,
+                                                 const float *R10, const float *t10, const float *bias0,
+                                                 const float *basis0, const float *code0, const int32_t *loc1d,
+                                                 const float *homo, const float *matched_2d, float scale0,
+                                                 const SageCamera *cam, float eps, float loss_param, float weight, int N,
+                                                 int CS)
+{
+  return reproj_common(ws, false, false, nullptr, nullptr, error_host, num_inliers_host, R10, t10, nullptr, nullptr,
+                       nullptr, nullptr, bias0, basis0, code0, loc1d, nullptr, homo, matched_2d, scale0, cam, eps,
+                       loss_param, weight, N, CS);
+}
+
+extern "C" int sage_tracker_reproj_jac_error_calculate(SageWorkspace *ws, float *AtA_dev, float *Atb_dev,
+                                                       float *error_host, float *num_inliers_host, const float *R,
+                                                       const float *t, const float *sampled_dpts0, const float *homo,
+                                                       const float *matched_2d, const SageCamera *cam, float eps,
+                                                       float loss_param, float weight, int N)
+{
+  return reproj_common(ws, true, true, AtA_dev, Atb_dev, error_host, num_inliers_host, R, t, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, sampled_dpts0, homo, matched_2d, 1.f, cam, eps,
+                       loss_param, weight, N, 16);
+}
+
+extern "C" int sage_tracker_reproj_error_calculate(SageWorkspace *ws, float *error_host, float *num_inliers_host,
+                                                   const float *R, const float *t, const float *sampled_dpts0,
+                                                   const float *homo, const float *matched_2d, const SageCamera *cam,
+                                                   float eps, float loss_param, float weight, int N)
+{
+  return reproj_common(ws, true, false, nullptr, nullptr, error_host, num_inliers_host, R, t, nullptr, nullptr, nullptr,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, sampled_dpts0, homo, matched_2d, 1.f, cam, eps,
+                       loss_param, weight, N, 16);
+}
+
 extern "C" int sage_valid_locations(SageWorkspace *ws, const float *mask_dev, const SageCamera *cam,
                                     int64_t *loc1d_dev, float *homo_dev, int *n_valid_host)
 {

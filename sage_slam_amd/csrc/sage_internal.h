@@ -157,6 +157,12 @@ hipError_t launch_presample_source(hipStream_t s, float *f0s, const float *feat_
 hipError_t launch_repack_groups(hipStream_t s, float *dst, const float *src, int C, int P);
 hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev, int K, int H, int W);
 hipError_t launch_stats_finalize(hipStream_t s, const LaunchCommon &lc, float *stats, float fallback, float scale);
+size_t reproj_scratch_floats(int N, int D);
+hipError_t launch_reproj(hipStream_t s, int CS, bool tracker, bool jac, const float *R10, const float *t10, const float *R0,
+                         const float *t0, const float *R1, const float *t1, const float *bias0, const float *basis0,
+                         const float *code0, const int32_t *loc, const float *dpts0, const float *homo,
+                         const float *matched, float scale0, const SageCamera &cam, float eps, float loss_param,
+                         float weight, int N, float *scratch, float *AtA, float *Atb, float *stats);
 hipError_t launch_valid_locations(hipStream_t s, const float *mask, const SageCamera &cam, long long *loc1d, float *homo,
                                   int *n_out_dev);
 hipError_t launch_gather_locations(hipStream_t s, const long long *vloc, const float *vhomo, const long long *index_dev,

@@ -478,3 +478,70 @@ def test_valid_locations_and_seeded_sampling(capi, orc):
             assert np.array_equal(sloc.cpu().numpy(), oloc[perm])
             assert np.array_equal(shomo.cpu().numpy(), ohomo[perm])
     ws.close()
+
+
+@pytest.mark.parametrize("CS,N", [(32, 300), (16, 129), (32, 1)])
+def test_reprojection_factor_parity(capi, orc, CS, N):
+    """f3 sparse reprojection factor (fair loss), mapper (D = 13+CS) and tracker (D = 6) variants, linearize and
+    error-only, against the fp32 oracle: AtA/Atb rel-L2 <= 2e-5, error rel <= 1e-5, inlier counts exact; keypoints
+    behind the camera are excluded; no inliers -> 10*weight and zeros; N = 0."""
+    import torch
+    rng = np.random.default_rng(100 + N)
+    H, W = 64, 80
+    cam = capi.SageCamera(72.0, 70.5, 39.5, 31.5, float(W), float(H))
+    bias0 = (1.0 + 0.2 * rng.random(H * W)).astype(np.float32)
+    basis0 = (0.05 * rng.standard_normal((H * W, CS))).astype(np.float32)
+    code0 = (0.3 * rng.standard_normal(CS)).astype(np.float32); s0 = 1.1
+    ys = rng.integers(0, H, N); xs = rng.integers(0, W, N)
+    loc = (ys * W + xs).astype(np.int32)
+    homo = np.stack([(xs - cam.cx) / cam.fx, (ys - cam.cy) / cam.fy, np.ones(N)], 1).astype(np.float32)
+    R0 = synth.so3_exp(np.array([0.03, -0.05, 0.02])).astype(np.float32); t0 = np.array([0.02, -0.01, 0.03], np.float32)
+    R1 = synth.so3_exp(np.array([-0.02, 0.04, 0.06])).astype(np.float32); t1 = np.array([-0.04, 0.02, -0.03], np.float32)
+    R10 = (R1.T @ R0).astype(np.float32); t10 = (R1.T @ (t0 - t1)).astype(np.float32)
+    d0 = s0 * (bias0[loc] + basis0[loc] @ code0)
+    X = (R10 @ (d0[:, None] * homo).T).T + t10
+    matched = (np.stack([X[:, 0] / X[:, 2] * cam.fx + cam.cx, X[:, 1] / X[:, 2] * cam.fy + cam.cy], 1)
+               + rng.normal(0, 2.0, (N, 2))).astype(np.float32)
+    eps, c, wgt = 1e-4, 1.7, 0.4
+    ws = capi.Workspace()
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    cases = [("nominal", t10)]
+    if N > 1:
+        cases.append(("some_behind", t10))        # handled below by flipping a few depths through the bias
+        cases.append(("all_behind", (t10 - np.array([0, 0, 100.0])).astype(np.float32)))
+    for name, tt in cases:
+        b = bias0.copy()
+        if name == "some_behind":
+            b[loc[::3]] = -5.0                      # negative depth -> behind the camera
+        o = orc.reproj_jac_error(R10, tt, R0, t0, R1, t1, b, basis0, code0, loc, homo, matched, s0, cam, eps, c, wgt)
+        h = capi.reprojection_jac_error(ws, dv(R10), dv(tt), dv(R0), dv(t0), dv(R1), dv(t1), dv(b), dv(basis0),
+                                        dv(code0), dv(loc), dv(homo), dv(matched), s0, cam, eps, c, wgt, CS)
+        assert h["num_inliers"] == o["num_inliers"], name
+        assert h["error"] == pytest.approx(o["error"], rel=1e-5), name
+        if o["num_inliers"] > 0:
+            assert rel(h["AtA"].cpu().numpy(), o["AtA"]) < TOL_H and rel(h["Atb"].cpu().numpy(), o["Atb"]) < TOL_H, name
+            if name == "some_behind":
+                assert o["num_inliers"] < N
+        else:
+            assert not h["AtA"].cpu().numpy().any() and not h["Atb"].cpu().numpy().any()
+            assert h["error"] == pytest.approx(10 * wgt)
+        eo, no = orc.reproj_error(R10, tt, b, basis0, code0, loc, homo, matched, s0, cam, eps, c, wgt)
+        eh, nh = capi.reprojection_error(ws, dv(R10), dv(tt), dv(b), dv(basis0), dv(code0), dv(loc), dv(homo),
+                                         dv(matched), s0, cam, eps, c, wgt, CS)
+        assert nh == no and eh == pytest.approx(eo, rel=1e-5)
+        # tracker variant on the same points (depths handed over, relative pose only)
+        dd = (s0 * (b[loc] + basis0[loc] @ code0)).astype(np.float32)
+        ot = orc.tracker_reproj_jac_error(R10, tt, dd, homo, matched, cam, eps, c, wgt)
+        ht = capi.tracker_reproj_jac_error(ws, dv(R10), dv(tt), dv(dd), dv(homo), dv(matched), cam, eps, c, wgt)
+        assert ht["num_inliers"] == ot["num_inliers"] and ht["error"] == pytest.approx(ot["error"], rel=1e-5)
+        if ot["num_inliers"] > 0:
+            assert rel(ht["AtA"].cpu().numpy(), ot["AtA"]) < TOL_H and rel(ht["Atb"].cpu().numpy(), ot["Atb"]) < TOL_H
+        et, nt = capi.tracker_reproj_error(ws, dv(R10), dv(tt), dv(dd), dv(homo), dv(matched), cam, eps, c, wgt)
+        eot, not_ = orc.tracker_reproj_error(R10, tt, dd, homo, matched, cam, eps, c, wgt)
+        assert nt == not_ and et == pytest.approx(eot, rel=1e-5)
+    # N = 0: fallback values, no kernel over points
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    h0 = capi.reprojection_jac_error(ws, dv(R10), dv(t10), dv(R0), dv(t0), dv(R1), dv(t1), dv(bias0), dv(basis0),
+                                     dv(code0), z(1).int(), z(0, 3), z(0, 2), s0, cam, eps, c, wgt, CS)
+    assert h0["num_inliers"] == 0 and h0["error"] == pytest.approx(10 * wgt) and not h0["AtA"].cpu().numpy().any()
+    ws.close()

@@ -169,3 +169,83 @@ def test_zero_overlap_fallback(orc, scene):
     assert not o["AtA"].any() and not o["Atb"].any()
     g = geo_rows(orc, s, x, 0.03)
     assert g["num_inliers"] == 0 and g["error"] == pytest.approx(10.0) and not g["AtA"].any()
+
+
+def test_reprojection_factor_jacobian_and_reduction(orc):
+    """f3 reprojection factor (cuda/reprojection_factor_kernels.cpp:27-213, :468-531): the oracle's unweighted rows
+    (J / sqrt fair weight) against central differences of the projection  pi(T1^-1 T0 d x~)  written independently in
+    numpy, for both world-frame poses (left retraction), the code and the scale; the fair-loss weights / error against
+    their closed forms; AtA/Atb against the weighted rows; the no-inlier fallback; the tracker variant's 6-dof rows
+    against the mapper rows of an identity-reference configuration."""
+    rng = np.random.default_rng(12)
+    H, W, CS, N = 48, 64, 8, 37
+    cam = synth.Camera(58.0, 56.0, 31.3, 23.9, W, H)
+    bias0 = 1.0 + 0.1 * rng.random(H * W); basis0 = 0.05 * rng.standard_normal((H * W, CS))
+    code0 = 0.3 * rng.standard_normal(CS); s0 = 1.17
+    ys = rng.integers(4, H - 4, N); xs = rng.integers(4, W - 4, N)
+    loc = (ys * W + xs).astype(np.int32)
+    homo = np.stack([(xs - cam.cx) / cam.fx, (ys - cam.cy) / cam.fy, np.ones(N)], 1)
+    R0, t0 = rot([0.05, -0.08, 0.03]), np.array([0.02, -0.01, 0.03])
+    R1, t1 = rot([-0.04, 0.06, 0.09]), np.array([-0.05, 0.02, -0.04])
+    eps, c, wgt = 1e-4, 2.5, 0.7
+
+    def project(R0_, t0_, R1_, t1_, code_, s_):
+        d = s_ * (bias0[loc] + basis0[loc] @ code_)
+        Xw = (R0_ @ (d[:, None] * homo).T).T + t0_
+        X = (R1_.T @ (Xw - t1_).T).T
+        return np.stack([X[:, 0] / X[:, 2] * cam.fx + cam.cx, X[:, 1] / X[:, 2] * cam.fy + cam.cy], 1), X
+
+    p0, X = project(R0, t0, R1, t1, code0, s0)
+    matched = p0 + rng.normal(0, 1.5, p0.shape)
+    R10, t10 = R1.T @ R0, R1.T @ (t0 - t1)
+    o = orc.reproj_jac_error(R10, t10, R0, t0, R1, t1, bias0, basis0, code0, loc, homo, matched, s0, cam, eps, c, wgt,
+                             prec="f64", want_rows=True)
+    D = 13 + CS
+    # closed forms of the fair loss (:79-91)
+    diff = matched - p0
+    nrm = np.abs(diff) / np.sqrt(c)
+    assert np.allclose(o["sw"], np.sqrt(1.0 / (c * (1 + nrm))), rtol=1e-12)
+    assert np.isclose(o["error"], wgt * np.sum(2 * (nrm.sum(1) - np.log1p(nrm).sum(1))) / N, rtol=1e-12)
+    assert o["num_inliers"] == N
+    Ju = o["J"] / o["sw"][:, :, None]                       # unweighted d(proj)/d(theta)
+    # central differences of the projection
+    h = 1e-6
+    def fd(f):
+        return (f(+h) - f(-h)) / (2 * h)
+    for j in range(6):
+        e = np.zeros(6); e[j] = 1.0
+        g0 = fd(lambda s: project(*retract(R0, t0, s * e), R1, t1, code0, s0)[0])
+        g1 = fd(lambda s: project(R0, t0, *retract(R1, t1, s * e), code0, s0)[0])
+        assert np.allclose(Ju[:, :, j], g0, rtol=1e-6, atol=1e-7), j
+        assert np.allclose(Ju[:, :, 6 + j], g1, rtol=1e-6, atol=1e-7), j
+    for i in range(CS):
+        e = np.zeros(CS); e[i] = 1.0
+        assert np.allclose(Ju[:, :, 12 + i], fd(lambda s: project(R0, t0, R1, t1, code0 + s * e, s0)[0]), rtol=1e-6, atol=1e-8)
+    assert np.allclose(Ju[:, :, 12 + CS], fd(lambda s: project(R0, t0, R1, t1, code0, s0 + s)[0]), rtol=1e-6, atol=1e-8)
+    # reduction (:507-520)
+    Jw = o["J"].reshape(-1, D); rw = o["r"].reshape(-1)
+    assert np.allclose(o["AtA"], (wgt / N) * Jw.T @ Jw, rtol=1e-12, atol=1e-14)
+    assert np.allclose(o["Atb"], (wgt / N) * Jw.T @ rw, rtol=1e-12, atol=1e-14)
+    assert np.allclose(rw.reshape(-1, 2), o["sw"] * diff, rtol=1e-12)
+    e_only, n_only = orc.reproj_error(R10, t10, bias0, basis0, code0, loc, homo, matched, s0, cam, eps, c, wgt, prec="f64")
+    assert np.isclose(e_only, o["error"], rtol=1e-13) and n_only == N
+    # behind the camera: no inliers -> 10*weight, zeros (:522-527)
+    ob = orc.reproj_jac_error(R10, t10 - np.array([0, 0, 50.0]), R0, t0, R1, t1, bias0, basis0, code0, loc, homo, matched,
+                              s0, cam, eps, c, wgt, prec="f64")
+    assert ob["num_inliers"] == 0 and ob["error"] == pytest.approx(10 * wgt) and not ob["AtA"].any() and not ob["Atb"].any()
+    # tracker variant (:288-366): with T0 = identity the relative-pose rows are MINUS the pose-1 block's ... no: for a
+    # left perturbation of the relative pose T10 the rows equal d(proj)/d(T10); check against central differences
+    d0 = s0 * (bias0[loc] + basis0[loc] @ code0)
+    ot = orc.tracker_reproj_jac_error(R10, t10, d0, homo, matched, cam, eps, c, wgt, prec="f64")
+    def proj_rel(R_, t_):
+        Xr = (R_ @ (d0[:, None] * homo).T).T + t_
+        return np.stack([Xr[:, 0] / Xr[:, 2] * cam.fx + cam.cx, Xr[:, 1] / Xr[:, 2] * cam.fy + cam.cy], 1)
+    Jt = np.zeros((N, 2, 6))
+    for j in range(6):
+        e = np.zeros(6); e[j] = 1.0
+        Jt[:, :, j] = fd(lambda s: proj_rel(*retract(R10, t10, s * e)))
+    Jtw = (o["sw"][:, :, None] * Jt).reshape(-1, 6)
+    assert np.allclose(ot["AtA"], (wgt / N) * Jtw.T @ Jtw, rtol=1e-6, atol=1e-10)
+    assert np.allclose(ot["Atb"], (wgt / N) * Jtw.T @ rw, rtol=1e-6, atol=1e-10)
+    et, nt = orc.tracker_reproj_error(R10, t10, d0, homo, matched, cam, eps, c, wgt, prec="f64")
+    assert np.isclose(et, o["error"], rtol=1e-12) and nt == N
