@@ -340,6 +340,50 @@ int sage_tracker_reproj_error_calculate(SageWorkspace *ws, float *error_host, fl
                                         const float *matched_2d, const SageCamera *cam, float eps, float loss_param,
                                         float weight, int N);
 
+/* ---- f3 (second part): 3-D match-geometry factors ----------------------------------------------------------------
+ * Replaces cuda/match_geometry_factor_kernels.h:9-78 (reference: match_geometry_factor_kernels.cpp).  One entry point
+ * pair per reference function family; `loss` replaces the reference's robust_loss_type string:
+ *   sage_match_geometry_{jac_,}error_calculate  <- match_geometry_{jac_,}error_calculate<CS>   (:1674-1858, :1565-1672)
+ *        D = 14+2CS [pose0 pose1 code0 code1 scale0 scale1]; loss SAGE_LOSS_FAIR | _L2 | _HUBER | _UNBIASED
+ *   sage_loop_mg_{jac_,}error_calculate          <- loop_mg_{jac_,}error_calculate             (:1510-1563, :1475-1508)
+ *        D = 14 [pose0 pose1 scale0 scale1], unscaled depths of the matched points handed over, fair loss
+ *   sage_tracker_match_geom_jac_error_calculate  <- tracker_match_geom_jac_error_calculate     (:1388-1431)   D = 6
+ *        with_scale != 0: ..._with_scale (:1433-1473), D = 7 (relative pose, scale0)
+ *   sage_tracker_match_geom_error_calculate      <- tracker_match_geom_error_calculate         (:1352-1386)
+ * All point arrays have N rows (N >= 1: the reference's mean over zero keypoints is NaN; N < 1 is SAGE_E_INVALID);
+ * loc1d arrays are int32; error = weight * mean(per-keypoint loss); AtA/Atb device, error host (synchronises). */
+enum { SAGE_LOSS_FAIR = 0, SAGE_LOSS_L2 = 1, SAGE_LOSS_HUBER = 2, SAGE_LOSS_UNBIASED = 3 };
+int sage_match_geometry_jac_error_calculate(SageWorkspace *ws, float *AtA_dev, float *Atb_dev, float *error_host,
+                                            const float *R10, const float *t10, const float *R0, const float *t0,
+                                            const float *R1, const float *t1, const float *bias0, const float *bias1,
+                                            const float *basis0, const float *basis1, const float *code0,
+                                            const float *code1, const float *homo0, const float *matched_homo1,
+                                            const int32_t *loc1d_0, const int32_t *matched_loc1d_1, float scale0,
+                                            float scale1, float loss_param, float weight, int loss, int N, int CS);
+int sage_match_geometry_error_calculate(SageWorkspace *ws, float *error_host, const float *R10, const float *t10,
+                                        const float *bias0, const float *bias1, const float *basis0, const float *basis1,
+                                        const float *code0, const float *code1, const float *homo0,
+                                        const float *matched_homo1, const int32_t *loc1d_0,
+                                        const int32_t *matched_loc1d_1, float scale0, float scale1, float loss_param,
+                                        float weight, int loss, int N, int CS);
+int sage_loop_mg_jac_error_calculate(SageWorkspace *ws, float *AtA_dev, float *Atb_dev, float *error_host,
+                                     const float *R10, const float *t10, const float *R0, const float *t0,
+                                     const float *R1, const float *t1, const float *unscaled_dpts0,
+                                     const float *matched_unscaled_dpts1, const float *homo0, const float *matched_homo1,
+                                     float scale0, float scale1, float loss_param, float weight, int N);
+int sage_loop_mg_error_calculate(SageWorkspace *ws, float *error_host, const float *R10, const float *t10,
+                                 const float *unscaled_dpts0, const float *matched_unscaled_dpts1, const float *homo0,
+                                 const float *matched_homo1, float scale0, float scale1, float loss_param, float weight,
+                                 int N);
+int sage_tracker_match_geom_jac_error_calculate(SageWorkspace *ws, float *AtA_dev, float *Atb_dev, float *error_host,
+                                                const float *R, const float *t, const float *sampled_dpts0,
+                                                const float *matched_dpts1, const float *homo0,
+                                                const float *matched_homo1, float scale0, float loss_param,
+                                                float weight, int with_scale, int N);
+int sage_tracker_match_geom_error_calculate(SageWorkspace *ws, float *error_host, const float *R, const float *t,
+                                            const float *sampled_dpts0, const float *matched_dpts1, const float *homo0,
+                                            const float *matched_homo1, float loss_param, float weight, int N);
+
 /* ---- f1 producers: valid-pixel enumeration and seeded keyframe sampling ------------------------------------
  * sage_valid_locations: core/mapping/mapping_utils.h:254-287 (GenerateValidLocations): flat indices of mask > 0.5 in
  *   ascending order and their normalised homogeneous coordinates ((x-u0)/fx, (y-v0)/fy, 1).  Outputs are device

@@ -338,3 +338,50 @@ def tracker_reproj_error(R, t, dpts0, homo, matched, cam, eps, loss_param, weigh
     e = fn(_p(_arr(R, dt)), _p(_arr(t, dt)), _p(_arr(dpts0, dt)), _p(homo), _p(_arr(matched, dt)), _p(_cams([cam], dt)),
            C.c_int(N), ct(eps), ct(loss_param), ct(weight), _p(nin))
     return float(e), float(nin[0])
+
+
+MG_LOSS = {"fair": 0, "L2": 1, "huber": 2, "unbiased": 3}
+
+
+def match_geom_jac_error(mode, loss, R10, t10, R0=None, t0=None, R1=None, t1=None, bias0=None, bias1=None, basis0=None,
+                         basis1=None, code0=None, code1=None, dpts0=None, dpts1=None, homo0=None, homo1=None, loc0=None,
+                         loc1=None, scale0=1.0, scale1=1.0, loss_param=1.0, weight=1.0, CS=0, prec="f32",
+                         want_rows=False):
+    """cuda/match_geometry_factor_kernels.cpp, all variants (see sage_oracle.h).  mode 0 mapper / 1 loop / 2 tracker /
+    3 tracker with scale; loss "fair" | "L2" | "huber" | "unbiased"."""
+    dt, ct, sfx = _dt(prec)
+    homo0 = _arr(homo0, dt); N = homo0.shape[0]
+    if mode == 0:
+        CS = np.asarray(basis0).shape[-1]
+    D = {0: 14 + 2 * CS, 1: 14, 2: 6, 3: 7}[mode]
+    a = lambda x: None if x is None else _arr(x, dt)
+    ai = lambda x: None if x is None else _arr(x, np.int32)
+    AtA = np.zeros((D, D), dt); Atb = np.zeros(D, dt); err = np.zeros(1, dt)
+    J = np.zeros((N, 3, D), dt) if want_rows else None
+    r = np.zeros((N, 3), dt) if want_rows else None
+    sw = np.zeros((N, 3), dt) if want_rows else None
+    keep = [a(R10), a(t10), a(R0), a(t0), a(R1), a(t1), a(bias0), a(bias1), a(basis0), a(basis1), a(code0), a(code1),
+            a(dpts0), a(dpts1), homo0, a(homo1), ai(loc0), ai(loc1)]
+    getattr(lib(), "orc_match_geom_jac_error" + sfx)(
+        _p(AtA), _p(Atb), _p(err), C.c_int(mode), C.c_int(MG_LOSS[loss]), *[_p(k) for k in keep], ct(scale0), ct(scale1),
+        C.c_int(N), C.c_int(CS), ct(loss_param), ct(weight), _p(J), _p(r), _p(sw))
+    out = dict(AtA=AtA, Atb=Atb, error=float(err[0]))
+    if want_rows:
+        out.update(J=J, r=r, sw=sw)
+    return out
+
+
+def match_geom_error(mode, loss, R10, t10, bias0=None, bias1=None, basis0=None, basis1=None, code0=None, code1=None,
+                     dpts0=None, dpts1=None, homo0=None, homo1=None, loc0=None, loc1=None, scale0=1.0, scale1=1.0,
+                     loss_param=1.0, weight=1.0, CS=0, prec="f32"):
+    dt, ct, sfx = _dt(prec)
+    homo0 = _arr(homo0, dt); N = homo0.shape[0]
+    if mode == 0:
+        CS = np.asarray(basis0).shape[-1]
+    a = lambda x: None if x is None else _arr(x, dt)
+    ai = lambda x: None if x is None else _arr(x, np.int32)
+    keep = [a(R10), a(t10), a(bias0), a(bias1), a(basis0), a(basis1), a(code0), a(code1), a(dpts0), a(dpts1), homo0,
+            a(homo1), ai(loc0), ai(loc1)]
+    fn = getattr(lib(), "orc_match_geom_error" + sfx); fn.restype = ct
+    return float(fn(C.c_int(mode), C.c_int(MG_LOSS[loss]), *[_p(k) for k in keep], ct(scale0), ct(scale1), C.c_int(N),
+                    C.c_int(CS), ct(loss_param), ct(weight)))

@@ -1228,3 +1228,214 @@ REAL ORC(tracker_reproj_error)(const REAL *R, const REAL *t, const REAL *dpts0, 
     *num_inliers = (REAL)n_in;
   return n_in > 0 ? (REAL)((double)weight * se / n_in) : weight * 10;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * f3: match-geometry factors, cuda/match_geometry_factor_kernels.cpp
+ * ------------------------------------------------------------------------------------------------ */
+static int mg_dim(int mode, int CS) { return mode == 0 ? 14 + 2 * CS : (mode == 1 ? 14 : (mode == 2 ? 6 : 7)); }
+
+/* depths of the two matched points and the (possibly rescaled) scale pair (:601-616, unbiased :429-447, loop :303-304) */
+static void mg_depths(int mode, int loss, int idx, const REAL *bias0, const REAL *bias1, const REAL *basis0,
+                      const REAL *basis1, const REAL *code0, const REAL *code1, const REAL *dpts0, const REAL *dpts1,
+                      const int32_t *loc0, const int32_t *loc1, REAL scale0, REAL scale1, int CS, REAL *d0, REAL *d1)
+{
+  if (mode == 0)
+  {
+    REAL a0 = bias0[loc0[idx]], a1 = bias1[loc1[idx]];
+    for (int i = 0; i < CS; ++i)
+      a0 += basis0[(size_t)loc0[idx] * CS + i] * code0[i];
+    for (int i = 0; i < CS; ++i)
+      a1 += basis1[(size_t)loc1[idx] * CS + i] * code1[i];
+    if (loss == 3)
+    {
+      const REAL ss = scale0 + scale1;
+      *d0 = a0 * scale0 / ss;
+      *d1 = a1 * scale1 / ss;
+    }
+    else
+    {
+      *d0 = a0 * scale0;
+      *d1 = a1 * scale1;
+    }
+  }
+  else if (mode == 1)
+  {
+    *d0 = dpts0[idx] * scale0;
+    *d1 = dpts1[idx] * scale1;
+  }
+  else
+  {
+    *d0 = dpts0[idx];
+    *d1 = dpts1[idx];
+  }
+}
+
+/* per-component error and sqrt weights of the loss (fair :640-656, L2 :792-797, huber :935-962) */
+static REAL mg_loss(int loss, const REAL diff[3], REAL loss_param, REAL sw[3])
+{
+  if (loss == 1)
+  {
+    sw[0] = sw[1] = sw[2] = 1;
+    return diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
+  }
+  if (loss == 2)
+  {
+    REAL e = 0;
+    for (int i = 0; i < 3; ++i)
+    {
+      const REAL sq = diff[i] * diff[i];
+      e += (sq <= loss_param) ? sq : (REAL)(2.0 * sqrt((double)(loss_param * sq)) - (double)loss_param);
+      const REAL q = (REAL)sqrt((double)(loss_param / sq));
+      sw[i] = q < 1 ? q : 1; /* min(1.0f, sqrt(c / sq)); sq == 0 -> inf -> 1 */
+    }
+    return e;
+  }
+  const REAL sl = (REAL)sqrt((double)loss_param);
+  REAL e = 0;
+  for (int i = 0; i < 3; ++i)
+  {
+    const REAL n = (REAL)fabs((double)diff[i]) / sl;
+    e += n - (REAL)log(1.0 + (double)n);
+    sw[i] = (REAL)sqrt(1.0 / (double)(loss_param * (1 + n)));
+  }
+  return 2 * e;
+}
+
+void ORC(match_geom_jac_error)(REAL *AtA, REAL *Atb, REAL *error, int mode, int loss,
+                               const REAL *R10, const REAL *t10, const REAL *R0, const REAL *t0, const REAL *R1,
+                               const REAL *t1, const REAL *bias0, const REAL *bias1, const REAL *basis0,
+                               const REAL *basis1, const REAL *code0, const REAL *code1, const REAL *dpts0,
+                               const REAL *dpts1, const REAL *homo0, const REAL *homo1, const int32_t *loc0,
+                               const int32_t *loc1, REAL scale0, REAL scale1, int N, int CS, REAL loss_param,
+                               REAL weight, REAL *J_out, REAL *r_out, REAL *sw_out)
+{
+  const int D = mg_dim(mode, CS);
+  REAL *J = J_out ? J_out : (REAL *)malloc((size_t)N * 3 * D * sizeof(REAL));
+  REAL *r = r_out ? r_out : (REAL *)malloc((size_t)N * 3 * sizeof(REAL));
+  double se = 0;
+  const REAL ss = scale0 + scale1;
+  for (int idx = 0; idx < N; ++idx)
+  {
+    const REAL *h0 = homo0 + (size_t)idx * 3, *h1 = homo1 + (size_t)idx * 3;
+    REAL d0, d1;
+    mg_depths(mode, loss, idx, bias0, bias1, basis0, basis1, code0, code1, dpts0, dpts1, loc0, loc1, scale0, scale1, CS,
+              &d0, &d1);
+    REAL rh[3], X[3], diff[3], sw[3];
+    for (int i = 0; i < 3; ++i)
+      rh[i] = R10[i * 3 + 0] * h0[0] + R10[i * 3 + 1] * h0[1] + R10[i * 3 + 2] * h0[2];
+    for (int i = 0; i < 3; ++i)
+    {
+      X[i] = d0 * rh[i] + t10[i];
+      diff[i] = d1 * h1[i] - X[i];
+    }
+    se += mg_loss(loss, diff, loss_param, sw);
+    REAL dX0[3][6];
+    if (mode <= 1)
+    {
+      REAL Xw[3];
+      for (int i = 0; i < 3; ++i)
+        Xw[i] = d0 * (R0[i * 3 + 0] * h0[0] + R0[i * 3 + 1] * h0[1] + R0[i * 3 + 2] * h0[2]) + t0[i];
+      const REAL E[3][6] = {{1, 0, 0, 0, Xw[2], -Xw[1]}, {0, 1, 0, -Xw[2], 0, Xw[0]}, {0, 0, 1, Xw[1], -Xw[0], 0}};
+      for (int i = 0; i < 3; ++i) /* :694-705 */
+        for (int j = 0; j < 6; ++j)
+          dX0[i][j] = R1[0 * 3 + i] * E[0][j] + R1[1 * 3 + i] * E[1][j] + R1[2 * 3 + i] * E[2][j];
+    }
+    else
+    {
+      const REAL E[3][6] = {{1, 0, 0, 0, X[2], -X[1]}, {0, 1, 0, -X[2], 0, X[0]}, {0, 0, 1, X[1], -X[0], 0}}; /* :197-199 */
+      for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 6; ++j)
+          dX0[i][j] = E[i][j];
+    }
+    for (int i = 0; i < 3; ++i)
+    {
+      REAL *row = J + ((size_t)idx * 3 + i) * D;
+      for (int j = 0; j < 6; ++j)
+        row[j] = sw[i] * dX0[i][j];
+      if (mode <= 1)
+      {
+        /* pose 1: -R1^T E(Xw), written out in the reference (:673-683) */
+        for (int j = 0; j < 6; ++j)
+          row[6 + j] = sw[i] * (-dX0[i][j]);
+      }
+      if (mode == 0)
+      {
+        const REAL *b0 = basis0 + (size_t)loc0[idx] * CS, *b1 = basis1 + (size_t)loc1[idx] * CS;
+        if (loss == 3)
+        {
+          for (int j = 0; j < CS; ++j)
+          {
+            row[12 + j] = sw[i] * (rh[i] * b0[j] * scale0 / ss);       /* :560-563 */
+            row[12 + CS + j] = sw[i] * (-h1[i] * b1[j] * scale1 / ss);
+          }
+          row[12 + 2 * CS] = sw[i] * (rh[i] * d0 * scale1 / (scale0 * ss) + h1[i] * d1 / ss);  /* :566-569 */
+          row[13 + 2 * CS] = sw[i] * (-rh[i] * d0 / ss - h1[i] * d1 * scale0 / (scale1 * ss));
+        }
+        else
+        {
+          for (int j = 0; j < CS; ++j)
+          {
+            row[12 + j] = sw[i] * (rh[i] * scale0 * b0[j]);            /* :716-719 */
+            row[12 + CS + j] = sw[i] * (-h1[i] * scale1 * b1[j]);
+          }
+          row[12 + 2 * CS] = sw[i] * (rh[i] * d0 / scale0);            /* :722-723 */
+          row[13 + 2 * CS] = sw[i] * (-h1[i] * d1 / scale1);
+        }
+      }
+      else if (mode == 1)
+      {
+        row[12] = sw[i] * (rh[i] * dpts0[idx]);                        /* :398-399 */
+        row[13] = sw[i] * (-h1[i] * dpts1[idx]);
+      }
+      else if (mode == 3)
+        row[6] = sw[i] * (rh[i] * dpts0[idx] / scale0);                /* :278 */
+      r[(size_t)idx * 3 + i] = sw[i] * diff[i];
+      if (sw_out)
+        sw_out[(size_t)idx * 3 + i] = sw[i];
+    }
+  }
+  const double sc = (double)weight / (double)N;
+  *error = (REAL)(sc * se);
+  for (int a = 0; a < D; ++a)
+  {
+    for (int b = 0; b < D; ++b)
+    {
+      double acc = 0;
+      for (int k = 0; k < 3 * N; ++k)
+        acc += (double)J[(size_t)k * D + a] * (double)J[(size_t)k * D + b];
+      AtA[a * D + b] = (REAL)(sc * acc);
+    }
+    double accb = 0;
+    for (int k = 0; k < 3 * N; ++k)
+      accb += (double)J[(size_t)k * D + a] * (double)r[k];
+    Atb[a] = (REAL)(sc * accb);
+  }
+  if (!J_out)
+    free(J);
+  if (!r_out)
+    free(r);
+}
+
+REAL ORC(match_geom_error)(int mode, int loss, const REAL *R10, const REAL *t10, const REAL *bias0, const REAL *bias1,
+                           const REAL *basis0, const REAL *basis1, const REAL *code0, const REAL *code1,
+                           const REAL *dpts0, const REAL *dpts1, const REAL *homo0, const REAL *homo1,
+                           const int32_t *loc0, const int32_t *loc1, REAL scale0, REAL scale1, int N, int CS,
+                           REAL loss_param, REAL weight)
+{
+  double se = 0;
+  for (int idx = 0; idx < N; ++idx)
+  {
+    const REAL *h0 = homo0 + (size_t)idx * 3, *h1 = homo1 + (size_t)idx * 3;
+    REAL d0, d1;
+    mg_depths(mode, loss, idx, bias0, bias1, basis0, basis1, code0, code1, dpts0, dpts1, loc0, loc1, scale0, scale1, CS,
+              &d0, &d1);
+    REAL diff[3], sw[3];
+    for (int i = 0; i < 3; ++i)
+    {
+      const REAL X = d0 * (R10[i * 3 + 0] * h0[0] + R10[i * 3 + 1] * h0[1] + R10[i * 3 + 2] * h0[2]) + t10[i];
+      diff[i] = d1 * h1[i] - X;
+    }
+    se += mg_loss(loss, diff, loss_param, sw);
+  }
+  return (REAL)((double)weight * se / (double)N);
+}

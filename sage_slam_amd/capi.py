@@ -95,6 +95,9 @@ SYMBOLS = [
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
+    "sage_match_geometry_jac_error_calculate", "sage_match_geometry_error_calculate",
+    "sage_loop_mg_jac_error_calculate", "sage_loop_mg_error_calculate",
+    "sage_tracker_match_geom_jac_error_calculate", "sage_tracker_match_geom_error_calculate",
 ]
 
 
@@ -697,3 +700,61 @@ def tracker_reproj_error(ws, R, t, dpts0, homo, matched, cam, eps, loss_param, w
         ws.h, C.byref(e), C.byref(n), _dptr(R), _dptr(t), _dptr(dpts0), _dptr(homo), _dptr(matched), C.byref(cam),
         C.c_float(eps), C.c_float(loss_param), C.c_float(weight), N), "sage_tracker_reproj_error_calculate")
     return e.value, n.value
+
+
+MG_LOSS = {"fair": 0, "L2": 1, "huber": 2, "unbiased": 3}
+
+
+def match_geometry(ws, loss, jac, R10, t10, R0, t0, R1, t1, bias0, bias1, basis0, basis1, code0, code1, homo0, homo1,
+                   loc0, loc1, scale0, scale1, loss_param, weight, CS):
+    """Mapper match-geometry factor; cuda tensors in, dict(AtA, Atb, error) or the error out."""
+    import torch
+    N = int(homo0.shape[0]); D = 14 + 2 * CS
+    e = C.c_float()
+    if jac:
+        AtA = torch.zeros(D, D, device="cuda"); Atb = torch.zeros(D, device="cuda")
+        _chk(lib().sage_match_geometry_jac_error_calculate(
+            ws.h, _dptr(AtA), _dptr(Atb), C.byref(e), _dptr(R10), _dptr(t10), _dptr(R0), _dptr(t0), _dptr(R1), _dptr(t1),
+            _dptr(bias0), _dptr(bias1), _dptr(basis0), _dptr(basis1), _dptr(code0), _dptr(code1), _dptr(homo0),
+            _dptr(homo1), _dptr(loc0), _dptr(loc1), C.c_float(scale0), C.c_float(scale1), C.c_float(loss_param),
+            C.c_float(weight), MG_LOSS[loss], N, CS), "sage_match_geometry_jac_error_calculate")
+        return dict(AtA=AtA, Atb=Atb, error=e.value)
+    _chk(lib().sage_match_geometry_error_calculate(
+        ws.h, C.byref(e), _dptr(R10), _dptr(t10), _dptr(bias0), _dptr(bias1), _dptr(basis0), _dptr(basis1), _dptr(code0),
+        _dptr(code1), _dptr(homo0), _dptr(homo1), _dptr(loc0), _dptr(loc1), C.c_float(scale0), C.c_float(scale1),
+        C.c_float(loss_param), C.c_float(weight), MG_LOSS[loss], N, CS), "sage_match_geometry_error_calculate")
+    return e.value
+
+
+def loop_mg(ws, jac, R10, t10, R0, t0, R1, t1, udpts0, udpts1, homo0, homo1, scale0, scale1, loss_param, weight):
+    import torch
+    N = int(homo0.shape[0])
+    e = C.c_float()
+    if jac:
+        AtA = torch.zeros(14, 14, device="cuda"); Atb = torch.zeros(14, device="cuda")
+        _chk(lib().sage_loop_mg_jac_error_calculate(
+            ws.h, _dptr(AtA), _dptr(Atb), C.byref(e), _dptr(R10), _dptr(t10), _dptr(R0), _dptr(t0), _dptr(R1), _dptr(t1),
+            _dptr(udpts0), _dptr(udpts1), _dptr(homo0), _dptr(homo1), C.c_float(scale0), C.c_float(scale1),
+            C.c_float(loss_param), C.c_float(weight), N), "sage_loop_mg_jac_error_calculate")
+        return dict(AtA=AtA, Atb=Atb, error=e.value)
+    _chk(lib().sage_loop_mg_error_calculate(
+        ws.h, C.byref(e), _dptr(R10), _dptr(t10), _dptr(udpts0), _dptr(udpts1), _dptr(homo0), _dptr(homo1),
+        C.c_float(scale0), C.c_float(scale1), C.c_float(loss_param), C.c_float(weight), N), "sage_loop_mg_error_calculate")
+    return e.value
+
+
+def tracker_match_geom(ws, jac, with_scale, R, t, dpts0, dpts1, homo0, homo1, scale0, loss_param, weight):
+    import torch
+    N = int(homo0.shape[0]); D = 7 if with_scale else 6
+    e = C.c_float()
+    if jac:
+        AtA = torch.zeros(D, D, device="cuda"); Atb = torch.zeros(D, device="cuda")
+        _chk(lib().sage_tracker_match_geom_jac_error_calculate(
+            ws.h, _dptr(AtA), _dptr(Atb), C.byref(e), _dptr(R), _dptr(t), _dptr(dpts0), _dptr(dpts1), _dptr(homo0),
+            _dptr(homo1), C.c_float(scale0), C.c_float(loss_param), C.c_float(weight), int(with_scale), N),
+            "sage_tracker_match_geom_jac_error_calculate")
+        return dict(AtA=AtA, Atb=Atb, error=e.value)
+    _chk(lib().sage_tracker_match_geom_error_calculate(
+        ws.h, C.byref(e), _dptr(R), _dptr(t), _dptr(dpts0), _dptr(dpts1), _dptr(homo0), _dptr(homo1),
+        C.c_float(loss_param), C.c_float(weight), N), "sage_tracker_match_geom_error_calculate")
+    return e.value

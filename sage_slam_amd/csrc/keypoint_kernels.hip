@@ -1,4 +1,5 @@
-// reproj_kernels.hip -- sparse reprojection factor (fair loss) for matched keypoints, mapper and tracker variants.
+// keypoint_kernels.hip -- the sparse matched-keypoint factors: reprojection (fair loss) and 3-D match geometry
+// (fair / L2 / huber / "unbiased"), mapper, loop and tracker variants.
 //
 // Replaces cuda/reprojection_factor_kernels.cpp of the reference: kernels :27-213 / :215-286 (mapper factor,
 // D = 13+CS, [pose0 pose1 code0 scale0]) and :288-366 / :367-415 (tracker, D = 6), hosts :417-628.
@@ -6,6 +7,7 @@
 // once (2N x (D+1) floats, the residual is the last column) and contracted by D workgroups in double -- two launches
 // per call, nothing clever.  Same conventions as the dense factors: world-frame left-perturbation Jacobians,
 // P_pose1 = -P_pose0, weight/num_inliers normalisation, 10*weight fallback without inliers.
+// Second half of the file: cuda/match_geometry_factor_kernels.cpp (13 kernels there, one templated kernel here).
 #include "sage_device.h"
 #include "sage_internal.h"
 
@@ -121,15 +123,15 @@ __global__ __launch_bounds__(256) void reproj_rows_kernel(const ReprojParams p)
 }
 
 // workgroup a: AtA[a][:] and Atb[a] = (weight/n) sum_rows J[row][a] * [J[row][:] | r[row]] in double; workgroup 0 also
-// writes stats = {error, num_inliers}.  D+1 <= 64 columns x 4 row groups per workgroup.
+// writes stats = {error, num_inliers}.  D+1 <= 128 columns x 2 row groups per workgroup (D <= 14+2*32 = 78).
 __global__ __launch_bounds__(256) void reproj_reduce_kernel(const float *__restrict__ rows, const float *__restrict__ serr,
                                                             const float *__restrict__ sval, int N, int D, float weight,
                                                             float *__restrict__ AtA, float *__restrict__ Atb,
-                                                            float *__restrict__ stats)
+                                                            float *__restrict__ stats, int rows_per_point)
 {
-  __shared__ double s_acc[4][64];
+  __shared__ double s_acc[2][128];
   __shared__ double s_n[256], s_e[256];
-  const int a = blockIdx.x, tid = threadIdx.x, j = tid & 63, grp = tid >> 6;
+  const int a = blockIdx.x, tid = threadIdx.x, j = tid & 127, grp = tid >> 7;
   double n_in = 0.0, se = 0.0;
   for (int i = tid; i < N; i += 256)
   {
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void reproj_reduce_kernel(const float *__restr
   s_e[tid] = se;
   double acc = 0.0;
   if (j <= D)
-    for (int k = grp; k < 2 * N; k += 4)
+    for (int k = grp; k < rows_per_point * N; k += 2)
       acc += (double)rows[(size_t)k * (D + 1) + a] * (double)rows[(size_t)k * (D + 1) + j];
   s_acc[grp][j] = acc;
   __syncthreads();
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(256) void reproj_reduce_kernel(const float *__restr
   const double sc = ninl > 0.0 ? (double)weight / ninl : 0.0;
   if (tid <= D)
   {
-    const double v = sc * ((s_acc[0][tid] + s_acc[1][tid]) + (s_acc[2][tid] + s_acc[3][tid]));
+    const double v = sc * (s_acc[0][tid] + s_acc[1][tid]);
     if (tid < D)
       AtA[(size_t)a * D + tid] = (float)v;
     else
@@ -217,7 +219,7 @@ static hipError_t reproj_impl(hipStream_t s, ReprojParams p, bool jac, float *sc
     if (grid > 0)
       hipLaunchKernelGGL((reproj_rows_kernel<CS, MODE, true>), dim3(grid), dim3(256), 0, s, p);
     hipLaunchKernelGGL(reproj_reduce_kernel, dim3(D), dim3(256), 0, s, p.rows, p.serr, p.sval, N, D, p.weight, AtA, Atb,
-                       stats);
+                       stats, 2);
   }
   else
   {
@@ -245,6 +247,234 @@ hipError_t launch_reproj(hipStream_t s, int CS, bool tracker, bool jac, const fl
   if (CS == 16)
     return reproj_impl<16, 0>(s, p, jac, scratch, AtA, Atb, stats);
   return hipErrorInvalidValue;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// match geometry: 3 residuals per matched keypoint, W (X1_matched - X0_in_1)
+//   MODE 0 mapper  D = 14+2CS [pose0 pose1 code0 code1 scale0 scale1]  (match_geometry_factor_kernels.cpp:421-1041)
+//   MODE 1 loop    D = 14     [pose0 pose1 scale0 scale1], unscaled depths handed over          (:296-419)
+//   MODE 2 tracker D = 6      relative pose                                                      (:136-213)
+//   MODE 3 tracker D = 7      relative pose + scale0                                             (:215-294)
+//   loss 0 fair, 1 L2, 2 huber, 3 unbiased (mapper only)
+// Normalisation: weight * mean over the N keypoints (hosts :1352-1858); every keypoint counts (sval = 1).
+// ------------------------------------------------------------------------------------------------
+struct MgParams
+{
+  const float *R10, *t10, *R0, *t0, *R1, *t1;
+  const float *bias0, *bias1, *basis0, *basis1, *code0, *code1; // MODE 0
+  const float *dpts0, *dpts1;                                   // MODE 1: unscaled; MODE 2/3: scaled
+  const float *homo0, *homo1;
+  const int32_t *loc0, *loc1;
+  float scale0, scale1, loss_param, weight;
+  int loss, N;
+  float *rows, *serr, *sval;
+};
+
+template <int CS, int MODE, bool JAC>
+__global__ __launch_bounds__(256) void mg_rows_kernel(const MgParams p)
+{
+  constexpr int D = MODE == 0 ? 14 + 2 * CS : (MODE == 1 ? 14 : (MODE == 2 ? 6 : 7));
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.N)
+    return;
+  const float h0[3] = {p.homo0[3 * idx + 0], p.homo0[3 * idx + 1], p.homo0[3 * idx + 2]};
+  const float h1[3] = {p.homo1[3 * idx + 0], p.homo1[3 * idx + 1], p.homo1[3 * idx + 2]};
+  const float ss = p.scale0 + p.scale1;
+  float d0, d1;
+  int l0 = 0, l1 = 0;
+  if (MODE == 0)
+  {
+    l0 = p.loc0[idx];
+    l1 = p.loc1[idx];
+    float a0 = p.bias0[l0], a1 = p.bias1[l1]; // :601-616
+    for (int i = 0; i < CS; ++i)
+      a0 += p.basis0[(size_t)l0 * CS + i] * p.code0[i];
+    for (int i = 0; i < CS; ++i)
+      a1 += p.basis1[(size_t)l1 * CS + i] * p.code1[i];
+    if (p.loss == 3) // :429-447
+    {
+      d0 = a0 * p.scale0 / ss;
+      d1 = a1 * p.scale1 / ss;
+    }
+    else
+    {
+      d0 = a0 * p.scale0;
+      d1 = a1 * p.scale1;
+    }
+  }
+  else if (MODE == 1)
+  {
+    d0 = p.dpts0[idx] * p.scale0; // :303-304
+    d1 = p.dpts1[idx] * p.scale1;
+  }
+  else
+  {
+    d0 = p.dpts0[idx];
+    d1 = p.dpts1[idx];
+  }
+  float rh[3], X[3], diff[3], sw[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+  {
+    rh[i] = p.R10[i * 3 + 0] * h0[0] + p.R10[i * 3 + 1] * h0[1] + p.R10[i * 3 + 2] * h0[2];
+    X[i] = d0 * rh[i] + p.t10[i];
+    diff[i] = d1 * h1[i] - X[i];
+  }
+  float err = 0.f;
+  if (p.loss == 1) // L2 (:792-797)
+  {
+    sw[0] = sw[1] = sw[2] = 1.f;
+    err = diff[0] * diff[0] + diff[1] * diff[1] + diff[2] * diff[2];
+  }
+  else if (p.loss == 2) // huber (:935-962)
+  {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+      const float sq = diff[i] * diff[i];
+      err += (sq <= p.loss_param) ? sq : (2.0f * sqrtf(p.loss_param * sq) - p.loss_param);
+      sw[i] = fminf(1.0f, sqrtf(p.loss_param / sq));
+    }
+  }
+  else // fair (:640-656), also the "unbiased" variant
+  {
+    const float sl = sqrtf(p.loss_param);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+    {
+      const float n = fabsf(diff[i]) / sl;
+      err += n - logf(1.0f + n);
+      sw[i] = sqrtf(1.0f / (p.loss_param * (1.0f + n)));
+    }
+    err *= 2.0f;
+  }
+  p.serr[idx] = err;
+  p.sval[idx] = 1.f;
+  if (!JAC)
+    return;
+  float dX[3][6];
+  if (MODE <= 1)
+  {
+    float Xw[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      Xw[i] = d0 * (p.R0[i * 3 + 0] * h0[0] + p.R0[i * 3 + 1] * h0[1] + p.R0[i * 3 + 2] * h0[2]) + p.t0[i];
+    Pose p1;
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      p1.R[i] = p.R1[i];
+    dX_dT0(p1, Xw, dX); // R1^T [I | -[Xw]x] (:694-705); pose 1 gets the negative (:673-683)
+  }
+  else
+  {
+    const float E[3][6] = {{1, 0, 0, 0, X[2], -X[1]}, {0, 1, 0, -X[2], 0, X[0]}, {0, 0, 1, X[1], -X[0], 0}}; // :197-199
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 6; ++j)
+        dX[i][j] = E[i][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+  {
+    float *row = p.rows + ((size_t)idx * 3 + i) * (D + 1);
+#pragma unroll
+    for (int j = 0; j < 6; ++j)
+    {
+      row[j] = sw[i] * dX[i][j];
+      if (MODE <= 1)
+        row[6 + j] = sw[i] * (-dX[i][j]);
+    }
+    if (MODE == 0)
+    {
+      const float *b0 = p.basis0 + (size_t)l0 * CS, *b1 = p.basis1 + (size_t)l1 * CS;
+      if (p.loss == 3)
+      {
+        for (int j = 0; j < CS; ++j)
+        {
+          row[12 + j] = sw[i] * (rh[i] * b0[j] * p.scale0 / ss); // :560-563
+          row[12 + CS + j] = sw[i] * (-h1[i] * b1[j] * p.scale1 / ss);
+        }
+        row[12 + 2 * CS] = sw[i] * (rh[i] * d0 * p.scale1 / (p.scale0 * ss) + h1[i] * d1 / ss); // :566-569
+        row[13 + 2 * CS] = sw[i] * (-rh[i] * d0 / ss - h1[i] * d1 * p.scale0 / (p.scale1 * ss));
+      }
+      else
+      {
+        for (int j = 0; j < CS; ++j)
+        {
+          row[12 + j] = sw[i] * (rh[i] * p.scale0 * b0[j]); // :716-719
+          row[12 + CS + j] = sw[i] * (-h1[i] * p.scale1 * b1[j]);
+        }
+        row[12 + 2 * CS] = sw[i] * (rh[i] * d0 / p.scale0); // :722-723
+        row[13 + 2 * CS] = sw[i] * (-h1[i] * d1 / p.scale1);
+      }
+    }
+    else if (MODE == 1)
+    {
+      row[12] = sw[i] * (rh[i] * p.dpts0[idx]); // :398-399
+      row[13] = sw[i] * (-h1[i] * p.dpts1[idx]);
+    }
+    else if (MODE == 3)
+      row[6] = sw[i] * (rh[i] * p.dpts0[idx] / p.scale0); // :278
+    row[D] = sw[i] * diff[i];
+  }
+}
+
+template <int CS, int MODE>
+static hipError_t mg_impl(hipStream_t s, MgParams p, bool jac, float *scratch, float *AtA, float *Atb, float *stats)
+{
+  constexpr int D = MODE == 0 ? 14 + 2 * CS : (MODE == 1 ? 14 : (MODE == 2 ? 6 : 7));
+  const int N = p.N;
+  p.rows = scratch;
+  p.serr = scratch + (size_t)3 * N * (D + 1);
+  p.sval = p.serr + N;
+  const int grid = (N + 255) / 256;
+  if (jac)
+  {
+    hipLaunchKernelGGL((mg_rows_kernel<CS, MODE, true>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(reproj_reduce_kernel, dim3(D), dim3(256), 0, s, p.rows, p.serr, p.sval, N, D, p.weight, AtA, Atb,
+                       stats, 3);
+  }
+  else
+  {
+    hipLaunchKernelGGL((mg_rows_kernel<CS, MODE, false>), dim3(grid), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(reproj_stats_kernel, dim3(1), dim3(256), 0, s, p.serr, p.sval, N, p.weight, stats);
+  }
+  return hipGetLastError();
+}
+
+size_t mg_scratch_floats(int N, int D) { return (size_t)3 * N * (D + 1) + (size_t)2 * N + 4; }
+
+hipError_t launch_match_geom(hipStream_t s, int mode, int loss, int CS, bool jac, const float *R10, const float *t10,
+                             const float *R0, const float *t0, const float *R1, const float *t1, const float *bias0,
+                             const float *bias1, const float *basis0, const float *basis1, const float *code0,
+                             const float *code1, const float *dpts0, const float *dpts1, const float *homo0,
+                             const float *homo1, const int32_t *loc0, const int32_t *loc1, float scale0, float scale1,
+                             float loss_param, float weight, int N, float *scratch, float *AtA, float *Atb, float *stats)
+{
+  MgParams p{};
+  p.R10 = R10; p.t10 = t10; p.R0 = R0; p.t0 = t0; p.R1 = R1; p.t1 = t1;
+  p.bias0 = bias0; p.bias1 = bias1; p.basis0 = basis0; p.basis1 = basis1; p.code0 = code0; p.code1 = code1;
+  p.dpts0 = dpts0; p.dpts1 = dpts1; p.homo0 = homo0; p.homo1 = homo1; p.loc0 = loc0; p.loc1 = loc1;
+  p.scale0 = scale0; p.scale1 = scale1; p.loss_param = loss_param; p.weight = weight; p.loss = loss; p.N = N;
+  switch (mode)
+  {
+  case 0:
+    if (CS == 32)
+      return mg_impl<32, 0>(s, p, jac, scratch, AtA, Atb, stats);
+    if (CS == 16)
+      return mg_impl<16, 0>(s, p, jac, scratch, AtA, Atb, stats);
+    return hipErrorInvalidValue;
+  case 1:
+    return mg_impl<16, 1>(s, p, jac, scratch, AtA, Atb, stats);
+  case 2:
+    return mg_impl<16, 2>(s, p, jac, scratch, AtA, Atb, stats);
+  case 3:
+    return mg_impl<16, 3>(s, p, jac, scratch, AtA, Atb, stats);
+  default:
+    return hipErrorInvalidValue;
+  }
 }
 
 } // namespace sage

@@ -483,6 +483,106 @@ extern "C" int sage_tracker_reproj_error_calculate(SageWorkspace *ws, float *err
                        loss_param, weight, N, 16);
 }
 
+// ---- match-geometry factors (keypoint_kernels.hip) ----
+static int mg_common(SageWorkspace *ws, int mode, int loss, bool jac, float *AtA, float *Atb, float *error_host,
+                     const float *R10, const float *t10, const float *R0, const float *t0, const float *R1,
+                     const float *t1, const float *bias0, const float *bias1, const float *basis0, const float *basis1,
+                     const float *code0, const float *code1, const float *dpts0, const float *dpts1, const float *homo0,
+                     const float *homo1, const int32_t *loc0, const int32_t *loc1, float scale0, float scale1,
+                     float loss_param, float weight, int N, int CS)
+{
+  if (!ws || N < 1 || !R10 || !t10 || !homo0 || !homo1 || (jac && (!AtA || !Atb)))
+    return SAGE_E_INVALID;
+  if (mode == 0 && (!bias0 || !bias1 || !basis0 || !basis1 || !code0 || !code1 || !loc0 || !loc1))
+    return SAGE_E_INVALID;
+  if (mode != 0 && (!dpts0 || !dpts1))
+    return SAGE_E_INVALID;
+  if (mode <= 1 && jac && (!R0 || !t0 || !R1 || !t1))
+    return SAGE_E_INVALID;
+  if (loss < 0 || loss > 3 || (loss == SAGE_LOSS_UNBIASED && mode != 0) || (mode != 0 && loss != SAGE_LOSS_FAIR))
+    return SAGE_E_INVALID;
+  if (mode == 0 && CS != 16 && CS != 32)
+    return SAGE_E_UNSUPPORTED;
+  const int D = mode == 0 ? 14 + 2 * CS : (mode == 1 ? 14 : (mode == 2 ? 6 : 7));
+  int rc;
+  if ((rc = ws->misc.reserve(mg_scratch_floats(N, D) * sizeof(float))) || (rc = ws->stats.reserve(4 * sizeof(float))))
+    return rc;
+  SAGE_HIP(launch_match_geom(ws->stream, mode, loss, CS, jac, R10, t10, R0, t0, R1, t1, bias0, bias1, basis0, basis1,
+                             code0, code1, dpts0, dpts1, homo0, homo1, loc0, loc1, scale0, scale1, loss_param, weight, N,
+                             ws->misc.as<float>(), AtA, Atb, ws->stats.as<float>()));
+  return ws_fetch_stats(ws, error_host, nullptr);
+}
+
+extern "C" int sage_match_geometry_jac_error_calculate(SageWorkspace *ws, float *AtA_dev, float *Atb_dev,
+                                                       float *error_host, const float *R10, const float *t10,
+                                                       const float *R0, const float *t0, const float *R1,
+                                                       const float *t1, const float *bias0, const float *bias1,
+                                                       const float *basis0, const float *basis1, const float *code0,
+                                                       const float *code1, const float *homo0,
+                                                       const float *matched_homo1, const int32_t *loc1d_0,
+                                                       const int32_t *matched_loc1d_1, float scale0, float scale1,
+                                                       float loss_param, float weight, int loss, int N, int CS)
+{
+  return mg_common(ws, 0, loss, true, AtA_dev, Atb_dev, error_host, R10, t10, R0, t0, R1, t1, bias0, bias1, basis0,
+                   basis1, code0, code1, nullptr, nullptr, homo0, matched_homo1, loc1d_0, matched_loc1d_1, scale0, scale1,
+                   loss_param, weight, N, CS);
+}
+
+extern "C" int sage_match_geometry_error_calculate(SageWorkspace *ws, float *error_host, const float *R10,
+                                                   const float *t10, const float *bias0, const float *bias1,
+                                                   const float *basis0, const float *basis1, const float *code0,
+                                                   const float *code1, const float *homo0, const float *matched_homo1,
+                                                   const int32_t *loc1d_0, const int32_t *matched_loc1d_1, float scale0,
+                                                   float scale1, float loss_param, float weight, int loss, int N, int CS)
+{
+  return mg_common(ws, 0, loss, false, nullptr, nullptr, error_host, R10, t10, nullptr, nullptr, nullptr, nullptr, bias0,
+                   bias1, basis0, basis1, code0, code1, nullptr, nullptr, homo0, matched_homo1, loc1d_0, matched_loc1d_1,
+                   scale0, scale1, loss_param, weight, N, CS);
+}
+
+extern "C" int sage_loop_mg_jac_error_calculate(SageWorkspace *ws, float *AtA_dev, float *Atb_dev, float *error_host,
+                                                const float *R10, const float *t10, const float *R0, const float *t0,
+                                                const float *R1, const float *t1, const float *unscaled_dpts0,
+                                                const float *matched_unscaled_dpts1, const float *homo0,
+                                                const float *matched_homo1, float scale0, float scale1, float loss_param,
+                                                float weight, int N)
+{
+  return mg_common(ws, 1, SAGE_LOSS_FAIR, true, AtA_dev, Atb_dev, error_host, R10, t10, R0, t0, R1, t1, nullptr, nullptr,
+                   nullptr, nullptr, nullptr, nullptr, unscaled_dpts0, matched_unscaled_dpts1, homo0, matched_homo1,
+                   nullptr, nullptr, scale0, scale1, loss_param, weight, N, 16);
+}
+
+extern "C" int sage_loop_mg_error_calculate(SageWorkspace *ws, float *error_host, const float *R10, const float *t10,
+                                            const float *unscaled_dpts0, const float *matched_unscaled_dpts1,
+                                            const float *homo0, const float *matched_homo1, float scale0, float scale1,
+                                            float loss_param, float weight, int N)
+{
+  return mg_common(ws, 1, SAGE_LOSS_FAIR, false, nullptr, nullptr, error_host, R10, t10, nullptr, nullptr, nullptr,
+                   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, unscaled_dpts0, matched_unscaled_dpts1,
+                   homo0, matched_homo1, nullptr, nullptr, scale0, scale1, loss_param, weight, N, 16);
+}
+
+extern "C" int sage_tracker_match_geom_jac_error_calculate(SageWorkspace *ws, float *AtA_dev, float *Atb_dev,
+                                                           float *error_host, const float *R, const float *t,
+                                                           const float *sampled_dpts0, const float *matched_dpts1,
+                                                           const float *homo0, const float *matched_homo1, float scale0,
+                                                           float loss_param, float weight, int with_scale, int N)
+{
+  return mg_common(ws, with_scale ? 3 : 2, SAGE_LOSS_FAIR, true, AtA_dev, Atb_dev, error_host, R, t, nullptr, nullptr,
+                   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sampled_dpts0, matched_dpts1,
+                   homo0, matched_homo1, nullptr, nullptr, scale0, 1.f, loss_param, weight, N, 16);
+}
+
+extern "C" int sage_tracker_match_geom_error_calculate(SageWorkspace *ws, float *error_host, const float *R,
+                                                       const float *t, const float *sampled_dpts0,
+                                                       const float *matched_dpts1, const float *homo0,
+                                                       const float *matched_homo1, float loss_param, float weight, int N)
+{
+  return mg_common(ws, 2, SAGE_LOSS_FAIR, false, nullptr, nullptr, error_host, R, t, nullptr, nullptr, nullptr, nullptr,
+                   nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, sampled_dpts0, matched_dpts1, homo0,
+                   matched_homo1, nullptr, nullptr, 1.f, 1.f, loss_param, weight, N, 16);
+}
+
 extern "C" int sage_valid_locations(SageWorkspace *ws, const float *mask_dev, const SageCamera *cam,
                                     int64_t *loc1d_dev, float *homo_dev, int *n_valid_host)
 {

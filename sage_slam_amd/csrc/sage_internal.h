@@ -163,6 +163,13 @@ hipError_t launch_reproj(hipStream_t s, int CS, bool tracker, bool jac, const fl
                          const float *code0, const int32_t *loc, const float *dpts0, const float *homo,
                          const float *matched, float scale0, const SageCamera &cam, float eps, float loss_param,
                          float weight, int N, float *scratch, float *AtA, float *Atb, float *stats);
+size_t mg_scratch_floats(int N, int D);
+hipError_t launch_match_geom(hipStream_t s, int mode, int loss, int CS, bool jac, const float *R10, const float *t10,
+                             const float *R0, const float *t0, const float *R1, const float *t1, const float *bias0,
+                             const float *bias1, const float *basis0, const float *basis1, const float *code0,
+                             const float *code1, const float *dpts0, const float *dpts1, const float *homo0,
+                             const float *homo1, const int32_t *loc0, const int32_t *loc1, float scale0, float scale1,
+                             float loss_param, float weight, int N, float *scratch, float *AtA, float *Atb, float *stats);
 hipError_t launch_valid_locations(hipStream_t s, const float *mask, const SageCamera &cam, long long *loc1d, float *homo,
                                   int *n_out_dev);
 hipError_t launch_gather_locations(hipStream_t s, const long long *vloc, const float *vhomo, const long long *index_dev,

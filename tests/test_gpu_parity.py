@@ -545,3 +545,79 @@ def test_reprojection_factor_parity(capi, orc, CS, N):
                                      dv(code0), z(1).int(), z(0, 3), z(0, 2), s0, cam, eps, c, wgt, CS)
     assert h0["num_inliers"] == 0 and h0["error"] == pytest.approx(10 * wgt) and not h0["AtA"].cpu().numpy().any()
     ws.close()
+
+
+@pytest.mark.parametrize("CS,N", [(32, 257), (16, 40)])
+def test_match_geometry_factor_family_parity(capi, orc, CS, N):
+    """f3 match-geometry factors against the fp32 oracle: mapper factor with the four losses (linearize + error), loop
+    factor, tracker (6-dof and 7-dof with scale, + error): AtA/Atb rel-L2 <= 2e-5, error rel <= 1e-5.  Includes an
+    exactly-zero difference component (huber weight min(1, sqrt(c/0)) = 1) and invalid-argument handling (N = 0)."""
+    import torch
+    rng = np.random.default_rng(300 + N)
+    HW = 2000
+    bias0 = (1.0 + 0.2 * rng.random(HW)).astype(np.float32); bias1 = (1.1 + 0.2 * rng.random(HW)).astype(np.float32)
+    basis0 = (0.05 * rng.standard_normal((HW, CS))).astype(np.float32)
+    basis1 = (0.05 * rng.standard_normal((HW, CS))).astype(np.float32)
+    code0 = (0.3 * rng.standard_normal(CS)).astype(np.float32); code1 = (0.3 * rng.standard_normal(CS)).astype(np.float32)
+    s0, s1 = 1.2, 0.9
+    loc0 = rng.integers(0, HW, N).astype(np.int32); loc1 = rng.integers(0, HW, N).astype(np.int32)
+    homo0 = np.concatenate([rng.uniform(-0.5, 0.5, (N, 2)), np.ones((N, 1))], 1).astype(np.float32)
+    homo1 = np.concatenate([rng.uniform(-0.5, 0.5, (N, 2)), np.ones((N, 1))], 1).astype(np.float32)
+    R0 = synth.so3_exp(np.array([0.03, -0.05, 0.02])).astype(np.float32); t0 = np.array([0.02, -0.01, 0.03], np.float32)
+    R1 = synth.so3_exp(np.array([-0.02, 0.04, 0.06])).astype(np.float32); t1 = np.array([-0.04, 0.02, -0.03], np.float32)
+    R10 = (R1.T @ R0).astype(np.float32); t10 = (R1.T @ (t0 - t1)).astype(np.float32)
+    c, wgt = 0.05, 0.8
+    ws = capi.Workspace()
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    for loss in ("fair", "L2", "huber", "unbiased"):
+        o = orc.match_geom_jac_error(0, loss, R10, t10, R0, t0, R1, t1, bias0, bias1, basis0, basis1, code0, code1,
+                                     homo0=homo0, homo1=homo1, loc0=loc0, loc1=loc1, scale0=s0, scale1=s1, loss_param=c,
+                                     weight=wgt)
+        h = capi.match_geometry(ws, loss, True, dv(R10), dv(t10), dv(R0), dv(t0), dv(R1), dv(t1), dv(bias0), dv(bias1),
+                                dv(basis0), dv(basis1), dv(code0), dv(code1), dv(homo0), dv(homo1), dv(loc0), dv(loc1),
+                                s0, s1, c, wgt, CS)
+        assert h["error"] == pytest.approx(o["error"], rel=1e-5), loss
+        assert rel(h["AtA"].cpu().numpy(), o["AtA"]) < TOL_H and rel(h["Atb"].cpu().numpy(), o["Atb"]) < TOL_H, loss
+        eo = orc.match_geom_error(0, loss, R10, t10, bias0, bias1, basis0, basis1, code0, code1, homo0=homo0, homo1=homo1,
+                                  loc0=loc0, loc1=loc1, scale0=s0, scale1=s1, loss_param=c, weight=wgt)
+        eh = capi.match_geometry(ws, loss, False, dv(R10), dv(t10), None, None, None, None, dv(bias0), dv(bias1),
+                                 dv(basis0), dv(basis1), dv(code0), dv(code1), dv(homo0), dv(homo1), dv(loc0), dv(loc1),
+                                 s0, s1, c, wgt, CS)
+        assert eh == pytest.approx(eo, rel=1e-5), loss
+    u0 = (bias0[loc0] + basis0[loc0] @ code0).astype(np.float32); u1 = (bias1[loc1] + basis1[loc1] @ code1).astype(np.float32)
+    ol = orc.match_geom_jac_error(1, "fair", R10, t10, R0, t0, R1, t1, dpts0=u0, dpts1=u1, homo0=homo0, homo1=homo1,
+                                  scale0=s0, scale1=s1, loss_param=c, weight=wgt)
+    hl = capi.loop_mg(ws, True, dv(R10), dv(t10), dv(R0), dv(t0), dv(R1), dv(t1), dv(u0), dv(u1), dv(homo0), dv(homo1),
+                      s0, s1, c, wgt)
+    assert hl["error"] == pytest.approx(ol["error"], rel=1e-5)
+    assert rel(hl["AtA"].cpu().numpy(), ol["AtA"]) < TOL_H and rel(hl["Atb"].cpu().numpy(), ol["Atb"]) < TOL_H
+    assert capi.loop_mg(ws, False, dv(R10), dv(t10), None, None, None, None, dv(u0), dv(u1), dv(homo0), dv(homo1), s0, s1,
+                        c, wgt) == pytest.approx(ol["error"], rel=1e-5)
+    d0 = (s0 * u0).astype(np.float32); d1 = (s1 * u1).astype(np.float32)
+    d1z = d1.copy(); homo1z = homo1.copy()
+    for mode, ws_flag in ((2, 0), (3, 1)):
+        ot = orc.match_geom_jac_error(mode, "fair", R10, t10, dpts0=d0, dpts1=d1z, homo0=homo0, homo1=homo1z, scale0=s0,
+                                      loss_param=c, weight=wgt)
+        ht = capi.tracker_match_geom(ws, True, ws_flag, dv(R10), dv(t10), dv(d0), dv(d1z), dv(homo0), dv(homo1z), s0, c, wgt)
+        assert ht["error"] == pytest.approx(ot["error"], rel=1e-5)
+        assert rel(ht["AtA"].cpu().numpy(), ot["AtA"]) < TOL_H and rel(ht["Atb"].cpu().numpy(), ot["Atb"]) < TOL_H
+    et = capi.tracker_match_geom(ws, False, 0, dv(R10), dv(t10), dv(d0), dv(d1), dv(homo0), dv(homo1), s0, c, wgt)
+    assert et == pytest.approx(orc.match_geom_error(2, "fair", R10, t10, dpts0=d0, dpts1=d1, homo0=homo0, homo1=homo1,
+                                                    loss_param=c, weight=wgt), rel=1e-5)
+    # huber with an exactly-zero difference component (x = 0 on both sides, identity pose): sqrt(c / 0) = inf must come
+    # out as weight 1, no NaN anywhere
+    I3 = np.eye(3, dtype=np.float32); z3 = np.zeros(3, np.float32)
+    hz0 = homo0.copy(); hz0[:, 0] = 0.0
+    hz1 = homo1.copy(); hz1[:, 0] = 0.0
+    oh = orc.match_geom_jac_error(0, "huber", I3, z3, I3, z3, I3, z3, bias0, bias1, basis0, basis1, code0, code1,
+                                  homo0=hz0, homo1=hz1, loc0=loc0, loc1=loc1, scale0=s0, scale1=s1, loss_param=c, weight=wgt)
+    hh = capi.match_geometry(ws, "huber", True, dv(I3), dv(z3), dv(I3), dv(z3), dv(I3), dv(z3), dv(bias0), dv(bias1),
+                             dv(basis0), dv(basis1), dv(code0), dv(code1), dv(hz0), dv(hz1), dv(loc0), dv(loc1),
+                             s0, s1, c, wgt, CS)
+    assert np.isfinite(hh["AtA"].cpu().numpy()).all() and np.isfinite(hh["Atb"].cpu().numpy()).all()
+    assert hh["error"] == pytest.approx(oh["error"], rel=1e-5)
+    assert rel(hh["AtA"].cpu().numpy(), oh["AtA"]) < TOL_H and rel(hh["Atb"].cpu().numpy(), oh["Atb"]) < TOL_H
+    with pytest.raises(RuntimeError):
+        capi.loop_mg(ws, False, dv(R10), dv(t10), None, None, None, None, dv(u0[:0]), dv(u1[:0]), dv(homo0[:0]),
+                     dv(homo1[:0]), s0, s1, c, wgt)
+    ws.close()

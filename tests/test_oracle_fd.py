@@ -249,3 +249,99 @@ def test_reprojection_factor_jacobian_and_reduction(orc):
     assert np.allclose(ot["Atb"], (wgt / N) * Jtw.T @ rw, rtol=1e-6, atol=1e-10)
     et, nt = orc.tracker_reproj_error(R10, t10, d0, homo, matched, cam, eps, c, wgt, prec="f64")
     assert np.isclose(et, o["error"], rtol=1e-12) and nt == N
+
+
+def test_match_geometry_factor_family(orc):
+    """f3 match-geometry factors (cuda/match_geometry_factor_kernels.cpp): for the mapper factor with every loss
+    ("fair", "L2", "huber", "unbiased"), the loop factor and the two tracker variants, the oracle's unweighted rows
+    against central differences of  X0_in_1 - X1_matched  written independently in numpy (both poses by left
+    retraction, both codes, both scales -- the "unbiased" variant rescales both depths by s/(s0+s1), which couples
+    the two scale columns), the loss weights/errors against closed forms, AtA/Atb against the weighted rows."""
+    rng = np.random.default_rng(21)
+    HW, CS, N = 600, 8, 29
+    bias0 = 1.0 + 0.2 * rng.random(HW); bias1 = 1.1 + 0.2 * rng.random(HW)
+    basis0 = 0.05 * rng.standard_normal((HW, CS)); basis1 = 0.05 * rng.standard_normal((HW, CS))
+    code0 = 0.3 * rng.standard_normal(CS); code1 = 0.3 * rng.standard_normal(CS)
+    s0, s1 = 1.2, 0.9
+    loc0 = rng.integers(0, HW, N).astype(np.int32); loc1 = rng.integers(0, HW, N).astype(np.int32)
+    homo0 = np.concatenate([rng.uniform(-0.5, 0.5, (N, 2)), np.ones((N, 1))], 1)
+    homo1 = np.concatenate([rng.uniform(-0.5, 0.5, (N, 2)), np.ones((N, 1))], 1)
+    R0, t0 = rot([0.05, -0.08, 0.03]), np.array([0.02, -0.01, 0.03])
+    R1, t1 = rot([-0.04, 0.06, 0.09]), np.array([-0.05, 0.02, -0.04])
+    R10, t10 = R1.T @ R0, R1.T @ (t0 - t1)
+    c, wgt, h = 0.04, 0.6, 1e-6
+    fd = lambda f: (f(+h) - f(-h)) / (2 * h)
+
+    def g(R0_, t0_, R1_, t1_, c0, c1, a0, a1, unbiased):      # X0_in_1 - X1_matched, [N,3]
+        d0 = (bias0[loc0] + basis0[loc0] @ c0); d1 = (bias1[loc1] + basis1[loc1] @ c1)
+        if unbiased:
+            d0, d1 = d0 * a0 / (a0 + a1), d1 * a1 / (a0 + a1)
+        else:
+            d0, d1 = d0 * a0, d1 * a1
+        Xw = (R0_ @ (d0[:, None] * homo0).T).T + t0_
+        return (R1_.T @ (Xw - t1_).T).T - d1[:, None] * homo1
+
+    for loss in ("fair", "L2", "huber", "unbiased"):
+        ub = loss == "unbiased"
+        o = orc.match_geom_jac_error(0, loss, R10, t10, R0, t0, R1, t1, bias0, bias1, basis0, basis1, code0, code1,
+                                     homo0=homo0, homo1=homo1, loc0=loc0, loc1=loc1, scale0=s0, scale1=s1, loss_param=c,
+                                     weight=wgt, prec="f64", want_rows=True)
+        D = 14 + 2 * CS
+        diff = -g(R0, t0, R1, t1, code0, code1, s0, s1, ub)
+        if loss == "L2":
+            sw_ref = np.ones_like(diff); e_ref = (diff ** 2).sum()
+        elif loss == "huber":
+            sq = diff ** 2
+            sw_ref = np.minimum(1.0, np.sqrt(c / sq)); e_ref = np.where(sq <= c, sq, 2 * np.sqrt(c * sq) - c).sum()
+        else:
+            nrm = np.abs(diff) / np.sqrt(c)
+            sw_ref = np.sqrt(1 / (c * (1 + nrm))); e_ref = 2 * (nrm - np.log1p(nrm)).sum()
+        assert np.allclose(o["sw"], sw_ref, rtol=1e-12), loss
+        assert np.isclose(o["error"], wgt * e_ref / N, rtol=1e-12), loss
+        if loss == "huber":
+            assert (sw_ref < 1).any() and (sw_ref == 1).any()     # both branches exercised
+        Ju = o["J"] / o["sw"][:, :, None]
+        for j in range(6):
+            e = np.zeros(6); e[j] = 1.0
+            assert np.allclose(Ju[:, :, j], fd(lambda s: g(*retract(R0, t0, s * e), R1, t1, code0, code1, s0, s1, ub)), rtol=1e-6, atol=1e-8)
+            assert np.allclose(Ju[:, :, 6 + j], fd(lambda s: g(R0, t0, *retract(R1, t1, s * e), code0, code1, s0, s1, ub)), rtol=1e-6, atol=1e-8)
+        for i in range(CS):
+            e = np.zeros(CS); e[i] = 1.0
+            assert np.allclose(Ju[:, :, 12 + i], fd(lambda s: g(R0, t0, R1, t1, code0 + s * e, code1, s0, s1, ub)), rtol=1e-6, atol=1e-9)
+            assert np.allclose(Ju[:, :, 12 + CS + i], fd(lambda s: g(R0, t0, R1, t1, code0, code1 + s * e, s0, s1, ub)), rtol=1e-6, atol=1e-9)
+        assert np.allclose(Ju[:, :, 12 + 2 * CS], fd(lambda s: g(R0, t0, R1, t1, code0, code1, s0 + s, s1, ub)), rtol=1e-6, atol=1e-9), loss
+        assert np.allclose(Ju[:, :, 13 + 2 * CS], fd(lambda s: g(R0, t0, R1, t1, code0, code1, s0, s1 + s, ub)), rtol=1e-6, atol=1e-9), loss
+        Jw = o["J"].reshape(-1, D); rw = o["r"].reshape(-1)
+        assert np.allclose(rw.reshape(-1, 3), o["sw"] * diff, rtol=1e-12)
+        assert np.allclose(o["AtA"], (wgt / N) * Jw.T @ Jw, rtol=1e-12, atol=1e-14)
+        assert np.allclose(o["Atb"], (wgt / N) * Jw.T @ rw, rtol=1e-12, atol=1e-14)
+        eo = orc.match_geom_error(0, loss, R10, t10, bias0, bias1, basis0, basis1, code0, code1, homo0=homo0, homo1=homo1,
+                                  loc0=loc0, loc1=loc1, scale0=s0, scale1=s1, loss_param=c, weight=wgt, prec="f64")
+        assert np.isclose(eo, o["error"], rtol=1e-13)
+
+    # loop factor: unscaled depths handed over, columns [pose0 pose1 scale0 scale1]
+    u0 = bias0[loc0] + basis0[loc0] @ code0; u1 = bias1[loc1] + basis1[loc1] @ code1
+    ol = orc.match_geom_jac_error(1, "fair", R10, t10, R0, t0, R1, t1, dpts0=u0, dpts1=u1, homo0=homo0, homo1=homo1,
+                                  scale0=s0, scale1=s1, loss_param=c, weight=wgt, prec="f64", want_rows=True)
+    om = orc.match_geom_jac_error(0, "fair", R10, t10, R0, t0, R1, t1, bias0, bias1, basis0, basis1, code0, code1,
+                                  homo0=homo0, homo1=homo1, loc0=loc0, loc1=loc1, scale0=s0, scale1=s1, loss_param=c,
+                                  weight=wgt, prec="f64", want_rows=True)
+    assert np.allclose(ol["J"][:, :, :12], om["J"][:, :, :12], rtol=1e-12)
+    assert np.allclose(ol["J"][:, :, 12:14], om["J"][:, :, 12 + 2 * CS:], rtol=1e-12)
+    assert np.isclose(ol["error"], om["error"], rtol=1e-13)
+    assert np.isclose(orc.match_geom_error(1, "fair", R10, t10, dpts0=u0, dpts1=u1, homo0=homo0, homo1=homo1, scale0=s0,
+                                           scale1=s1, loss_param=c, weight=wgt, prec="f64"), ol["error"], rtol=1e-13)
+    # tracker variants: relative pose rows E(X0_in_1) (left perturbation of T10), optional scale column
+    d0 = s0 * u0; d1 = s1 * u1
+    def g_rel(R_, t_, a0):
+        return (R_ @ ((d0 * a0 / s0)[:, None] * homo0).T).T + t_ - d1[:, None] * homo1
+    for mode in (2, 3):
+        ot = orc.match_geom_jac_error(mode, "fair", R10, t10, dpts0=d0, dpts1=d1, homo0=homo0, homo1=homo1, scale0=s0,
+                                      loss_param=c, weight=wgt, prec="f64", want_rows=True)
+        Ju = ot["J"] / ot["sw"][:, :, None]
+        for j in range(6):
+            e = np.zeros(6); e[j] = 1.0
+            assert np.allclose(Ju[:, :, j], fd(lambda s: g_rel(*retract(R10, t10, s * e), s0)), rtol=1e-6, atol=1e-8)
+        if mode == 3:
+            assert np.allclose(Ju[:, :, 6], fd(lambda s: g_rel(R10, t10, s0 + s)), rtol=1e-6, atol=1e-9)
+        assert np.isclose(ot["error"], om["error"], rtol=1e-12)
