@@ -384,6 +384,16 @@ int sage_tracker_match_geom_error_calculate(SageWorkspace *ws, float *error_host
                                             const float *sampled_dpts0, const float *matched_dpts1, const float *homo0,
                                             const float *matched_homo1, float loss_param, float weight, int N);
 
+/* ---- f4 (matching core): descriptor response argmax with cycle consistency ------------------------------------------
+ * Replaces the tensor expression of core/gtsam/match_geometry_factor.cpp:62-97 and
+ * core/system/camera_tracker.cpp:608-633: for K keypoints of frame 0 (flat indices kp_loc1d_0, int64) the best match in
+ * desc1 [C,H,W] under -sum_c (d0 - d1)^2, the best match of THAT descriptor back in desc0, and the inlier flag
+ * |kp - cyc|_2 <= cyc_thresh (pixels).  The K x H*W response maps are never materialised.  Outputs are device arrays
+ * of K entries; *n_inliers_host receives the number of flags set (synchronises).  TEASER++ filtering stays on the host. */
+int sage_cycle_match(SageWorkspace *ws, const float *desc0_dev, const float *desc1_dev, const int64_t *kp_loc1d_0,
+                     int K, int C, int H, int W, float cyc_thresh, int64_t *raw_matched_loc1d_1,
+                     int64_t *cyc_matched_loc1d_0, int32_t *inlier_flags, int *n_inliers_host);
+
 /* ---- f1 producers: valid-pixel enumeration and seeded keyframe sampling ------------------------------------
  * sage_valid_locations: core/mapping/mapping_utils.h:254-287 (GenerateValidLocations): flat indices of mask > 0.5 in
  *   ascending order and their normalised homogeneous coordinates ((x-u0)/fx, (y-v0)/fy, 1).  Outputs are device

@@ -385,3 +385,15 @@ def match_geom_error(mode, loss, R10, t10, bias0=None, bias1=None, basis0=None, 
     fn = getattr(lib(), "orc_match_geom_error" + sfx); fn.restype = ct
     return float(fn(C.c_int(mode), C.c_int(MG_LOSS[loss]), *[_p(k) for k in keep], ct(scale0), ct(scale1), C.c_int(N),
                     C.c_int(CS), ct(loss_param), ct(weight)))
+
+
+def cycle_match(desc0, desc1, kp_loc0, H, W, cyc_thresh, prec="f32"):
+    """match_geometry_factor.cpp:62-97 / camera_tracker.cpp:608-633 -> (raw_matched1, cyc_matched0, inlier flags)."""
+    dt, ct, sfx = _dt(prec)
+    desc0 = _arr(desc0, dt).reshape(-1, H * W); desc1 = _arr(desc1, dt).reshape(-1, H * W)
+    kp = np.ascontiguousarray(kp_loc0, np.int64); K = kp.shape[0]
+    m1 = np.zeros(max(K, 1), np.int64); c0 = np.zeros(max(K, 1), np.int64); fl = np.zeros(max(K, 1), np.int32)
+    fn = getattr(lib(), "orc_cycle_match" + sfx); fn.restype = C.c_int
+    fn(m1.ctypes.data_as(C.c_void_p), c0.ctypes.data_as(C.c_void_p), fl.ctypes.data_as(C.c_void_p), _p(desc0), _p(desc1),
+       kp.ctypes.data_as(C.c_void_p), C.c_int(K), C.c_int(desc0.shape[0]), C.c_int(H), C.c_int(W), ct(cyc_thresh))
+    return m1[:K], c0[:K], fl[:K]

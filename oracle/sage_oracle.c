@@ -1439,3 +1439,49 @@ REAL ORC(match_geom_error)(int mode, int loss, const REAL *R10, const REAL *t10,
   }
   return (REAL)((double)weight * se / (double)N);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * f4: cycle-consistent descriptor matching (match_geometry_factor.cpp:62-97, camera_tracker.cpp:608-633)
+ * ------------------------------------------------------------------------------------------------ */
+static long long best_match(const REAL *query_desc, long long query_loc, const REAL *target, int C, long long HW)
+{
+  long long best = 0;
+  REAL best_resp = 0;
+  for (long long p = 0; p < HW; ++p)
+  {
+    REAL acc = 0;
+    for (int c = 0; c < C; ++c)
+    {
+      const REAL d = query_desc[(size_t)c * HW + query_loc] - target[(size_t)c * HW + p];
+      acc += d * d;
+    }
+    const REAL resp = -acc;
+    if (p == 0 || resp > best_resp)
+    {
+      best_resp = resp;
+      best = p;
+    }
+  }
+  return best;
+}
+
+int ORC(cycle_match)(long long *raw_matched1, long long *cyc_matched0, int32_t *inlier, const REAL *desc0,
+                     const REAL *desc1, const long long *kp_loc0, int K, int C, int H, int W, REAL cyc_thresh)
+{
+  const long long HW = (long long)H * W;
+  int n = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic) reduction(+ : n)
+#endif
+  for (int k = 0; k < K; ++k)
+  {
+    const long long m1 = best_match(desc0, kp_loc0[k], desc1, C, HW);
+    const long long c0 = best_match(desc1, m1, desc0, C, HW);
+    raw_matched1[k] = m1;
+    cyc_matched0[k] = c0;
+    const REAL dx = (REAL)(kp_loc0[k] % W) - (REAL)(c0 % W), dy = (REAL)(kp_loc0[k] / W) - (REAL)(c0 / W);
+    inlier[k] = (dx * dx + dy * dy) <= cyc_thresh * cyc_thresh;
+    n += inlier[k];
+  }
+  return n;
+}

@@ -97,7 +97,7 @@ SYMBOLS = [
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
     "sage_match_geometry_jac_error_calculate", "sage_match_geometry_error_calculate",
     "sage_loop_mg_jac_error_calculate", "sage_loop_mg_error_calculate",
-    "sage_tracker_match_geom_jac_error_calculate", "sage_tracker_match_geom_error_calculate",
+    "sage_tracker_match_geom_jac_error_calculate", "sage_tracker_match_geom_error_calculate", "sage_cycle_match",
 ]
 
 
@@ -758,3 +758,15 @@ def tracker_match_geom(ws, jac, with_scale, R, t, dpts0, dpts1, homo0, homo1, sc
         ws.h, C.byref(e), _dptr(R), _dptr(t), _dptr(dpts0), _dptr(dpts1), _dptr(homo0), _dptr(homo1),
         C.c_float(loss_param), C.c_float(weight), N), "sage_tracker_match_geom_error_calculate")
     return e.value
+
+
+def cycle_match(ws, desc0, desc1, kp_loc0, H, W, cyc_thresh):
+    """desc0/desc1: [C,H,W] cuda float tensors; kp_loc0: int64 cuda tensor [K] -> (raw_matched1, cyc_matched0, flags, n)."""
+    import torch
+    K = int(kp_loc0.shape[0]); Cc = int(desc0.shape[0])
+    m1 = torch.zeros(max(K, 1), dtype=torch.int64, device="cuda"); c0 = torch.zeros_like(m1)
+    fl = torch.zeros(max(K, 1), dtype=torch.int32, device="cuda")
+    n = C.c_int()
+    _chk(lib().sage_cycle_match(ws.h, _dptr(desc0), _dptr(desc1), _dptr(kp_loc0), K, Cc, H, W, C.c_float(cyc_thresh),
+                                _dptr(m1), _dptr(c0), _dptr(fl), C.byref(n)), "sage_cycle_match")
+    return m1[:K], c0[:K], fl[:K], n.value

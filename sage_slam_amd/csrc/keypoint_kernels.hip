@@ -477,4 +477,121 @@ hipError_t launch_match_geom(hipStream_t s, int mode, int loss, int CS, bool jac
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// f4 matching core: response-map argmax with cycle consistency (core/gtsam/match_geometry_factor.cpp:62-97,
+// core/system/camera_tracker.cpp:608-633).  response[k][p] = -sum_c (q[c][k] - target[c][p])^2 is never materialised
+// (the reference builds two K x H*W tensors): one workgroup owns KPB query descriptors (LDS), streams the target
+// descriptor map once (coalesced over pixels, channel sum sequential in fp32 like the restated reference) and keeps a
+// running (response, index) pair per query and lane; first index wins ties.
+// ------------------------------------------------------------------------------------------------
+constexpr int kMatchKPB = 8; // queries per workgroup: the target map is read K/8 times instead of K times
+
+__global__ __launch_bounds__(256) void best_match_kernel(const float *__restrict__ query_map, const long long *__restrict__ query_loc,
+                                                         const float *__restrict__ target_map, int K, int C, int HW,
+                                                         long long *__restrict__ best_out)
+{
+  extern __shared__ float s_dyn[]; // [KPB][C] query descriptors, then the reduction scratch
+  float *s_q = s_dyn;
+  const int tid = threadIdx.x, k0 = blockIdx.x * kMatchKPB;
+  const int nk = min(kMatchKPB, K - k0);
+  for (int i = tid; i < kMatchKPB * C; i += 256)
+  {
+    const int kk = i / C, c = i - kk * C;
+    s_q[i] = kk < nk ? query_map[(size_t)c * HW + query_loc[k0 + kk]] : 0.f;
+  }
+  __syncthreads();
+  float best_r[kMatchKPB];
+  int best_p[kMatchKPB];
+#pragma unroll
+  for (int kk = 0; kk < kMatchKPB; ++kk)
+  {
+    best_r[kk] = -INFINITY;
+    best_p[kk] = 0x7fffffff;
+  }
+  for (int p = tid; p < HW; p += 256)
+  {
+    float acc[kMatchKPB];
+#pragma unroll
+    for (int kk = 0; kk < kMatchKPB; ++kk)
+      acc[kk] = 0.f;
+    for (int c = 0; c < C; ++c)
+    {
+      const float t = target_map[(size_t)c * HW + p];
+#pragma unroll
+      for (int kk = 0; kk < kMatchKPB; ++kk)
+      {
+        const float d = s_q[kk * C + c] - t;
+        acc[kk] = __fadd_rn(acc[kk], __fmul_rn(d, d)); // no FMA contraction: the argmax must not depend on it
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < kMatchKPB; ++kk)
+    {
+      const float r = -acc[kk];
+      if (r > best_r[kk]) // ascending p per lane: '>' keeps the first maximum
+      {
+        best_r[kk] = r;
+        best_p[kk] = p;
+      }
+    }
+  }
+  // cross-lane: larger response wins, equal responses -> smaller index
+  float *s_r = s_dyn + kMatchKPB * C;
+  int *s_p = reinterpret_cast<int *>(s_r + 256);
+  for (int kk = 0; kk < nk; ++kk)
+  {
+    __syncthreads();
+    s_r[tid] = best_r[kk];
+    s_p[tid] = best_p[kk];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1)
+    {
+      if (tid < off)
+      {
+        const float r2 = s_r[tid + off];
+        const int p2 = s_p[tid + off];
+        if (r2 > s_r[tid] || (r2 == s_r[tid] && p2 < s_p[tid]))
+        {
+          s_r[tid] = r2;
+          s_p[tid] = p2;
+        }
+      }
+      __syncthreads();
+    }
+    if (tid == 0)
+      best_out[k0 + kk] = s_p[0];
+  }
+}
+
+__global__ void cycle_flags_kernel(const long long *__restrict__ kp_loc0, const long long *__restrict__ cyc_loc0, int K,
+                                   int W, float thresh, int32_t *__restrict__ inlier, int *__restrict__ n_out)
+{
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K)
+    return;
+  const float dx = (float)(kp_loc0[k] % W) - (float)(cyc_loc0[k] % W);
+  const float dy = (float)(kp_loc0[k] / W) - (float)(cyc_loc0[k] / W);
+  const int in = (dx * dx + dy * dy) <= thresh * thresh; // match_geometry_factor.cpp:91-94
+  inlier[k] = in;
+  if (in)
+    atomicAdd(n_out, 1); // integer count: order independent
+}
+
+hipError_t launch_cycle_match(hipStream_t s, const float *desc0, const float *desc1, const long long *kp_loc0, int K,
+                              int C, int H, int W, float cyc_thresh, long long *raw_matched1, long long *cyc_matched0,
+                              int32_t *inlier, int *n_inliers_dev)
+{
+  if (K <= 0)
+    return hipSuccess;
+  const int HW = H * W;
+  const size_t shm = ((size_t)kMatchKPB * C + 512) * sizeof(float);
+  const int grid = (K + kMatchKPB - 1) / kMatchKPB;
+  hipLaunchKernelGGL(best_match_kernel, dim3(grid), dim3(256), shm, s, desc0, kp_loc0, desc1, K, C, HW, raw_matched1);
+  hipLaunchKernelGGL(best_match_kernel, dim3(grid), dim3(256), shm, s, desc1, raw_matched1, desc0, K, C, HW, cyc_matched0);
+  hipLaunchKernelGGL(cycle_flags_kernel, dim3((K + 255) / 256), dim3(256), 0, s, kp_loc0, cyc_matched0, K, W, cyc_thresh,
+                     inlier, n_inliers_dev);
+  return hipGetLastError();
+}
+
 } // namespace sage

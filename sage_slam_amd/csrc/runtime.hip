@@ -583,6 +583,25 @@ extern "C" int sage_tracker_match_geom_error_calculate(SageWorkspace *ws, float 
                    matched_homo1, nullptr, nullptr, 1.f, 1.f, loss_param, weight, N, 16);
 }
 
+extern "C" int sage_cycle_match(SageWorkspace *ws, const float *desc0, const float *desc1, const int64_t *kp_loc1d_0,
+                                int K, int C, int H, int W, float cyc_thresh, int64_t *raw_matched_loc1d_1,
+                                int64_t *cyc_matched_loc1d_0, int32_t *inlier_flags, int *n_inliers_host)
+{
+  if (!ws || K < 0 || C < 1 || C > 1024 || H < 1 || W < 1 || !n_inliers_host ||
+      (K > 0 && (!desc0 || !desc1 || !kp_loc1d_0 || !raw_matched_loc1d_1 || !cyc_matched_loc1d_0 || !inlier_flags)))
+    return SAGE_E_INVALID;
+  int rc = ws->misc.reserve(sizeof(int));
+  if (rc)
+    return rc;
+  SAGE_HIP(hipMemsetAsync(ws->misc.p, 0, sizeof(int), ws->stream));
+  SAGE_HIP(launch_cycle_match(ws->stream, desc0, desc1, reinterpret_cast<const long long *>(kp_loc1d_0), K, C, H, W,
+                              cyc_thresh, reinterpret_cast<long long *>(raw_matched_loc1d_1),
+                              reinterpret_cast<long long *>(cyc_matched_loc1d_0), inlier_flags, ws->misc.as<int>()));
+  SAGE_HIP(hipMemcpyAsync(n_inliers_host, ws->misc.p, sizeof(int), hipMemcpyDeviceToHost, ws->stream));
+  SAGE_HIP(hipStreamSynchronize(ws->stream));
+  return SAGE_OK;
+}
+
 extern "C" int sage_valid_locations(SageWorkspace *ws, const float *mask_dev, const SageCamera *cam,
                                     int64_t *loc1d_dev, float *homo_dev, int *n_valid_host)
 {

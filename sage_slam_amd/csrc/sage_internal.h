@@ -163,6 +163,9 @@ hipError_t launch_reproj(hipStream_t s, int CS, bool tracker, bool jac, const fl
                          const float *code0, const int32_t *loc, const float *dpts0, const float *homo,
                          const float *matched, float scale0, const SageCamera &cam, float eps, float loss_param,
                          float weight, int N, float *scratch, float *AtA, float *Atb, float *stats);
+hipError_t launch_cycle_match(hipStream_t s, const float *desc0, const float *desc1, const long long *kp_loc0, int K,
+                              int C, int H, int W, float cyc_thresh, long long *raw_matched1, long long *cyc_matched0,
+                              int32_t *inlier, int *n_inliers_dev);
 size_t mg_scratch_floats(int N, int D);
 hipError_t launch_match_geom(hipStream_t s, int mode, int loss, int CS, bool jac, const float *R10, const float *t10,
                              const float *R0, const float *t0, const float *R1, const float *t1, const float *bias0,

@@ -621,3 +621,40 @@ def test_match_geometry_factor_family_parity(capi, orc, CS, N):
         capi.loop_mg(ws, False, dv(R10), dv(t10), None, None, None, None, dv(u0[:0]), dv(u1[:0]), dv(homo0[:0]),
                      dv(homo1[:0]), s0, s1, c, wgt)
     ws.close()
+
+
+@pytest.mark.parametrize("C_,H,W,K", [(16, 32, 40, 37), (32, 24, 24, 8), (16, 64, 80, 200)])
+def test_cycle_match_bit_exact(capi, orc, C_, H, W, K):
+    """f4 matching core (match_geometry_factor.cpp:62-97, camera_tracker.cpp:608-633): raw matches, cycle matches and
+    inlier flags are integers -> bit exact against the oracle; descriptors of frame 1 are a shifted, noisy copy of
+    frame 0 so that most cycles close, plus exact duplicates (ties -> first index) and K not a multiple of the
+    per-workgroup query count."""
+    import torch
+    rng = np.random.default_rng(7 + K)
+    d0 = rng.standard_normal((C_, H, W)).astype(np.float32)
+    d1 = np.roll(d0, (1, 2), axis=(1, 2)) + 0.05 * rng.standard_normal((C_, H, W)).astype(np.float32)
+    d1[:, 3, 5] = d1[:, 10, 11]                       # exact duplicate descriptors in the target map
+    d0[:, 7, 7] = d0[:, 2, 9]
+    kp = rng.choice(H * W, K, replace=False).astype(np.int64)
+    kp[0] = 2 * W + 9                                  # a query that has an exact twin in its own map
+    thresh = 2.0
+    om1, oc0, ofl = orc.cycle_match(d0, d1, kp, H, W, thresh)
+    ws = capi.Workspace()
+    hm1, hc0, hfl, hn = capi.cycle_match(ws, torch.from_numpy(d0).cuda(), torch.from_numpy(d1).cuda(),
+                                         torch.from_numpy(kp).cuda(), H, W, thresh)
+    assert np.array_equal(hm1.cpu().numpy(), om1)
+    assert np.array_equal(hc0.cpu().numpy(), oc0)
+    assert np.array_equal(hfl.cpu().numpy(), ofl) and hn == int(ofl.sum())
+    assert hn > 0
+    # unrelated target map: most cycles do not close -> flags of both kinds
+    dn = rng.standard_normal((C_, H, W)).astype(np.float32)
+    om1, oc0, ofl = orc.cycle_match(d0, dn, kp, H, W, thresh)
+    hm1, hc0, hfl, hn = capi.cycle_match(ws, torch.from_numpy(d0).cuda(), torch.from_numpy(dn).cuda(),
+                                         torch.from_numpy(kp).cuda(), H, W, thresh)
+    assert np.array_equal(hm1.cpu().numpy(), om1) and np.array_equal(hc0.cpu().numpy(), oc0)
+    assert np.array_equal(hfl.cpu().numpy(), ofl) and hn == int(ofl.sum()) and hn < K
+    # K = 0: nothing to do
+    e = capi.cycle_match(ws, torch.from_numpy(d0).cuda(), torch.from_numpy(d1).cuda(),
+                         torch.zeros(0, dtype=torch.int64, device="cuda"), H, W, thresh)
+    assert e[3] == 0 and e[0].numel() == 0
+    ws.close()
