@@ -1,0 +1,21 @@
+"""dev tool: how does the oracle (CPU port of the reference path) scale with OpenMP threads on this host?"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as orc
+from sage_slam_amd import synth
+orc.build()
+w = synth.make_window(K=4, H=128, W=160, FS=16, CS=32, L=4, seed=0)
+A, Bk = w.keyframes[0], w.keyframes[1]
+R10, t10 = synth.relative_pose(A.R, A.t, Bk.R, Bk.t)
+D1, g1 = synth.depth_and_grad(Bk, w.H, w.W)
+def once():
+    t0 = time.perf_counter()
+    orc.photo_jac_error(R10, t10, A.R, A.t, Bk.R, Bk.t, A.bias, A.basis, A.code, w.mask, A.loc1d, A.homo, A.feat_pyr,
+                        Bk.feat_pyr, Bk.grad_pyr, w.level_offsets, A.scale, w.cams, w.eps, w.photo_weights)
+    orc.geo_jac_error(R10, t10, A.R, A.t, Bk.R, Bk.t, A.bias, A.basis, A.code, D1, g1, Bk.basis.reshape(w.H, w.W, w.CS),
+                      w.mask, A.loc1d, A.homo, A.scale, Bk.scale, w.cams[0], w.eps, w.geo_loss_param, w.geo_weight)
+    return time.perf_counter() - t0
+res = A.homo.shape[0] * (w.L * w.FS + 1)
+for th in (1, 8, 32, 64, 128, os.cpu_count()):
+    orc.set_threads(th); once(); t = min(once() for _ in range(2))
+    print(f"threads {th}: {t*1e3:.1f} ms per directed-edge linearize pair, {res / t / 1e6:.2f} Mresiduals/s")
