@@ -924,9 +924,7 @@ struct SageWindow
   DevBuf vars[2];                       // [K][VS]: pose 12, scale 1, code CS
   DevBuf dpt, dgrad, depth_items[2];    // per-keyframe depth maps of the set being evaluated
   DevBuf pk;                            // engine-internal channel-group pyramids [K][3 (f,gx,gy)][FS/4][P][4]
-  DevBuf idxmap, tile_list;             // per keyframe: sample index per pixel, packed 16x16 tile origins
   DevBuf f0s;                           // per keyframe: pre-sampled source features [L][FS/4][N][4]
-  bool tiled = false;                   // photometric kernels run on 2-D tiles with LDS-staged patches
   DevBuf ptab[2], gtab[2];              // edge tables per variable set
   DevBuf work_p, first_p, tiles_p, work_g, first_g, tiles_g;
   DevBuf part_p, part_g;
@@ -1044,7 +1042,7 @@ extern "C" void sage_window_destroy(SageWindow *w)
   if (!w)
     return;
   DevBuf *bufs[] = {&w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
-                    &w->pk, &w->idxmap, &w->tile_list, &w->f0s, &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
+                    &w->pk, &w->f0s, &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
                     &w->work_g, &w->first_g, &w->tiles_g, &w->part_p, &w->part_g, &w->AtA_p, &w->Atb_p,
                     &w->stats_p, &w->AtA_g, &w->Atb_g, &w->stats_g, &w->adj_start, &w->adj, &w->link_edges,
                     &w->packed, &w->errbuf};
@@ -1175,43 +1173,16 @@ extern "C" int sage_window_finalize(SageWindow *w)
     SAGE_HIP(launch_presample_source(w->stream, w->f0s.as<float>() + f0s_off[k],
                                      w->pk.as<float>() + (size_t)k * 3 * plane_f, w->views[k].homo, w->views[k].N, FS,
                                      c.pyr));
-  // ---- 2-D tiling of every keyframe's sample set (LDS-staged photometric sampler)
-  std::vector<int32_t> h_idx((size_t)K * HW, -1), h_tiles;
-  std::vector<int> tile_off(K + 1, 0);
+  // ---- validate the sample locations once (the kernels index the depth maps / basis rows with them unchecked)
+  for (int k = 0; k < K; ++k)
   {
-    const int TD = 16, tX = (W + TD - 1) / TD, tY = (H + TD - 1) / TD;
-    long long total_samples = 0, total_slots = 0;
-    for (int k = 0; k < K; ++k)
-    {
-      const int Nk = w->views[k].N;
-      std::vector<int64_t> loc((size_t)std::max(1, Nk));
-      if (Nk > 0)
-        SAGE_HIP(hipMemcpy(loc.data(), w->views[k].loc1d, (size_t)Nk * sizeof(int64_t), hipMemcpyDeviceToHost));
-      std::vector<char> used((size_t)tX * tY, 0);
-      for (int i = 0; i < Nk; ++i)
-      {
-        const int64_t l = loc[i];
-        if (l < 0 || l >= HW)
-          return SAGE_E_INVALID;
-        h_idx[(size_t)k * HW + l] = i;
-        used[(size_t)((l / W) / TD) * tX + (l % W) / TD] = 1;
-      }
-      tile_off[k] = (int)h_tiles.size();
-      for (int ty = 0; ty < tY; ++ty)
-        for (int tx = 0; tx < tX; ++tx)
-          if (used[(size_t)ty * tX + tx])
-            h_tiles.push_back((tx * TD) | ((ty * TD) << 16));
-      total_samples += Nk;
-      total_slots += (long long)((int)h_tiles.size() - tile_off[k]) * TD * TD;
-    }
-    tile_off[K] = (int)h_tiles.size();
-    // use the tiled sampler when the lanes of the tiles are reasonably filled (dense / near-dense samplings)
-    // EXPERIMENTAL (off by default): the block-wide LDS-staged sampler is parity-green but barrier/latency bound
-    // (4.2 ms vs 1.1 ms for direct gathers on the headline window); opt in with SAGE_TILED=1.
-    w->tiled = total_slots > 0 && (double)total_samples >= 0.4 * (double)total_slots && getenv("SAGE_TILED") != nullptr;
-    if ((rc = upload(w->idxmap, h_idx, w->stream)) || (rc = upload(w->tile_list, h_tiles, w->stream)))
-      return rc;
-    SAGE_HIP(hipStreamSynchronize(w->stream));
+    const int Nk = w->views[k].N;
+    std::vector<int64_t> loc((size_t)std::max(1, Nk));
+    if (Nk > 0)
+      SAGE_HIP(hipMemcpy(loc.data(), w->views[k].loc1d, (size_t)Nk * sizeof(int64_t), hipMemcpyDeviceToHost));
+    for (int i = 0; i < Nk; ++i)
+      if (loc[i] < 0 || loc[i] >= HW)
+        return SAGE_E_INVALID;
   }
   // ---- local links / edges
   w->local_links.clear();
@@ -1245,9 +1216,6 @@ extern "C" int sage_window_finalize(SageWindow *w)
         pe.feat1_pk = w->pk.as<float>() + (size_t)k1 * 3 * plane_f;
         pe.gx1_pk = pe.feat1_pk + plane_f;
         pe.gy1_pk = pe.feat1_pk + 2 * plane_f;
-        pe.index_map0 = w->idxmap.as<int32_t>() + (size_t)k0 * HW;
-        pe.tiles0 = w->tile_list.as<int32_t>() + tile_off[k0];
-        pe.n_tiles0 = tile_off[k0 + 1] - tile_off[k0];
         pe.f0s = w->f0s.as<float>() + f0s_off[k0];
         pe.dpt0 = w->dpt.as<float>() + (size_t)k0 * HW;
         pe.basis0 = v0.basis; pe.mask1 = c.mask_dev; pe.homo = v0.homo; pe.loc = v0.loc1d; pe.loc_is_i64 = 1;
@@ -1309,31 +1277,20 @@ extern "C" int sage_window_finalize(SageWindow *w)
       (rc = upload(w->tiles_g, wl.edge_tiles, w->stream)))
     return rc;
   SAGE_HIP(hipStreamSynchronize(w->stream));
-  if (w->tiled)
   {
-    // photometric work items = (edge, first 16x16 tile of the source keyframe); a "tile count" stands in for N
-    std::vector<int> Tedge(w->n_edges);
-    for (size_t li = 0; li < w->local_links.size(); ++li)
-    {
-      const int l = w->local_links[li];
-      const int ab[2] = {w->links[l].first, w->links[l].second};
-      for (int dir = 0; dir < 2; ++dir)
-        Tedge[2 * li + dir] = (tile_off[ab[dir] + 1] - tile_off[ab[dir]]) * kTile; // in "pixels" of kTile per tile
-    }
-    WorkList wt;
-    wt.build(Tedge);
-    w->n_work_p = (int)wt.work.size();
-    w->tpb_p = wt.tiles_per_block;
-    if ((rc = upload(w->work_p, wt.work, w->stream)) || (rc = upload(w->first_p, wt.edge_first, w->stream)) ||
-        (rc = upload(w->tiles_p, wt.edge_tiles, w->stream)))
-      return rc;
-  }
-  else
-  {
-    w->n_work_p = w->n_work_g;
-    w->tpb_p = w->tpb_g;
-    if ((rc = upload(w->work_p, wl.work, w->stream)) || (rc = upload(w->first_p, wl.edge_first, w->stream)) ||
-        (rc = upload(w->tiles_p, wl.edge_tiles, w->stream)))
+    // photometric work list: its own sub-tile run length
+    WorkList wp;
+    long long total = 0;
+    for (int n : Nedge)
+      total += (n + kTile - 1) / kTile;
+    int tpb = total >= 8192 ? 8 : 0; // measured on the headline window: 2..16 are within noise, 8 halves the partials of 4
+    if (const char *e = getenv("SAGE_PHOTO_TPB"))
+      tpb = std::max(1, atoi(e));
+    wp.build(Nedge, tpb);
+    w->n_work_p = (int)wp.work.size();
+    w->tpb_p = wp.tiles_per_block;
+    if ((rc = upload(w->work_p, wp.work, w->stream)) || (rc = upload(w->first_p, wp.edge_first, w->stream)) ||
+        (rc = upload(w->tiles_p, wp.edge_tiles, w->stream)))
       return rc;
   }
   SAGE_HIP(hipStreamSynchronize(w->stream));
@@ -1385,7 +1342,6 @@ static LaunchCommon window_lc(SageWindow *w, bool photo)
   lc.partials = photo ? w->part_p.as<float>() : w->part_g.as<float>();
   lc.tiles_per_block = photo ? w->tpb_p : w->tpb_g;
   lc.packed = photo;
-  lc.tiled = photo && w->tiled;
   return lc;
 }
 

@@ -25,11 +25,6 @@ struct PhotoEdge
   // engine-internal channel-group layout [FS/4][P][4] (float4 per texel per group of 4 channels): one
   // buffer_load_dwordx4 per tap and group, fully coalesced across the wave.  nullptr -> use the reference layout.
   const float *feat0_pk, *feat1_pk, *gx1_pk, *gy1_pk;
-  // 2-D tiled work decomposition of the SOURCE keyframe (LDS-staged sampler): sample index per pixel (-1 = not
-  // sampled) and the list of 16x16 tiles that contain samples, packed as x0 | (y0 << 16)
-  const int32_t *index_map0;
-  const int32_t *tiles0;
-  int32_t n_tiles0;
   // pose-independent pre-sampled source features of the source keyframe [L][FS/4][N][4] (what the reference's
   // tracker calls cat_sampled_features_0, camera_tracker.cpp:1104-1123), built once per keyframe
   const float *f0s;
@@ -116,7 +111,6 @@ struct LaunchCommon
   int32_t tiles_per_block;   // consecutive kTile sub-tiles per work item (work[i].tile = first sub-tile)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr; // optional: recorded around the main kernel only
   bool packed = false;       // edges carry the channel-group (float4) pyramids
-  bool tiled = false;        // work items are (edge, first 16x16 tile) and the sampler stages patches in LDS
 };
 
 // per-edge results, reference layouts
