@@ -539,8 +539,10 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   const int Bp = solver_bp(B);
   if ((Bp != 40 && Bp != 24) || K < 1)
     return SAGE_E_UNSUPPORTED;
+  const bool device_factor = getenv("SAGE_DEVICE_SOLVE") != nullptr;
+  if (device_factor)
   {
-    // the back substitution keeps x [K*Bp], L_jj and the partial sums in the panel's LDS
+    // the device factorisation keeps x [K*Bp], L_jj and the partial sums of the back substitution in the panel's LDS
     const int NC = Bp == 40 ? kSolveNC40 : kSolveNC24;
     if (K * Bp + Bp * (Bp + 1) + (kSolveThreads / Bp) * Bp > (NC + 1) * Bp * (Bp + 1))
       return SAGE_E_UNSUPPORTED;
@@ -590,6 +592,8 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
     max_rows = std::max(max_rows, (int)rows.size());
     for (int i : rows)
       col_rows.push_back(i);
+    if (!device_factor)
+      continue; // the tile-job lists below are only used by the device factorisation
     for (size_t s = 0; s < rows.size(); ++s)
       for (size_t s2 = 0; s2 <= s; ++s2)
       {
@@ -605,8 +609,8 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   }
   col_ptr[K] = (int)col_rows.size();
   job_ptr[K] = (int)jobs.size();
-  if (max_rows > (Bp == 40 ? kSolveNC40 : kSolveNC24))
-    return SAGE_E_UNSUPPORTED; // envelope wider than the LDS panel: the caller keeps the host solver
+  if (device_factor && max_rows > (Bp == 40 ? kSolveNC40 : kSolveNC24))
+    return SAGE_E_UNSUPPORTED; // envelope wider than the LDS panel (the hybrid path has no such limit)
   if (col_rows.empty())
     col_rows.push_back(0);
   if (jobs.empty())
@@ -648,7 +652,7 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   S->d_y = reinterpret_cast<double *>(S->d_L) + (size_t)nblk * Bp * Bp;
   if (getenv("SAGE_DEBUG_TIMING") && hipMalloc(&S->d_dbg, 8 * sizeof(unsigned long long)) != hipSuccess)
     return fail((int)hipErrorOutOfMemory);
-  S->device_factor = getenv("SAGE_DEVICE_SOLVE") != nullptr;
+  S->device_factor = device_factor;
   S->h_row_first = row_first;
   S->h_row_off = row_off;
   if (!S->device_factor)

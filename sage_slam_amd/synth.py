@@ -252,6 +252,11 @@ def make_window(K: int, H: int, W: int, FS: int = 16, CS: int = 32, L: int = 4,
             loc = valid[perm]
         else:
             loc = valid
+        import os as _os
+        _tile = int(_os.environ.get("SAGE_SYNTH_TILE_ORDER", "0"))              # dev experiment: 2-D tile order of the samples
+        if _tile:
+            ty, tx = (loc // W) // _tile, (loc % W) // _tile
+            loc = loc[np.lexsort((loc % W, loc // W, tx, ty))]
         lx = (loc % W).astype(np.float64)
         ly = (loc // W).astype(np.float64)
         homo = np.stack([(lx - cx) / fx, (ly - cy) / fy, np.ones_like(lx)], -1)

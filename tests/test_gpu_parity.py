@@ -412,7 +412,8 @@ def test_full_size_properties(capi, orc, cfg):
     win.close()
 
 
-@pytest.mark.parametrize("CS,K,back,extra", [(32, 6, 2, [(0, 5)]), (16, 7, 3, []), (32, 12, 3, [(0, 11), (2, 9)])])
+@pytest.mark.parametrize("CS,K,back,extra", [(32, 6, 2, [(0, 5)]), (16, 7, 3, []), (32, 12, 3, [(0, 11), (2, 9)]),
+                                              (16, 14, 13, [])])   # all-to-all: envelope wider than the device panel
 def test_device_solver_matches_host_cholesky(capi, CS, K, back, extra):
     """The one-workgroup block-envelope Cholesky (solve_kernels.hip) against the host envelope Cholesky
     (sage_block_solve, double) on the SAME packed normal equations, priors and damping: both are fp64 direct
