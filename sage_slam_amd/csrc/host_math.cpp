@@ -13,7 +13,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <random>
 #include <vector>
@@ -1058,79 +1060,83 @@ static inline __attribute__((always_inline)) bool factor_diag(double *S, double 
   return true;
 }
 
+// One pass over a range of block rows.  phase 0: factorise rows [lo,hi) ascending and forward-substitute y;
+// phase 1: back-substitute rows [lo,hi) descending.  Rows only touch the blocks of their own column ranges, so two
+// row ranges that do not reference each other can run on two cores.
 template <int NV>
-static inline __attribute__((always_inline)) int block_chol_impl(int K, const int32_t *row_first, const int32_t *row_off,
-                                                                 double *T, double *X, double *y)
+static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnvelope &E, double *T, double *X, double *y,
+                                                                 int phase, int lo, int hi)
 {
   constexpr int BP = NV * 8, BB = BP * BP;
-  auto blk = [&](int i, int j) { return T + (size_t)(row_off[i] + j - row_first[i]) * BB; };
-#ifdef SAGE_CHOL_PROFILE
-  double tp[5] = {0, 0, 0, 0, 0};
-  unsigned long long tlast = __builtin_readcyclecounter();
-  auto lap = [&](int k) { const unsigned long long t = __builtin_readcyclecounter(); tp[k] += (double)(t - tlast); tlast = t; };
-#else
-  auto lap = [](int) {};
-#endif
-  for (int i = 0; i < K; ++i)
+  const int K = E.K;
+  const int32_t *row_first = E.row_first, *row_off = E.row_off;
+  auto afirst = [&](int i) { return E.a_cnt ? E.a_first[i] : 0; };
+  auto acnt = [&](int i) { return E.a_cnt ? E.a_cnt[i] : 0; };
+  auto has = [&](int i, int j) { return (j >= row_first[i] && j <= i) || (j >= afirst(i) && j < afirst(i) + acnt(i)); };
+  auto blk = [&](int i, int j) {
+    return T + (size_t)(j < row_first[i] ? E.a_off[i] + j - E.a_first[i] : row_off[i] + j - row_first[i]) * BB;
+  };
+  if (phase == 0)
   {
-    const int fi = row_first[i];
-    for (int j = fi; j < i; ++j)
+    for (int i = lo; i < hi; ++i)
     {
-      double *CT = blk(i, j);
-      for (int k = std::max(fi, (int)row_first[j]); k < j; ++k)
-        tn_sub<NV>(CT, blk(j, k), blk(i, k), false);
-      lap(0);
-      apply_inverse<NV>(CT, X + (size_t)j * BB);
-      lap(1);
-    }
-    double *S = blk(i, i);
-    for (int k = fi; k < i; ++k)
-      tn_sub<NV>(S, blk(i, k), blk(i, k), true);
-    lap(2);
-    if (!factor_diag<NV>(S, X + (size_t)i * BB))
-      return 1 + i;
-    lap(3);
-    // forward substitution: y_i = L_ii^-1 (g_i - sum_k L_ik y_k)
-    double w[BP];
-    for (int r = 0; r < BP; ++r)
-      w[r] = y[(size_t)i * BP + r];
-    for (int k = fi; k < i; ++k)
-    {
-      const double *Tk = blk(i, k), *yk = y + (size_t)k * BP;
+      // the column ranges of row i, in ascending order
+      const int r0[2] = {afirst(i), row_first[i]}, r1[2] = {afirst(i) + acnt(i), i};
+      for (int rg = 0; rg < 2; ++rg)
+        for (int j = r0[rg]; j < r1[rg]; ++j)
+        {
+          double *CT = blk(i, j);
+          for (int rk = 0; rk <= rg; ++rk)
+            for (int k = r0[rk]; k < std::min(r1[rk], j); ++k)
+              if (has(j, k))
+                tn_sub<NV>(CT, blk(j, k), blk(i, k), false);
+          apply_inverse<NV>(CT, X + (size_t)j * BB);
+        }
+      double *S = blk(i, i);
+      for (int rg = 0; rg < 2; ++rg)
+        for (int k = r0[rg]; k < r1[rg]; ++k)
+          tn_sub<NV>(S, blk(i, k), blk(i, k), true);
+      if (!factor_diag<NV>(S, X + (size_t)i * BB))
+        return 1 + i;
+      // forward substitution: y_i = L_ii^-1 (g_i - sum_k L_ik y_k)
+      double w[BP];
+      for (int r = 0; r < BP; ++r)
+        w[r] = y[(size_t)i * BP + r];
+      for (int rg = 0; rg < 2; ++rg)
+        for (int k = r0[rg]; k < r1[rg]; ++k)
+        {
+          const double *Tk = blk(i, k), *yk = y + (size_t)k * BP;
+          for (int t = 0; t < BP; ++t)
+          {
+            const double f = yk[t];
+            for (int r = 0; r < BP; ++r)
+              w[r] -= f * Tk[t * BP + r];
+          }
+        }
+      double yi[BP];
+      for (int c = 0; c < BP; ++c)
+        yi[c] = 0.0;
+      const double *Xi = X + (size_t)i * BB;
       for (int t = 0; t < BP; ++t)
       {
-        const double f = yk[t];
-        for (int r = 0; r < BP; ++r)
-          w[r] -= f * Tk[t * BP + r];
+        const double f = w[t];
+        for (int c = 0; c < BP; ++c) // X[t][c] = 0 for c < t
+          yi[c] += f * Xi[t * BP + c];
       }
+      for (int c = 0; c < BP; ++c)
+        y[(size_t)i * BP + c] = yi[c];
     }
-    double yi[BP];
-    for (int c = 0; c < BP; ++c)
-      yi[c] = 0.0;
-    const double *Xi = X + (size_t)i * BB;
-    for (int t = 0; t < BP; ++t)
-    {
-      const double f = w[t];
-      for (int c = 0; c < BP; ++c) // X[t][c] = 0 for c < t
-        yi[c] += f * Xi[t * BP + c];
-    }
-    for (int c = 0; c < BP; ++c)
-      y[(size_t)i * BP + c] = yi[c];
-    lap(4);
+    return 0;
   }
-#ifdef SAGE_CHOL_PROFILE
-  fprintf(stderr, "[chol profile] kcycles(tsc): offdiag-gemm %.1f apply-inverse %.1f diag-gemm %.1f factor+inv %.1f fwd-subst %.1f\n", tp[0] * 1e-3,
-          tp[1] * 1e-3, tp[2] * 1e-3, tp[3] * 1e-3, tp[4] * 1e-3);
-#endif
-  // back substitution: x_i = L_ii^-T (y_i - sum_{m>i, first[m]<=i} L_mi^T x_m)
-  for (int i = K - 1; i >= 0; --i)
+  // back substitution: x_i = L_ii^-T (y_i - sum_{m>i, (m,i) stored} L_mi^T x_m)
+  for (int i = hi - 1; i >= lo; --i)
   {
     double z[BP];
     for (int t = 0; t < BP; ++t)
       z[t] = y[(size_t)i * BP + t];
     for (int m = i + 1; m < K; ++m)
     {
-      if (row_first[m] > i)
+      if (!has(m, i))
         continue;
       const double *Tm = blk(m, i), *xm = y + (size_t)m * BP;
       for (int t = 0; t < BP; ++t)
@@ -1153,27 +1159,295 @@ static inline __attribute__((always_inline)) int block_chol_impl(int K, const in
   return 0;
 }
 
-__attribute__((target_clones("avx512f", "avx2", "default"))) static int block_chol_40(int K, const int32_t *row_first,
-                                                                                      const int32_t *row_off, double *T,
-                                                                                      double *X, double *y)
+__attribute__((target_clones("avx512f", "avx2", "default"))) static int block_chol_40(const BlockEnvelope &E, double *T,
+                                                                                      double *X, double *y, int phase,
+                                                                                      int lo, int hi)
 {
-  return block_chol_impl<5>(K, row_first, row_off, T, X, y);
+  return block_chol_pass<5>(E, T, X, y, phase, lo, hi);
 }
-__attribute__((target_clones("avx512f", "avx2", "default"))) static int block_chol_24(int K, const int32_t *row_first,
-                                                                                      const int32_t *row_off, double *T,
-                                                                                      double *X, double *y)
+__attribute__((target_clones("avx512f", "avx2", "default"))) static int block_chol_24(const BlockEnvelope &E, double *T,
+                                                                                      double *X, double *y, int phase,
+                                                                                      int lo, int hi)
 {
-  return block_chol_impl<3>(K, row_first, row_off, T, X, y);
+  return block_chol_pass<3>(E, T, X, y, phase, lo, hi);
+}
+static int block_chol_range(const BlockEnvelope &E, double *T, double *X, double *y, int phase, int lo, int hi)
+{
+  return E.Bp == 40 ? block_chol_40(E, T, X, y, phase, lo, hi) : block_chol_24(E, T, X, y, phase, lo, hi);
+}
+
+// The helper thread that takes the second half of a split window.  It sleeps on a condition variable, is woken by
+// block_chol_arm() (called while the caller still waits for the device), then spins for a job so that picking one up
+// costs no wake-up latency.  The caller never depends on it: a job the helper has not claimed by the time the caller
+// is done with its own half is claimed back and run by the caller.
+struct CholHelper
+{
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<bool> armed{false};
+  std::atomic<unsigned> posted{0};
+  std::atomic<int> claim{0};   // 0 free, 1 helper, 2 caller
+  std::atomic<int> p1_rc{-2};  // result of the helper's factorisation pass (-2: not finished)
+  std::atomic<int> go_p2{0};   // 1: run the back substitution, 2: skip it
+  std::atomic<int> p2_done{0};
+  std::atomic<bool> busy{false}; // one client at a time
+  const BlockEnvelope *E = nullptr;
+  double *T = nullptr, *X = nullptr, *y = nullptr;
+  std::thread th;
+  bool started = false;
+  static void cpu_relax() { __builtin_ia32_pause(); }
+  void loop()
+  {
+    unsigned seen = 0;
+    for (;;)
+    {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return armed.load(std::memory_order_acquire); });
+      }
+      const auto t0 = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (armed.load(std::memory_order_acquire))
+      {
+        const unsigned p = posted.load(std::memory_order_acquire);
+        if (p != seen)
+        {
+          seen = p;
+          int expect = 0;
+          if (claim.compare_exchange_strong(expect, 1, std::memory_order_acq_rel))
+          {
+            const BlockEnvelope &e = *E;
+            const int rc = block_chol_range(e, T, X, y, 0, e.n1, e.n1 + e.n2);
+            p1_rc.store(rc, std::memory_order_release);
+            int g;
+            while ((g = go_p2.load(std::memory_order_acquire)) == 0)
+              cpu_relax();
+            if (g == 1)
+              block_chol_range(e, T, X, y, 1, e.n1, e.n1 + e.n2);
+            p2_done.store(1, std::memory_order_release);
+          }
+        }
+        cpu_relax();
+        if ((++spins & 1023) == 0 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) // nobody came: back to sleep
+          armed.store(false, std::memory_order_release);
+      }
+    }
+  }
+};
+static CholHelper *chol_helper()
+{
+  // deliberately leaked: the thread may still be parked on the condition variable when the process exits
+  static CholHelper *h = [] {
+    if (getenv("SAGE_SOLVE_NO_HELPER") || std::thread::hardware_concurrency() < 2)
+      return (CholHelper *)nullptr;
+    CholHelper *p = new CholHelper;
+    p->th = std::thread([p] { p->loop(); });
+    p->th.detach();
+    return p;
+  }();
+  return h;
 }
 } // namespace
 
-int block_chol_solve_tr(int K, int Bp, const int32_t *row_first, const int32_t *row_off, double *T, double *X, double *y)
+void block_chol_arm()
 {
-  if (Bp == 40)
-    return block_chol_40(K, row_first, row_off, T, X, y);
-  if (Bp == 24)
-    return block_chol_24(K, row_first, row_off, T, X, y);
-  return -1;
+  CholHelper *h = chol_helper();
+  if (!h || h->armed.load(std::memory_order_acquire))
+    return;
+  {
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->armed.store(true, std::memory_order_release);
+  }
+  h->cv.notify_one();
+}
+
+int plan_blocks(int K, const std::vector<std::pair<int, int>> &links, bool allow_split, BlockPlan &out)
+{
+  std::vector<int32_t> &perm = out.perm, &pos = out.pos, &row_first = out.row_first, &row_off = out.row_off,
+                       &a_first = out.a_first, &a_cnt = out.a_cnt, &a_off = out.a_off, &blk_row = out.blk_row,
+                       &blk_col = out.blk_col, &blk_src = out.blk_src;
+  int &n1 = out.n1, &n2 = out.n2, &nblk = out.nblk;
+  // ---- elimination order.  A chain-like window (every keyframe linked to a few predecessors) splits at a separator of
+  // w consecutive keyframes into two halves without a link between them: order = [first half ascending | second half
+  // DESCENDING | separator].  The two halves are then two independent banded factorisations (the host runs them on two
+  // cores), only the w separator rows see both.  Windows with long-range links (loop closures) keep the identity order.
+  perm.assign(K, 0);
+  pos.assign(K, 0);
+  for (int k = 0; k < K; ++k)
+    perm[k] = k;
+  n1 = n2 = 0;
+  for (auto &l : links)
+    if (l.first < 0 || l.second <= l.first || l.second >= K)
+      return SAGE_E_INVALID;
+  if (allow_split && K >= 16)
+  {
+    int best_m = -1, best_w = 0, best_cost = K;
+    for (int m = K / 4; m <= (3 * K) / 4; ++m)
+    {
+      int wdt = 0;
+      for (auto &l : links)
+        if (l.first < m && l.second >= m)
+          wdt = std::max(wdt, l.second - m + 1);
+      if (wdt < 1 || wdt > 8 || m + wdt > K - 2)
+        continue;
+      const int cost = std::max(m, K - m - wdt) + 2 * wdt;
+      if (cost < best_cost)
+      {
+        best_cost = cost;
+        best_m = m;
+        best_w = wdt;
+      }
+    }
+    if (best_m > 0)
+    {
+      n1 = best_m;
+      n2 = K - best_m - best_w;
+      int q = 0;
+      for (int k = 0; k < best_m; ++k)
+        perm[q++] = k;
+      for (int k = K - 1; k >= best_m + best_w; --k)
+        perm[q++] = k;
+      for (int k = best_m; k < best_m + best_w; ++k)
+        perm[q++] = k;
+    }
+  }
+  for (int q = 0; q < K; ++q)
+    pos[perm[q]] = q;
+  // block storage: row i keeps the envelope range B = [row_first[i], i]; a separator row additionally keeps a range
+  // A = [a_first[i], n1) over the tail of the first half (the columns in between -- the whole second half up to its
+  // own tail -- are structurally zero in the factor and are neither stored nor visited).
+  const bool split = n1 > 0;
+  const int sep0 = n1 + n2;
+  row_first.assign(K, 0);
+  row_off.assign(K, 0);
+  a_first.assign(K, 0);
+  a_cnt.assign(K, 0);
+  a_off.assign(K, 0);
+  for (int k = 0; k < K; ++k)
+  {
+    row_first[k] = k;
+    a_first[k] = n1;
+  }
+  for (auto &l : links)
+  {
+    const int i = std::max(pos[l.first], pos[l.second]), j = std::min(pos[l.first], pos[l.second]);
+    if (split && i >= sep0 && j < n1)
+      a_first[i] = std::min(a_first[i], j);
+    else
+      row_first[i] = std::min(row_first[i], j);
+  }
+  if (split)
+    for (int i = sep0; i < K; ++i)
+    {
+      row_first[i] = std::min(row_first[i], (int32_t)sep0); // separator rows couple through both halves
+      a_cnt[i] = n1 - a_first[i];
+    }
+  nblk = 0;
+  for (int k = 0; k < K; ++k)
+  {
+    a_off[k] = nblk;
+    nblk += a_cnt[k];
+    row_off[k] = nblk;
+    nblk += k - row_first[k] + 1;
+  }
+  auto bidx = [&](int i, int j) {
+    return j < row_first[i] ? a_off[i] + j - a_first[i] : row_off[i] + j - row_first[i];
+  };
+  blk_row.assign(nblk, 0);
+  blk_col.assign(nblk, 0);
+  blk_src.assign(nblk, -1);
+  for (int k = 0; k < K; ++k)
+  {
+    for (int j = a_first[k]; j < a_first[k] + a_cnt[k]; ++j)
+    {
+      blk_row[bidx(k, j)] = k;
+      blk_col[bidx(k, j)] = j;
+    }
+    for (int j = row_first[k]; j <= k; ++j)
+    {
+      blk_row[bidx(k, j)] = k;
+      blk_col[bidx(k, j)] = j;
+    }
+  }
+  for (size_t l = 0; l < links.size(); ++l)
+  {
+    const int a = links[l].first, b = links[l].second;
+    const int i = std::max(pos[a], pos[b]), j = std::min(pos[a], pos[b]);
+    int &src = blk_src[bidx(i, j)];
+    if (src >= 0)
+      return SAGE_E_UNSUPPORTED; // duplicate link: the host path accumulates, this one does not
+    // the packed link block is H[a rows][b cols]; block (i,j) is H[perm[i] rows][perm[j] cols]
+    src = (int)l | (perm[i] == a ? 0x40000000 : 0);
+  }
+  return SAGE_OK;
+}
+
+int block_chol_solve_tr(const BlockEnvelope &E, double *T, double *X, double *y)
+{
+  if (E.Bp != 40 && E.Bp != 24)
+    return -1;
+  const int K = E.K;
+  if (E.n1 <= 0 || E.n2 <= 0)
+  {
+    const int rc = block_chol_range(E, T, X, y, 0, 0, K);
+    return rc ? rc : block_chol_range(E, T, X, y, 1, 0, K);
+  }
+  const int sep0 = E.n1 + E.n2;
+  CholHelper *h = chol_helper();
+  bool shared = false;
+  if (h && h->armed.load(std::memory_order_acquire))
+  {
+    bool expect = false;
+    if (h->busy.compare_exchange_strong(expect, true, std::memory_order_acq_rel))
+    {
+      shared = true;
+      h->E = &E; h->T = T; h->X = X; h->y = y;
+      h->claim.store(0, std::memory_order_relaxed);
+      h->p1_rc.store(-2, std::memory_order_relaxed);
+      h->go_p2.store(0, std::memory_order_relaxed);
+      h->p2_done.store(0, std::memory_order_relaxed);
+      h->posted.fetch_add(1, std::memory_order_release);
+    }
+  }
+  int rc = block_chol_range(E, T, X, y, 0, 0, E.n1);
+  bool helper_has_it = false;
+  if (shared)
+  {
+    int expect = 0;
+    helper_has_it = !h->claim.compare_exchange_strong(expect, 2, std::memory_order_acq_rel);
+  }
+  int rc2;
+  if (helper_has_it)
+  {
+    while ((rc2 = h->p1_rc.load(std::memory_order_acquire)) == -2)
+      CholHelper::cpu_relax();
+  }
+  else
+    rc2 = block_chol_range(E, T, X, y, 0, E.n1, sep0);
+  if (rc == 0)
+    rc = rc2;
+  if (rc == 0)
+    rc = block_chol_range(E, T, X, y, 0, sep0, K);
+  if (rc == 0)
+    block_chol_range(E, T, X, y, 1, sep0, K);
+  if (helper_has_it)
+    h->go_p2.store(rc == 0 ? 1 : 2, std::memory_order_release);
+  if (rc == 0)
+  {
+    block_chol_range(E, T, X, y, 1, 0, E.n1);
+    if (!helper_has_it)
+      block_chol_range(E, T, X, y, 1, E.n1, sep0);
+  }
+  if (helper_has_it)
+    while (!h->p2_done.load(std::memory_order_acquire))
+      CholHelper::cpu_relax();
+  if (shared)
+  {
+    h->armed.store(false, std::memory_order_release); // the helper goes back to sleep until the next arm
+    h->busy.store(false, std::memory_order_release);
+  }
+  return rc;
 }
 } // namespace sage
 
@@ -1203,19 +1477,37 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
   static const bool force_envelope = getenv("SAGE_SOLVE_ENVELOPE") != nullptr;
   if ((Bp == 40 || Bp == 24) && !force_envelope)
   {
-    // fixed-size transposed-block path (the one the window engine runs on the device-scattered storage)
+    // fixed-size transposed-block path (the one the window engine runs on the device-scattered storage), with the
+    // same elimination order and two-core split
     const int BBp = Bp * Bp;
-    std::vector<int32_t> row_first(first_blk.begin(), first_blk.end()), row_off(K);
-    int nblk = 0;
-    for (int k = 0; k < K; ++k)
+    std::vector<std::pair<int, int>> lk(nlinks);
+    for (int l = 0; l < nlinks; ++l)
+      lk[l] = {links[2 * l], links[2 * l + 1]};
+    sage::BlockPlan bp;
     {
-      row_off[k] = nblk;
-      nblk += k - row_first[k] + 1;
+      const int rcp = sage::plan_blocks(K, lk, getenv("SAGE_SOLVE_NO_SPLIT") == nullptr, bp);
+      if (rcp == SAGE_E_UNSUPPORTED) // duplicate links accumulate on this path: plan without them
+      {
+        std::sort(lk.begin(), lk.end());
+        lk.erase(std::unique(lk.begin(), lk.end()), lk.end());
+        const int rcq = sage::plan_blocks(K, lk, getenv("SAGE_SOLVE_NO_SPLIT") == nullptr, bp);
+        if (rcq != SAGE_OK)
+          return rcq;
+      }
+      else if (rcp != SAGE_OK)
+        return rcp;
     }
+    if (bp.n1 > 0)
+      sage::block_chol_arm();
+    const int nblk = bp.nblk;
+    auto bidx = [&](int i, int j) {
+      return j < bp.row_first[i] ? bp.a_off[i] + j - bp.a_first[i] : bp.row_off[i] + j - bp.row_first[i];
+    };
     std::vector<double> T((size_t)nblk * BBp, 0.0), X((size_t)K * BBp), y((size_t)K * Bp, 0.0);
-    for (int k = 0; k < K; ++k)
+    for (int q = 0; q < K; ++q)
     {
-      double *D = T.data() + (size_t)(row_off[k] + k - row_first[k]) * BBp;
+      const int k = bp.perm[q];
+      double *D = T.data() + (size_t)bidx(q, q) * BBp;
       for (int i = 0; i < Bp; ++i)
         for (int j = 0; j < Bp; ++j)
         {
@@ -1231,26 +1523,33 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
           D[i * Bp + j] = v;
         }
       for (int i = 0; i < B; ++i)
-        y[(size_t)k * Bp + i] = g[(size_t)k * B + i] + (g_add ? g_add[k * B + i] : 0.0);
+        y[(size_t)q * Bp + i] = g[(size_t)k * B + i] + (g_add ? g_add[k * B + i] : 0.0);
     }
     for (int l = 0; l < nlinks; ++l)
     {
-      const int a = links[2 * l], b = links[2 * l + 1]; // block (row b, col a), stored transposed: [c in a][r in b]
-      double *D = T.data() + (size_t)(row_off[b] + a - row_first[b]) * BBp;
+      const int a = links[2 * l], b = links[2 * l + 1];
+      const int qi = std::max(bp.pos[a], bp.pos[b]), qj = std::min(bp.pos[a], bp.pos[b]);
+      // stored block is [c in column keyframe][r in row keyframe]; the packed link block is [r in a][c in b]
+      double *D = T.data() + (size_t)bidx(qi, qj) * BBp;
+      const bool row_is_a = bp.perm[qi] == a;
       for (int i = 0; i < B; ++i)
         for (int j = 0; j < B; ++j)
-          D[i * Bp + j] += lnk[(size_t)l * BB + i * B + j];
+          D[row_is_a ? j * Bp + i : i * Bp + j] += lnk[(size_t)l * BB + i * B + j];
     }
     static const bool dbg2 = getenv("SAGE_DEBUG_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
-    const int rcf = sage::block_chol_solve_tr(K, Bp, row_first.data(), row_off.data(), T.data(), X.data(), y.data());
+    sage::BlockEnvelope env;
+    env.K = K; env.Bp = Bp; env.row_first = bp.row_first.data(); env.row_off = bp.row_off.data();
+    env.a_first = bp.a_first.data(); env.a_cnt = bp.a_cnt.data(); env.a_off = bp.a_off.data();
+    env.n1 = bp.n1; env.n2 = bp.n2;
+    const int rcf = sage::block_chol_solve_tr(env, T.data(), X.data(), y.data());
     if (dbg2)
       fprintf(stderr, "[sage block_solve] fixed-block Cholesky + substitution %.3f ms\n",
               std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     if (rcf != 0)
       return SAGE_E_NOT_PSD;
     for (int k = 0; k < K; ++k)
-      std::memcpy(delta + (size_t)k * B, y.data() + (size_t)k * Bp, sizeof(double) * B);
+      std::memcpy(delta + (size_t)k * B, y.data() + (size_t)bp.pos[k] * Bp, sizeof(double) * B);
     return SAGE_OK;
   }
   std::vector<int> first(n);

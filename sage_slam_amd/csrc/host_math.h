@@ -2,6 +2,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <utility>
 #include <vector>
 
 namespace sage
@@ -25,11 +26,37 @@ struct EnvelopeMatrix
   void solve_inplace(std::vector<double> &b) const; // after cholesky_inplace: b <- A^-1 b
 };
 
-// Block-envelope Cholesky solve on the storage the device scatter kernel produces (solve_kernels.hip): block (i,j),
-// row_first[i] <= j <= i, lives at T + (row_off[i] + j - row_first[i]) * Bp*Bp and holds the TRANSPOSED block
-// ([c][r] = A[i*Bp + r][j*Bp + c]); Bp is 40 or 24.  In place: T becomes L^T blockwise, X (K*Bp*Bp) receives the
-// inverses of the diagonal factors, y (K*Bp) the right-hand side on entry and the solution on return.
-// Returns 0, or 1 + the block column of the first non-positive pivot.
-int block_chol_solve_tr(int K, int Bp, const int32_t *row_first, const int32_t *row_off, double *T, double *X,
-                        double *y);
+// Block-envelope Cholesky solve on the storage the device scatter kernel produces (solve_kernels.hip).  Row i keeps
+// the blocks of columns B = [row_first[i], i] at T + (row_off[i] + j - row_first[i]) * Bp*Bp and, optionally, a
+// second range A = [a_first[i], a_first[i] + a_cnt[i]) (all < row_first[i]) at T + (a_off[i] + j - a_first[i]) * Bp*Bp;
+// columns between the two ranges are structurally zero in the factor.  Every block holds the TRANSPOSED block
+// ([c][r] = A[i*Bp + r][j*Bp + c]); Bp is 40 or 24.
+// n1/n2 > 0 declare that rows [0,n1) and [n1,n1+n2) do not reference each other (two halves of a window split at a
+// separator, solve_kernels.hip solver_create): they are factorised concurrently on two cores when a helper thread is
+// available (block_chol_arm), otherwise one after the other.
+struct BlockEnvelope
+{
+  int K = 0, Bp = 0;
+  const int32_t *row_first = nullptr, *row_off = nullptr;
+  const int32_t *a_first = nullptr, *a_cnt = nullptr, *a_off = nullptr; // may be null: no A ranges
+  int n1 = 0, n2 = 0;
+};
+// In place: T becomes L^T blockwise, X (K*Bp*Bp) receives the inverses of the diagonal factors, y (K*Bp) the
+// right-hand side on entry and the solution on return.  Returns 0, or 1 + the block column of the first non-positive
+// pivot, or -1 for an unsupported Bp.
+int block_chol_solve_tr(const BlockEnvelope &env, double *T, double *X, double *y);
+// Wake the helper thread ahead of a block_chol_solve_tr call with n1 > 0 (it then spins for the job for a few
+// milliseconds at most); call it when the system is about to be produced, e.g. before waiting on the D2H copy.
+void block_chol_arm();
+
+// Elimination order and block storage plan of a window's normal equations (K keyframe blocks, links (a,b), a < b).
+// perm[position] = keyframe, pos[keyframe] = position.  Block b of the storage is (blk_row[b], blk_col[b]) in
+// positions; blk_src[b] = link index, | 0x40000000 when the stored (transposed) block is the packed link block read
+// row-major (row keyframe == a), or -1 for diagonal / fill-in blocks.
+struct BlockPlan
+{
+  std::vector<int32_t> perm, pos, row_first, row_off, a_first, a_cnt, a_off, blk_row, blk_col, blk_src;
+  int nblk = 0, n1 = 0, n2 = 0;
+};
+int plan_blocks(int K, const std::vector<std::pair<int, int>> &links, bool allow_split, BlockPlan &out);
 } // namespace sage

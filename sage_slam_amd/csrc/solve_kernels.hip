@@ -50,7 +50,9 @@ struct SolvePlan
   const int32_t *col_rows;  // rows i > j with row_first[i] <= j, ascending
   const int32_t *job_ptr;   // [K+1]
   const int2 *jobs;         // trailing-update tile jobs of column j
-  const int32_t *blk_row, *blk_col, *blk_src; // [nblk]; src = link index or -1
+  const int32_t *blk_row, *blk_col, *blk_src; // [nblk]; src = link index (bit 30: stored block is the link block
+                                               // itself rather than its transpose) or -1
+  const int32_t *perm, *pos; // elimination order: perm[position] = keyframe, pos[keyframe] = position
 };
 
 struct SolvePriors
@@ -89,16 +91,19 @@ __global__ __launch_bounds__(256) void solve_scatter_kernel(const SolvePlan P, c
 {
   const int b = blockIdx.x, tid = threadIdx.x;
   const int B = P.B, Bp = P.Bp, BB = B * B;
-  const int i = P.blk_row[b], j = P.blk_col[b], src = P.blk_src[b];
-  const double *diag = packed + (size_t)i * BB;
+  const int i = P.blk_row[b], j = P.blk_col[b], srcf = P.blk_src[b];
+  const int src = srcf < 0 ? -1 : (srcf & 0x3fffffff);
+  const bool flip = srcf >= 0 && (srcf & 0x40000000);
+  const int kf = P.perm[i]; // keyframe of this block row
+  const double *diag = packed + (size_t)kf * BB;
   const double *lnk = packed + (size_t)P.K * BB + (size_t)(src < 0 ? 0 : src) * BB;
-  const double *g = packed + (size_t)P.K * BB + (size_t)P.nlinks * BB + (size_t)i * B;
+  const double *g = packed + (size_t)P.K * BB + (size_t)P.nlinks * BB + (size_t)kf * B;
   double *out = L + (size_t)b * Bp * Bp;
   __shared__ double s_dadd[64], s_gadd[64];
   if (i == j)
   {
     // diagonal priors (a9): code prior on every keyframe (zero prior mean), scale / pose priors on keyframe 0
-    const float *var = vars0 + (size_t)i * VS; // pose 12, scale, code CS
+    const float *var = vars0 + (size_t)kf * VS; // pose 12, scale, code CS
     if (tid < B)
     {
       double da = 0.0, ga = 0.0;
@@ -107,13 +112,13 @@ __global__ __launch_bounds__(256) void solve_scatter_kernel(const SolvePlan P, c
         da = pri.code_w;
         ga = pri.code_w * (0.0 - (double)var[13 + tid - 6]);
       }
-      if (i == 0 && tid == 6 + CS && pri.scale_w > 0)
+      if (kf == 0 && tid == 6 + CS && pri.scale_w > 0)
       {
         const double s = (double)var[12];
         da = pri.scale_w / (s * s);
         ga = pri.scale_w / s * (log((double)pri.scale_init0) - log(s));
       }
-      if (i == 0 && tid < 6 && pri.pose_w > 0)
+      if (kf == 0 && tid < 6 && pri.pose_w > 0)
       {
         double loc[6];
         pose_local_dev(var, pri.pose_init0, loc);
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256) void solve_scatter_kernel(const SolvePlan P, c
         v = 1.0 + damp; // identity padding: delta 0 on the padding rows
     }
     else if (src >= 0 && r < B && c < B)
-      v = lnk[c * B + r]; // packed link block is (a,b) with a < b: transposed into the lower triangle
+      v = flip ? lnk[r * B + c] : lnk[c * B + r]; // packed link block is (a,b), a < b; this block is (row kf, col kf)
     out[transposed ? c * Bp + r : idx] = v; // transposed: block stored [c][r] (the host factorisation's layout)
   }
   if (i == j)
@@ -456,7 +461,8 @@ __device__ inline void se3_exp_dev(const float *omega, const float *v, float *R,
 // One workgroup.  Besides the candidate variables (device) it writes the host mirror -- candidate variables, delta and
 // |delta|^2 -- straight into pinned host memory (h_*: device-visible), so no copy follows the solve.
 __global__ __launch_bounds__(256) void solve_retract_kernel(const double *__restrict__ x, int K, int B, int Bp, int CS,
-                                                            int VS, const float *__restrict__ vars0,
+                                                            int VS, const int32_t *__restrict__ pos,
+                                                            const float *__restrict__ vars0,
                                                             float *__restrict__ vars1, float *__restrict__ h_vars,
                                                             double *__restrict__ h_delta, double *__restrict__ h_tail)
 {
@@ -465,7 +471,7 @@ __global__ __launch_bounds__(256) void solve_retract_kernel(const double *__rest
   for (int idx = tid; idx < K * B; idx += blockDim.x)
   {
     const int k = idx / B, r = idx - k * B;
-    const double d = x[(size_t)k * Bp + r];
+    const double d = x[(size_t)pos[k] * Bp + r]; // x is in elimination order
     h_delta[idx] = d;
     nrm += d * d;
     const float *v0 = vars0 + (size_t)k * VS;
@@ -479,7 +485,7 @@ __global__ __launch_bounds__(256) void solve_retract_kernel(const double *__rest
   }
   for (int k = tid; k < K; k += blockDim.x)
   {
-    const double *xk = x + (size_t)k * Bp;
+    const double *xk = x + (size_t)pos[k] * Bp;
     const float *v0 = vars0 + (size_t)k * VS;
     float d6[6], dR[9], dt[3], o[12];
     for (int i = 0; i < 6; ++i)
@@ -524,7 +530,8 @@ struct DeviceSolver
   bool device_factor = false;               // SAGE_DEVICE_SOLVE=1
   void *h_T = nullptr, *h_y = nullptr;       // pinned, one allocation like d_L/d_y (hybrid path)
   std::vector<double> h_X;                   // inverses of the diagonal factors
-  std::vector<int32_t> h_row_first, h_row_off;
+  std::vector<int32_t> h_row_first, h_row_off, h_a_first, h_a_cnt, h_a_off;
+  int n1 = 0, n2 = 0; // two independent leading row ranges [0,n1) and [n1,n1+n2) of the elimination order (0: none)
 };
 
 constexpr int kSolveNC40 = 10; // sub-diagonal blocks of one block column kept in LDS (BP = 40)
@@ -547,36 +554,16 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
     if (K * Bp + Bp * (Bp + 1) + (kSolveThreads / Bp) * Bp > (NC + 1) * Bp * (Bp + 1))
       return SAGE_E_UNSUPPORTED;
   }
-  std::vector<int32_t> row_first(K), row_off(K);
-  for (int k = 0; k < K; ++k)
-    row_first[k] = k;
-  for (auto &l : links)
+  BlockPlan bp;
   {
-    if (l.first < 0 || l.second <= l.first || l.second >= K)
-      return SAGE_E_INVALID;
-    row_first[l.second] = std::min(row_first[l.second], l.first);
+    const int rcp = plan_blocks(K, links, !device_factor && !getenv("SAGE_SOLVE_NO_SPLIT"), bp);
+    if (rcp != SAGE_OK)
+      return rcp;
   }
-  int nblk = 0;
-  for (int k = 0; k < K; ++k)
-  {
-    row_off[k] = nblk;
-    nblk += k - row_first[k] + 1;
-  }
-  std::vector<int32_t> blk_row(nblk), blk_col(nblk), blk_src(nblk, -1);
-  for (int k = 0; k < K; ++k)
-    for (int j = row_first[k]; j <= k; ++j)
-    {
-      blk_row[row_off[k] + j - row_first[k]] = k;
-      blk_col[row_off[k] + j - row_first[k]] = j;
-    }
-  for (size_t l = 0; l < links.size(); ++l)
-  {
-    const int a = links[l].first, b = links[l].second;
-    int &src = blk_src[row_off[b] + a - row_first[b]];
-    if (src >= 0)
-      return SAGE_E_UNSUPPORTED; // duplicate link: the host path accumulates, this one does not
-    src = (int)l;
-  }
+  const int n1 = bp.n1, n2 = bp.n2, nblk = bp.nblk;
+  const std::vector<int32_t> &perm = bp.perm, &pos = bp.pos, &row_first = bp.row_first, &row_off = bp.row_off,
+                             &a_first = bp.a_first, &a_cnt = bp.a_cnt, &a_off = bp.a_off, &blk_row = bp.blk_row,
+                             &blk_col = bp.blk_col, &blk_src = bp.blk_src;
   std::vector<int32_t> col_ptr(K + 1, 0), col_rows, job_ptr(K + 1, 0);
   std::vector<int2> jobs;
   int max_rows = 0;
@@ -628,7 +615,8 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
     return off;
   };
   const size_t o_rf = put(row_first), o_ro = put(row_off), o_cp = put(col_ptr), o_cr = put(col_rows),
-               o_jp = put(job_ptr), o_br = put(blk_row), o_bc = put(blk_col), o_bs = put(blk_src);
+               o_jp = put(job_ptr), o_br = put(blk_row), o_bc = put(blk_col), o_bs = put(blk_src), o_pm = put(perm),
+               o_ps = put(pos);
   const size_t o_jobs = all.size();
   for (auto &jb : jobs)
   {
@@ -655,6 +643,9 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   S->device_factor = device_factor;
   S->h_row_first = row_first;
   S->h_row_off = row_off;
+  S->h_a_first = a_first;
+  S->h_a_cnt = a_cnt;
+  S->h_a_off = a_off;
   if (!S->device_factor)
   {
     if (hipHostMalloc(&S->h_T, ty_doubles * sizeof(double), hipHostMallocDefault) != hipSuccess)
@@ -673,7 +664,9 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   P.K = K; P.B = B; P.Bp = Bp; P.nblk = nblk; P.nlinks = (int)links.size();
   P.row_first = base + o_rf; P.row_off = base + o_ro; P.col_ptr = base + o_cp; P.col_rows = base + o_cr;
   P.job_ptr = base + o_jp; P.jobs = reinterpret_cast<const int2 *>(base + o_jobs);
-  P.blk_row = base + o_br; P.blk_col = base + o_bc; P.blk_src = base + o_bs;
+  P.blk_row = base + o_br; P.blk_col = base + o_bc; P.blk_src = base + o_bs; P.perm = base + o_pm; P.pos = base + o_ps;
+  S->n1 = n1;
+  S->n2 = n2;
   std::memset(S->h_pinned, 0, S->h_bytes);
   *out = S;
   return SAGE_OK;
@@ -735,13 +728,19 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
     static const bool dbgt = getenv("SAGE_DEBUG_TIMING") != nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     hipError_t eh;
+    if (S->n1 > 0)
+      block_chol_arm(); // the helper core wakes up while this thread waits for the device
     if ((eh = hipMemcpyAsync(S->h_T, dL, ((size_t)S->nblk * S->Bp * S->Bp + (size_t)S->K * S->Bp) * sizeof(double),
                              hipMemcpyDeviceToHost, stream)) != hipSuccess ||
         (eh = hipStreamSynchronize(stream)) != hipSuccess)
       return (int)eh;
     const auto t1 = std::chrono::steady_clock::now();
-    const int bad = block_chol_solve_tr(S->K, S->Bp, S->h_row_first.data(), S->h_row_off.data(),
-                                        reinterpret_cast<double *>(S->h_T), S->h_X.data(),
+    BlockEnvelope env;
+    env.K = S->K; env.Bp = S->Bp;
+    env.row_first = S->h_row_first.data(); env.row_off = S->h_row_off.data();
+    env.a_first = S->h_a_first.data(); env.a_cnt = S->h_a_cnt.data(); env.a_off = S->h_a_off.data();
+    env.n1 = S->n1; env.n2 = S->n2;
+    const int bad = block_chol_solve_tr(env, reinterpret_cast<double *>(S->h_T), S->h_X.data(),
                                         reinterpret_cast<double *>(S->h_y));
     const auto t2 = std::chrono::steady_clock::now();
     if (dbgt)
@@ -756,7 +755,7 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
   }
   char *h = reinterpret_cast<char *>(S->h_pinned);
   hipLaunchKernelGGL(solve_retract_kernel, dim3(1), dim3(256), 0, stream, reinterpret_cast<const double *>(S->d_y), S->K,
-                     S->B, S->Bp, CS, S->VS, vars0, vars1, reinterpret_cast<float *>(h + S->h_vars_off),
+                     S->B, S->Bp, CS, S->VS, S->plan.pos, vars0, vars1, reinterpret_cast<float *>(h + S->h_vars_off),
                      reinterpret_cast<double *>(h + S->h_delta_off), reinterpret_cast<double *>(h + S->h_tail_off));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess)

@@ -118,6 +118,39 @@ def test_block_solve_matches_dense():
         capi.block_solve(-packed, K, links, B, 0.0)
 
 
+@pytest.mark.parametrize("K,CS,window", [(24, 32, 3), (20, 16, 5), (33, 32, 1)])
+def test_block_solve_split_window_matches_dense(K, CS, window, monkeypatch):
+    """chain-like windows of >= 16 keyframes are eliminated as two independent halves + a separator (on two
+    cores when the helper thread picks its half up); the result is the dense solve either way, and a loop
+    closure falls back to the plain order."""
+    rng = np.random.default_rng(K)
+    B = 7 + CS
+    n = K * B
+    for extra in ([], [(1, K - 2)]):
+        links = [(j, i) for i in range(K) for j in range(max(0, i - window), i)] + extra
+        mask = np.eye(K, dtype=bool)
+        for a, b in links:
+            mask[a, b] = mask[b, a] = True
+        J = rng.normal(size=(2 * n, n))
+        Hs = (J.T @ J) * np.kron(mask, np.ones((B, B))) + 6 * n * np.eye(n)
+        g = rng.normal(size=n)
+        diag = np.stack([Hs[k * B:(k + 1) * B, k * B:(k + 1) * B] for k in range(K)])
+        lnk = np.stack([Hs[a * B:(a + 1) * B, b * B:(b + 1) * B] for a, b in links])
+        packed = np.concatenate([diag.reshape(-1), lnk.reshape(-1), g, np.zeros(4)])
+        ref = np.linalg.solve(Hs + 1e-4 * np.diag(np.diag(Hs)), g)
+        out = []
+        for no_split, no_helper in ((None, None), ("1", None)):
+            if no_split:
+                monkeypatch.setenv("SAGE_SOLVE_NO_SPLIT", no_split)
+            else:
+                monkeypatch.delenv("SAGE_SOLVE_NO_SPLIT", raising=False)
+            for _ in range(3):                                          # repeated: helper claimed / not claimed
+                d = capi.block_solve(packed, K, links, B, 1e-4)
+                assert rel(d, ref) < 1e-9
+                out.append(d)
+        assert rel(out[0], out[-1]) < 1e-11
+
+
 def test_tracker_lm_policy_with_oracle_backend(orc):
     """the product's LM driver (sage_track_lm) with the oracle as evaluation back-end: converges on a
     consistent scene, and its trace obeys the reference policy (camera_tracker.cpp:1156-1279)."""
