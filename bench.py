@@ -120,9 +120,11 @@ def main():
     dev_index = 0 if one_dev else local_rank
     torch.cuda.set_device(dev_index)
     dist = None
-    if world > 1:
+    # SAGE_BENCH_FORCE_DIST=1 (dev knob): take the sharded code path (process group, all-reduces) with one rank too
+    if world > 1 or os.environ.get("SAGE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if one_dev:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -151,10 +153,17 @@ def main():
     state = capi.SageLmState()
     cfg.max_inner_evals = 1          # one linearize + one solve + one error pass per step, as the multi-GPU path
 
+    # SAGE_BENCH_PY_STEPS=1 (dev knob): drive the sharded window from Python call by call instead of through
+    # sage_window_lm_step + the all-reduce hook
+    py_steps = os.environ.get("SAGE_BENCH_PY_STEPS") == "1"
+    if dist is not None and not py_steps:
+        win.set_allreduce(dist)
+
     def lm_step():
         nonlocal damp
-        if dist is None:
-            # single GPU: the engine's own LM iteration (sage_window_lm_step), no Python between the launches
+        if dist is None or not py_steps:
+            # the engine's own LM iteration (sage_window_lm_step): no Python between the launches; a sharded window
+            # enters Python only for its two all-reduces (packed normal equations, 4-double error totals)
             state.damp = damp
             win.lm_step(state, cfg)
             damp = state.damp

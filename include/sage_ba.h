@@ -408,8 +408,16 @@ int sage_shuffle_indices(int64_t seed, int64_t n, int64_t *idx_host);
 int sage_sample_locations(SageWorkspace *ws, const int64_t *valid_loc1d_dev, const float *valid_homo_dev, int n_valid,
                           int64_t seed, int num_samples, int64_t *loc1d_dev, float *homo_dev, int *n_out_host);
 
-/* one full LM iteration on a single GPU: linearize -> solve -> error at candidate -> accept/reject
- * (policy of camera_tracker.cpp:1156-1279). */
+/* sharded windows (sage_window_set_shard, world > 1): the in-place SUM all-reduce of a device buffer of n doubles
+ * over all ranks, enqueued so that it is ordered with the window's stream (an RCCL ncclAllReduce on that stream, or
+ * torch.distributed.all_reduce when the window runs on torch's current stream).  Returns 0 on success.  With the
+ * hook installed sage_window_lm_step drives a sharded window as well: the host code between the launches stays
+ * native, the hook is entered twice per iteration (packed buffer, 4-double error buffer). */
+typedef int (*SageAllReduceFn)(double *dev_buf, size_t n, void *user);
+int sage_window_set_allreduce(SageWindow *w, SageAllReduceFn fn, void *user);
+
+/* one full LM iteration: linearize -> (all-reduce) -> solve -> error at candidate -> (all-reduce) -> accept/reject
+ * (policy of camera_tracker.cpp:1156-1279).  Sharded windows need sage_window_set_allreduce first. */
 typedef struct SageLmState
 {
   double damp, error, candidate_error;

@@ -66,6 +66,9 @@ class SageWindowConfig(C.Structure):
                 ("use_photo", C.c_int32), ("use_geo", C.c_int32)]
 
 
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
 class SageLmState(C.Structure):
     _fields_ = [("damp", C.c_double), ("error", C.c_double), ("candidate_error", C.c_double),
                 ("accepted", C.c_int), ("iters", C.c_int)]
@@ -91,7 +94,7 @@ SYMBOLS = [
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step",
+    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_set_allreduce",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
@@ -489,6 +492,28 @@ class Window:
 
     def reset(self):
         _chk(lib().sage_window_reset(self.h), "sage_window_reset")
+
+    def set_allreduce(self, dist_module, group=None):
+        """Install ``torch.distributed.all_reduce`` as the window's all-reduce hook (``sage_window_set_allreduce``):
+        ``lm_step`` then drives a sharded window too, entering Python only for the two collectives."""
+        tensors = {}
+        for t in (self.packed_tensor(), self.error_tensor()):
+            tensors[(t.data_ptr(), t.numel())] = t
+
+        def hook(ptr, n, _user):
+            try:
+                t = tensors.get((ptr, n))
+                if t is None:
+                    t = tensors[(ptr, n)] = _tensor_from_ptr(ptr, n)
+                dist_module.all_reduce(t, group=group)
+                return 0
+            except Exception:                      # never unwind through the C frames
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._allreduce_cb = ALLREDUCE_FN(hook)    # keep the trampoline alive as long as the window
+        _chk(lib().sage_window_set_allreduce(self.h, self._allreduce_cb, None), "sage_window_set_allreduce")
 
     def lm_step(self, state: SageLmState, cfg: SageLmConfig):
         _chk(lib().sage_window_lm_step(self.h, C.byref(state), C.byref(cfg)), "sage_window_lm_step")

@@ -78,16 +78,20 @@ __global__ void depth_grad_batch_kernel(const DepthItem *__restrict__ items, int
   it.grad[((size_t)H + y) * W + x] = 0.5f * (a[(size_t)yp * W + x] - a[(size_t)ym * W + x]);
 }
 
-hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev, int K, int H, int W)
+hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev, int K, int H, int W, bool with_depth,
+                              bool with_grad)
 {
   const int HW = H * W;
-  if (CS == 32)
+  if (!with_depth)
+    ;
+  else if (CS == 32)
     hipLaunchKernelGGL((depth_batch_kernel<32>), dim3((HW * 8 + 255) / 256, K), dim3(256), 0, s, items_dev, HW);
   else if (CS == 16)
     hipLaunchKernelGGL((depth_batch_kernel<16>), dim3((HW * 4 + 255) / 256, K), dim3(256), 0, s, items_dev, HW);
   else
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL(depth_grad_batch_kernel, dim3((W + 63) / 64, H, K), dim3(64), 0, s, items_dev, H, W);
+  if (with_grad)
+    hipLaunchKernelGGL(depth_grad_batch_kernel, dim3((W + 63) / 64, H, K), dim3(64), 0, s, items_dev, H, W);
   return hipGetLastError();
 }
 

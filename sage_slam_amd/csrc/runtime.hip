@@ -749,6 +749,7 @@ struct AssembleParams
   const AdjEntry *adj;
   const LinkEdges *links; // [nlinks]
   double *packed;
+  double *tail_mirror; // pinned host copy of the 4-double tail (single-rank windows), or null
   int K, nlinks, CS, n_edges_p, n_edges_g;
 };
 
@@ -874,12 +875,16 @@ __global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
     for (int off = 32; off > 0; off >>= 1)
       acc += __shfl_down(acc, off);
     if (lane == 0 && wave < 4)
+    {
       tail[which * 2 + (photo ? 0 : 1)] = acc; // [err_photo err_geo n_photo n_geo]
+      if (p.tail_mirror)
+        p.tail_mirror[which * 2 + (photo ? 0 : 1)] = acc;
+    }
   }
 }
 
 __global__ __launch_bounds__(256) void sum_stats_kernel(const float *stats_p, int np, const float *stats_g, int ng,
-                                                        double *out)
+                                                        double *out, double *mirror)
 {
   // out = {sum err_photo, sum err_geo, sum n_photo, sum n_geo}; wave w sums one of the four in a fixed lane order
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -894,7 +899,22 @@ __global__ __launch_bounds__(256) void sum_stats_kernel(const float *stats_p, in
   for (int off = 32; off > 0; off >>= 1)
     acc += __shfl_down(acc, off);
   if (lane == 0)
+  {
     out[which * 2 + (photo ? 0 : 1)] = acc;
+    if (mirror) // pinned host memory: the host reads the totals after a stream sync, without a copy of its own
+      mirror[which * 2 + (photo ? 0 : 1)] = acc;
+  }
+}
+
+// sharded windows: the reduced totals (tail of the packed buffer, error buffer) -> pinned host mirror
+__global__ void mirror_totals_kernel(const double *__restrict__ tail, const double *__restrict__ err,
+                                     double *__restrict__ mirror)
+{
+  const int t = threadIdx.x;
+  if (t < 4)
+    mirror[t] = tail[t];
+  else if (t < 8)
+    mirror[t] = err[t - 4];
 }
 
 } // namespace sage
@@ -923,6 +943,11 @@ struct SageWindow
   // device
   DevBuf vars[2];                       // [K][VS]: pose 12, scale 1, code CS
   DevBuf dpt, dgrad, depth_items[2];    // per-keyframe depth maps of the set being evaluated
+  int dpt_set = -1;                     // variable set the depth maps currently hold (-1: none) ...
+  bool dgrad_valid = false;             // ... and whether their gradients are up to date as well
+  SageAllReduceFn allreduce = nullptr;  // sharded windows: caller-provided sum all-reduce (see sage_ba.h)
+  void *allreduce_user = nullptr;
+  double *h_err = nullptr;              // pinned [8]: {linearize tail[4], error pass totals[4]} written by the kernels
   DevBuf pk;                            // engine-internal channel-group pyramids [K][3 (f,gx,gy)][FS/4][P][4]
   DevBuf f0s;                           // per keyframe: pre-sampled source features [L][FS/4][N][4]
   DevBuf ptab[2], gtab[2];              // edge tables per variable set
@@ -1007,6 +1032,8 @@ static void upload_vars_host(SageWindow *w, int set, std::vector<float> &buf)
 
 static int upload_vars(SageWindow *w, int set)
 {
+  if (w->dpt_set == set)
+    w->dpt_set = -1;
   std::vector<float> buf;
   upload_vars_host(w, set, buf);
   SAGE_HIP(hipMemcpyAsync(w->vars[set].p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, w->stream));
@@ -1049,6 +1076,8 @@ extern "C" void sage_window_destroy(SageWindow *w)
   for (DevBuf *b : bufs)
     b->release();
   solver_destroy(w->solver);
+  if (w->h_err)
+    (void)hipHostFree(w->h_err);
   if (w->ev_fork)
     (void)hipEventDestroy(w->ev_fork);
   if (w->ev_join)
@@ -1084,6 +1113,15 @@ extern "C" int sage_window_add_link(SageWindow *w, int a, int b)
     return SAGE_E_INVALID;
   w->links.emplace_back(std::min(a, b), std::max(a, b));
   return (int)w->links.size() - 1;
+}
+
+extern "C" int sage_window_set_allreduce(SageWindow *w, SageAllReduceFn fn, void *user)
+{
+  if (!w)
+    return SAGE_E_INVALID;
+  w->allreduce = fn;
+  w->allreduce_user = user;
+  return SAGE_OK;
 }
 
 extern "C" int sage_window_set_shard(SageWindow *w, int rank, int world)
@@ -1319,6 +1357,11 @@ extern "C" int sage_window_finalize(SageWindow *w)
     return rc;
   SAGE_HIP(hipMemsetAsync(w->packed.p, 0, sage_window_packed_count(w) * sizeof(double), w->stream));
   SAGE_HIP(hipMemsetAsync(w->errbuf.p, 0, 4 * sizeof(double), w->stream));
+  if (!w->h_err)
+  {
+    SAGE_HIP(hipHostMalloc(reinterpret_cast<void **>(&w->h_err), 8 * sizeof(double), hipHostMallocDefault));
+    std::memset(w->h_err, 0, 8 * sizeof(double));
+  }
   w->host_packed.assign(sage_window_packed_count(w), 0.0);
   w->delta.assign((size_t)K * w->B, 0.0);
   if (!getenv("SAGE_HOST_SOLVE"))
@@ -1354,7 +1397,13 @@ extern "C" int sage_window_linearize(SageWindow *w)
   if (w->n_edges > 0)
   {
     // depth maps of every keyframe at the current variables: both factor types read their sample depths from them
-    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[0].as<DepthItem>(), w->K, H, W));
+    // (an accepted candidate's maps from the error pass are still valid: only the gradients are missing then)
+    static const bool no_reuse = getenv("SAGE_NO_DEPTH_REUSE") != nullptr;
+    const bool have_depth = w->dpt_set == 0 && !no_reuse;
+    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[0].as<DepthItem>(), w->K, H, W, !have_depth,
+                                !(have_depth && w->dgrad_valid)));
+    w->dpt_set = 0;
+    w->dgrad_valid = true;
     const bool fork = w->two_streams && c.use_photo && c.use_geo;
     hipStream_t gs = fork ? w->stream2 : w->stream;
     if (fork)
@@ -1396,6 +1445,7 @@ extern "C" int sage_window_linearize(SageWindow *w)
   ap.adj = w->adj.as<AdjEntry>();
   ap.links = w->link_edges.as<LinkEdges>();
   ap.packed = w->packed.as<double>();
+  ap.tail_mirror = w->world == 1 ? w->h_err : nullptr;
   ap.K = w->K;
   ap.nlinks = (int)w->links.size();
   ap.CS = c.CS;
@@ -1414,8 +1464,12 @@ extern "C" int sage_window_error(SageWindow *w, int which)
   const SageWindowConfig &c = w->cfg;
   const int H = (int)c.pyr.cam[0].h, W = (int)c.pyr.cam[0].w;
   const bool has = w->n_edges > 0;
-  if (has)
-    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[which].as<DepthItem>(), w->K, H, W));
+  if (has && w->dpt_set != which)
+  {
+    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[which].as<DepthItem>(), w->K, H, W, true, false));
+    w->dpt_set = which;
+    w->dgrad_valid = false;
+  }
   if (has && c.use_photo)
   {
     LaunchCommon lc = window_lc(w, true);
@@ -1432,7 +1486,8 @@ extern "C" int sage_window_error(SageWindow *w, int which)
   }
   hipLaunchKernelGGL(sum_stats_kernel, dim3(1), dim3(256), 0, w->stream,
                      (has && c.use_photo) ? w->stats_p.as<float>() : nullptr, w->n_edges,
-                     (has && c.use_geo) ? w->stats_g.as<float>() : nullptr, w->n_edges, w->errbuf.as<double>());
+                     (has && c.use_geo) ? w->stats_g.as<float>() : nullptr, w->n_edges, w->errbuf.as<double>(),
+                     w->world == 1 && w->h_err ? w->h_err + 4 : nullptr);
   SAGE_HIP(hipGetLastError());
   return SAGE_OK;
 }
@@ -1515,6 +1570,14 @@ extern "C" int sage_window_total_error(SageWindow *w, int from_linearize, double
   int rcs = sync_candidate(w);
   if (rcs)
     return rcs;
+  if (w->world == 1 && w->h_err)
+  {
+    // single-rank window: the kernels mirrored the totals into pinned host memory
+    SAGE_HIP(hipStreamSynchronize(w->stream));
+    const double *m = w->h_err + (from_linearize ? 0 : 4);
+    *err = m[0] + m[1] + prior_error(w, from_linearize ? 0 : 1);
+    return SAGE_OK;
+  }
   if (from_linearize)
   {
     const size_t off = sage_window_packed_count(w) - 4;
@@ -1540,6 +1603,8 @@ extern "C" int sage_window_solve(SageWindow *w, double damp, double *step_norm)
     int rc = sync_candidate(w); // an unconsumed earlier candidate (a re-solve with another damping)
     if (rc && rc != SAGE_E_NOT_PSD)
       return rc;
+    if (w->dpt_set == 1)
+      w->dpt_set = -1; // the solve rewrites the candidate set
     rc = solver_run(w->solver, w->stream, w->packed.as<double>(), w->vars[0].as<float>(), w->vars[1].as<float>(), CS,
                     damp, c.code_prior_weight, c.scale_prior_weight, c.pose_prior_weight, w->scale_init[0],
                     &w->pose_init[0]);
@@ -1638,6 +1703,7 @@ extern "C" int sage_window_accept(SageWindow *w)
   w->pose[0] = w->pose[1];
   w->code[0] = w->code[1];
   w->scale[0] = w->scale[1];
+  w->dpt_set = w->dpt_set == 1 ? 0 : -1; // depth maps evaluated at the candidate now belong to the current set
   SAGE_HIP(hipMemcpyAsync(w->vars[0].p, w->vars[1].p, (size_t)w->K * w->VS * sizeof(float), hipMemcpyDeviceToDevice,
                           w->stream));
   return SAGE_OK;
@@ -1741,11 +1807,16 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
   if (!w || !st || !cfg)
     return SAGE_E_INVALID;
   int rc;
+  if (w->world > 1 && !w->allreduce)
+    return SAGE_E_STATE;
+  const bool sharded = w->allreduce != nullptr; // (a hook on a single-rank window is honoured too)
   if (st->iters == 0 && st->damp <= 0)
     st->damp = cfg->init_damp;
   auto clampd = [&](double d) { return std::min(std::max((double)cfg->min_damp, d), (double)cfg->max_damp); };
   if ((rc = sage_window_linearize(w)))
     return rc;
+  if (sharded && w->allreduce(w->packed.as<double>(), sage_window_packed_count(w), w->allreduce_user))
+    return SAGE_E_STATE;
   int evals = 0;
   st->accepted = 0;
   while (true)
@@ -1756,10 +1827,26 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
       return rc;
     if ((rc = sage_window_error(w, 1)))
       return rc;
-    if (evals == 0 && (rc = sage_window_total_error(w, 1, &st->error)))
-      return rc;
-    if ((rc = sage_window_total_error(w, 0, &st->candidate_error)))
-      return rc;
+    if (sharded)
+    {
+      if (w->allreduce(w->errbuf.as<double>(), 4, w->allreduce_user))
+        return SAGE_E_STATE;
+      hipLaunchKernelGGL(mirror_totals_kernel, dim3(1), dim3(64), 0, w->stream,
+                         w->packed.as<double>() + sage_window_packed_count(w) - 4, w->errbuf.as<double>(), w->h_err);
+      if ((rc = sync_candidate(w)))
+        return rc;
+      SAGE_HIP(hipStreamSynchronize(w->stream));
+      if (evals == 0)
+        st->error = w->h_err[0] + w->h_err[1] + prior_error(w, 0);
+      st->candidate_error = w->h_err[4] + w->h_err[5] + prior_error(w, 1);
+    }
+    else
+    {
+      if (evals == 0 && (rc = sage_window_total_error(w, 1, &st->error)))
+        return rc;
+      if ((rc = sage_window_total_error(w, 0, &st->candidate_error)))
+        return rc;
+    }
     ++evals;
     if (st->candidate_error < st->error)
     {

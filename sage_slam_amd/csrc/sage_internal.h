@@ -149,7 +149,9 @@ struct DepthItem
 hipError_t launch_presample_source(hipStream_t s, float *f0s, const float *feat_pk, const float *homo, int N, int FS,
                                    const SagePyramid &pyr);
 hipError_t launch_repack_groups(hipStream_t s, float *dst, const float *src, int C, int P);
-hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev, int K, int H, int W);
+// depth maps (and, for the Jacobian pass, their central-difference gradients) of all keyframes of a window
+hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev, int K, int H, int W, bool with_depth,
+                              bool with_grad);
 hipError_t launch_stats_finalize(hipStream_t s, const LaunchCommon &lc, float *stats, float fallback, float scale);
 size_t reproj_scratch_floats(int N, int D);
 hipError_t launch_reproj(hipStream_t s, int CS, bool tracker, bool jac, const float *R10, const float *t10, const float *R0,
