@@ -433,7 +433,7 @@ struct GeoFinalizeParams
 };
 
 template <int CS>
-__global__ __launch_bounds__(kBlock) void geo_finalize_kernel(const GeoFinalizeParams prm)
+__global__ __launch_bounds__(kFinalizeBlock) void geo_finalize_kernel(const GeoFinalizeParams prm)
 {
   constexpr int PP = geo_partial_floats(CS);
   constexpr int D = 14 + 2 * CS;
@@ -445,13 +445,22 @@ __global__ __launch_bounds__(kBlock) void geo_finalize_kernel(const GeoFinalizeP
   const float s0 = E.scale0 ? *E.scale0 : E.scale0_val;
   const float s1 = E.scale1 ? *E.scale1 : E.scale1_val;
   const int first = prm.edge_first[e], nt = prm.edge_tiles[e];
-  for (int idx = tid; idx < PP; idx += kBlock)
+  for (int idx = tid; idx < PP; idx += kFinalizeBlock)
   {
     double a = 0.0; // the per-workgroup partials are summed in double: free (a few dozen adds), and it keeps the
                     // engine's accumulation noise below the reference's own fp32 floor
-    for (int t = 0; t < nt; ++t)
-      a += (double)prm.partials[(size_t)(first + t) * PP + idx];
-    s[idx] = a;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0; // four independent chains: the loads of a round are in flight together
+    const float *pp = prm.partials + (size_t)first * PP + idx;
+    int t = 0;
+    for (; t + 4 <= nt; t += 4)
+    {
+      const float v0 = pp[(size_t)t * PP], v1 = pp[(size_t)(t + 1) * PP], v2 = pp[(size_t)(t + 2) * PP],
+                  v3 = pp[(size_t)(t + 3) * PP];
+      a += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+    }
+    for (; t < nt; ++t)
+      a += (double)pp[(size_t)t * PP];
+    s[idx] = (a + a1) + (a2 + a3);
   }
   __syncthreads();
   const double n_in = s[45];
@@ -504,7 +513,7 @@ __global__ __launch_bounds__(kBlock) void geo_finalize_kernel(const GeoFinalizeP
   };
   float *AtA = prm.AtA + (size_t)e * D * D;
   float *Atb = prm.Atb + (size_t)e * D;
-  for (int q = tid; q < D * D + D; q += kBlock)
+  for (int q = tid; q < D * D + D; q += kFinalizeBlock)
   {
     double val = 0.0;
     if (ok)
@@ -573,7 +582,7 @@ static hipError_t geo_lin_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   f.Atb = out.Atb;
   f.stats = out.stats;
   f.weight = weight;
-  hipLaunchKernelGGL((geo_finalize_kernel<CS>), dim3(lc.n_edges), dim3(kBlock), 0, s, f);
+  hipLaunchKernelGGL((geo_finalize_kernel<CS>), dim3(lc.n_edges), dim3(kFinalizeBlock), 0, s, f);
   return hipGetLastError();
 }
 

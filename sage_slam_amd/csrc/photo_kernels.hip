@@ -523,7 +523,7 @@ __device__ __forceinline__ double tile_elem(const double *s, int base, int tile,
 }
 
 template <int CS>
-__global__ __launch_bounds__(kBlock) void photo_finalize_kernel(const PhotoFinalizeParams prm)
+__global__ __launch_bounds__(kFinalizeBlock) void photo_finalize_kernel(const PhotoFinalizeParams prm)
 {
   constexpr int PP = photo_partial_floats(CS);
   constexpr int D = 13 + CS;
@@ -532,13 +532,22 @@ __global__ __launch_bounds__(kBlock) void photo_finalize_kernel(const PhotoFinal
   const PhotoEdge &E = prm.table ? prm.table[e] : prm.single;
   const float s0 = E.scale0 ? *E.scale0 : E.scale0_val;
   const int first = prm.edge_first[e], nt = prm.edge_tiles[e];
-  for (int idx = tid; idx < PP; idx += kBlock)
+  for (int idx = tid; idx < PP; idx += kFinalizeBlock)
   {
     double a = 0.0; // the per-workgroup partials are summed in double: free (a few dozen adds), and it keeps the
                     // engine's accumulation noise below the reference's own fp32 floor
-    for (int t = 0; t < nt; ++t)
-      a += (double)prm.partials[(size_t)(first + t) * PP + idx];
-    s[idx] = a;
+    double a1 = 0.0, a2 = 0.0, a3 = 0.0; // four independent chains: the loads of a round are in flight together
+    const float *pp = prm.partials + (size_t)first * PP + idx;
+    int t = 0;
+    for (; t + 4 <= nt; t += 4)
+    {
+      const float v0 = pp[(size_t)t * PP], v1 = pp[(size_t)(t + 1) * PP], v2 = pp[(size_t)(t + 2) * PP],
+                  v3 = pp[(size_t)(t + 3) * PP];
+      a += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+    }
+    for (; t < nt; ++t)
+      a += (double)pp[(size_t)t * PP];
+    s[idx] = (a + a1) + (a2 + a3);
   }
   __syncthreads();
   const double s0d = (double)s0;
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(kBlock) void photo_finalize_kernel(const PhotoFinal
     }
     return tile_elem(s, kPhotoScalars, 0, i, j);
   };
-  for (int idx = tid; idx < D * D + D; idx += kBlock)
+  for (int idx = tid; idx < D * D + D; idx += kFinalizeBlock)
   {
     double val = 0.0;
     if (ok)
@@ -719,7 +728,7 @@ static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const P
   f.Atb = out.Atb;
   f.stats = out.stats;
   f.wsum = wsum;
-  hipLaunchKernelGGL((photo_finalize_kernel<CS>), dim3(lc.n_edges), dim3(kBlock), 0, s, f);
+  hipLaunchKernelGGL((photo_finalize_kernel<CS>), dim3(lc.n_edges), dim3(kFinalizeBlock), 0, s, f);
   return hipGetLastError();
 }
 

@@ -13,6 +13,7 @@ namespace sage
 {
 
 constexpr int kBlock = 256;          // 4 waves of 64
+constexpr int kFinalizeBlock = 1024; // per-edge finalize kernels: one workgroup per edge, latency bound -> wide workgroups
 constexpr int kWaves = kBlock / 64;
 constexpr int kTile = 256;           // source pixels per sub-tile (one per lane)
 
