@@ -15,6 +15,7 @@
 #include <thread>
 #include <condition_variable>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <numeric>
 #include <random>
@@ -1060,6 +1061,37 @@ static inline __attribute__((always_inline)) bool factor_diag(double *S, double 
   return true;
 }
 
+// The device streams the blocks in row order (solve_kernels.hip): wait until every block of row i carries this solve's
+// ticket.  (Not inlined: keeps <chrono> out of the target_clones bodies.)
+static double mono_seconds()
+{
+  timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+static __attribute__((noinline)) bool wait_row_tickets(const BlockEnvelope &E, int i)
+{
+  const int na = E.a_cnt ? E.a_cnt[i] : 0;
+  const int b0[2] = {na ? E.a_off[i] : 0, E.row_off[i]}, nb[2] = {na, i - E.row_first[i] + 1};
+  for (int rg = 0; rg < 2; ++rg)
+    for (int q = 0; q < nb[rg]; ++q)
+    {
+      const volatile unsigned *f = E.ready + b0[rg] + q;
+      if (*f == E.epoch)
+        continue;
+      const double t0 = mono_seconds();
+      unsigned spins = 0;
+      while (*f != E.epoch)
+      {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfff) == 0 && mono_seconds() - t0 > 2.0)
+          return false;
+      }
+    }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return true;
+}
+
 // One pass over a range of block rows.  phase 0: factorise rows [lo,hi) ascending and forward-substitute y;
 // phase 1: back-substitute rows [lo,hi) descending.  Rows only touch the blocks of their own column ranges, so two
 // row ranges that do not reference each other can run on two cores.
@@ -1080,6 +1112,8 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
   {
     for (int i = lo; i < hi; ++i)
     {
+      if (E.ready && !wait_row_tickets(E, i))
+        return -2;
       // the column ranges of row i, in ascending order
       const int r0[2] = {afirst(i), row_first[i]}, r1[2] = {afirst(i) + acnt(i), i};
       for (int rg = 0; rg < 2; ++rg)
@@ -1205,7 +1239,7 @@ struct CholHelper
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return armed.load(std::memory_order_acquire); });
       }
-      const auto t0 = std::chrono::steady_clock::now();
+      const double t0 = mono_seconds();
       unsigned spins = 0;
       while (armed.load(std::memory_order_acquire))
       {
@@ -1228,8 +1262,7 @@ struct CholHelper
           }
         }
         cpu_relax();
-        if ((++spins & 1023) == 0 &&
-            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) // nobody came: back to sleep
+        if ((++spins & 1023) == 0 && mono_seconds() - t0 > 8e-3) // nobody came: back to sleep
           armed.store(false, std::memory_order_release);
       }
     }

@@ -40,10 +40,14 @@ struct BlockEnvelope
   const int32_t *row_first = nullptr, *row_off = nullptr;
   const int32_t *a_first = nullptr, *a_cnt = nullptr, *a_off = nullptr; // may be null: no A ranges
   int n1 = 0, n2 = 0;
+  // optional: ready[b] == epoch once block b of the storage (and, for a diagonal block, its rows of y) has been
+  // delivered by the device; a row is only touched after all its blocks have arrived
+  const volatile unsigned *ready = nullptr;
+  unsigned epoch = 0;
 };
 // In place: T becomes L^T blockwise, X (K*Bp*Bp) receives the inverses of the diagonal factors, y (K*Bp) the
 // right-hand side on entry and the solution on return.  Returns 0, or 1 + the block column of the first non-positive
-// pivot, or -1 for an unsupported Bp.
+// pivot, -1 for an unsupported Bp, -2 when a block's ticket did not arrive within two seconds.
 int block_chol_solve_tr(const BlockEnvelope &env, double *T, double *X, double *y);
 // Wake the helper thread ahead of a block_chol_solve_tr call with n1 > 0 (it then spins for the job for a few
 // milliseconds at most); call it when the system is about to be produced, e.g. before waiting on the D2H copy.

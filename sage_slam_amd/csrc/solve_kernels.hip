@@ -82,76 +82,95 @@ __device__ inline void pose_local_dev(const float *origin, const float *other, d
 }
 
 // ------------------------------------------------------------------------------------------------
-// scatter: one workgroup per envelope block
+// scatter: a workgroup per envelope block (device factorisation), or a few workgroups walking the blocks in the order
+// the host factorisation consumes them and writing straight into pinned host memory (hybrid path): every block is
+// followed by a ticket in `flags`, so the host starts on row 0 while the later rows are still crossing PCIe.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void solve_scatter_kernel(const SolvePlan P, const double *__restrict__ packed,
                                                             const float *__restrict__ vars0, int VS, int CS,
                                                             const SolvePriors pri, double damp, int transposed,
-                                                            double *__restrict__ L, double *__restrict__ y)
+                                                            double *__restrict__ L, double *__restrict__ y,
+                                                            const int32_t *__restrict__ order, unsigned *flags,
+                                                            unsigned epoch)
 {
-  const int b = blockIdx.x, tid = threadIdx.x;
+  const int tid = threadIdx.x;
   const int B = P.B, Bp = P.Bp, BB = B * B;
-  const int i = P.blk_row[b], j = P.blk_col[b], srcf = P.blk_src[b];
-  const int src = srcf < 0 ? -1 : (srcf & 0x3fffffff);
-  const bool flip = srcf >= 0 && (srcf & 0x40000000);
-  const int kf = P.perm[i]; // keyframe of this block row
-  const double *diag = packed + (size_t)kf * BB;
-  const double *lnk = packed + (size_t)P.K * BB + (size_t)(src < 0 ? 0 : src) * BB;
-  const double *g = packed + (size_t)P.K * BB + (size_t)P.nlinks * BB + (size_t)kf * B;
-  double *out = L + (size_t)b * Bp * Bp;
   __shared__ double s_dadd[64], s_gadd[64];
-  if (i == j)
+  for (int it = blockIdx.x; it < P.nblk; it += gridDim.x)
   {
-    // diagonal priors (a9): code prior on every keyframe (zero prior mean), scale / pose priors on keyframe 0
-    const float *var = vars0 + (size_t)kf * VS; // pose 12, scale, code CS
-    if (tid < B)
-    {
-      double da = 0.0, ga = 0.0;
-      if (tid >= 6 && tid < 6 + CS)
-      {
-        da = pri.code_w;
-        ga = pri.code_w * (0.0 - (double)var[13 + tid - 6]);
-      }
-      if (kf == 0 && tid == 6 + CS && pri.scale_w > 0)
-      {
-        const double s = (double)var[12];
-        da = pri.scale_w / (s * s);
-        ga = pri.scale_w / s * (log((double)pri.scale_init0) - log(s));
-      }
-      if (kf == 0 && tid < 6 && pri.pose_w > 0)
-      {
-        double loc[6];
-        pose_local_dev(var, pri.pose_init0, loc);
-        da = pri.pose_w;
-        ga = pri.pose_w * loc[tid];
-      }
-      s_dadd[tid] = da;
-      s_gadd[tid] = ga;
-    }
-    __syncthreads();
-  }
-  for (int idx = tid; idx < Bp * Bp; idx += blockDim.x)
-  {
-    const int r = idx / Bp, c = idx - r * Bp;
-    double v = 0.0;
+    const int b = order ? order[it] : it;
+    const int i = P.blk_row[b], j = P.blk_col[b], srcf = P.blk_src[b];
+    const int src = srcf < 0 ? -1 : (srcf & 0x3fffffff);
+    const bool flip = srcf >= 0 && (srcf & 0x40000000);
+    const int kf = P.perm[i]; // keyframe of this block row
+    const double *diag = packed + (size_t)kf * BB;
+    const double *lnk = packed + (size_t)P.K * BB + (size_t)(src < 0 ? 0 : src) * BB;
+    const double *g = packed + (size_t)P.K * BB + (size_t)P.nlinks * BB + (size_t)kf * B;
+    double *out = L + (size_t)b * Bp * Bp;
     if (i == j)
     {
-      if (r < B && c < B)
+      // diagonal priors (a9): code prior on every keyframe (zero prior mean), scale / pose priors on keyframe 0
+      const float *var = vars0 + (size_t)kf * VS; // pose 12, scale, code CS
+      if (tid < B)
       {
-        v = 0.5 * (diag[r * B + c] + diag[c * B + r]);
-        if (r == c)
-          v = (v + s_dadd[r]) * (1.0 + damp); // LM damping H + damp*diag(H) (camera_tracker.cpp:1182)
+        double da = 0.0, ga = 0.0;
+        if (tid >= 6 && tid < 6 + CS)
+        {
+          da = pri.code_w;
+          ga = pri.code_w * (0.0 - (double)var[13 + tid - 6]);
+        }
+        if (kf == 0 && tid == 6 + CS && pri.scale_w > 0)
+        {
+          const double s = (double)var[12];
+          da = pri.scale_w / (s * s);
+          ga = pri.scale_w / s * (log((double)pri.scale_init0) - log(s));
+        }
+        if (kf == 0 && tid < 6 && pri.pose_w > 0)
+        {
+          double loc[6];
+          pose_local_dev(var, pri.pose_init0, loc);
+          da = pri.pose_w;
+          ga = pri.pose_w * loc[tid];
+        }
+        s_dadd[tid] = da;
+        s_gadd[tid] = ga;
       }
-      else if (r == c)
-        v = 1.0 + damp; // identity padding: delta 0 on the padding rows
+      __syncthreads();
     }
-    else if (src >= 0 && r < B && c < B)
-      v = flip ? lnk[r * B + c] : lnk[c * B + r]; // packed link block is (a,b), a < b; this block is (row kf, col kf)
-    out[transposed ? c * Bp + r : idx] = v; // transposed: block stored [c][r] (the host factorisation's layout)
+    // consecutive threads write consecutive doubles (the stores may be crossing PCIe); (r, c) = element of the block
+    for (int o = tid; o < Bp * Bp; o += blockDim.x)
+    {
+      const int hi = o / Bp, lo = o - hi * Bp;
+      const int r = transposed ? lo : hi, c = transposed ? hi : lo; // transposed: block stored [c][r]
+      double v = 0.0;
+      if (i == j)
+      {
+        if (r < B && c < B)
+        {
+          v = 0.5 * (diag[r * B + c] + diag[c * B + r]);
+          if (r == c)
+            v = (v + s_dadd[r]) * (1.0 + damp); // LM damping H + damp*diag(H) (camera_tracker.cpp:1182)
+        }
+        else if (r == c)
+          v = 1.0 + damp; // identity padding: delta 0 on the padding rows
+      }
+      else if (src >= 0 && r < B && c < B)
+        v = flip ? lnk[r * B + c] : lnk[c * B + r]; // packed link block is (a,b), a < b; this block is (row kf, col kf)
+      out[o] = v;
+    }
+    if (i == j)
+      for (int r = tid; r < Bp; r += blockDim.x)
+        y[(size_t)i * Bp + r] = r < B ? g[r] + s_gadd[r] : 0.0;
+    if (flags)
+    {
+      __threadfence_system(); // the block (and its rhs rows) are visible to the host before the ticket is
+      __syncthreads();
+      if (tid == 0)
+        *reinterpret_cast<volatile unsigned *>(flags + b) = epoch;
+    }
+    else
+      __syncthreads(); // s_dadd / s_gadd are reused by the next block
   }
-  if (i == j)
-    for (int r = tid; r < Bp; r += blockDim.x)
-      y[(size_t)i * Bp + r] = r < B ? g[r] + s_gadd[r] : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -532,6 +551,12 @@ struct DeviceSolver
   std::vector<double> h_X;                   // inverses of the diagonal factors
   std::vector<int32_t> h_row_first, h_row_off, h_a_first, h_a_cnt, h_a_off;
   int n1 = 0, n2 = 0; // two independent leading row ranges [0,n1) and [n1,n1+n2) of the elimination order (0: none)
+  // hybrid path: the scatter kernel writes blocks + rhs straight into h_T / h_y in consumption order and posts a
+  // ticket (the epoch of this solve) per block in h_flags
+  const int32_t *d_order = nullptr;
+  unsigned *h_flags = nullptr;
+  unsigned epoch = 0;
+  int scatter_wgs = 32;
 };
 
 constexpr int kSolveNC40 = 10; // sub-diagonal blocks of one block column kept in LDS (BP = 40)
@@ -617,6 +642,32 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   const size_t o_rf = put(row_first), o_ro = put(row_off), o_cp = put(col_ptr), o_cr = put(col_rows),
                o_jp = put(job_ptr), o_br = put(blk_row), o_bc = put(blk_col), o_bs = put(blk_src), o_pm = put(perm),
                o_ps = put(pos);
+  // consumption order of the host factorisation: the two halves row by row side by side, the separator last
+  std::vector<int32_t> order;
+  {
+    auto push_row = [&](int i) {
+      for (int q = 0; q < a_cnt[i]; ++q)
+        order.push_back(a_off[i] + q);
+      for (int q = 0; q <= i - row_first[i]; ++q)
+        order.push_back(row_off[i] + q);
+    };
+    if (n1 > 0)
+    {
+      for (int t = 0; t < std::max(n1, n2); ++t)
+      {
+        if (t < n1)
+          push_row(t);
+        if (t < n2)
+          push_row(n1 + t);
+      }
+      for (int i = n1 + n2; i < K; ++i)
+        push_row(i);
+    }
+    else
+      for (int i = 0; i < K; ++i)
+        push_row(i);
+  }
+  const size_t o_ord = put(order);
   const size_t o_jobs = all.size();
   for (auto &jb : jobs)
   {
@@ -648,9 +699,14 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   S->h_a_off = a_off;
   if (!S->device_factor)
   {
-    if (hipHostMalloc(&S->h_T, ty_doubles * sizeof(double), hipHostMallocDefault) != hipSuccess)
+    if (hipHostMalloc(&S->h_T, ty_doubles * sizeof(double) + (size_t)nblk * sizeof(unsigned), hipHostMallocDefault) !=
+        hipSuccess)
       return fail((int)hipErrorOutOfMemory);
     S->h_y = reinterpret_cast<double *>(S->h_T) + (size_t)nblk * Bp * Bp;
+    S->h_flags = reinterpret_cast<unsigned *>(reinterpret_cast<double *>(S->h_T) + ty_doubles);
+    std::memset(S->h_flags, 0, (size_t)nblk * sizeof(unsigned));
+    if (const char *e = getenv("SAGE_SCATTER_WGS"))
+      S->scatter_wgs = std::max(1, atoi(e));
     S->h_X.assign((size_t)K * Bp * Bp, 0.0);
   }
   S->h_vars_off = 0;
@@ -667,6 +723,7 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   P.blk_row = base + o_br; P.blk_col = base + o_bc; P.blk_src = base + o_bs; P.perm = base + o_pm; P.pos = base + o_ps;
   S->n1 = n1;
   S->n2 = n2;
+  S->d_order = base + o_ord;
   std::memset(S->h_pinned, 0, S->h_bytes);
   *out = S;
   return SAGE_OK;
@@ -702,8 +759,9 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
   if (S->device_factor && hipMemsetAsync(S->d_tail, 0, 2 * sizeof(double), stream) != hipSuccess)
     return (int)hipGetLastError();
   double *dL = reinterpret_cast<double *>(S->d_L), *dy = reinterpret_cast<double *>(S->d_y);
-  hipLaunchKernelGGL(solve_scatter_kernel, dim3(S->nblk), dim3(256), 0, stream, S->plan, packed_dev, vars0, S->VS, CS,
-                     pri, damp, S->device_factor ? 0 : 1, dL, dy);
+  if (S->device_factor)
+    hipLaunchKernelGGL(solve_scatter_kernel, dim3(S->nblk), dim3(256), 0, stream, S->plan, packed_dev, vars0, S->VS, CS,
+                       pri, damp, 0, dL, dy, (const int32_t *)nullptr, (unsigned *)nullptr, 0u);
   if (S->device_factor)
   {
     unsigned long long *dbg = reinterpret_cast<unsigned long long *>(S->d_dbg);
@@ -724,15 +782,20 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
   }
   else
   {
-    // hybrid: the dependency chain of the factorisation runs on a host core, everything around it stays on the device
+    // hybrid: the dependency chain of the factorisation runs on host cores, everything around it stays on the device.
+    // The scatter kernel streams the blocks into pinned host memory in the order the factorisation consumes them and
+    // tickets each one, so the host works on row 0 while the rest is still crossing PCIe (no D2H copy, no stream sync).
     static const bool dbgt = getenv("SAGE_DEBUG_TIMING") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
     hipError_t eh;
     if (S->n1 > 0)
       block_chol_arm(); // the helper core wakes up while this thread waits for the device
-    if ((eh = hipMemcpyAsync(S->h_T, dL, ((size_t)S->nblk * S->Bp * S->Bp + (size_t)S->K * S->Bp) * sizeof(double),
-                             hipMemcpyDeviceToHost, stream)) != hipSuccess ||
-        (eh = hipStreamSynchronize(stream)) != hipSuccess)
+    S->epoch += 1;
+    if (S->epoch == 0) // wrapped: 0 is the "never written" value
+      S->epoch = 1;
+    hipLaunchKernelGGL(solve_scatter_kernel, dim3(std::min(S->scatter_wgs, S->nblk)), dim3(256), 0, stream, S->plan,
+                       packed_dev, vars0, S->VS, CS, pri, damp, 1, reinterpret_cast<double *>(S->h_T),
+                       reinterpret_cast<double *>(S->h_y), S->d_order, S->h_flags, S->epoch);
+    if ((eh = hipGetLastError()) != hipSuccess)
       return (int)eh;
     const auto t1 = std::chrono::steady_clock::now();
     BlockEnvelope env;
@@ -740,21 +803,23 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
     env.row_first = S->h_row_first.data(); env.row_off = S->h_row_off.data();
     env.a_first = S->h_a_first.data(); env.a_cnt = S->h_a_cnt.data(); env.a_off = S->h_a_off.data();
     env.n1 = S->n1; env.n2 = S->n2;
+    env.ready = S->h_flags; env.epoch = S->epoch;
     const int bad = block_chol_solve_tr(env, reinterpret_cast<double *>(S->h_T), S->h_X.data(),
                                         reinterpret_cast<double *>(S->h_y));
     const auto t2 = std::chrono::steady_clock::now();
     if (dbgt)
-      fprintf(stderr, "[sage hybrid solve] wait+scatter+d2h %.3f host cholesky %.3f ms\n",
-              std::chrono::duration<double, std::milli>(t1 - t0).count(),
+      fprintf(stderr, "[sage hybrid solve] wait for the system + host cholesky %.3f ms\n",
               std::chrono::duration<double, std::milli>(t2 - t1).count());
+    if (bad == -2)
+      return SAGE_E_STATE; // the device never delivered a block (see block_chol_solve_tr)
     if (bad)
       return SAGE_E_NOT_PSD;
-    if ((eh = hipMemcpyAsync(dy, S->h_y, (size_t)S->K * S->Bp * sizeof(double), hipMemcpyHostToDevice, stream)) !=
-        hipSuccess)
-      return (int)eh;
+    (void)eh;
   }
   char *h = reinterpret_cast<char *>(S->h_pinned);
-  hipLaunchKernelGGL(solve_retract_kernel, dim3(1), dim3(256), 0, stream, reinterpret_cast<const double *>(S->d_y), S->K,
+  // (hybrid: the solution is read straight from the pinned buffer the host solved in)
+  hipLaunchKernelGGL(solve_retract_kernel, dim3(1), dim3(256), 0, stream,
+                     reinterpret_cast<const double *>(S->device_factor ? S->d_y : S->h_y), S->K,
                      S->B, S->Bp, CS, S->VS, S->plan.pos, vars0, vars1, reinterpret_cast<float *>(h + S->h_vars_off),
                      reinterpret_cast<double *>(h + S->h_delta_off), reinterpret_cast<double *>(h + S->h_tail_off));
   hipError_t e = hipGetLastError();
