@@ -16,6 +16,8 @@
 #include <condition_variable>
 #include <cstring>
 #include <ctime>
+#include <pthread.h>
+#include <sched.h>
 #include <mutex>
 #include <numeric>
 #include <random>
@@ -1228,6 +1230,8 @@ struct CholHelper
   const BlockEnvelope *E = nullptr;
   double *T = nullptr, *X = nullptr, *y = nullptr;
   std::thread th;
+  pthread_t tid{};
+  int near_cpu = -1;
   bool started = false;
   static void cpu_relax() { __builtin_ia32_pause(); }
   void loop()
@@ -1276,6 +1280,7 @@ static CholHelper *chol_helper()
       return (CholHelper *)nullptr;
     CholHelper *p = new CholHelper;
     p->th = std::thread([p] { p->loop(); });
+    p->tid = p->th.native_handle();
     p->th.detach();
     return p;
   }();
@@ -1283,11 +1288,73 @@ static CholHelper *chol_helper()
 }
 } // namespace
 
+// CPU list file of sysfs ("0-7,128-135") -> cpu numbers
+static std::vector<int> read_cpu_list(const char *path)
+{
+  std::vector<int> out;
+  FILE *f = fopen(path, "r");
+  if (!f)
+    return out;
+  char buf[4096];
+  if (fgets(buf, sizeof(buf), f))
+  {
+    const char *p = buf;
+    while (*p)
+    {
+      char *end;
+      const long a = strtol(p, &end, 10);
+      if (end == p)
+        break;
+      long b = a;
+      p = end;
+      if (*p == '-')
+      {
+        b = strtol(p + 1, &end, 10);
+        p = end;
+      }
+      for (long c = a; c <= b && out.size() < 4096; ++c)
+        out.push_back((int)c);
+      if (*p == ',')
+        ++p;
+    }
+  }
+  fclose(f);
+  return out;
+}
+
+// Keep the helper on a core that shares the caller's L3 (same CCX, not its SMT sibling): the two halves then work out
+// of one cache and one NUMA node -- on a two-socket host a helper on the far socket takes ~35 % longer for its half.
+static void place_helper_near(CholHelper *h, int cpu)
+{
+  if (cpu < 0 || cpu == h->near_cpu || getenv("SAGE_SOLVE_NO_AFFINITY"))
+    return;
+  h->near_cpu = cpu;
+  char path[128];
+  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+  const std::vector<int> l3 = read_cpu_list(path);
+  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+  const std::vector<int> sib = read_cpu_list(path);
+  cpu_set_t allowed, want;
+  if (l3.empty() || sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
+    return;
+  CPU_ZERO(&want);
+  int n = 0;
+  for (int c : l3)
+    if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed) && std::find(sib.begin(), sib.end(), c) == sib.end() && c != cpu)
+    {
+      CPU_SET(c, &want);
+      ++n;
+    }
+  if (n > 0)
+    (void)pthread_setaffinity_np(h->tid, sizeof(want), &want);
+}
+
 void block_chol_arm()
 {
   CholHelper *h = chol_helper();
   if (!h || h->armed.load(std::memory_order_acquire))
     return;
+  place_helper_near(h, sched_getcpu());
   {
     std::lock_guard<std::mutex> lk(h->mu);
     h->armed.store(true, std::memory_order_release);
@@ -1315,7 +1382,10 @@ int plan_blocks(int K, const std::vector<std::pair<int, int>> &links, bool allow
       return SAGE_E_INVALID;
   if (allow_split && K >= 16)
   {
-    int best_m = -1, best_w = 0, best_cost = K;
+    // the helper's half runs a little slower than the caller's (it wakes from sleep for every solve): give it
+    // `bias` rows less
+    static const int bias = getenv("SAGE_SPLIT_BIAS") ? atoi(getenv("SAGE_SPLIT_BIAS")) : 3;
+    int best_m = -1, best_w = 0, best_cost = 2 * K;
     for (int m = K / 4; m <= (3 * K) / 4; ++m)
     {
       int wdt = 0;
@@ -1324,7 +1394,7 @@ int plan_blocks(int K, const std::vector<std::pair<int, int>> &links, bool allow
           wdt = std::max(wdt, l.second - m + 1);
       if (wdt < 1 || wdt > 8 || m + wdt > K - 2)
         continue;
-      const int cost = std::max(m, K - m - wdt) + 2 * wdt;
+      const int cost = std::max(m, K - m - wdt + bias) + 2 * wdt;
       if (cost < best_cost)
       {
         best_cost = cost;
@@ -1443,7 +1513,13 @@ int block_chol_solve_tr(const BlockEnvelope &E, double *T, double *X, double *y)
       h->posted.fetch_add(1, std::memory_order_release);
     }
   }
+  static const bool dbg = getenv("SAGE_DEBUG_TIMING") != nullptr;
+  double tp[6] = {0, 0, 0, 0, 0, 0};
+  if (dbg)
+    tp[0] = mono_seconds();
   int rc = block_chol_range(E, T, X, y, 0, 0, E.n1);
+  if (dbg)
+    tp[1] = mono_seconds();
   bool helper_has_it = false;
   if (shared)
   {
@@ -1458,12 +1534,16 @@ int block_chol_solve_tr(const BlockEnvelope &E, double *T, double *X, double *y)
   }
   else
     rc2 = block_chol_range(E, T, X, y, 0, E.n1, sep0);
+  if (dbg)
+    tp[2] = mono_seconds();
   if (rc == 0)
     rc = rc2;
   if (rc == 0)
     rc = block_chol_range(E, T, X, y, 0, sep0, K);
   if (rc == 0)
     block_chol_range(E, T, X, y, 1, sep0, K);
+  if (dbg)
+    tp[3] = mono_seconds();
   if (helper_has_it)
     h->go_p2.store(rc == 0 ? 1 : 2, std::memory_order_release);
   if (rc == 0)
@@ -1472,9 +1552,18 @@ int block_chol_solve_tr(const BlockEnvelope &E, double *T, double *X, double *y)
     if (!helper_has_it)
       block_chol_range(E, T, X, y, 1, E.n1, sep0);
   }
+  if (dbg)
+    tp[4] = mono_seconds();
   if (helper_has_it)
     while (!h->p2_done.load(std::memory_order_acquire))
       CholHelper::cpu_relax();
+  if (dbg)
+  {
+    tp[5] = mono_seconds();
+    fprintf(stderr, "[sage block chol] us: first half %.0f (+wait for the %s %.0f) separator %.0f back-subst %.0f (+wait %.0f)\n",
+            1e6 * (tp[1] - tp[0]), helper_has_it ? "helper" : "second half, same thread", 1e6 * (tp[2] - tp[1]),
+            1e6 * (tp[3] - tp[2]), 1e6 * (tp[4] - tp[3]), 1e6 * (tp[5] - tp[4]));
+  }
   if (shared)
   {
     h->armed.store(false, std::memory_order_release); // the helper goes back to sleep until the next arm
