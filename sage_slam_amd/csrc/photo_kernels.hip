@@ -51,7 +51,8 @@ __device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i 
 
 // per-pixel hand-over from the sampling phase (lane = pixel) to the contraction phase (lane = (channel i, pixel k)):
 //   [0..7] rows of the cross tile: c(6) = S(0:6,6), sigma*d, u6      [8] sigma = S66     [9] loc*CS*4 (int bits)
-constexpr int kPhotoStashLD = 12; // floats per pixel, 16-byte aligned rows
+//   [12..27] A rows of the pose tile: G*Q rows (2 x 6), v (2), 0, 0   [28..43] its B columns: Q (2 x 6), q6*d (2), 0, 0
+constexpr int kPhotoStashLD = 44; // floats per pixel, 16-byte aligned rows
 
 // One (level, channel-group) step of the sampler in the engine's channel-group layout: 4 taps x (f1, gx, gy) dwordx4
 // loads + the pre-sampled source features.
@@ -69,7 +70,11 @@ struct TapBatch
 // Phases per 64-pixel wave slice (no workgroup barrier inside the sub-tile loop, the waves only meet for the final sum):
 //   A  warp: depth from the keyframe's depth map, projection, mask                      (lane = pixel)
 //   B  sampling: G, v, e accumulated over levels and channels                           (lane = pixel)
-//   C  per-pixel 7x7 reduced system, 37 scalar sums (DPP), rows for the contraction -> wave-private LDS stash
+//   C  per-pixel 7x7 reduced system; rows for the contractions -> wave-private LDS stash.  The 34 pose / scale
+//      scalar sums (Q^T G Q, Q^T G q6 d, Q^T v, q6^T v d) are one more MFMA tile (A = [GQ0 GQ1 v], B = [Q0 Q1 q6 d]):
+//      a DPP reduction + LDS accumulate per scalar costs ~15 VALU and a serialised LDS round trip each
+//      (36 x per 64 pixels was a fifth of the kernel's instruction stream); err, n_inliers and sigma d^2 are
+//      accumulated per lane and reduced once per workgroup
 //   D  code blocks: f32 MFMA 16x16x4 with the basis rows loaded from global memory directly in operand layout
 //      (lane = (channel pair i, pixel k): 16 lanes x dwordx2 = one 128-byte basis row; CS = 32: operand block 0 = even
 //      channels, block 1 = odd channels)
@@ -80,8 +85,9 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   constexpr int NB = CS / 16;
   constexpr int NG = FS / 4;
   constexpr int NT = photo_tiles(CS);
+  constexpr int YY = NT; // the pose tile: accumulated like the code tiles, folded into the scalar slots at the end
   constexpr int STASH = JAC ? kWaves * 64 * kPhotoStashLD : 1;
-  constexpr int SUMBUF = JAC ? NT * 256 : 1;
+  constexpr int SUMBUF = JAC ? (NT + 1) * 256 : 1;
   __shared__ __attribute__((aligned(16))) float s_mem[STASH > SUMBUF ? STASH : SUMBUF];
   __shared__ float s_red[kWaves * kPhotoScalars];
 
@@ -121,11 +127,11 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
 
   for (int k = tid; k < kWaves * kPhotoScalars; k += kBlock)
     s_red[k] = 0.f;
-  f32x4 acc[NT];
+  f32x4 acc[NT + 1];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT + 1; ++t)
     acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float err_acc = 0.f, vm_acc = 0.f; // error-only path: lane-local sums over the sub-tiles
+  float err_acc = 0.f, vm_acc = 0.f, sdd_acc = 0.f; // lane-local sums over the sub-tiles: error, inliers, sigma d^2
   float *st_w = s_mem + wave * 64 * kPhotoStashLD; // this wave's stash
   __syncthreads();                                 // s_red zeroed
 
@@ -340,49 +346,37 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     Q[0][6] = rh[0] * inv_z - X[0] * rh[2] * inv_z * inv_z; // :324-325 without fx, fy
     Q[1][6] = rh[1] * inv_z - X[1] * rh[2] * inv_z * inv_z;
   }
-  float sc[kPhotoScalars];
   float S6[7], u6;
   {
     float GQ0[7], GQ1[7];
 #pragma unroll
     for (int j = 0; j < 7; ++j)
     {
+      // dead pixels: G and v are exactly zero (vm = 0), Q may hold inf/nan -> zero it so that every product vanishes
+      Q[0][j] = live ? Q[0][j] : 0.f;
+      Q[1][j] = live ? Q[1][j] : 0.f;
       GQ0[j] = G00 * Q[0][j] + G01 * Q[1][j];
       GQ1[j] = G01 * Q[0][j] + G11 * Q[1][j];
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-      for (int j = i; j < 6; ++j)
-        sc[sidx6(i, j)] = live ? Q[0][i] * GQ0[j] + Q[1][i] * GQ1[j] : 0.f;
-#pragma unroll
     for (int i = 0; i < 7; ++i)
-      S6[i] = live ? Q[0][i] * GQ0[6] + Q[1][i] * GQ1[6] : 0.f;
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-    {
-      sc[21 + j] = S6[j] * d;
-      sc[28 + j] = live ? Q[0][j] * v0 + Q[1][j] * v1 : 0.f;
-    }
-    u6 = live ? Q[0][6] * v0 + Q[1][6] * v1 : 0.f;
-    sc[27] = S6[6] * d * d;
-    sc[34] = u6 * d;
-    sc[35] = err;
-    sc[36] = vm;
-  }
-  // stash the rows that multiply b_n: c (6), sigma*d, u6, then sigma itself and the byte offset of the basis row
-  {
+      S6[i] = Q[0][i] * GQ0[6] + Q[1][i] * GQ1[6];
+    u6 = Q[0][6] * v0 + Q[1][6] * v1;
+    sdd_acc += S6[6] * d * d;
+    // stash: the rows that multiply b_n (c (6), sigma*d, u6), sigma and the byte offset of the basis row, then the
+    // operands of the pose tile
     f32x4 *st = reinterpret_cast<f32x4 *>(st_w + lane * kPhotoStashLD);
     st[0] = f32x4{S6[0], S6[1], S6[2], S6[3]};
     st[1] = f32x4{S6[4], S6[5], S6[6] * d, u6};
     st[2] = f32x4{S6[6], __int_as_float(my_loc * (CS * 4)), 0.f, 0.f};
-  }
-#pragma unroll
-  for (int k = 0; k < 37; ++k)
-  {
-    const float s = wave_sum(sc[k]);
-    if (lane == 63)
-      s_red[wave * kPhotoScalars + k] += s; // only this lane ever touches this slot
+    st[3] = f32x4{GQ0[0], GQ0[1], GQ0[2], GQ0[3]};
+    st[4] = f32x4{GQ0[4], GQ0[5], GQ1[0], GQ1[1]};
+    st[5] = f32x4{GQ1[2], GQ1[3], GQ1[4], GQ1[5]};
+    st[6] = f32x4{v0, v1, 0.f, 0.f};
+    st[7] = f32x4{Q[0][0], Q[0][1], Q[0][2], Q[0][3]};
+    st[8] = f32x4{Q[0][4], Q[0][5], Q[1][0], Q[1][1]};
+    st[9] = f32x4{Q[1][2], Q[1][3], Q[1][4], Q[1][5]};
+    st[10] = f32x4{Q[0][6] * d, Q[1][6] * d, 0.f, 0.f};
   }
   __builtin_amdgcn_wave_barrier(); // same-wave LDS hand-over (in-order LDS pipe): no workgroup barrier needed
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -393,7 +387,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     const int i = lane & 15, k = lane >> 4;
     const uint32_t lane_off = (uint32_t)i * (NB == 2 ? 8u : 4u);
     constexpr int G = 16, AHEAD = 3;
-    float bl[G], bh[G], ai[G], sg[G];
+    float bl[G], bh[G], ai[G], sg[G], ya[G], yb[G];
     int locp[G];
 #define SAGE_PHOTO_READ_STASH(g)                                                        \
   {                                                                                     \
@@ -402,6 +396,12 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     const f32x2 sl_ = *reinterpret_cast<const f32x2 *>(p_ + 8); /* sigma, loc */        \
     sg[g] = sl_[0];                                                                     \
     locp[g] = __float_as_int(sl_[1]);                                                   \
+  }
+#define SAGE_PHOTO_READ_POSE(g)                                                         \
+  {                                                                                     \
+    const float *p_ = st_w + ((g) * 4 + k) * kPhotoStashLD;                             \
+    ya[g] = p_[12 + i];                                                                 \
+    yb[g] = p_[28 + i];                                                                 \
   }
 #define SAGE_PHOTO_ISSUE(g)                                                             \
   {                                                                                     \
@@ -424,14 +424,18 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     for (int g = 0; g < AHEAD; ++g)
       SAGE_PHOTO_ISSUE(g)
     const float asel = (i < 8) ? 1.f : 0.f; // rows 8..15 of the cross operand are zero
+    SAGE_PHOTO_READ_POSE(0)
 #pragma unroll
     for (int g = 0; g < G; ++g)
     {
+      if (g + 1 < G)
+        SAGE_PHOTO_READ_POSE(g + 1) // LDS only: one group ahead is enough
       if (g + AHEAD < G)
         SAGE_PHOTO_ISSUE(g + AHEAD)
       if (g + AHEAD + 1 < G)
         SAGE_PHOTO_READ_STASH(g + AHEAD + 1)
       const float a = asel * ai[g];
+      acc[YY] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[g], yb[g], acc[YY], 0, 0, 0);
       if (CS == 32)
       {
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bl[g], bl[g], acc[0], 0, 0, 0);
@@ -470,14 +474,14 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     return;
   }
 
-  // ---- cross-wave sum in a fixed order (deterministic), NT*256 floats in the (now idle) stash memory ----
+  // ---- cross-wave sum in a fixed order (deterministic), (NT+1)*256 floats in the (now idle) stash memory ----
   for (int w = 0; w < kWaves; ++w)
   {
     __syncthreads();
     if (wave == w)
     {
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT + 1; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
         {
@@ -486,12 +490,41 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
         }
     }
   }
+  {
+    const float se = wave_sum(err_acc), sn = wave_sum(vm_acc), sd = wave_sum(sdd_acc);
+    if (lane == 63)
+    {
+      s_red[wave * kPhotoScalars + 27] = sd;
+      s_red[wave * kPhotoScalars + 35] = se;
+      s_red[wave * kPhotoScalars + 36] = sn;
+    }
+  }
   __syncthreads();
   float *out = prm.partials + (size_t)blockIdx.x * photo_partial_floats(CS);
   if (tid < kPhotoScalars)
   {
+    // scalar slots of the partial record (layout unchanged): [0..20] Q^T G Q (upper triangle), [21..26] Q^T G q6 d,
+    // [27] sigma d^2, [28..33] Q^T v, [34] q6^T v d, [35] error, [36] inliers.  Pose tile element (row r of A, col c of B):
+    auto yy = [&](int r, int c) { return s_mem[YY * 256 + (r & 3) * 64 + ((r >> 2) * 16 + c)]; };
     float a = 0.f;
-    if (tid < 37)
+    if (tid < 21)
+    {
+      int i = 0, rem = tid;
+      while (rem >= 6 - i)
+      {
+        rem -= 6 - i;
+        ++i;
+      }
+      const int j = i + rem; // sidx6(i, j) == tid, i <= j
+      a = yy(j, i) + yy(6 + j, 6 + i);
+    }
+    else if (tid < 27)
+      a = yy(tid - 21, 12) + yy(6 + tid - 21, 13);
+    else if (tid >= 28 && tid < 34)
+      a = yy(12, tid - 28) + yy(13, 6 + tid - 28);
+    else if (tid == 34)
+      a = yy(12, 12) + yy(13, 13);
+    else if (tid == 27 || tid == 35 || tid == 36)
 #pragma unroll
       for (int w = 0; w < kWaves; ++w)
         a += s_red[w * kPhotoScalars + tid];
