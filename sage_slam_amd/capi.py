@@ -94,7 +94,7 @@ SYMBOLS = [
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_set_allreduce",
+    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_set_allreduce", "sage_sort_locations",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
@@ -678,6 +678,18 @@ def sample_locations(ws: "Workspace", vloc, vhomo, seed: int, num_samples: int):
 
 def _dptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def sort_locations(ws, loc1d, homo, H, W):
+    """``sage_sort_locations``: raster-ordered copies of a keyframe's sampled locations -> (loc1d, homo, sorted?)."""
+    import torch
+    n = int(loc1d.shape[0])
+    lo = torch.empty_like(loc1d)
+    ho = torch.empty_like(homo)
+    flag = C.c_int()
+    _chk(lib().sage_sort_locations(ws.h, _dptr(loc1d), _dptr(homo), n, H, W, _dptr(lo), _dptr(ho), C.byref(flag)),
+         "sage_sort_locations")
+    return lo, ho, bool(flag.value)
 
 
 def reprojection_jac_error(ws, R10, t10, R0, t0, R1, t1, bias0, basis0, code0, loc1d_i32, homo, matched, scale0, cam,

@@ -335,4 +335,87 @@ hipError_t launch_gather_locations(hipStream_t s, const long long *vloc, const f
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------------
+// engine-internal relayout of a keyframe's sampled locations: raster order.  The factor sums do not depend on the order
+// of the samples, the vector L1 does: a wave whose 64 pixels are neighbours touches ~10 cache lines per tap load, a
+// shuffled sample list (mapper.cpp:1326-1340 keeps the first N of a std::shuffle) 64 -- the photometric linearize is
+// 7.5x slower on it.  Sort = scatter the sample index into a per-pixel mark plane, then an ordered compaction of the
+// plane (one workgroup per keyframe).  status[2k] counts out-of-range locations, status[2k+1] the compacted samples
+// (< n when a pixel is sampled twice: the caller then keeps the original order).
+// ------------------------------------------------------------------------------------------------
+__global__ void mark_locations_kernel(const SortItem *__restrict__ items, int HW, int *__restrict__ mark,
+                                      int *__restrict__ status)
+{
+  const int k = blockIdx.y;
+  const SortItem it = items[k];
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= it.n)
+    return;
+  const long long l = it.loc[i];
+  if (l < 0 || l >= HW)
+    atomicAdd(&status[2 * k], 1);
+  else
+    mark[(size_t)k * HW + l] = i;
+}
+
+__global__ __launch_bounds__(1024) void order_locations_kernel(const SortItem *__restrict__ items, int HW,
+                                                               const int *__restrict__ mark, int *__restrict__ status)
+{
+  __shared__ int s_wave[16];
+  __shared__ int s_base;
+  const int k = blockIdx.x;
+  const SortItem it = items[k];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0)
+    s_base = 0;
+  __syncthreads();
+  for (int c0 = 0; c0 < HW; c0 += 1024)
+  {
+    const int i = c0 + tid;
+    const int src = i < HW ? mark[(size_t)k * HW + i] : -1;
+    const bool v = src >= 0;
+    const unsigned long long b = __ballot(v);
+    const int before = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0)
+      s_wave[wave] = __popcll(b);
+    __syncthreads();
+    int off = s_base;
+    for (int w = 0; w < wave; ++w)
+      off += s_wave[w];
+    if (v)
+    {
+      const int n = off + before;
+      it.loc_out[n] = i;
+      it.homo_out[3 * n + 0] = it.homo[3 * src + 0];
+      it.homo_out[3 * n + 1] = it.homo[3 * src + 1];
+      it.homo_out[3 * n + 2] = it.homo[3 * src + 2];
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w)
+        tot += s_wave[w];
+      s_base += tot;
+    }
+    __syncthreads();
+  }
+  if (tid == 0)
+    status[2 * k + 1] = s_base;
+}
+
+hipError_t launch_sort_locations(hipStream_t s, const SortItem *items_dev, int K, int max_n, int HW, int *mark_dev,
+                                 int *status_dev)
+{
+  hipError_t e;
+  if ((e = hipMemsetAsync(mark_dev, 0xff, (size_t)K * HW * sizeof(int), s)) != hipSuccess ||
+      (e = hipMemsetAsync(status_dev, 0, (size_t)2 * K * sizeof(int), s)) != hipSuccess)
+    return e;
+  if (max_n > 0)
+    hipLaunchKernelGGL(mark_locations_kernel, dim3((max_n + 255) / 256, K), dim3(256), 0, s, items_dev, HW, mark_dev,
+                       status_dev);
+  hipLaunchKernelGGL(order_locations_kernel, dim3(K), dim3(1024), 0, s, items_dev, HW, mark_dev, status_dev);
+  return hipGetLastError();
+}
+
 } // namespace sage

@@ -642,6 +642,40 @@ extern "C" int sage_sample_locations(SageWorkspace *ws, const int64_t *valid_loc
   return SAGE_OK;
 }
 
+extern "C" int sage_sort_locations(SageWorkspace *ws, const int64_t *loc1d_dev, const float *homo_dev, int n, int H,
+                                   int W, int64_t *loc1d_out_dev, float *homo_out_dev, int *sorted_host)
+{
+  if (!ws || !loc1d_dev || !homo_dev || n < 0 || H < 1 || W < 1 || !loc1d_out_dev || !homo_out_dev || !sorted_host ||
+      loc1d_out_dev == loc1d_dev || homo_out_dev == homo_dev)
+    return SAGE_E_INVALID;
+  const int HW = H * W;
+  // scratch: [item | status (2 ints) | mark plane]
+  const size_t off_status = (sizeof(SortItem) + 15) / 16 * 16, off_mark = off_status + 16;
+  int rc = ws->misc.reserve(off_mark + (size_t)HW * sizeof(int));
+  if (rc)
+    return rc;
+  char *base = ws->misc.as<char>();
+  const SortItem it{reinterpret_cast<const long long *>(loc1d_dev), homo_dev, reinterpret_cast<long long *>(loc1d_out_dev),
+                    homo_out_dev, n};
+  int status[2] = {0, 0};
+  SAGE_HIP(hipMemcpyAsync(base, &it, sizeof(it), hipMemcpyHostToDevice, ws->stream));
+  SAGE_HIP(launch_sort_locations(ws->stream, reinterpret_cast<const SortItem *>(base), 1, n, HW,
+                                 reinterpret_cast<int *>(base + off_mark), reinterpret_cast<int *>(base + off_status)));
+  SAGE_HIP(hipMemcpyAsync(status, base + off_status, sizeof(status), hipMemcpyDeviceToHost, ws->stream));
+  SAGE_HIP(hipStreamSynchronize(ws->stream)); // `it` and `status` are locals
+  if (status[0] > 0)
+    return SAGE_E_INVALID;
+  *sorted_host = status[1] == n;
+  if (!*sorted_host && n > 0)
+  {
+    // a pixel listed twice: keep the caller's order (and every sample)
+    SAGE_HIP(hipMemcpyAsync(loc1d_out_dev, loc1d_dev, (size_t)n * sizeof(int64_t), hipMemcpyDeviceToDevice, ws->stream));
+    SAGE_HIP(hipMemcpyAsync(homo_out_dev, homo_dev, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, ws->stream));
+    SAGE_HIP(hipStreamSynchronize(ws->stream));
+  }
+  return SAGE_OK;
+}
+
 extern "C" int sage_gaussian_pyramid_with_grad(SageWorkspace *ws, float *pyr_dev, float *grad_dev,
                                                const float *feat, const float *mask, const SagePyramid *pyr, int FS)
 {
@@ -942,6 +976,8 @@ struct SageWindow
   int n_edges = 0;                        // local directed edges per factor type (= 2 * local links)
   // device
   DevBuf vars[2];                       // [K][VS]: pose 12, scale 1, code CS
+  DevBuf sorted_loc, sorted_homo;       // raster-ordered copies of the keyframes' sampled locations
+  std::vector<std::pair<const int64_t *, const float *>> user_samples; // the caller's arrays
   DevBuf dpt, dgrad, depth_items[2];    // per-keyframe depth maps of the set being evaluated
   int dpt_set = -1;                     // variable set the depth maps currently hold (-1: none) ...
   bool dgrad_valid = false;             // ... and whether their gradients are up to date as well
@@ -1068,7 +1104,7 @@ extern "C" void sage_window_destroy(SageWindow *w)
 {
   if (!w)
     return;
-  DevBuf *bufs[] = {&w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
+  DevBuf *bufs[] = {&w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
                     &w->pk, &w->f0s, &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
                     &w->work_g, &w->first_g, &w->tiles_g, &w->part_p, &w->part_g, &w->AtA_p, &w->Atb_p,
                     &w->stats_p, &w->AtA_g, &w->Atb_g, &w->stats_g, &w->adj_start, &w->adj, &w->link_edges,
@@ -1201,6 +1237,61 @@ extern "C" int sage_window_finalize(SageWindow *w)
     SAGE_HIP(launch_repack_groups(w->stream, base + plane_f, w->views[k].grad_pyr, FS, c.pyr.P));
     SAGE_HIP(launch_repack_groups(w->stream, base + 2 * plane_f, w->views[k].grad_pyr + plane_f, FS, c.pyr.P));
   }
+  // ---- sampled locations: validated (the kernels index depth maps / basis rows with them unchecked) and relaid in
+  //      raster order (engine-owned copies; see producers.hip: the sums are order independent, the L1 is not)
+  {
+    std::vector<size_t> soff(K + 1, 0);
+    int max_n = 0;
+    for (int k = 0; k < K; ++k)
+    {
+      soff[k + 1] = soff[k] + (size_t)std::max(1, w->views[k].N);
+      max_n = std::max(max_n, w->views[k].N);
+    }
+    if ((rc = w->sorted_loc.reserve(soff[K] * sizeof(int64_t))) || (rc = w->sorted_homo.reserve(soff[K] * 3 * sizeof(float))))
+      return rc;
+    if ((int)w->user_samples.size() != K) // (a retried finalize must not sort the sorted copies onto themselves)
+    {
+      w->user_samples.resize(K);
+      for (int k = 0; k < K; ++k)
+        w->user_samples[k] = {w->views[k].loc1d, w->views[k].homo};
+    }
+    std::vector<SortItem> items(K);
+    for (int k = 0; k < K; ++k)
+      items[k] = SortItem{reinterpret_cast<const long long *>(w->user_samples[k].first), w->user_samples[k].second,
+                          w->sorted_loc.as<long long>() + soff[k], w->sorted_homo.as<float>() + 3 * soff[k],
+                          w->views[k].N};
+    DevBuf d_items, d_mark, d_status;
+    std::vector<int> status((size_t)2 * K, 0);
+    rc = upload(d_items, items, w->stream);
+    if (!rc)
+      rc = d_mark.reserve((size_t)K * HW * sizeof(int));
+    if (!rc)
+      rc = d_status.reserve((size_t)2 * K * sizeof(int));
+    hipError_t he = hipSuccess;
+    if (!rc)
+      he = launch_sort_locations(w->stream, d_items.as<SortItem>(), K, max_n, HW, d_mark.as<int>(), d_status.as<int>());
+    if (!rc && he == hipSuccess)
+      he = hipMemcpyAsync(status.data(), d_status.p, status.size() * sizeof(int), hipMemcpyDeviceToHost, w->stream);
+    if (!rc && he == hipSuccess)
+      he = hipStreamSynchronize(w->stream);
+    d_items.release();
+    d_mark.release();
+    d_status.release();
+    if (rc)
+      return rc;
+    if (he != hipSuccess)
+      return (int)he;
+    static const bool no_sort = getenv("SAGE_NO_SAMPLE_SORT") != nullptr;
+    for (int k = 0; k < K; ++k)
+    {
+      if (status[2 * k] > 0)
+        return SAGE_E_INVALID; // a location outside the image
+      if (no_sort || status[2 * k + 1] != w->views[k].N)
+        continue; // (a pixel sampled twice: the compaction dropped a sample -> keep the caller's order)
+      w->views[k].loc1d = reinterpret_cast<const int64_t *>(items[k].loc_out);
+      w->views[k].homo = items[k].homo_out;
+    }
+  }
   // ---- pose-independent pre-sampled source features, once per keyframe
   std::vector<size_t> f0s_off(K + 1, 0);
   for (int k = 0; k < K; ++k)
@@ -1211,17 +1302,6 @@ extern "C" int sage_window_finalize(SageWindow *w)
     SAGE_HIP(launch_presample_source(w->stream, w->f0s.as<float>() + f0s_off[k],
                                      w->pk.as<float>() + (size_t)k * 3 * plane_f, w->views[k].homo, w->views[k].N, FS,
                                      c.pyr));
-  // ---- validate the sample locations once (the kernels index the depth maps / basis rows with them unchecked)
-  for (int k = 0; k < K; ++k)
-  {
-    const int Nk = w->views[k].N;
-    std::vector<int64_t> loc((size_t)std::max(1, Nk));
-    if (Nk > 0)
-      SAGE_HIP(hipMemcpy(loc.data(), w->views[k].loc1d, (size_t)Nk * sizeof(int64_t), hipMemcpyDeviceToHost));
-    for (int i = 0; i < Nk; ++i)
-      if (loc[i] < 0 || loc[i] >= HW)
-        return SAGE_E_INVALID;
-  }
   // ---- local links / edges
   w->local_links.clear();
   for (size_t l = 0; l < w->links.size(); ++l)

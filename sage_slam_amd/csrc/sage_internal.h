@@ -150,6 +150,17 @@ struct DepthItem
 hipError_t launch_presample_source(hipStream_t s, float *f0s, const float *feat_pk, const float *homo, int N, int FS,
                                    const SagePyramid &pyr);
 hipError_t launch_repack_groups(hipStream_t s, float *dst, const float *src, int C, int P);
+// raster-order relayout of sampled locations (producers.hip)
+struct SortItem
+{
+  const long long *loc;
+  const float *homo;
+  long long *loc_out;
+  float *homo_out;
+  int n;
+};
+hipError_t launch_sort_locations(hipStream_t s, const SortItem *items_dev, int K, int max_n, int HW, int *mark_dev,
+                                 int *status_dev);
 // depth maps (and, for the Jacobian pass, their central-difference gradients) of all keyframes of a window
 hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev, int K, int H, int W, bool with_depth,
                               bool with_grad);

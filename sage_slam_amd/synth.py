@@ -253,6 +253,8 @@ def make_window(K: int, H: int, W: int, FS: int = 16, CS: int = 32, L: int = 4,
         else:
             loc = valid
         import os as _os
+        if _os.environ.get("SAGE_SYNTH_SHUFFLE") == "1":                        # dev experiment: same samples, shuffled order
+            loc = loc[krng.permutation(loc.size)]
         _tile = int(_os.environ.get("SAGE_SYNTH_TILE_ORDER", "0"))              # dev experiment: 2-D tile order of the samples
         if _tile:
             ty, tx = (loc // W) // _tile, (loc % W) // _tile

@@ -326,6 +326,50 @@ def test_sharded_window_sums_to_full(capi):
     full.close()
 
 
+def test_window_sample_order_is_internal(capi):
+    """the window engine relays every keyframe's sampled locations in raster order (L1 locality); the normal equations
+    do not depend on the caller's order beyond fp32 summation noise.  A pixel sampled twice disables the relayout for
+    that keyframe (still exact), a location outside the image is rejected at finalize."""
+    import copy
+    w = synth.make_window(K=4, H=32, W=40, FS=16, CS=32, L=3, seed=23)          # dense = raster order
+    ref = capi.Window(w); ref.linearize(); p_ref = ref.packed_host().astype(np.float64); ref.close()
+    rng = np.random.default_rng(0)
+    ws_ = copy.deepcopy(w)
+    for kf in ws_.keyframes:                                                    # same samples, shuffled
+        perm = rng.permutation(kf.loc1d.size)
+        kf.loc1d = np.ascontiguousarray(kf.loc1d[perm]); kf.homo = np.ascontiguousarray(kf.homo[perm])
+    sh = capi.Window(ws_); sh.linearize(); p_sh = sh.packed_host().astype(np.float64); sh.close()
+    assert rel(p_sh, p_ref) < 1e-9                                              # sorted back to the same order
+    wd = copy.deepcopy(ws_)
+    kf = wd.keyframes[1]                                                        # duplicate one sample
+    kf.loc1d = np.ascontiguousarray(np.concatenate([kf.loc1d, kf.loc1d[:1]]))
+    kf.homo = np.ascontiguousarray(np.concatenate([kf.homo, kf.homo[:1]]))
+    dup = capi.Window(wd); dup.linearize(); p_dup = dup.packed_host().astype(np.float64); dup.close()
+    assert np.isfinite(p_dup).all() and 0 < rel(p_dup, p_ref) < 5e-2            # one more sample, nothing lost
+    wb = copy.deepcopy(w)
+    wb.keyframes[2].loc1d = wb.keyframes[2].loc1d.copy()
+    wb.keyframes[2].loc1d[5] = w.H * w.W                                        # outside the image
+    with pytest.raises(capi.SageError):
+        capi.Window(wb)
+
+
+def test_sort_locations(capi, ws):
+    import torch
+    H, W = 24, 32
+    rng = np.random.default_rng(4)
+    loc = rng.permutation(H * W)[:500].astype(np.int64)
+    homo = rng.normal(size=(500, 3)).astype(np.float32)
+    lo, ho, ok = capi.sort_locations(ws, torch.from_numpy(loc).cuda(), torch.from_numpy(homo).cuda(), H, W)
+    order = np.argsort(loc)
+    assert ok and np.array_equal(lo.cpu().numpy(), loc[order]) and np.array_equal(ho.cpu().numpy(), homo[order])
+    loc2 = loc.copy(); loc2[7] = loc2[3]                                         # a pixel listed twice: order kept
+    lo, ho, ok = capi.sort_locations(ws, torch.from_numpy(loc2).cuda(), torch.from_numpy(homo).cuda(), H, W)
+    assert not ok and np.array_equal(lo.cpu().numpy(), loc2) and np.array_equal(ho.cpu().numpy(), homo)
+    loc3 = loc.copy(); loc3[0] = -1
+    with pytest.raises(capi.SageError):
+        capi.sort_locations(ws, torch.from_numpy(loc3).cuda(), torch.from_numpy(homo).cuda(), H, W)
+
+
 def test_track_frame_lm(capi, ws, orc):
     """host LM (a8) wired to the HIP tracker kernels == the same policy driven by the oracle."""
     import ctypes as C
