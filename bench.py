@@ -12,7 +12,7 @@ A "step" is one LM iteration = one pass of the hot path over the whole window:
 Inputs are resident in HBM before the timed region.  Residuals per step = E_photo*L*N*FS + E_geo*N
 (linearisation residuals only; the error-evaluation pass is not double counted).
 
-Multi-GPU: factor-graph links are sharded over ranks (link l -> rank l % world), keyframes replicated, one
+Multi-GPU: factor-graph links are sharded over ranks (rank r owns the contiguous link range [r*n/world, (r+1)*n/world)), keyframes replicated, one
 all-reduce of the packed normal equations and one of the 4-double error tail per step (strong scaling).
 
 Prints ONE JSON line on rank 0.

@@ -262,7 +262,8 @@ int sage_window_add_keyframe(SageWindow *w, const SageKeyframeView *view, const 
                              const float *code, float scale);
 /* a link contributes both directed edges of every enabled factor type (mapper.cpp:346-374). */
 int sage_window_add_link(SageWindow *w, int kf_a, int kf_b);
-/* edge sharding for multi-GPU: this process evaluates links l with (l % world) == rank. Default (0,1). */
+/* edge sharding for multi-GPU: this process evaluates the contiguous range [rank*n/world, (rank+1)*n/world) of the
+ * n links (in the order they were added). Default (0,1). */
 int sage_window_set_shard(SageWindow *w, int rank, int world);
 /* must be called once after the last add_keyframe/add_link and before linearize/error. */
 int sage_window_finalize(SageWindow *w);

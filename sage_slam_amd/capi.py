@@ -581,8 +581,9 @@ def _tensor_from_ptr(ptr: int, n: int):
 # --------------------------------------------------------------------------- host-side window algebra
 # (pure numpy; used by the multi-process CPU tests of the sharded reduction and by parity tests)
 def shard_links(nlinks: int, rank: int, world: int) -> List[int]:
-    """link ownership rule of ``sage_window_set_shard``: link l belongs to rank l % world."""
-    return [l for l in range(nlinks) if l % world == rank]
+    """link ownership rule of ``sage_window_set_shard``: rank r owns the contiguous range
+    [r*n/world, (r+1)*n/world) of the link list."""
+    return list(range(nlinks * rank // world, nlinks * (rank + 1) // world))
 
 
 def edge_col(type_: int, role: int, bi: int, CS: int) -> int:

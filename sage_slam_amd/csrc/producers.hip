@@ -82,6 +82,8 @@ hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev,
                               bool with_grad)
 {
   const int HW = H * W;
+  if (K <= 0)
+    return hipSuccess;
   if (!with_depth)
     ;
   else if (CS == 32)

@@ -979,6 +979,7 @@ struct SageWindow
   DevBuf sorted_loc, sorted_homo;       // raster-ordered copies of the keyframes' sampled locations
   std::vector<std::pair<const int64_t *, const float *>> user_samples; // the caller's arrays
   DevBuf dpt, dgrad, depth_items[2];    // per-keyframe depth maps of the set being evaluated
+  int n_depth = 0;                      // keyframes this rank's edges touch (= entries of depth_items)
   int dpt_set = -1;                     // variable set the depth maps currently hold (-1: none) ...
   bool dgrad_valid = false;             // ... and whether their gradients are up to date as well
   SageAllReduceFn allreduce = nullptr;  // sharded windows: caller-provided sum all-reduce (see sage_ba.h)
@@ -1213,14 +1214,32 @@ extern "C" int sage_window_finalize(SageWindow *w)
   }
   if ((rc = w->dpt.reserve((size_t)K * HW * sizeof(float))) || (rc = w->dgrad.reserve((size_t)K * 2 * HW * sizeof(float))))
     return rc;
+  // ---- local links: rank r owns the contiguous range [r*n/world, (r+1)*n/world) of the link list.  Links are added
+  //      keyframe by keyframe, so a contiguous range touches ~K/world + (back links) keyframes: only those need depth
+  //      maps on this rank
+  w->local_links.clear();
+  {
+    const long long nl = (long long)w->links.size();
+    const int lo = (int)(nl * w->rank / w->world), hi = (int)(nl * (w->rank + 1) / w->world);
+    for (int l = lo; l < hi; ++l)
+      w->local_links.push_back(l);
+  }
+  std::vector<char> needed(K, 0);
+  for (int l : w->local_links)
+    needed[w->links[l].first] = needed[w->links[l].second] = 1;
+  w->n_depth = 0;
+  for (int k = 0; k < K; ++k)
+    w->n_depth += needed[k];
   for (int s = 0; s < 2; ++s)
   {
-    std::vector<DepthItem> items(K);
+    std::vector<DepthItem> items;
     for (int k = 0; k < K; ++k)
     {
+      if (!needed[k])
+        continue;
       const float *vp = w->vars[s].as<float>() + (size_t)k * w->VS;
-      items[k] = DepthItem{w->views[k].bias, w->views[k].basis, vp + 13, vp + 12,
-                           w->dpt.as<float>() + (size_t)k * HW, w->dgrad.as<float>() + (size_t)k * 2 * HW};
+      items.push_back(DepthItem{w->views[k].bias, w->views[k].basis, vp + 13, vp + 12,
+                                w->dpt.as<float>() + (size_t)k * HW, w->dgrad.as<float>() + (size_t)k * 2 * HW});
     }
     if ((rc = upload(w->depth_items[s], items, w->stream)))
       return rc;
@@ -1302,11 +1321,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
     SAGE_HIP(launch_presample_source(w->stream, w->f0s.as<float>() + f0s_off[k],
                                      w->pk.as<float>() + (size_t)k * 3 * plane_f, w->views[k].homo, w->views[k].N, FS,
                                      c.pyr));
-  // ---- local links / edges
-  w->local_links.clear();
-  for (size_t l = 0; l < w->links.size(); ++l)
-    if ((int)(l % w->world) == w->rank)
-      w->local_links.push_back((int)l);
+  // ---- local edges
   w->n_edges = 2 * (int)w->local_links.size();
   std::vector<LinkEdges> le(w->links.size(), LinkEdges{-1, -1});
   std::vector<int> Nedge(w->n_edges);
@@ -1480,7 +1495,7 @@ extern "C" int sage_window_linearize(SageWindow *w)
     // (an accepted candidate's maps from the error pass are still valid: only the gradients are missing then)
     static const bool no_reuse = getenv("SAGE_NO_DEPTH_REUSE") != nullptr;
     const bool have_depth = w->dpt_set == 0 && !no_reuse;
-    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[0].as<DepthItem>(), w->K, H, W, !have_depth,
+    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[0].as<DepthItem>(), w->n_depth, H, W, !have_depth,
                                 !(have_depth && w->dgrad_valid)));
     w->dpt_set = 0;
     w->dgrad_valid = true;
@@ -1546,7 +1561,7 @@ extern "C" int sage_window_error(SageWindow *w, int which)
   const bool has = w->n_edges > 0;
   if (has && w->dpt_set != which)
   {
-    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[which].as<DepthItem>(), w->K, H, W, true, false));
+    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[which].as<DepthItem>(), w->n_depth, H, W, true, false));
     w->dpt_set = which;
     w->dgrad_valid = false;
   }
