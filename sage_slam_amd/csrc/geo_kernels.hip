@@ -430,6 +430,7 @@ struct GeoFinalizeParams
   const float *partials;
   float *AtA, *Atb, *stats;
   float weight;
+  int edge_base; // blockIdx.x = edge - edge_base
 };
 
 template <int CS>
@@ -440,12 +441,12 @@ __global__ __launch_bounds__(kFinalizeBlock) void geo_finalize_kernel(const GeoF
   constexpr int N16 = geo_n16(CS);
   constexpr int NTT = N16 * (N16 + 1) / 2;
   __shared__ double s[PP]; // partial sums and every derived product stay in double until the single final rounding
-  const int e = blockIdx.x, tid = threadIdx.x;
+  const int e = prm.edge_base + blockIdx.x, tid = threadIdx.x;
   const GeoEdge &E = prm.table ? prm.table[e] : prm.single;
   const float s0 = E.scale0 ? *E.scale0 : E.scale0_val;
   const float s1 = E.scale1 ? *E.scale1 : E.scale1_val;
   const int first = prm.edge_first[e], nt = prm.edge_tiles[e];
-  for (int idx = tid; idx < PP; idx += kFinalizeBlock)
+  for (int idx = tid; idx < PP; idx += (int)blockDim.x)
   {
     double a = 0.0; // the per-workgroup partials are summed in double: free (a few dozen adds), and it keeps the
                     // engine's accumulation noise below the reference's own fp32 floor
@@ -513,7 +514,7 @@ __global__ __launch_bounds__(kFinalizeBlock) void geo_finalize_kernel(const GeoF
   };
   float *AtA = prm.AtA + (size_t)e * D * D;
   float *Atb = prm.Atb + (size_t)e * D;
-  for (int q = tid; q < D * D + D; q += kFinalizeBlock)
+  for (int q = tid; q < D * D + D; q += (int)blockDim.x)
   {
     double val = 0.0;
     if (ok)
@@ -566,11 +567,16 @@ static hipError_t geo_lin_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   p.tiles_per_block = lc.tiles_per_block;
   p.width = (int)cam.w;
   p.height = (int)cam.h;
-  if (lc.ev_start)
-    (void)hipEventRecord(lc.ev_start, s);
-  hipLaunchKernelGGL((geo_kernel<CS, true>), dim3(lc.n_work), dim3(kGeoLinBlock), 0, s, p);
-  if (lc.ev_stop)
-    (void)hipEventRecord(lc.ev_stop, s);
+  if (lc.stage != 2)
+  {
+    if (lc.ev_start)
+      (void)hipEventRecord(lc.ev_start, s);
+    hipLaunchKernelGGL((geo_kernel<CS, true>), dim3(lc.n_work), dim3(kGeoLinBlock), 0, s, p);
+    if (lc.ev_stop)
+      (void)hipEventRecord(lc.ev_stop, s);
+  }
+  if (lc.stage == 1)
+    return hipGetLastError();
   GeoFinalizeParams f{};
   if (single)
     f.single = *single;
@@ -582,7 +588,10 @@ static hipError_t geo_lin_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   f.Atb = out.Atb;
   f.stats = out.stats;
   f.weight = weight;
-  hipLaunchKernelGGL((geo_finalize_kernel<CS>), dim3(lc.n_edges), dim3(kFinalizeBlock), 0, s, f);
+  f.edge_base = lc.stage == 2 ? lc.edge_base : 0;
+  const int n_fin = lc.stage == 2 ? lc.edge_count : lc.n_edges;
+  if (n_fin > 0)
+    hipLaunchKernelGGL((geo_finalize_kernel<CS>), dim3(n_fin), dim3(lc.fin_block), 0, s, f);
   return hipGetLastError();
 }
 

@@ -1089,6 +1089,8 @@ static __attribute__((noinline)) bool wait_row_tickets(const BlockEnvelope &E, i
         if ((++spins & 0xfff) == 0 && mono_seconds() - t0 > 2.0)
           return false;
       }
+      if (E.t_ticket_wait)
+        *E.t_ticket_wait += mono_seconds() - t0;
     }
   std::atomic_thread_fence(std::memory_order_acquire);
   return true;
@@ -1114,6 +1116,8 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
   {
     for (int i = lo; i < hi; ++i)
     {
+      if (E.before_row && E.before_row(E.user, i))
+        return -2;
       if (E.ready && !wait_row_tickets(E, i))
         return -2;
       // the column ranges of row i, in ascending order

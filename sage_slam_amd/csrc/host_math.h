@@ -44,6 +44,11 @@ struct BlockEnvelope
   // delivered by the device; a row is only touched after all its blocks have arrived
   const volatile unsigned *ready = nullptr;
   unsigned epoch = 0;
+  // optional: called before row i is waited for / touched (the pipelined window solve launches the device work that
+  // produces the next rows from here); a non-zero return aborts the factorisation with -2
+  int (*before_row)(void *user, int row) = nullptr;
+  void *user = nullptr;
+  double *t_ticket_wait = nullptr; // optional: accumulates the seconds spent waiting for tickets (diagnostics)
 };
 // In place: T becomes L^T blockwise, X (K*Bp*Bp) receives the inverses of the diagonal factors, y (K*Bp) the
 // right-hand side on entry and the solution on return.  Returns 0, or 1 + the block column of the first non-positive

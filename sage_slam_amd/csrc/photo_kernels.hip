@@ -33,6 +33,12 @@ struct PhotoParams
   int width, height;   // level-0 size as integers (scalar values for the basis descriptor)
   float rx[SAGE_MAX_LEVELS], ry[SAGE_MAX_LEVELS]; // fx_l/fx_0, fy_l/fy_0 (host-computed: no per-level divisions on the device)
   int lw[SAGE_MAX_LEVELS], lh[SAGE_MAX_LEVELS];   // level sizes as integers
+  // progress signalling (LaunchCommon::sig_*), null when unused
+  const int32_t *sig_group;
+  int32_t *sig_cnt;
+  const int32_t *sig_total;
+  unsigned *sig_flag_host;
+  unsigned sig_epoch;
 };
 
 __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
@@ -528,10 +534,35 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
 #pragma unroll
       for (int w = 0; w < kWaves; ++w)
         a += s_red[w * kPhotoScalars + tid];
-    out[tid] = a;
+    if (prm.sig_cnt) // signalling launches write the record through to memory (agent-scope stores): the consumer is
+      __hip_atomic_store(out + tid, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // a kernel on another stream
+    else
+      out[tid] = a;
   }
-  for (int idx = tid; idx < NT * 256; idx += kBlock)
-    out[kPhotoScalars + idx] = s_mem[idx];
+  if (prm.sig_cnt)
+    for (int idx = tid; idx < NT * 256; idx += kBlock)
+      __hip_atomic_store(out + kPhotoScalars + idx, s_mem[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else
+    for (int idx = tid; idx < NT * 256; idx += kBlock)
+      out[kPhotoScalars + idx] = s_mem[idx];
+  if (prm.sig_cnt)
+  {
+    // this workgroup's partial record is complete: agent-scope release, then count it; the
+    // last one of the group tells the host, which launches the group's post-processing on another stream
+    // the record went out as write-through stores: no L2 write-back (an agent-scope release fence per workgroup costs
+    // 0.15 ms over the launch), only their completion before the count
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    if (tid == 0)
+    {
+      const int g = prm.sig_group[blockIdx.x];
+      if (atomicAdd(&prm.sig_cnt[g], 1) == prm.sig_total[g] - 1)
+      { // (every record of the group is in memory already; the host only reads this flag, kernels launched after it
+        // start with fresh caches)
+        *reinterpret_cast<volatile unsigned *>(prm.sig_flag_host + g) = prm.sig_epoch;
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -548,6 +579,7 @@ struct PhotoFinalizeParams
   const float *partials;
   float *AtA, *Atb, *stats;
   float wsum;
+  int edge_base; // blockIdx.x = edge - edge_base
 };
 
 __device__ __forceinline__ double tile_elem(const double *s, int base, int tile, int row, int col)
@@ -561,11 +593,11 @@ __global__ __launch_bounds__(kFinalizeBlock) void photo_finalize_kernel(const Ph
   constexpr int PP = photo_partial_floats(CS);
   constexpr int D = 13 + CS;
   __shared__ double s[PP]; // partial sums and every derived product stay in double until the single final rounding
-  const int e = blockIdx.x, tid = threadIdx.x;
+  const int e = prm.edge_base + blockIdx.x, tid = threadIdx.x;
   const PhotoEdge &E = prm.table ? prm.table[e] : prm.single;
   const float s0 = E.scale0 ? *E.scale0 : E.scale0_val;
   const int first = prm.edge_first[e], nt = prm.edge_tiles[e];
-  for (int idx = tid; idx < PP; idx += kFinalizeBlock)
+  for (int idx = tid; idx < PP; idx += (int)blockDim.x)
   {
     double a = 0.0; // the per-workgroup partials are summed in double: free (a few dozen adds), and it keeps the
                     // engine's accumulation noise below the reference's own fp32 floor
@@ -610,7 +642,7 @@ __global__ __launch_bounds__(kFinalizeBlock) void photo_finalize_kernel(const Ph
     }
     return tile_elem(s, kPhotoScalars, 0, i, j);
   };
-  for (int idx = tid; idx < D * D + D; idx += kFinalizeBlock)
+  for (int idx = tid; idx < D * D + D; idx += (int)blockDim.x)
   {
     double val = 0.0;
     if (ok)
@@ -724,6 +756,8 @@ static PhotoParams make_params(const PhotoEdge *single, const PhotoEdge *table, 
   p.tiles_per_block = lc.tiles_per_block;
   p.width = (int)pyr.cam[0].w;
   p.height = (int)pyr.cam[0].h;
+  p.sig_group = lc.sig_group; p.sig_cnt = lc.sig_cnt; p.sig_total = lc.sig_total;
+  p.sig_flag_host = lc.sig_flag_host; p.sig_epoch = lc.sig_epoch;
   for (int l = 0; l < pyr.levels; ++l)
   {
     p.rx[l] = pyr.cam[l].fx / pyr.cam[0].fx; // same fp32 quotient the kernels used to form per pixel
@@ -742,14 +776,19 @@ static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const P
 {
   float wsum;
   PhotoParams p = make_params(single, table, lc, pyr, wh, eps, &wsum);
-  if (lc.ev_start)
-    (void)hipEventRecord(lc.ev_start, s);
-  if (lc.packed)
-    hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
-  else
-    hipLaunchKernelGGL((photo_kernel<CS, FS, true, 0>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
-  if (lc.ev_stop)
-    (void)hipEventRecord(lc.ev_stop, s);
+  if (lc.stage != 2)
+  {
+    if (lc.ev_start)
+      (void)hipEventRecord(lc.ev_start, s);
+    if (lc.packed)
+      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+    else
+      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 0>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+    if (lc.ev_stop)
+      (void)hipEventRecord(lc.ev_stop, s);
+  }
+  if (lc.stage == 1)
+    return hipGetLastError();
   PhotoFinalizeParams f{};
   if (single)
     f.single = *single;
@@ -761,7 +800,10 @@ static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const P
   f.Atb = out.Atb;
   f.stats = out.stats;
   f.wsum = wsum;
-  hipLaunchKernelGGL((photo_finalize_kernel<CS>), dim3(lc.n_edges), dim3(kFinalizeBlock), 0, s, f);
+  f.edge_base = lc.stage == 2 ? lc.edge_base : 0;
+  const int n_fin = lc.stage == 2 ? lc.edge_count : lc.n_edges;
+  if (n_fin > 0)
+    hipLaunchKernelGGL((photo_finalize_kernel<CS>), dim3(n_fin), dim3(lc.fin_block), 0, s, f);
   return hipGetLastError();
 }
 

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -785,6 +786,8 @@ struct AssembleParams
   double *packed;
   double *tail_mirror; // pinned host copy of the 4-double tail (single-rank windows), or null
   int K, nlinks, CS, n_edges_p, n_edges_g;
+  const int32_t *blk_list; // optional: blockIdx.x -> output block (pipelined solve assembles row chunks), else identity
+  int split;               // > 1: every output block is shared by `split` consecutive workgroups (small workgroups)
 };
 
 // B-index (0..6+CS: pose 6, code CS, scale) -> column of the per-edge system, or -1 if absent
@@ -808,7 +811,10 @@ __global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
 {
   const int B = 7 + p.CS, BB = B * B;
   const int Dp = 13 + p.CS, Dg = 14 + 2 * p.CS;
-  const int blk = blockIdx.x;
+  const int split = p.split > 1 ? p.split : 1;
+  const int part = (int)blockIdx.x % split, bslot = (int)blockIdx.x / split;
+  const int blk = p.blk_list ? p.blk_list[bslot] : bslot;
+  const int tstride = (int)blockDim.x * split, tfirst = part * (int)blockDim.x + (int)threadIdx.x; // element striding
   double *diag = p.packed;
   double *lnk = diag + (size_t)p.K * BB;
   double *g = lnk + (size_t)p.nlinks * BB;
@@ -821,13 +827,15 @@ __global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
     const int k = blk;
     const int a0 = p.adj_start[k], a1 = p.adj_start[k + 1];
     constexpr int S = 2;
+    for (int base = 0; base < BB + B; base += S * tstride) // one pass with 1024 threads (or 4 x 256)
+    {
     double acc[S] = {0.0, 0.0};
     int bi[S], bj[S];
     bool isg[S], valid[S];
 #pragma unroll
     for (int s = 0; s < S; ++s)
     {
-      const int idx = (int)threadIdx.x + s * (int)blockDim.x;
+      const int idx = base + tfirst + s * tstride;
       valid[s] = idx < BB + B;
       isg[s] = idx >= BB;
       bi[s] = isg[s] ? idx - BB : idx / B;
@@ -855,7 +863,7 @@ __global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
 #pragma unroll
     for (int s = 0; s < S; ++s)
     {
-      const int idx = (int)threadIdx.x + s * (int)blockDim.x;
+      const int idx = base + tfirst + s * tstride;
       if (!valid[s])
         continue;
       if (isg[s])
@@ -863,12 +871,13 @@ __global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
       else
         diag[(size_t)k * BB + idx] = acc[s];
     }
+    } // passes
   }
   else if (blk < p.K + p.nlinks)
   {
     const int l = blk - p.K;
     const LinkEdges le = p.links[l];
-    for (int idx = threadIdx.x; idx < BB; idx += blockDim.x)
+    for (int idx = tfirst; idx < BB; idx += tstride)
     {
       const int bi = idx / B, bj = idx % B; // bi indexes keyframe a (older), bj keyframe b
       double acc = 0.0;
@@ -897,6 +906,8 @@ __global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
   else
   {
     // tail: total errors / inlier counts of the local edges; one wave per sum, fixed lane order (deterministic)
+    if (part != 0)
+      return;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const bool photo = (wave & 1) == 0;
     const int which = wave >> 1; // 0: error, 1: inliers
@@ -982,6 +993,27 @@ struct SageWindow
   int n_depth = 0;                      // keyframes this rank's edges touch (= entries of depth_items)
   int dpt_set = -1;                     // variable set the depth maps currently hold (-1: none) ...
   bool dgrad_valid = false;             // ... and whether their gradients are up to date as well
+  // pipelined LM iteration (single-rank windows, sage_window_lm_step): the photometric linearize reports finished
+  // links through pinned flags, the host launches the post-processing of finished row chunks on `pstream` and factors
+  // their rows while the rest of the window is still being linearised (see pipe_* below)
+  struct PipeChunk
+  {
+    int row0, row1;     // block rows (= keyframes) of the chunk
+    int need_link;      // every local link <= need_link must be linearised before the rows are final
+    int blk_first, blk_count; // slice of blk_list (assemble blocks of the chunk)
+  };
+  bool pipe_enabled = false;
+  DeviceSolver *pipe_solver = nullptr; // same system, rows in keyframe order (no two-halves split)
+  hipStream_t pstream = nullptr;
+  hipEvent_t ev_geo = nullptr;
+  DevBuf pipe_group, pipe_cnt, pipe_total, pipe_blk_list;
+  unsigned *pipe_flags = nullptr;      // pinned [local links]
+  unsigned pipe_epoch = 0;
+  std::vector<PipeChunk> pipe_chunks;
+  std::vector<int> pipe_chunk_of_row;
+  double pipe_t_wait = 0, pipe_t_launch = 0; // SAGE_DEBUG_TIMING: seconds in flag waits / chunk launches of a solve
+  int pipe_next = 0, pipe_fin_links = 0; // per solve: next chunk to launch, links whose photometric edges are finalised
+  DeviceSolver *last_solver = nullptr;   // the solver whose pinned mirror holds the pending candidate
   SageAllReduceFn allreduce = nullptr;  // sharded windows: caller-provided sum all-reduce (see sage_ba.h)
   void *allreduce_user = nullptr;
   double *h_err = nullptr;              // pinned [8]: {linearize tail[4], error pass totals[4]} written by the kernels
@@ -1113,6 +1145,14 @@ extern "C" void sage_window_destroy(SageWindow *w)
   for (DevBuf *b : bufs)
     b->release();
   solver_destroy(w->solver);
+  solver_destroy(w->pipe_solver);
+  if (w->pipe_flags)
+    (void)hipHostFree(w->pipe_flags);
+  if (w->ev_geo)
+    (void)hipEventDestroy(w->ev_geo);
+  if (w->pstream)
+    (void)hipStreamDestroy(w->pstream);
+  w->pipe_group.release(); w->pipe_cnt.release(); w->pipe_total.release(); w->pipe_blk_list.release();
   if (w->h_err)
     (void)hipHostFree(w->h_err);
   if (w->ev_fork)
@@ -1195,6 +1235,8 @@ static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t s)
     SAGE_HIP(hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s));
   return 0;
 }
+
+static int pipe_setup(SageWindow *w, const std::vector<int32_t> &group_of_work);
 
 extern "C" int sage_window_finalize(SageWindow *w)
 {
@@ -1392,6 +1434,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
   w->residuals_per_lin = residuals;
   w->bytes_per_lin = bytes;
   // ---- work lists
+  std::vector<int32_t> wp_group_of_work; // photometric work item -> local link (progress signalling, pipe_setup)
   WorkList wl;
   {
     // geometric linearize: the two wave groups of a workgroup alternate over its sub-tiles (geo_kernels.hip), so a
@@ -1420,6 +1463,9 @@ extern "C" int sage_window_finalize(SageWindow *w)
     if (const char *e = getenv("SAGE_PHOTO_TPB"))
       tpb = std::max(1, atoi(e));
     wp.build(Nedge, tpb);
+    wp_group_of_work.resize(wp.work.size());
+    for (size_t i = 0; i < wp.work.size(); ++i)
+      wp_group_of_work[i] = wp.work[i].edge / 2; // group = local link of the edge
     w->n_work_p = (int)wp.work.size();
     w->tpb_p = wp.tiles_per_block;
     if ((rc = upload(w->work_p, wp.work, w->stream)) || (rc = upload(w->first_p, wp.edge_first, w->stream)) ||
@@ -1465,6 +1511,8 @@ extern "C" int sage_window_finalize(SageWindow *w)
     if (rc != SAGE_OK && rc != SAGE_E_UNSUPPORTED)
       return rc;
   }
+  if ((rc = pipe_setup(w, wp_group_of_work)))
+    return rc;
   w->finalized = true;
   return SAGE_OK;
 }
@@ -1481,6 +1529,32 @@ static LaunchCommon window_lc(SageWindow *w, bool photo)
   lc.tiles_per_block = photo ? w->tpb_p : w->tpb_g;
   lc.packed = photo;
   return lc;
+}
+
+static AssembleParams window_assemble_params(SageWindow *w)
+{
+  const SageWindowConfig &c = w->cfg;
+  AssembleParams ap{};
+  const bool has = w->n_edges > 0;
+  ap.AtA_p = (has && c.use_photo) ? w->AtA_p.as<float>() : nullptr;
+  ap.Atb_p = w->Atb_p.as<float>();
+  ap.stats_p = (has && c.use_photo) ? w->stats_p.as<float>() : nullptr;
+  ap.AtA_g = (has && c.use_geo) ? w->AtA_g.as<float>() : nullptr;
+  ap.Atb_g = w->Atb_g.as<float>();
+  ap.stats_g = (has && c.use_geo) ? w->stats_g.as<float>() : nullptr;
+  ap.adj_start = w->adj_start.as<int32_t>();
+  ap.adj = w->adj.as<AdjEntry>();
+  ap.links = w->link_edges.as<LinkEdges>();
+  ap.packed = w->packed.as<double>();
+  ap.tail_mirror = w->world == 1 ? w->h_err : nullptr;
+  ap.K = w->K;
+  ap.nlinks = (int)w->links.size();
+  ap.CS = c.CS;
+  ap.n_edges_p = w->n_edges;
+  ap.n_edges_g = w->n_edges;
+  ap.blk_list = nullptr;
+  ap.split = 1;
+  return ap;
 }
 
 extern "C" int sage_window_linearize(SageWindow *w)
@@ -1528,24 +1602,7 @@ extern "C" int sage_window_linearize(SageWindow *w)
       }
     }
   }
-  AssembleParams ap{};
-  const bool has = w->n_edges > 0;
-  ap.AtA_p = (has && c.use_photo) ? w->AtA_p.as<float>() : nullptr;
-  ap.Atb_p = w->Atb_p.as<float>();
-  ap.stats_p = (has && c.use_photo) ? w->stats_p.as<float>() : nullptr;
-  ap.AtA_g = (has && c.use_geo) ? w->AtA_g.as<float>() : nullptr;
-  ap.Atb_g = w->Atb_g.as<float>();
-  ap.stats_g = (has && c.use_geo) ? w->stats_g.as<float>() : nullptr;
-  ap.adj_start = w->adj_start.as<int32_t>();
-  ap.adj = w->adj.as<AdjEntry>();
-  ap.links = w->link_edges.as<LinkEdges>();
-  ap.packed = w->packed.as<double>();
-  ap.tail_mirror = w->world == 1 ? w->h_err : nullptr;
-  ap.K = w->K;
-  ap.nlinks = (int)w->links.size();
-  ap.CS = c.CS;
-  ap.n_edges_p = w->n_edges;
-  ap.n_edges_g = w->n_edges;
+  AssembleParams ap = window_assemble_params(w);
   hipLaunchKernelGGL(assemble_kernel, dim3(w->K + ap.nlinks + 1), dim3(1024), 0, w->stream, ap);
   SAGE_HIP(hipGetLastError());
   w->have_lin = true;
@@ -1596,17 +1653,18 @@ static int sync_candidate(SageWindow *w)
     return SAGE_OK;
   SAGE_HIP(hipStreamSynchronize(w->stream));
   w->cand_pending = false;
-  if (solver_host_status(w->solver) != 0)
+  const DeviceSolver *S = w->last_solver ? w->last_solver : w->solver;
+  if (solver_host_status(S) != 0)
     return SAGE_E_NOT_PSD;
   const int K = w->K, CS = w->cfg.CS, VS = w->VS;
-  const float *v = solver_host_vars(w->solver);
+  const float *v = solver_host_vars(S);
   for (int k = 0; k < K; ++k)
   {
     std::memcpy(&w->pose[1][(size_t)k * 12], v + (size_t)k * VS, 12 * sizeof(float));
     w->scale[1][k] = v[(size_t)k * VS + 12];
     std::memcpy(&w->code[1][(size_t)k * CS], v + (size_t)k * VS + 13, CS * sizeof(float));
   }
-  std::memcpy(w->delta.data(), solver_host_delta(w->solver), w->delta.size() * sizeof(double));
+  std::memcpy(w->delta.data(), solver_host_delta(S), w->delta.size() * sizeof(double));
   return SAGE_OK;
 }
 
@@ -1706,11 +1764,12 @@ extern "C" int sage_window_solve(SageWindow *w, double damp, double *step_norm)
     if (rc)
       return rc;
     w->cand_pending = true;
+    w->last_solver = w->solver;
     if (step_norm)
     {
       if ((rc = sync_candidate(w)))
         return rc;
-      *step_norm = std::sqrt(solver_host_step_norm2(w->solver));
+      *step_norm = std::sqrt(solver_host_step_norm2(w->last_solver ? w->last_solver : w->solver));
     }
     return SAGE_OK;
   }
@@ -1897,6 +1956,300 @@ extern "C" int sage_window_get_edge(const SageWindow *w, int type, int e, float 
   return SAGE_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Pipelined LM iteration (single-rank windows).  In the classic sequence the host factorisation (0.4 ms on two cores)
+// starts when the whole window has been linearised, finalised, assembled and scattered.  Here
+//   * the geometric linearize runs first, the photometric one second and signals every finished LINK (both directed
+//     edges) through a pinned flag;
+//   * rows (= keyframes, in keyframe order) are grouped in chunks; a chunk is final once every link touching its
+//     keyframes is done.  When the host is about to need a chunk it waits for those flags and launches, on a second
+//     stream, the per-edge finalize of the new links, the assembly of the chunk's blocks and their scatter to pinned
+//     host memory (tickets) -- while the photometric kernel keeps linearising later links;
+//   * the host factorises rows as they arrive (one core keeps up with the device), so after the last link only the
+//     last chunk's rows and the back substitution remain.
+// Links that were added in keyframe order (the mapper's temporal links) pipeline well; a loop closure to an early
+// keyframe simply makes the early chunks wait for it (correct, less overlap).
+// ------------------------------------------------------------------------------------------------
+static int pipe_setup(SageWindow *w, const std::vector<int32_t> &group_of_work)
+{
+  w->pipe_enabled = false;
+  const int K = w->K, nl = (int)w->local_links.size();
+  // opt-in (SAGE_PIPELINE=1): measured on MI355X + EPYC 9575F, K=64 headline window, same box, three alternating runs:
+  // 2.35 ms/step pipelined vs 2.27-2.33 classic.  The tail after the last link shrinks from 0.44 to ~0.26 ms, but the
+  // photometric kernel pays 0.09 ms for it (0.03 signalling stores, 0.06 the small kernels that squeeze in next to its
+  // workgroups), and one host core (0.78 ms of factorisation + substitution) barely fits under the 0.92 ms photometric
+  // phase -- the classic path's two-halves factorisation on two cores is as fast.  What would tip it: linearising the
+  // links from both ends of the window inwards, so that both halves' rows arrive early and both cores factor under the
+  // device's shadow.
+  if (w->world != 1 || !w->solver || nl < 1 || !w->cfg.use_photo || !getenv("SAGE_PIPELINE") ||
+      getenv("SAGE_DEVICE_SOLVE"))
+    return SAGE_OK;
+  int rc = solver_create(&w->pipe_solver, K, w->B, w->VS, w->links, w->stream, /*allow_split=*/false);
+  if (rc == SAGE_E_UNSUPPORTED)
+    return SAGE_OK;
+  if (rc)
+    return rc;
+  if (!w->pstream)
+  {
+    // highest priority: the post-processing kernels are tiny and on the critical path of the host factorisation
+    int lo = 0, hi = 0;
+    SAGE_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    SAGE_HIP(hipStreamCreateWithPriority(&w->pstream, hipStreamNonBlocking, hi));
+  }
+  if (!w->ev_geo)
+    SAGE_HIP(hipEventCreateWithFlags(&w->ev_geo, hipEventDisableTiming));
+  // group (= local link) sizes in photometric work items
+  std::vector<int32_t> total(nl, 0);
+  for (int32_t g : group_of_work)
+    total[g] += 1;
+  if ((rc = upload(w->pipe_group, group_of_work, w->stream)) || (rc = upload(w->pipe_total, total, w->stream)) ||
+      (rc = w->pipe_cnt.reserve((size_t)nl * sizeof(int32_t))))
+    return rc;
+  if (w->pipe_flags)
+    (void)hipHostFree(w->pipe_flags);
+  SAGE_HIP(hipHostMalloc(reinterpret_cast<void **>(&w->pipe_flags), (size_t)nl * sizeof(unsigned), hipHostMallocDefault));
+  std::memset(w->pipe_flags, 0, (size_t)nl * sizeof(unsigned));
+  // chunks of rows: every chunk costs one round of small launches (~50 us from "links done" to "rows on the host"),
+  // so the early ones are long (the host still keeps up with the device) and the last ones short (what is left to do
+  // after the last link = latency + the last chunk's rows + the back substitution).  SAGE_PIPE_ROWS=n: uniform chunks.
+  std::vector<int> sizes;
+  if (const char *e = getenv("SAGE_PIPE_ROWS"))
+  {
+    const int rows = std::max(1, atoi(e));
+    for (int r = 0; r < K; r += rows)
+      sizes.push_back(std::min(rows, K - r));
+  }
+  else
+  {
+    int left = K;
+    while (left > 32)
+    {
+      sizes.push_back(16);
+      left -= 16;
+    }
+    const int tail_plan[] = {16, 8, 4, 4};
+    for (int t : tail_plan)
+      if (left > 0)
+      {
+        const int n = std::min(t, left);
+        sizes.push_back(n);
+        left -= n;
+      }
+    if (left > 0)
+      sizes.push_back(left);
+  }
+  std::vector<int> last_link_of_kf(K, -1);
+  for (int li = 0; li < nl; ++li)
+  {
+    const auto &l = w->links[w->local_links[li]];
+    last_link_of_kf[l.first] = std::max(last_link_of_kf[l.first], li);
+    last_link_of_kf[l.second] = std::max(last_link_of_kf[l.second], li);
+  }
+  w->pipe_chunks.clear();
+  w->pipe_chunk_of_row.assign(K, 0);
+  std::vector<int32_t> blk_list;
+  const int nlinks = (int)w->links.size();
+  int need = -1;
+  int r0 = 0;
+  for (int rows : sizes)
+  {
+    SageWindow::PipeChunk ch{};
+    ch.row0 = r0;
+    ch.row1 = std::min(K, r0 + rows);
+    r0 = ch.row1;
+    for (int k = ch.row0; k < ch.row1; ++k)
+    {
+      need = std::max(need, last_link_of_kf[k]);
+      w->pipe_chunk_of_row[k] = (int)w->pipe_chunks.size();
+    }
+    ch.need_link = need;
+    ch.blk_first = (int)blk_list.size();
+    for (int k = ch.row0; k < ch.row1; ++k)
+      blk_list.push_back(k); // diagonal block + gradient of keyframe k
+    for (int l = 0; l < nlinks; ++l)
+    {
+      const int later = std::max(w->links[l].first, w->links[l].second);
+      if (later >= ch.row0 && later < ch.row1)
+        blk_list.push_back(K + l); // the link block sits in the row of its later keyframe
+    }
+    if (ch.row1 == K)
+      blk_list.push_back(K + nlinks); // error / inlier totals
+    ch.blk_count = (int)blk_list.size() - ch.blk_first;
+    w->pipe_chunks.push_back(ch);
+  }
+  if ((rc = upload(w->pipe_blk_list, blk_list, w->stream)))
+    return rc;
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  w->pipe_enabled = true;
+  return SAGE_OK;
+}
+
+// enqueue the linearisation of a pipelined iteration: depth maps, geometric linearize (+ its finalize on the second
+// stream), photometric linearize with progress signalling.  Finalize / assembly / scatter follow chunk by chunk.
+static int pipe_linearize(SageWindow *w)
+{
+  const SageWindowConfig &c = w->cfg;
+  const int H = (int)c.pyr.cam[0].h, W = (int)c.pyr.cam[0].w;
+  const int nl = (int)w->local_links.size();
+  SAGE_HIP(hipStreamSynchronize(w->pstream)); // (idle unless an earlier iteration failed half way)
+  SAGE_HIP(hipMemsetAsync(w->pipe_cnt.p, 0, (size_t)nl * sizeof(int32_t), w->stream));
+  w->pipe_epoch += 1;
+  if (w->pipe_epoch == 0)
+    w->pipe_epoch = 1;
+  static const bool no_reuse = getenv("SAGE_NO_DEPTH_REUSE") != nullptr;
+  const bool have_depth = w->dpt_set == 0 && !no_reuse;
+  SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[0].as<DepthItem>(), w->n_depth, H, W, !have_depth,
+                              !(have_depth && w->dgrad_valid)));
+  w->dpt_set = 0;
+  w->dgrad_valid = true;
+  if (c.use_geo)
+  {
+    EdgeOut out{w->AtA_g.as<float>(), w->Atb_g.as<float>(), w->stats_g.as<float>()};
+    LaunchCommon lc = window_lc(w, false);
+    prof_attach(w, 1, lc);
+    lc.stage = 1;
+    SAGE_HIP(launch_geo_linearize(w->stream, c.CS, nullptr, w->gtab[0].as<GeoEdge>(), lc, c.pyr.cam[0], c.eps,
+                                  c.geo_loss_param, c.geo_weight, out));
+    SAGE_HIP(hipEventRecord(w->ev_geo, w->stream));
+    SAGE_HIP(hipStreamWaitEvent(w->pstream, w->ev_geo, 0));
+    LaunchCommon lf = window_lc(w, false);
+    lf.stage = 2;
+    lf.fin_block = 256;
+    lf.edge_base = 0;
+    lf.edge_count = w->n_edges;
+    SAGE_HIP(launch_geo_linearize(w->pstream, c.CS, nullptr, w->gtab[0].as<GeoEdge>(), lf, c.pyr.cam[0], c.eps,
+                                  c.geo_loss_param, c.geo_weight, out));
+  }
+  {
+    EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>()};
+    LaunchCommon lc = window_lc(w, true);
+    prof_attach(w, 0, lc);
+    lc.stage = 1;
+    lc.sig_group = w->pipe_group.as<int32_t>();
+    lc.sig_cnt = w->pipe_cnt.as<int32_t>();
+    lc.sig_total = w->pipe_total.as<int32_t>();
+    lc.sig_flag_host = w->pipe_flags;
+    lc.sig_epoch = w->pipe_epoch;
+    SAGE_HIP(launch_photo_linearize(w->stream, c.CS, c.FS, nullptr, w->ptab[0].as<PhotoEdge>(), lc, c.pyr,
+                                    c.photo_weights, c.eps, out));
+  }
+  w->pipe_next = 0;
+  w->pipe_fin_links = 0;
+  w->have_lin = true;
+  return SAGE_OK;
+}
+
+static bool pipe_chunk_ready(const SageWindow *w, int chunk)
+{
+  const volatile unsigned *f = w->pipe_flags;
+  for (int li = w->pipe_fin_links; li <= w->pipe_chunks[chunk].need_link; ++li)
+    if (f[li] != w->pipe_epoch)
+      return false;
+  return true;
+}
+
+// post-processing of one chunk on the second stream: finalize the newly finished links' photometric edges, assemble
+// the chunk's blocks, scatter its rows to the host
+static int pipe_launch_chunk(SageWindow *w, int chunk)
+{
+  const SageWindowConfig &c = w->cfg;
+  const SageWindow::PipeChunk &ch = w->pipe_chunks[chunk];
+  std::atomic_thread_fence(std::memory_order_acquire);
+  if (ch.need_link + 1 > w->pipe_fin_links)
+  {
+    EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>()};
+    LaunchCommon lf = window_lc(w, true);
+    lf.stage = 2;
+    lf.fin_block = 256;
+    lf.edge_base = 2 * w->pipe_fin_links;
+    lf.edge_count = 2 * (ch.need_link + 1 - w->pipe_fin_links);
+    SAGE_HIP(launch_photo_linearize(w->pstream, c.CS, c.FS, nullptr, w->ptab[0].as<PhotoEdge>(), lf, c.pyr,
+                                    c.photo_weights, c.eps, out));
+    w->pipe_fin_links = ch.need_link + 1;
+  }
+  AssembleParams ap = window_assemble_params(w);
+  ap.blk_list = w->pipe_blk_list.as<int32_t>() + ch.blk_first;
+  // (256-thread workgroups here and in the finalize kernels: they have to find room next to the photometric kernel's
+  // resident workgroups -- a 1024-thread workgroup only fits a CU that has drained completely)
+  ap.split = 4;
+  hipLaunchKernelGGL(assemble_kernel, dim3(ch.blk_count * ap.split), dim3(256), 0, w->pstream, ap);
+  SAGE_HIP(hipGetLastError());
+  return solver_pipe_scatter(w->pipe_solver, w->pstream, w->packed.as<double>(), w->vars[0].as<float>(), c.CS, ch.row0,
+                             ch.row1);
+}
+
+// BlockEnvelope::before_row of the pipelined factorisation
+static int pipe_before_row(void *user, int row)
+{
+  SageWindow *w = static_cast<SageWindow *>(user);
+  const int c = w->pipe_chunk_of_row[row], nch = (int)w->pipe_chunks.size();
+  while (w->pipe_next <= c)
+  {
+    // the chunk this row belongs to: wait for its links (bounded: the photometric kernel is running)
+    const auto t0 = std::chrono::steady_clock::now();
+    unsigned spins = 0;
+    while (!pipe_chunk_ready(w, w->pipe_next))
+    {
+      __builtin_ia32_pause();
+      if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2000))
+        return 1;
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    if (pipe_launch_chunk(w, w->pipe_next))
+      return 1;
+    w->pipe_t_wait += std::chrono::duration<double>(t1 - t0).count();
+    w->pipe_t_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+    w->pipe_next += 1;
+  }
+  // look ahead: launch later chunks whose links are already done, so that their rows are here when the host gets there
+  while (w->pipe_next < nch && w->pipe_next <= c + 2 && pipe_chunk_ready(w, w->pipe_next))
+  {
+    if (pipe_launch_chunk(w, w->pipe_next))
+      return 1;
+    w->pipe_next += 1;
+  }
+  return 0;
+}
+
+// solve of a pipelined iteration (after pipe_linearize)
+static int pipe_solve(SageWindow *w, double damp)
+{
+  const SageWindowConfig &c = w->cfg;
+  int rc = sync_candidate(w);
+  if (rc && rc != SAGE_E_NOT_PSD)
+    return rc;
+  if (w->dpt_set == 1)
+    w->dpt_set = -1; // the solve rewrites the candidate set
+  if ((rc = solver_pipe_begin(w->pipe_solver, damp, c.code_prior_weight, c.scale_prior_weight, c.pose_prior_weight,
+                              w->scale_init[0], &w->pose_init[0])))
+    return rc;
+  static const bool dbgt = getenv("SAGE_DEBUG_TIMING") != nullptr;
+  w->pipe_t_wait = w->pipe_t_launch = 0;
+  const auto tp0 = std::chrono::steady_clock::now();
+  rc = solver_pipe_factor(w->pipe_solver, w->stream, pipe_before_row, w, w->vars[0].as<float>(),
+                          w->vars[1].as<float>(), c.CS);
+  if (dbgt)
+    fprintf(stderr, "[sage pipelined solve] %.3f ms in the factorisation call: %.3f waiting for links, %.3f launching chunks\n",
+            1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count(), 1e3 * w->pipe_t_wait,
+            1e3 * w->pipe_t_launch);
+  // whatever happened, leave no chunk behind: the packed system / per-edge results must be complete afterwards
+  const int nch = (int)w->pipe_chunks.size();
+  while (w->pipe_next < nch)
+  {
+    SAGE_HIP(hipStreamSynchronize(w->stream)); // every link is done once the photometric kernel has finished
+    const int rl = pipe_launch_chunk(w, w->pipe_next);
+    if (rl)
+      return rl;
+    w->pipe_next += 1;
+  }
+  SAGE_HIP(hipStreamSynchronize(w->pstream));
+  if (rc)
+    return rc;
+  w->cand_pending = true;
+  w->last_solver = w->pipe_solver;
+  return SAGE_OK;
+}
+
 extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmConfig *cfg)
 {
   if (!w || !st || !cfg)
@@ -1908,7 +2261,8 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
   if (st->iters == 0 && st->damp <= 0)
     st->damp = cfg->init_damp;
   auto clampd = [&](double d) { return std::min(std::max((double)cfg->min_damp, d), (double)cfg->max_damp); };
-  if ((rc = sage_window_linearize(w)))
+  const bool pipelined = w->pipe_enabled && !sharded && w->n_edges > 0;
+  if ((rc = pipelined ? pipe_linearize(w) : sage_window_linearize(w)))
     return rc;
   if (sharded && w->allreduce(w->packed.as<double>(), sage_window_packed_count(w), w->allreduce_user))
     return SAGE_E_STATE;
@@ -1918,7 +2272,7 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
   {
     // everything of one evaluation is enqueued before the host looks at a number: the error at the linearisation
     // point (tail of the packed buffer) is read together with the candidate's
-    if ((rc = sage_window_solve(w, st->damp, nullptr)))
+    if ((rc = (pipelined && evals == 0) ? pipe_solve(w, st->damp) : sage_window_solve(w, st->damp, nullptr)))
       return rc;
     if ((rc = sage_window_error(w, 1)))
       return rc;

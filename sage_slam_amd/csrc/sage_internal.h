@@ -112,6 +112,17 @@ struct LaunchCommon
   int32_t tiles_per_block;   // consecutive kTile sub-tiles per work item (work[i].tile = first sub-tile)
   hipEvent_t ev_start = nullptr, ev_stop = nullptr; // optional: recorded around the main kernel only
   bool packed = false;       // edges carry the channel-group (float4) pyramids
+  // linearize launchers: stage 0 = main kernel + per-edge finalize (default), 1 = main kernel only,
+  // 2 = finalize only, for the edges [edge_base, edge_base + edge_count)
+  int32_t stage = 0, edge_base = 0, edge_count = 0;
+  int32_t fin_block = kFinalizeBlock; // threads per workgroup of the finalize kernel
+  // progress signalling of the photometric linearize (pipelined window solve, runtime.hip): work item i belongs to
+  // group sig_group[i]; the last workgroup of a group to finish publishes sig_epoch in sig_flag_host[group] (pinned)
+  const int32_t *sig_group = nullptr;
+  int32_t *sig_cnt = nullptr;
+  const int32_t *sig_total = nullptr;
+  unsigned *sig_flag_host = nullptr;
+  unsigned sig_epoch = 0;
 };
 
 // per-edge results, reference layouts
@@ -193,10 +204,17 @@ hipError_t launch_gaussian_pyramid_with_grad(hipStream_t s, float *pyr, float *g
 struct DeviceSolver;
 // SAGE_E_UNSUPPORTED when the block envelope is wider than the LDS panel (the caller keeps the host solver)
 int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<std::pair<int, int>> &links,
-                  hipStream_t stream);
+                  hipStream_t stream, bool allow_split = true);
 void solver_destroy(DeviceSolver *S);
 int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, const float *vars0, float *vars1, int CS,
                double damp, double code_w, double scale_w, double pose_w, float scale_init0, const float *pose_init0);
+// pipelined hybrid solve (solver created with allow_split = false): see solve_kernels.hip
+int solver_pipe_begin(DeviceSolver *S, double damp, double code_w, double scale_w, double pose_w, float scale_init0,
+                      const float *pose_init0);
+int solver_pipe_scatter(DeviceSolver *S, hipStream_t stream, const double *packed_dev, const float *vars0, int CS,
+                        int row0, int row1);
+int solver_pipe_factor(DeviceSolver *S, hipStream_t stream, int (*before_row)(void *, int), void *user,
+                       const float *vars0, float *vars1, int CS);
 // valid after the stream has been synchronised
 const float *solver_host_vars(const DeviceSolver *S);
 const double *solver_host_delta(const DeviceSolver *S);

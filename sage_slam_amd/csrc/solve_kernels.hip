@@ -91,12 +91,12 @@ __global__ __launch_bounds__(256) void solve_scatter_kernel(const SolvePlan P, c
                                                             const SolvePriors pri, double damp, int transposed,
                                                             double *__restrict__ L, double *__restrict__ y,
                                                             const int32_t *__restrict__ order, unsigned *flags,
-                                                            unsigned epoch)
+                                                            unsigned epoch, int first, int count)
 {
   const int tid = threadIdx.x;
   const int B = P.B, Bp = P.Bp, BB = B * B;
   __shared__ double s_dadd[64], s_gadd[64];
-  for (int it = blockIdx.x; it < P.nblk; it += gridDim.x)
+  for (int it = first + blockIdx.x; it < first + count; it += gridDim.x) // [first, first+count) of the order list
   {
     const int b = order ? order[it] : it;
     const int i = P.blk_row[b], j = P.blk_col[b], srcf = P.blk_src[b];
@@ -557,6 +557,9 @@ struct DeviceSolver
   unsigned *h_flags = nullptr;
   unsigned epoch = 0;
   int scatter_wgs = 32;
+  // pipelined solve (solver_pipe_*): parameters of the solve in progress
+  SolvePriors pipe_pri{};
+  double pipe_damp = 0.0;
 };
 
 constexpr int kSolveNC40 = 10; // sub-diagonal blocks of one block column kept in LDS (BP = 40)
@@ -565,7 +568,7 @@ constexpr int kSolveNC24 = 10;
 static int solver_bp(int B) { return (B + 7) / 8 * 8; }
 
 int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<std::pair<int, int>> &links,
-                  hipStream_t stream)
+                  hipStream_t stream, bool allow_split)
 {
   *out = nullptr;
   const int Bp = solver_bp(B);
@@ -581,7 +584,7 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   }
   BlockPlan bp;
   {
-    const int rcp = plan_blocks(K, links, !device_factor && !getenv("SAGE_SOLVE_NO_SPLIT"), bp);
+    const int rcp = plan_blocks(K, links, allow_split && !device_factor && !getenv("SAGE_SOLVE_NO_SPLIT"), bp);
     if (rcp != SAGE_OK)
       return rcp;
   }
@@ -761,7 +764,7 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
   double *dL = reinterpret_cast<double *>(S->d_L), *dy = reinterpret_cast<double *>(S->d_y);
   if (S->device_factor)
     hipLaunchKernelGGL(solve_scatter_kernel, dim3(S->nblk), dim3(256), 0, stream, S->plan, packed_dev, vars0, S->VS, CS,
-                       pri, damp, 0, dL, dy, (const int32_t *)nullptr, (unsigned *)nullptr, 0u);
+                       pri, damp, 0, dL, dy, (const int32_t *)nullptr, (unsigned *)nullptr, 0u, 0, S->nblk);
   if (S->device_factor)
   {
     unsigned long long *dbg = reinterpret_cast<unsigned long long *>(S->d_dbg);
@@ -794,7 +797,7 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
       S->epoch = 1;
     hipLaunchKernelGGL(solve_scatter_kernel, dim3(std::min(S->scatter_wgs, S->nblk)), dim3(256), 0, stream, S->plan,
                        packed_dev, vars0, S->VS, CS, pri, damp, 1, reinterpret_cast<double *>(S->h_T),
-                       reinterpret_cast<double *>(S->h_y), S->d_order, S->h_flags, S->epoch);
+                       reinterpret_cast<double *>(S->h_y), S->d_order, S->h_flags, S->epoch, 0, S->nblk);
     if ((eh = hipGetLastError()) != hipSuccess)
       return (int)eh;
     const auto t1 = std::chrono::steady_clock::now();
@@ -830,6 +833,69 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
           hipSuccess)
     return (int)e;
   return SAGE_OK;
+}
+
+// ---- pipelined use of the hybrid path (runtime.hip, sage_window_lm_step): the caller scatters row chunks as the
+// linearisation produces them (solver_pipe_scatter, any stream) while solver_pipe_factor runs the host factorisation
+// and calls `before_row` ahead of every block row.  Only for solvers created without the two-halves split (rows are
+// consumed in keyframe order).
+int solver_pipe_begin(DeviceSolver *S, double damp, double code_w, double scale_w, double pose_w, float scale_init0,
+                      const float *pose_init0)
+{
+  if (S->device_factor || S->n1 > 0)
+    return SAGE_E_STATE;
+  S->pipe_pri = SolvePriors{};
+  S->pipe_pri.code_w = code_w; S->pipe_pri.scale_w = scale_w; S->pipe_pri.pose_w = pose_w;
+  S->pipe_pri.scale_init0 = scale_init0;
+  for (int i = 0; i < 12; ++i)
+    S->pipe_pri.pose_init0[i] = pose_init0[i];
+  S->pipe_damp = damp;
+  S->epoch += 1;
+  if (S->epoch == 0)
+    S->epoch = 1;
+  return SAGE_OK;
+}
+
+int solver_pipe_scatter(DeviceSolver *S, hipStream_t stream, const double *packed_dev, const float *vars0, int CS,
+                        int row0, int row1)
+{
+  const int first = S->h_row_off[row0], last = row1 < S->K ? S->h_row_off[row1] : S->nblk;
+  if (last <= first)
+    return SAGE_OK;
+  hipLaunchKernelGGL(solve_scatter_kernel, dim3(std::min(S->scatter_wgs, last - first)), dim3(256), 0, stream, S->plan,
+                     packed_dev, vars0, S->VS, CS, S->pipe_pri, S->pipe_damp, 1, reinterpret_cast<double *>(S->h_T),
+                     reinterpret_cast<double *>(S->h_y), S->d_order, S->h_flags, S->epoch, first, last - first);
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SAGE_OK : (int)e;
+}
+
+int solver_pipe_factor(DeviceSolver *S, hipStream_t stream, int (*before_row)(void *, int), void *user,
+                       const float *vars0, float *vars1, int CS)
+{
+  BlockEnvelope env;
+  env.K = S->K; env.Bp = S->Bp;
+  env.row_first = S->h_row_first.data(); env.row_off = S->h_row_off.data();
+  env.a_first = S->h_a_first.data(); env.a_cnt = S->h_a_cnt.data(); env.a_off = S->h_a_off.data();
+  env.ready = S->h_flags; env.epoch = S->epoch;
+  env.before_row = before_row; env.user = user;
+  static const bool dbgt = getenv("SAGE_DEBUG_TIMING") != nullptr;
+  double t_tickets = 0.0;
+  if (dbgt)
+    env.t_ticket_wait = &t_tickets;
+  const int bad = block_chol_solve_tr(env, reinterpret_cast<double *>(S->h_T), S->h_X.data(),
+                                      reinterpret_cast<double *>(S->h_y));
+  if (dbgt)
+    fprintf(stderr, "[sage pipelined solve] %.3f ms waiting for tickets\n", 1e3 * t_tickets);
+  if (bad == -2)
+    return SAGE_E_STATE;
+  if (bad)
+    return SAGE_E_NOT_PSD;
+  char *h = reinterpret_cast<char *>(S->h_pinned);
+  hipLaunchKernelGGL(solve_retract_kernel, dim3(1), dim3(256), 0, stream, reinterpret_cast<const double *>(S->h_y), S->K,
+                     S->B, S->Bp, CS, S->VS, S->plan.pos, vars0, vars1, reinterpret_cast<float *>(h + S->h_vars_off),
+                     reinterpret_cast<double *>(h + S->h_delta_off), reinterpret_cast<double *>(h + S->h_tail_off));
+  const hipError_t e = hipGetLastError();
+  return e == hipSuccess ? SAGE_OK : (int)e;
 }
 
 const float *solver_host_vars(const DeviceSolver *S) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(S->h_pinned) + S->h_vars_off); }

@@ -353,6 +353,35 @@ def test_window_sample_order_is_internal(capi):
         capi.Window(wb)
 
 
+def test_pipelined_lm_step_matches_classic(capi, monkeypatch):
+    """SAGE_PIPELINE=1: the LM iteration that post-processes finished row chunks while the photometric kernel is still
+    running, and factors rows as they arrive, walks the same trajectory as the classic sequence (same per-edge
+    arithmetic; the factorisation order differs: one piece vs two halves)."""
+    w = synth.make_window(K=20, H=48, W=64, FS=16, CS=32, L=3, n_samples=1200, seed=12)
+
+    def run():
+        win = capi.Window(w)
+        cfg = capi.lm_config_default(); cfg.max_inner_evals = 1
+        st = capi.SageLmState()
+        tr = []
+        for _ in range(5):
+            win.lm_step(st, cfg)
+            tr.append((st.error, st.candidate_error, st.accepted, st.damp))
+        d = win.delta().copy()
+        p = win.packed_host().astype(np.float64)
+        win.close()
+        return np.array(tr), d, p
+
+    monkeypatch.delenv("SAGE_PIPELINE", raising=False)
+    t0, d0, p0 = run()
+    monkeypatch.setenv("SAGE_PIPELINE", "1")
+    monkeypatch.setenv("SAGE_PIPE_ROWS", "3")                                   # 7 chunks, the last one ragged
+    t1, d1, p1 = run()
+    assert np.array_equal(t0[:, 2], t1[:, 2])                                   # same accept / reject decisions
+    np.testing.assert_allclose(t1[:, :2], t0[:, :2], rtol=1e-6)
+    assert rel(p1, p0) < 1e-6 and rel(d1, d0) < 1e-5
+
+
 def test_sort_locations(capi, ws):
     import torch
     H, W = 24, 32
