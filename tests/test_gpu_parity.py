@@ -382,6 +382,37 @@ def test_pipelined_lm_step_matches_classic(capi, monkeypatch):
     assert rel(p1, p0) < 1e-6 and rel(d1, d0) < 1e-5
 
 
+def test_long_window_lm(capi):
+    """a window longer than the headline one (K = 150 keyframes, small images, padded B = 23 -> 24): the device
+    scatter + two-halves host factorisation agree with the host block solve of the assembled system, and the LM
+    iteration reduces the error."""
+    K, CS = 150, 16
+    w = synth.make_window(K=K, H=24, W=32, FS=16, CS=CS, L=2, n_samples=300, seed=41)
+    win = capi.Window(w)
+    win.linearize()
+    packed = win.packed_host().astype(np.float64)
+    B = 7 + CS
+    dadd = np.zeros(K * B); gadd = np.zeros(K * B)
+    for k, kf in enumerate(w.keyframes):
+        idx = np.arange(k * B + 6, k * B + 6 + CS)
+        dadd[idx] += 1e-3
+        gadd[idx] += 1e-3 * (0 - kf.code.astype(np.float64))
+    s = float(w.keyframes[0].scale)
+    dadd[6 + CS] += 1e4 / (s * s)
+    dadd[:6] += 1e4
+    win.solve(1e-3)
+    dref = capi.block_solve(packed[:-4], K, w.links, B, 1e-3, dadd, gadd)
+    assert rel(win.delta(), dref) < 1e-7
+    cfg = capi.lm_config_default(); cfg.max_inner_evals = 1
+    st = capi.SageLmState()
+    errs = []
+    for _ in range(4):
+        win.lm_step(st, cfg)
+        errs.append(st.error)
+    assert errs[-1] < errs[0]
+    win.close()
+
+
 def test_sort_locations(capi, ws):
     import torch
     H, W = 24, 32
