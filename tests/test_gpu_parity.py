@@ -364,10 +364,12 @@ def test_pipelined_lm_step_matches_classic(capi, monkeypatch):
         cfg = capi.lm_config_default(); cfg.max_inner_evals = 1
         st = capi.SageLmState()
         tr = []
+        d = None
         for _ in range(5):
             win.lm_step(st, cfg)
             tr.append((st.error, st.candidate_error, st.accepted, st.damp))
-        d = win.delta().copy()
+            if d is None:
+                d = win.delta().copy()          # the first (large) step: later ones shrink into the solve's noise
         p = win.packed_host().astype(np.float64)
         win.close()
         return np.array(tr), d, p
