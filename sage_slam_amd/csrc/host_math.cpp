@@ -1086,6 +1086,8 @@ static __attribute__((noinline)) bool wait_row_tickets(const BlockEnvelope &E, i
       while (*f != E.epoch)
       {
         __builtin_ia32_pause();
+        if (E.idle && (spins & 0x3f) == 0)
+          E.idle(E.user);
         if ((++spins & 0xfff) == 0 && mono_seconds() - t0 > 2.0)
           return false;
       }

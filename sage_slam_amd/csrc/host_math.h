@@ -47,6 +47,7 @@ struct BlockEnvelope
   // optional: called before row i is waited for / touched (the pipelined window solve launches the device work that
   // produces the next rows from here); a non-zero return aborts the factorisation with -2
   int (*before_row)(void *user, int row) = nullptr;
+  void (*idle)(void *user) = nullptr; // optional: polled while a thread waits for tickets (e.g. to launch more work)
   void *user = nullptr;
   double *t_ticket_wait = nullptr; // optional: accumulates the seconds spent waiting for tickets (diagnostics)
 };

@@ -74,7 +74,9 @@ struct WorkList
   std::vector<WorkItem> work;
   std::vector<int32_t> edge_first, edge_tiles;
   int tiles_per_block = 1;
-  void build(const std::vector<int> &N, int tpb_override = 0)
+  // `order`: optional sequence of the edges (a permutation of 0..N.size()-1) the work items are laid out in; every
+  // edge's items stay contiguous
+  void build(const std::vector<int> &N, int tpb_override = 0, const std::vector<int> *order = nullptr)
   {
     long long total = 0;
     for (int n : N)
@@ -83,8 +85,9 @@ struct WorkList
     work.clear();
     edge_first.assign(N.size(), 0);
     edge_tiles.assign(N.size(), 0);
-    for (size_t e = 0; e < N.size(); ++e)
+    for (size_t i = 0; i < N.size(); ++i)
     {
+      const size_t e = order ? (size_t)(*order)[i] : i;
       const int tiles = (N[e] + kTile - 1) / kTile;
       edge_first[e] = (int32_t)work.size();
       for (int t = 0; t < tiles; t += tiles_per_block)
@@ -993,26 +996,30 @@ struct SageWindow
   int n_depth = 0;                      // keyframes this rank's edges touch (= entries of depth_items)
   int dpt_set = -1;                     // variable set the depth maps currently hold (-1: none) ...
   bool dgrad_valid = false;             // ... and whether their gradients are up to date as well
-  // pipelined LM iteration (single-rank windows, sage_window_lm_step): the photometric linearize reports finished
-  // links through pinned flags, the host launches the post-processing of finished row chunks on `pstream` and factors
-  // their rows while the rest of the window is still being linearised (see pipe_* below)
+  // pipelined LM iteration (single-rank windows, sage_window_lm_step, opt-in): the photometric linearize works through
+  // the links from both ends of the window inwards and reports finished links through pinned flags; the host launches
+  // the post-processing of finished row chunks on `pstream` while both halves of the two-core factorisation consume
+  // their rows (see pipe_* below)
   struct PipeChunk
   {
-    int row0, row1;     // block rows (= keyframes) of the chunk
-    int need_link;      // every local link <= need_link must be linearised before the rows are final
+    int ord_first, ord_count; // slice of the solver's order list (rows of both halves, or the separator)
+    int need_lo, need_hi;     // local links [0, need_lo] and [need_hi, n) must be linearised before the rows are final
     int blk_first, blk_count; // slice of blk_list (assemble blocks of the chunk)
   };
   bool pipe_enabled = false;
-  DeviceSolver *pipe_solver = nullptr; // same system, rows in keyframe order (no two-halves split)
+  int device = 0;
   hipStream_t pstream = nullptr;
   hipEvent_t ev_geo = nullptr;
   DevBuf pipe_group, pipe_cnt, pipe_total, pipe_blk_list;
   unsigned *pipe_flags = nullptr;      // pinned [local links]
   unsigned pipe_epoch = 0;
   std::vector<PipeChunk> pipe_chunks;
-  std::vector<int> pipe_chunk_of_row;
+  std::vector<int> pipe_chunk_of_pos;  // elimination position -> chunk
+  std::atomic<int> pipe_next{0};       // per solve: next chunk to launch (both factorisation threads read it)
+  std::atomic_flag pipe_lock = ATOMIC_FLAG_INIT;
+  int pipe_fin_lo = 0, pipe_fin_hi = 0; // links [0, fin_lo) and [fin_hi, n) have their photometric edges finalised
+  std::chrono::steady_clock::time_point pipe_t0; // start of the current pipelined linearize (diagnostics)
   double pipe_t_wait = 0, pipe_t_launch = 0; // SAGE_DEBUG_TIMING: seconds in flag waits / chunk launches of a solve
-  int pipe_next = 0, pipe_fin_links = 0; // per solve: next chunk to launch, links whose photometric edges are finalised
   DeviceSolver *last_solver = nullptr;   // the solver whose pinned mirror holds the pending candidate
   SageAllReduceFn allreduce = nullptr;  // sharded windows: caller-provided sum all-reduce (see sage_ba.h)
   void *allreduce_user = nullptr;
@@ -1145,7 +1152,6 @@ extern "C" void sage_window_destroy(SageWindow *w)
   for (DevBuf *b : bufs)
     b->release();
   solver_destroy(w->solver);
-  solver_destroy(w->pipe_solver);
   if (w->pipe_flags)
     (void)hipHostFree(w->pipe_flags);
   if (w->ev_geo)
@@ -1237,6 +1243,8 @@ static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t s)
 }
 
 static int pipe_setup(SageWindow *w, const std::vector<int32_t> &group_of_work);
+static bool pipe_wanted(const SageWindow *w);
+static std::vector<int> pipe_link_sequence(int nl);
 
 extern "C" int sage_window_finalize(SageWindow *w)
 {
@@ -1462,7 +1470,14 @@ extern "C" int sage_window_finalize(SageWindow *w)
     int tpb = total >= 8192 ? 8 : 0; // measured on the headline window: 2..16 are within noise, 8 halves the partials of 4
     if (const char *e = getenv("SAGE_PHOTO_TPB"))
       tpb = std::max(1, atoi(e));
-    wp.build(Nedge, tpb);
+    std::vector<int> edge_order;
+    if (pipe_wanted(w))
+      for (int li : pipe_link_sequence((int)w->local_links.size()))
+      {
+        edge_order.push_back(2 * li); // both directed edges of a link stay together
+        edge_order.push_back(2 * li + 1);
+      }
+    wp.build(Nedge, tpb, edge_order.empty() ? nullptr : &edge_order);
     wp_group_of_work.resize(wp.work.size());
     for (size_t i = 0; i < wp.work.size(); ++i)
       wp_group_of_work[i] = wp.work[i].edge / 2; // group = local link of the edge
@@ -1957,38 +1972,53 @@ extern "C" int sage_window_get_edge(const SageWindow *w, int type, int e, float 
 }
 
 // ------------------------------------------------------------------------------------------------
-// Pipelined LM iteration (single-rank windows).  In the classic sequence the host factorisation (0.4 ms on two cores)
-// starts when the whole window has been linearised, finalised, assembled and scattered.  Here
-//   * the geometric linearize runs first, the photometric one second and signals every finished LINK (both directed
-//     edges) through a pinned flag;
-//   * rows (= keyframes, in keyframe order) are grouped in chunks; a chunk is final once every link touching its
-//     keyframes is done.  When the host is about to need a chunk it waits for those flags and launches, on a second
-//     stream, the per-edge finalize of the new links, the assembly of the chunk's blocks and their scatter to pinned
-//     host memory (tickets) -- while the photometric kernel keeps linearising later links;
-//   * the host factorises rows as they arrive (one core keeps up with the device), so after the last link only the
-//     last chunk's rows and the back substitution remain.
-// Links that were added in keyframe order (the mapper's temporal links) pipeline well; a loop closure to an early
-// keyframe simply makes the early chunks wait for it (correct, less overlap).
+// Pipelined LM iteration (single-rank windows, opt-in: SAGE_PIPELINE=1).  In the classic sequence the host
+// factorisation starts when the whole window has been linearised, finalised, assembled and scattered.  Here
+//   * the geometric linearize runs first; the photometric one second, over the links from BOTH ENDS of the window
+//     inwards (link 0, link n-1, link 1, ...), and it signals every finished link through a pinned flag;
+//   * the two-halves factorisation eliminates keyframes 0,1,2,.. on one core and K-1,K-2,.. on the other, so both
+//     cores' next rows become final at the same pace.  Rows are grouped in chunks of "pair rows"; when a thread is
+//     about to need a chunk it waits for the links touching its keyframes and launches, on a second stream, the
+//     per-edge finalize of the newly finished links, the assembly of the chunk's blocks and their scatter to pinned
+//     host memory (tickets) -- while the photometric kernel keeps linearising the links further inside;
+//   * after the last link only the innermost rows, the separator and the back substitution remain.
+// Links added in keyframe order (the mapper's temporal links) pipeline well; a loop closure prevents the two-halves
+// split in the first place (plan_blocks) and with it this path.
+// Measured (MI355X + EPYC 9575F, K = 64 headline window, same box, alternating runs): 2.20 / 2.23 ms per step against
+// 2.30 / 2.24 classic -- the host is done 0.28 ms after the last link instead of 0.44, but the photometric kernel
+// pays 0.09 ms for it (0.03 the write-through records and counters, 0.06 the small kernels squeezing in next to its
+// workgroups: 0.92 instead of 0.84 ms per launch).  Opt-in: 2-3 % of the step for 9 % of the dominant kernel's
+// roofline fraction is not a trade the default should make.
 // ------------------------------------------------------------------------------------------------
+static bool pipe_wanted(const SageWindow *w)
+{
+  return w->world == 1 && w->cfg.use_photo && getenv("SAGE_PIPELINE") && !getenv("SAGE_DEVICE_SOLVE") &&
+         !getenv("SAGE_HOST_SOLVE");
+}
+
+// the order the photometric work list walks the local links in: both ends inwards
+static std::vector<int> pipe_link_sequence(int nl)
+{
+  std::vector<int> seq;
+  for (int a = 0, b = nl - 1; a <= b; ++a, --b)
+  {
+    seq.push_back(a);
+    if (b != a)
+      seq.push_back(b);
+  }
+  return seq;
+}
+
 static int pipe_setup(SageWindow *w, const std::vector<int32_t> &group_of_work)
 {
   w->pipe_enabled = false;
   const int K = w->K, nl = (int)w->local_links.size();
-  // opt-in (SAGE_PIPELINE=1): measured on MI355X + EPYC 9575F, K=64 headline window, same box, three alternating runs:
-  // 2.35 ms/step pipelined vs 2.27-2.33 classic.  The tail after the last link shrinks from 0.44 to ~0.26 ms, but the
-  // photometric kernel pays 0.09 ms for it (0.03 signalling stores, 0.06 the small kernels that squeeze in next to its
-  // workgroups), and one host core (0.78 ms of factorisation + substitution) barely fits under the 0.92 ms photometric
-  // phase -- the classic path's two-halves factorisation on two cores is as fast.  What would tip it: linearising the
-  // links from both ends of the window inwards, so that both halves' rows arrive early and both cores factor under the
-  // device's shadow.
-  if (w->world != 1 || !w->solver || nl < 1 || !w->cfg.use_photo || !getenv("SAGE_PIPELINE") ||
-      getenv("SAGE_DEVICE_SOLVE"))
+  int n1 = 0, n2 = 0, npo = 0;
+  const int32_t *pos = nullptr, *perm = nullptr, *pair_off = nullptr;
+  if (!pipe_wanted(w) || !w->solver || nl < 2 || !solver_split_info(w->solver, &n1, &n2, &pos, &perm, &pair_off, &npo))
     return SAGE_OK;
-  int rc = solver_create(&w->pipe_solver, K, w->B, w->VS, w->links, w->stream, /*allow_split=*/false);
-  if (rc == SAGE_E_UNSUPPORTED)
-    return SAGE_OK;
-  if (rc)
-    return rc;
+  int rc;
+  SAGE_HIP(hipGetDevice(&w->device));
   if (!w->pstream)
   {
     // highest priority: the post-processing kernels are tiny and on the critical path of the host factorisation
@@ -2009,73 +2039,107 @@ static int pipe_setup(SageWindow *w, const std::vector<int32_t> &group_of_work)
     (void)hipHostFree(w->pipe_flags);
   SAGE_HIP(hipHostMalloc(reinterpret_cast<void **>(&w->pipe_flags), (size_t)nl * sizeof(unsigned), hipHostMallocDefault));
   std::memset(w->pipe_flags, 0, (size_t)nl * sizeof(unsigned));
-  // chunks of rows: every chunk costs one round of small launches (~50 us from "links done" to "rows on the host"),
-  // so the early ones are long (the host still keeps up with the device) and the last ones short (what is left to do
-  // after the last link = latency + the last chunk's rows + the back substitution).  SAGE_PIPE_ROWS=n: uniform chunks.
+  // chunks of pair rows.  Every chunk costs one round of small launches (~50 us from "links done" to "rows on the
+  // host") and disturbs the photometric kernel a little, so the early ones are long (both cores have slack under the
+  // device's shadow) and the last ones short (what is left after the last link = latency + the innermost rows + the
+  // separator + the back substitution).  SAGE_PIPE_ROWS=n: uniform chunks of n pair rows.
+  const int T = std::max(n1, n2); // pair rows; npo == T + 2
+  if (npo != T + 2)
+    return SAGE_OK;
   std::vector<int> sizes;
   if (const char *e = getenv("SAGE_PIPE_ROWS"))
   {
     const int rows = std::max(1, atoi(e));
-    for (int r = 0; r < K; r += rows)
-      sizes.push_back(std::min(rows, K - r));
+    for (int r = 0; r < T; r += rows)
+      sizes.push_back(std::min(rows, T - r));
   }
   else
   {
-    int left = K;
-    while (left > 32)
+    const double frac[] = {0.40, 0.25, 0.15, 0.10};
+    int left = T;
+    for (double f : frac)
     {
-      sizes.push_back(16);
-      left -= 16;
-    }
-    const int tail_plan[] = {16, 8, 4, 4};
-    for (int t : tail_plan)
-      if (left > 0)
-      {
-        const int n = std::min(t, left);
+      const int n = std::min(left, std::max(1, (int)(f * T + 0.5)));
+      if (n > 0)
         sizes.push_back(n);
-        left -= n;
-      }
+      left -= n;
+    }
     if (left > 0)
       sizes.push_back(left);
   }
-  std::vector<int> last_link_of_kf(K, -1);
+  // links touching a keyframe, as the extreme indices on the low / high side of the both-ends sequence
+  const int mid = (nl + 1) / 2; // links [0, mid) are walked upwards, [mid, nl) downwards
+  std::vector<int> lo_of_kf(K, -1), hi_of_kf(K, nl);
   for (int li = 0; li < nl; ++li)
   {
     const auto &l = w->links[w->local_links[li]];
-    last_link_of_kf[l.first] = std::max(last_link_of_kf[l.first], li);
-    last_link_of_kf[l.second] = std::max(last_link_of_kf[l.second], li);
+    for (int k : {l.first, l.second})
+    {
+      if (li < mid)
+        lo_of_kf[k] = std::max(lo_of_kf[k], li);
+      else
+        hi_of_kf[k] = std::min(hi_of_kf[k], li);
+    }
   }
   w->pipe_chunks.clear();
-  w->pipe_chunk_of_row.assign(K, 0);
+  w->pipe_chunk_of_pos.assign(K, 0);
   std::vector<int32_t> blk_list;
   const int nlinks = (int)w->links.size();
-  int need = -1;
-  int r0 = 0;
-  for (int rows : sizes)
-  {
+  int need_lo = -1, need_hi = nl, t0 = 0;
+  auto add_chunk = [&](const std::vector<int> &positions, int ord_first, int ord_count, bool last) {
     SageWindow::PipeChunk ch{};
-    ch.row0 = r0;
-    ch.row1 = std::min(K, r0 + rows);
-    r0 = ch.row1;
-    for (int k = ch.row0; k < ch.row1; ++k)
+    ch.ord_first = ord_first;
+    ch.ord_count = ord_count;
+    std::vector<char> in_chunk(K, 0);
+    for (int q : positions)
     {
-      need = std::max(need, last_link_of_kf[k]);
-      w->pipe_chunk_of_row[k] = (int)w->pipe_chunks.size();
+      const int k = perm[q];
+      need_lo = std::max(need_lo, lo_of_kf[k]);
+      need_hi = std::min(need_hi, hi_of_kf[k]);
+      w->pipe_chunk_of_pos[q] = (int)w->pipe_chunks.size();
+      in_chunk[q] = 1;
     }
-    ch.need_link = need;
+    if (last)
+    {
+      need_lo = mid - 1;
+      need_hi = mid;
+    }
+    ch.need_lo = need_lo;
+    ch.need_hi = need_hi;
     ch.blk_first = (int)blk_list.size();
-    for (int k = ch.row0; k < ch.row1; ++k)
-      blk_list.push_back(k); // diagonal block + gradient of keyframe k
+    for (int q : positions)
+      blk_list.push_back(perm[q]); // diagonal block + gradient of the keyframe
     for (int l = 0; l < nlinks; ++l)
     {
-      const int later = std::max(w->links[l].first, w->links[l].second);
-      if (later >= ch.row0 && later < ch.row1)
-        blk_list.push_back(K + l); // the link block sits in the row of its later keyframe
+      // a link block sits in the row of the endpoint that is eliminated later
+      const int row = std::max(pos[w->links[l].first], pos[w->links[l].second]);
+      if (in_chunk[row])
+        blk_list.push_back(K + l);
     }
-    if (ch.row1 == K)
+    if (last)
       blk_list.push_back(K + nlinks); // error / inlier totals
     ch.blk_count = (int)blk_list.size() - ch.blk_first;
     w->pipe_chunks.push_back(ch);
+  };
+  for (int rows : sizes)
+  {
+    const int t1 = std::min(T, t0 + rows);
+    std::vector<int> positions;
+    for (int t = t0; t < t1; ++t)
+    {
+      if (t < n1)
+        positions.push_back(t);
+      if (t < n2)
+        positions.push_back(n1 + t);
+    }
+    add_chunk(positions, pair_off[t0], pair_off[t1] - pair_off[t0], false);
+    t0 = t1;
+  }
+  {
+    std::vector<int> positions;
+    for (int q = n1 + n2; q < K; ++q)
+      positions.push_back(q);
+    add_chunk(positions, pair_off[T], pair_off[T + 1] - pair_off[T], true);
   }
   if ((rc = upload(w->pipe_blk_list, blk_list, w->stream)))
     return rc;
@@ -2092,6 +2156,7 @@ static int pipe_linearize(SageWindow *w)
   const int H = (int)c.pyr.cam[0].h, W = (int)c.pyr.cam[0].w;
   const int nl = (int)w->local_links.size();
   SAGE_HIP(hipStreamSynchronize(w->pstream)); // (idle unless an earlier iteration failed half way)
+  w->pipe_t0 = std::chrono::steady_clock::now();
   SAGE_HIP(hipMemsetAsync(w->pipe_cnt.p, 0, (size_t)nl * sizeof(int32_t), w->stream));
   w->pipe_epoch += 1;
   if (w->pipe_epoch == 0)
@@ -2133,8 +2198,9 @@ static int pipe_linearize(SageWindow *w)
     SAGE_HIP(launch_photo_linearize(w->stream, c.CS, c.FS, nullptr, w->ptab[0].as<PhotoEdge>(), lc, c.pyr,
                                     c.photo_weights, c.eps, out));
   }
-  w->pipe_next = 0;
-  w->pipe_fin_links = 0;
+  w->pipe_next.store(0, std::memory_order_release);
+  w->pipe_fin_lo = 0;
+  w->pipe_fin_hi = nl;
   w->have_lin = true;
   return SAGE_OK;
 }
@@ -2142,73 +2208,142 @@ static int pipe_linearize(SageWindow *w)
 static bool pipe_chunk_ready(const SageWindow *w, int chunk)
 {
   const volatile unsigned *f = w->pipe_flags;
-  for (int li = w->pipe_fin_links; li <= w->pipe_chunks[chunk].need_link; ++li)
+  const SageWindow::PipeChunk &ch = w->pipe_chunks[chunk];
+  for (int li = w->pipe_fin_lo; li <= ch.need_lo; ++li)
+    if (f[li] != w->pipe_epoch)
+      return false;
+  for (int li = ch.need_hi; li < w->pipe_fin_hi; ++li)
     if (f[li] != w->pipe_epoch)
       return false;
   return true;
 }
 
 // post-processing of one chunk on the second stream: finalize the newly finished links' photometric edges, assemble
-// the chunk's blocks, scatter its rows to the host
+// the chunk's blocks, scatter its rows to the host.  (256-thread workgroups here and in the finalize kernels: they have
+// to find room next to the photometric kernel's resident workgroups -- a 1024-thread workgroup only fits a CU that has
+// drained completely.)
 static int pipe_launch_chunk(SageWindow *w, int chunk)
 {
   const SageWindowConfig &c = w->cfg;
   const SageWindow::PipeChunk &ch = w->pipe_chunks[chunk];
   std::atomic_thread_fence(std::memory_order_acquire);
-  if (ch.need_link + 1 > w->pipe_fin_links)
-  {
-    EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>()};
-    LaunchCommon lf = window_lc(w, true);
-    lf.stage = 2;
-    lf.fin_block = 256;
-    lf.edge_base = 2 * w->pipe_fin_links;
-    lf.edge_count = 2 * (ch.need_link + 1 - w->pipe_fin_links);
-    SAGE_HIP(launch_photo_linearize(w->pstream, c.CS, c.FS, nullptr, w->ptab[0].as<PhotoEdge>(), lf, c.pyr,
-                                    c.photo_weights, c.eps, out));
-    w->pipe_fin_links = ch.need_link + 1;
-  }
+  EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>()};
+  const int ranges[2][2] = {{w->pipe_fin_lo, ch.need_lo + 1}, {ch.need_hi, w->pipe_fin_hi}};
+  for (const auto &r : ranges)
+    if (r[1] > r[0])
+    {
+      LaunchCommon lf = window_lc(w, true);
+      lf.stage = 2;
+      lf.fin_block = 256;
+      lf.edge_base = 2 * r[0];
+      lf.edge_count = 2 * (r[1] - r[0]);
+      SAGE_HIP(launch_photo_linearize(w->pstream, c.CS, c.FS, nullptr, w->ptab[0].as<PhotoEdge>(), lf, c.pyr,
+                                      c.photo_weights, c.eps, out));
+    }
+  w->pipe_fin_lo = std::max(w->pipe_fin_lo, ch.need_lo + 1);
+  w->pipe_fin_hi = std::min(w->pipe_fin_hi, ch.need_hi);
   AssembleParams ap = window_assemble_params(w);
   ap.blk_list = w->pipe_blk_list.as<int32_t>() + ch.blk_first;
-  // (256-thread workgroups here and in the finalize kernels: they have to find room next to the photometric kernel's
-  // resident workgroups -- a 1024-thread workgroup only fits a CU that has drained completely)
   ap.split = 4;
   hipLaunchKernelGGL(assemble_kernel, dim3(ch.blk_count * ap.split), dim3(256), 0, w->pstream, ap);
   SAGE_HIP(hipGetLastError());
-  return solver_pipe_scatter(w->pipe_solver, w->pstream, w->packed.as<double>(), w->vars[0].as<float>(), c.CS, ch.row0,
-                             ch.row1);
+  return solver_pipe_scatter(w->solver, w->pstream, w->packed.as<double>(), w->vars[0].as<float>(), c.CS, ch.ord_first,
+                             ch.ord_count);
 }
 
-// BlockEnvelope::before_row of the pipelined factorisation
-static int pipe_before_row(void *user, int row)
+// make sure the chunks up to `chunk` have been launched (and look a little ahead); called by both factorisation threads
+static int pipe_ensure(SageWindow *w, int chunk)
 {
-  SageWindow *w = static_cast<SageWindow *>(user);
-  const int c = w->pipe_chunk_of_row[row], nch = (int)w->pipe_chunks.size();
-  while (w->pipe_next <= c)
+  if (w->pipe_next.load(std::memory_order_acquire) > chunk)
+    return 0;
+  static thread_local int device_set = -1;
+  if (device_set != w->device)
   {
-    // the chunk this row belongs to: wait for its links (bounded: the photometric kernel is running)
+    if (hipSetDevice(w->device) != hipSuccess) // (the helper thread starts on the default device)
+      return 1;
+    device_set = w->device;
+  }
+  while (w->pipe_lock.test_and_set(std::memory_order_acquire))
+    __builtin_ia32_pause();
+  int rc = 0;
+  const int nch = (int)w->pipe_chunks.size();
+  int next = w->pipe_next.load(std::memory_order_relaxed);
+  while (!rc && next <= chunk)
+  {
+    // wait for the chunk's links (bounded: the photometric kernel is running)
     const auto t0 = std::chrono::steady_clock::now();
     unsigned spins = 0;
-    while (!pipe_chunk_ready(w, w->pipe_next))
+    while (!pipe_chunk_ready(w, next))
     {
       __builtin_ia32_pause();
       if ((++spins & 0xfff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2000))
-        return 1;
+      {
+        rc = 1;
+        break;
+      }
     }
+    if (rc)
+      break;
     const auto t1 = std::chrono::steady_clock::now();
-    if (pipe_launch_chunk(w, w->pipe_next))
-      return 1;
+    rc = pipe_launch_chunk(w, next) ? 1 : 0;
+    if (getenv("SAGE_DEBUG_TIMING"))
+      fprintf(stderr, "[sage pipeline] chunk %d launched at %.3f ms (waited %.3f for its links)\n", next,
+              1e3 * std::chrono::duration<double>(t1 - w->pipe_t0).count(),
+              1e3 * std::chrono::duration<double>(t1 - t0).count());
     w->pipe_t_wait += std::chrono::duration<double>(t1 - t0).count();
     w->pipe_t_launch += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
-    w->pipe_next += 1;
+    next += 1;
+    w->pipe_next.store(next, std::memory_order_release);
   }
-  // look ahead: launch later chunks whose links are already done, so that their rows are here when the host gets there
-  while (w->pipe_next < nch && w->pipe_next <= c + 2 && pipe_chunk_ready(w, w->pipe_next))
+  // look ahead: a later chunk whose links are already done is launched now, so that its rows are on the host when the
+  // factorisation gets there
+  while (!rc && next < nch && next <= chunk + 1 && pipe_chunk_ready(w, next))
   {
-    if (pipe_launch_chunk(w, w->pipe_next))
-      return 1;
-    w->pipe_next += 1;
+    if (getenv("SAGE_DEBUG_TIMING"))
+      fprintf(stderr, "[sage pipeline] chunk %d launched ahead at %.3f ms\n", next,
+              1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w->pipe_t0).count());
+    rc = pipe_launch_chunk(w, next) ? 1 : 0;
+    next += 1;
+    w->pipe_next.store(next, std::memory_order_release);
   }
-  return 0;
+  w->pipe_lock.clear(std::memory_order_release);
+  return rc;
+}
+
+// BlockEnvelope::idle: a thread that waits for tickets launches the next chunk as soon as its links are done (eager
+// launches keep the ~0.1 ms a chunk's small kernels need next to the photometric kernel off the critical path)
+static void pipe_idle(void *user)
+{
+  SageWindow *w = static_cast<SageWindow *>(user);
+  const int nch = (int)w->pipe_chunks.size();
+  if (w->pipe_next.load(std::memory_order_acquire) >= nch || w->pipe_lock.test_and_set(std::memory_order_acquire))
+    return;
+  static thread_local int device_set = -1;
+  bool ok = true;
+  if (device_set != w->device)
+  {
+    ok = hipSetDevice(w->device) == hipSuccess;
+    if (ok)
+      device_set = w->device;
+  }
+  int next = w->pipe_next.load(std::memory_order_relaxed);
+  if (ok && next < nch && pipe_chunk_ready(w, next))
+  {
+    if (getenv("SAGE_DEBUG_TIMING"))
+      fprintf(stderr, "[sage pipeline] chunk %d launched eagerly at %.3f ms\n", next,
+              1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w->pipe_t0).count());
+    if (pipe_launch_chunk(w, next) == 0)
+      w->pipe_next.store(next + 1, std::memory_order_release);
+  }
+  w->pipe_lock.clear(std::memory_order_release);
+}
+
+// BlockEnvelope::before_row of the pipelined factorisation (row = elimination position)
+static int pipe_before_row(void *user, int row)
+{
+  SageWindow *w = static_cast<SageWindow *>(user);
+  pipe_idle(user); // between two rows: a chunk whose links have finished in the meantime goes out now
+  return pipe_ensure(w, w->pipe_chunk_of_pos[row]);
 }
 
 // solve of a pipelined iteration (after pipe_linearize)
@@ -2220,33 +2355,35 @@ static int pipe_solve(SageWindow *w, double damp)
     return rc;
   if (w->dpt_set == 1)
     w->dpt_set = -1; // the solve rewrites the candidate set
-  if ((rc = solver_pipe_begin(w->pipe_solver, damp, c.code_prior_weight, c.scale_prior_weight, c.pose_prior_weight,
+  if ((rc = solver_pipe_begin(w->solver, damp, c.code_prior_weight, c.scale_prior_weight, c.pose_prior_weight,
                               w->scale_init[0], &w->pose_init[0])))
     return rc;
   static const bool dbgt = getenv("SAGE_DEBUG_TIMING") != nullptr;
   w->pipe_t_wait = w->pipe_t_launch = 0;
   const auto tp0 = std::chrono::steady_clock::now();
-  rc = solver_pipe_factor(w->pipe_solver, w->stream, pipe_before_row, w, w->vars[0].as<float>(),
+  rc = solver_pipe_factor(w->solver, w->stream, pipe_before_row, pipe_idle, w, w->vars[0].as<float>(),
                           w->vars[1].as<float>(), c.CS);
+  if (dbgt)
+    fprintf(stderr, "[sage pipeline] factorisation done at %.3f ms\n",
+            1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w->pipe_t0).count());
   if (dbgt)
     fprintf(stderr, "[sage pipelined solve] %.3f ms in the factorisation call: %.3f waiting for links, %.3f launching chunks\n",
             1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count(), 1e3 * w->pipe_t_wait,
             1e3 * w->pipe_t_launch);
   // whatever happened, leave no chunk behind: the packed system / per-edge results must be complete afterwards
   const int nch = (int)w->pipe_chunks.size();
-  while (w->pipe_next < nch)
+  if (w->pipe_next.load(std::memory_order_acquire) < nch)
   {
     SAGE_HIP(hipStreamSynchronize(w->stream)); // every link is done once the photometric kernel has finished
-    const int rl = pipe_launch_chunk(w, w->pipe_next);
+    const int rl = pipe_ensure(w, nch - 1);
     if (rl)
-      return rl;
-    w->pipe_next += 1;
+      return SAGE_E_STATE;
   }
   SAGE_HIP(hipStreamSynchronize(w->pstream));
   if (rc)
     return rc;
   w->cand_pending = true;
-  w->last_solver = w->pipe_solver;
+  w->last_solver = w->solver;
   return SAGE_OK;
 }
 

@@ -208,13 +208,15 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
 void solver_destroy(DeviceSolver *S);
 int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, const float *vars0, float *vars1, int CS,
                double damp, double code_w, double scale_w, double pose_w, float scale_init0, const float *pose_init0);
-// pipelined hybrid solve (solver created with allow_split = false): see solve_kernels.hip
+// pipelined use of the hybrid two-halves solve: see solve_kernels.hip
+bool solver_split_info(const DeviceSolver *S, int *n1, int *n2, const int32_t **pos, const int32_t **perm,
+                       const int32_t **pair_off, int *n_pair_off);
 int solver_pipe_begin(DeviceSolver *S, double damp, double code_w, double scale_w, double pose_w, float scale_init0,
                       const float *pose_init0);
 int solver_pipe_scatter(DeviceSolver *S, hipStream_t stream, const double *packed_dev, const float *vars0, int CS,
-                        int row0, int row1);
-int solver_pipe_factor(DeviceSolver *S, hipStream_t stream, int (*before_row)(void *, int), void *user,
-                       const float *vars0, float *vars1, int CS);
+                        int ord_first, int ord_count);
+int solver_pipe_factor(DeviceSolver *S, hipStream_t stream, int (*before_row)(void *, int), void (*idle)(void *),
+                       void *user, const float *vars0, float *vars1, int CS);
 // valid after the stream has been synchronised
 const float *solver_host_vars(const DeviceSolver *S);
 const double *solver_host_delta(const DeviceSolver *S);

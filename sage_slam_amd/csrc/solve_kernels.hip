@@ -557,6 +557,9 @@ struct DeviceSolver
   unsigned *h_flags = nullptr;
   unsigned epoch = 0;
   int scatter_wgs = 32;
+  std::vector<int32_t> h_pos, h_perm; // elimination order (host copies)
+  std::vector<int32_t> h_pair_off;    // order-list offset of "pair row" t (row t of the first half + row t of the second);
+                                      // entry T = start of the separator rows, entry T+1 = nblk
   // pipelined solve (solver_pipe_*): parameters of the solve in progress
   SolvePriors pipe_pri{};
   double pipe_damp = 0.0;
@@ -646,7 +649,7 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
                o_jp = put(job_ptr), o_br = put(blk_row), o_bc = put(blk_col), o_bs = put(blk_src), o_pm = put(perm),
                o_ps = put(pos);
   // consumption order of the host factorisation: the two halves row by row side by side, the separator last
-  std::vector<int32_t> order;
+  std::vector<int32_t> order, pair_off;
   {
     auto push_row = [&](int i) {
       for (int q = 0; q < a_cnt[i]; ++q)
@@ -658,13 +661,16 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
     {
       for (int t = 0; t < std::max(n1, n2); ++t)
       {
+        pair_off.push_back((int32_t)order.size());
         if (t < n1)
           push_row(t);
         if (t < n2)
           push_row(n1 + t);
       }
+      pair_off.push_back((int32_t)order.size());
       for (int i = n1 + n2; i < K; ++i)
         push_row(i);
+      pair_off.push_back((int32_t)order.size());
     }
     else
       for (int i = 0; i < K; ++i)
@@ -727,6 +733,9 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   S->n1 = n1;
   S->n2 = n2;
   S->d_order = base + o_ord;
+  S->h_pos = pos;
+  S->h_perm = perm;
+  S->h_pair_off = pair_off;
   std::memset(S->h_pinned, 0, S->h_bytes);
   *out = S;
   return SAGE_OK;
@@ -835,14 +844,24 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
   return SAGE_OK;
 }
 
-// ---- pipelined use of the hybrid path (runtime.hip, sage_window_lm_step): the caller scatters row chunks as the
-// linearisation produces them (solver_pipe_scatter, any stream) while solver_pipe_factor runs the host factorisation
-// and calls `before_row` ahead of every block row.  Only for solvers created without the two-halves split (rows are
-// consumed in keyframe order).
+// ---- pipelined use of the hybrid path (runtime.hip, sage_window_lm_step): the caller scatters slices of the order
+// list as the linearisation produces their rows (solver_pipe_scatter, any stream) while solver_pipe_factor runs the
+// two-halves host factorisation, which calls `before_row` ahead of every block row (from both threads).
+bool solver_split_info(const DeviceSolver *S, int *n1, int *n2, const int32_t **pos, const int32_t **perm,
+                       const int32_t **pair_off, int *n_pair_off)
+{
+  if (S->device_factor || S->n1 <= 0)
+    return false;
+  *n1 = S->n1; *n2 = S->n2;
+  *pos = S->h_pos.data(); *perm = S->h_perm.data();
+  *pair_off = S->h_pair_off.data(); *n_pair_off = (int)S->h_pair_off.size();
+  return true;
+}
+
 int solver_pipe_begin(DeviceSolver *S, double damp, double code_w, double scale_w, double pose_w, float scale_init0,
                       const float *pose_init0)
 {
-  if (S->device_factor || S->n1 > 0)
+  if (S->device_factor)
     return SAGE_E_STATE;
   S->pipe_pri = SolvePriors{};
   S->pipe_pri.code_w = code_w; S->pipe_pri.scale_w = scale_w; S->pipe_pri.pose_w = pose_w;
@@ -853,35 +872,37 @@ int solver_pipe_begin(DeviceSolver *S, double damp, double code_w, double scale_
   S->epoch += 1;
   if (S->epoch == 0)
     S->epoch = 1;
+  if (S->n1 > 0)
+    block_chol_arm();
   return SAGE_OK;
 }
 
 int solver_pipe_scatter(DeviceSolver *S, hipStream_t stream, const double *packed_dev, const float *vars0, int CS,
-                        int row0, int row1)
+                        int ord_first, int ord_count)
 {
-  const int first = S->h_row_off[row0], last = row1 < S->K ? S->h_row_off[row1] : S->nblk;
-  if (last <= first)
+  if (ord_count <= 0)
     return SAGE_OK;
-  hipLaunchKernelGGL(solve_scatter_kernel, dim3(std::min(S->scatter_wgs, last - first)), dim3(256), 0, stream, S->plan,
+  hipLaunchKernelGGL(solve_scatter_kernel, dim3(std::min(S->scatter_wgs, ord_count)), dim3(256), 0, stream, S->plan,
                      packed_dev, vars0, S->VS, CS, S->pipe_pri, S->pipe_damp, 1, reinterpret_cast<double *>(S->h_T),
-                     reinterpret_cast<double *>(S->h_y), S->d_order, S->h_flags, S->epoch, first, last - first);
+                     reinterpret_cast<double *>(S->h_y), S->d_order, S->h_flags, S->epoch, ord_first, ord_count);
   const hipError_t e = hipGetLastError();
   return e == hipSuccess ? SAGE_OK : (int)e;
 }
 
-int solver_pipe_factor(DeviceSolver *S, hipStream_t stream, int (*before_row)(void *, int), void *user,
-                       const float *vars0, float *vars1, int CS)
+int solver_pipe_factor(DeviceSolver *S, hipStream_t stream, int (*before_row)(void *, int), void (*idle)(void *),
+                       void *user, const float *vars0, float *vars1, int CS)
 {
   BlockEnvelope env;
   env.K = S->K; env.Bp = S->Bp;
   env.row_first = S->h_row_first.data(); env.row_off = S->h_row_off.data();
   env.a_first = S->h_a_first.data(); env.a_cnt = S->h_a_cnt.data(); env.a_off = S->h_a_off.data();
+  env.n1 = S->n1; env.n2 = S->n2;
   env.ready = S->h_flags; env.epoch = S->epoch;
-  env.before_row = before_row; env.user = user;
+  env.before_row = before_row; env.idle = idle; env.user = user;
   static const bool dbgt = getenv("SAGE_DEBUG_TIMING") != nullptr;
   double t_tickets = 0.0;
   if (dbgt)
-    env.t_ticket_wait = &t_tickets;
+    env.t_ticket_wait = &t_tickets; // (both threads add to it: indicative only)
   const int bad = block_chol_solve_tr(env, reinterpret_cast<double *>(S->h_T), S->h_X.data(),
                                       reinterpret_cast<double *>(S->h_y));
   if (dbgt)
