@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Generate golden vectors from the REFERENCE's own Python implementation of the
 photometric / geometric BA terms (``representation/models/diff_ba.py``:
-``photo_term`` :953-1061, ``geometry_term`` :1164-1287).
+``photo_term`` :953-1061, ``geometry_term`` :1164-1287) and of the keypoint terms
+(``match_geometry_term`` :891-951, the projection Jacobians :322-386 the reprojection term uses).
 
 Runs ONLY in the build container (needs /root/reference); the outputs
 (``tests/golden/diffba_*.npz``: seeded inputs + the reference's outputs) are
@@ -128,8 +129,47 @@ def run_case(ba, c):
     return out
 
 
+def make_keypoint_case(seed, N=40, CS=16):
+    """sparse keypoints with matches (match-geometry / reprojection factors): relative pose + code + scale"""
+    rng = np.random.default_rng(seed)
+    W, H = 80, 64
+    fx, fy, cx, cy = 70.0, 68.0, 40.3, 31.8
+    px = rng.uniform(5, W - 5, N); py = rng.uniform(5, H - 6, N)
+    homo = np.stack([(px - cx) / fx, (py - cy) / fy, np.ones(N)], 0)         # 3 x N
+    bias = 1.0 + 0.2 * rng.standard_normal(N)
+    basis = 0.05 * rng.standard_normal((N, CS))
+    code = 0.1 * rng.standard_normal(CS)
+    scale = 1.3
+    R = rot(np.array([0.02, -0.03, 0.015])); t = np.array([0.05, -0.02, 0.03])
+    X = scale * (bias + basis @ code) * (R @ homo) + t[:, None]
+    mh = X / X[2] + 0.01 * rng.standard_normal((3, N)); mh[2] = 1              # matched homogeneous coordinates
+    md = X[2] * (1 + 0.05 * rng.standard_normal(N))                             # matched depths
+    return dict(N=N, CS=CS, W=W, H=H, intr=np.array([fx, fy, cx, cy]), homo=homo, bias=bias, basis=basis, code=code,
+                scale=scale, R=R, t=t, match_homo=mh, match_depths=md, mean_sq=float(np.mean(md ** 2)))
+
+
+def run_keypoint_case(ba, c):
+    """match_geometry_term (diff_ba.py:891-951) and the projection Jacobians the reprojection term is built from
+    (:322-386; reproj_term itself reads attributes the constructor never sets)."""
+    f32 = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    sc = torch.tensor(c["scale"], dtype=torch.float32)
+    A, diff, err = ba.match_geometry_term(f32(c["bias"]), f32(c["basis"]), f32(c["homo"]), f32(c["match_homo"]),
+                                          f32(c["match_depths"]), torch.tensor(c["mean_sq"], dtype=torch.float32),
+                                          f32(c["R"]), f32(c["t"]), f32(c["code"]), sc)
+    d0 = c["scale"] * (c["bias"] + c["basis"] @ c["code"])
+    X = d0 * (c["R"] @ c["homo"]) + c["t"][:, None]
+    fx, fy = (torch.tensor(float(v), dtype=torch.float32) for v in c["intr"][:2])
+    Jp = ba.jacobian_projected_2d_location_wrt_camera_pose(f32(X), fx, fy, mode="wh")
+    Jd = ba.jacobian_projected_2d_location_wrt_src_depth(f32(c["R"] @ c["homo"]), f32(X), fx, fy, mode="wh")
+    out = {k: (np.asarray(v, dtype=np.float32) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    out.update(mg_A=A.detach().numpy(), mg_diff=diff.detach().numpy(), mg_err=err.detach().numpy(),
+               mg_param_factor=np.float32(MG_FACTOR), proj_J_pose=Jp.detach().numpy(), proj_J_depth=Jd.detach().numpy())
+    return out
+
+
 GEO_CAUCHY = 0.03
 DEPTH_EPS = 1.0e-4
+MG_FACTOR = 0.1
 
 
 def main():
@@ -137,8 +177,13 @@ def main():
     # ctor args (diff_ba.py:16-18): match_geom_param_factor, match_geom_term_weight, code_term_weight,
     # geometry_cauchy_param_factor, geometry_term_weight, scale_term_weight, photo_pow_factor,
     # photo_weight, num_photo_level, depth_eps, num_display_matches
-    ba = DBA(0.1, 0.1, 1.0e-3, GEO_CAUCHY, 0.1, 1.0, 1.0, 1.0, 1, DEPTH_EPS, 0)
+    ba = DBA(MG_FACTOR, 0.1, 1.0e-3, GEO_CAUCHY, 0.1, 1.0, 1.0, 1.0, 1, DEPTH_EPS, 0)
     with torch.no_grad():
+        for name, kw in {"diffba_keypoints": dict(seed=21, N=40, CS=16),
+                         "diffba_keypoints32": dict(seed=22, N=25, CS=32)}.items():
+            out = run_keypoint_case(ba, make_keypoint_case(**kw))
+            np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
+            print(name, "mg_A", out["mg_A"].shape, "proj_J_pose", out["proj_J_pose"].shape)
         for name, kw in {
             "diffba_allvalid": dict(seed=11, H=16, W=20, N=24, FS=16, CS=32, with_invalid=False),
             "diffba_invalid": dict(seed=12, H=16, W=20, N=24, FS=16, CS=16, with_invalid=True),

@@ -2,6 +2,9 @@
 photometric / geometric terms (fixtures: tests/golden/diffba_*.npz, generated from
 /root/reference/representation/models/diff_ba.py by tests/golden/make_diffba_golden.py).
 
+Keypoint terms (fixtures diffba_keypoints*.npz): the match-geometry factor and the projection Jacobians of the
+reprojection factor.
+
 What this pins (SURVEY.md s8c "Python secondary oracle"): sampling conventions
 (zero-padded bilinear == grid_sample(align_corners=False)), the relative-pose
 projection Jacobian (a3), the depth/code/scale Jacobians (a1/a3/a4), the geometric
@@ -119,6 +122,82 @@ def test_geometric_rows_match_diffba(orc, name, prec):
     assert np.all(J[~valid] == 0)
     assert o["num_inliers"] == pytest.approx(valid.sum())
     assert o["error"] == pytest.approx(float(c["geo_err"].sum()) / valid.sum(), rel=1e-5)
+
+
+KP_CASES = ["diffba_keypoints", "diffba_keypoints32"]
+
+
+def _kp(c):
+    from types import SimpleNamespace
+    N, CS = int(c["N"]), int(c["CS"])
+    fx, fy, cx, cy = (float(v) for v in c["intr"])
+    cam = SimpleNamespace(fx=fx, fy=fy, cx=cx, cy=cy, w=int(c["W"]), h=int(c["H"]))
+    homo = np.ascontiguousarray(c["homo"].T)
+    return N, CS, cam, homo, np.arange(N)
+
+
+@pytest.mark.parametrize("name", KP_CASES)
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_match_geometry_rows_match_diffba(orc, name, prec):
+    """f3 match-geometry factor against diff_ba.match_geometry_term (:891-951): residual match - keypoint, fair-loss
+    weights and error, translation / code0 / scale0 columns, and the rotation columns except the one entry where the
+    Python reference has a sign typo (compute_loc_3d_diff_jac_rel_pose :881 writes row 2 as [-Y, -X, 0]; the C++ kernel,
+    match_geometry_factor_kernels.cpp:196-198, and this oracle have the skew-symmetric [Y, -X, 0]).  Mapper variant with
+    T1 = identity (world pose0 == relative pose), matched depths as keyframe 1's bias; tracker variant with scale."""
+    c = load(name)
+    N, CS, cam, homo, loc = _kp(c)
+    I3, z3 = np.eye(3), np.zeros(3)
+    lp = float(c["mg_param_factor"]) * float(c["mean_sq"])
+    A = c["mg_A"].reshape(N, 3, 7 + CS); diff = c["mg_diff"].reshape(N, 3)
+    tol = 2e-5 if prec == "f32" else 5e-6           # (the fixture itself is fp32 arithmetic)
+    o = orc.match_geom_jac_error(0, "fair", c["R"], c["t"], c["R"], c["t"], I3, z3, bias0=c["bias"],
+                                 bias1=c["match_depths"], basis0=c["basis"], basis1=np.zeros((N, CS)), code0=c["code"],
+                                 code1=np.zeros(CS), homo0=homo, homo1=np.ascontiguousarray(c["match_homo"].T), loc0=loc,
+                                 loc1=loc, scale0=float(c["scale"]), scale1=1.0, loss_param=lp, weight=1.0, prec=prec,
+                                 want_rows=True)
+    J = o["J"]
+    keep = np.ones((3, 3), bool); keep[2, 0] = False
+    assert rel(o["r"], diff) < tol
+    assert rel(J[..., 0:3], A[..., 3:6]) < tol                                  # translation
+    assert rel(J[..., 3:6][:, keep], A[..., 0:3][:, keep]) < tol                # rotation (but the typo entry)
+    assert np.allclose(J[:, 2, 3], -A[:, 2, 0], rtol=1e-4, atol=1e-7)           # ... which differs exactly by its sign
+    assert np.array_equal(J[..., 6:12], -J[..., 0:6]) or rel(J[..., 6:12], -J[..., 0:6]) < 1e-6   # T1 = I
+    assert rel(J[..., 12:12 + CS], A[..., 7:]) < tol                            # code0
+    assert rel(J[..., 12 + 2 * CS], A[..., 6]) < tol                            # scale0
+    assert o["error"] == pytest.approx(float(c["mg_err"].mean()), rel=1e-5)     # weight * mean fair error
+    # tracker variant with scale (pose 6 + scale), depths given
+    d0 = float(c["scale"]) * (c["bias"] + c["basis"] @ c["code"])
+    ot = orc.match_geom_jac_error(3, "fair", c["R"], c["t"], dpts0=d0, dpts1=c["match_depths"], homo0=homo,
+                                  homo1=np.ascontiguousarray(c["match_homo"].T), scale0=float(c["scale"]), loss_param=lp,
+                                  weight=1.0, prec=prec, want_rows=True)
+    assert rel(ot["J"][..., 0:3], A[..., 3:6]) < tol and rel(ot["J"][..., 6], A[..., 6]) < tol
+    assert rel(ot["r"], diff) < tol
+
+
+@pytest.mark.parametrize("name", KP_CASES)
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_reprojection_jacobians_match_diffba(orc, name, prec):
+    """f3 reprojection factor: the unweighted projection Jacobians wrt the relative pose, the code and the scale against
+    diff_ba's jacobian_projected_2d_location_wrt_camera_pose / _wrt_src_depth (:322-386), residual = matched - projected
+    (diff_ba.reproj_term itself cannot run: it reads attributes its constructor never sets)."""
+    c = load(name)
+    N, CS, cam, homo, loc = _kp(c)
+    I3, z3 = np.eye(3), np.zeros(3)
+    rng = np.random.default_rng(1)
+    d0 = float(c["scale"]) * (c["bias"] + c["basis"] @ c["code"])
+    X = d0 * (c["R"].astype(np.float64) @ c["homo"]) + c["t"][:, None]
+    proj = np.stack([X[0] / X[2] * cam.fx + cam.cx, X[1] / X[2] * cam.fy + cam.cy], 1)
+    matched = proj + rng.standard_normal((N, 2))
+    o = orc.reproj_jac_error(c["R"], c["t"], c["R"], c["t"], I3, z3, c["bias"], c["basis"], c["code"], loc, homo,
+                             matched, float(c["scale"]), cam, 1e-4, 2.0, 1.0, prec=prec, want_rows=True)
+    Ju = o["J"] / o["sw"][:, :, None]
+    Jp, Jd = c["proj_J_pose"], c["proj_J_depth"]                                # [N,2,6] = [rot, trans], [N,2,1]
+    tol = 2e-5 if prec == "f32" else 5e-6
+    assert rel(Ju[..., 0:3], Jp[..., 3:6]) < tol
+    assert rel(Ju[..., 3:6], Jp[..., 0:3]) < tol
+    assert rel(Ju[..., 12:12 + CS], Jd * (float(c["scale"]) * c["basis"])[:, None, :]) < tol
+    assert rel(Ju[..., 12 + CS], Jd[..., 0] * (d0 / float(c["scale"]))[:, None]) < tol
+    assert rel(o["r"] / o["sw"], matched - proj) < (1e-4 if prec == "f32" else 1e-6)
 
 
 def test_shuffle_restatement_matches_std_shuffle_golden(orc):
