@@ -167,6 +167,39 @@ def run_keypoint_case(ba, c):
     return out
 
 
+def import_reference_se3_exp():
+    """representation/utils/processing.py:596-633 (se3_exp + so3_hat), the function DiffBundleAdjustment.update_variables
+    (:830-842) retracts with.  The module imports torchgeometry at the top (absent, unused here): stubbed."""
+    if "torchgeometry" not in sys.modules:
+        sys.modules["torchgeometry"] = types.ModuleType("torchgeometry")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_processing", os.path.join(REF, "utils", "processing.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod.se3_exp
+
+
+def run_retract_cases(DBA, se3_exp):
+    """se3_exp on a spread of twists and update_variables (:830-842, left-multiplicative pose update, additive scale /
+    code) -- what a13 / a8's UpdateVariables restate."""
+    rng = np.random.default_rng(31)
+    xis = [rng.standard_normal(6) * s for s in (1e-4, 1e-2, 0.1, 0.5, 1.0, 2.5) for _ in range(2)]
+    xis = np.array(xis, dtype=np.float32)                                        # [omega(3), v(3)]
+    exps = np.stack([se3_exp(torch.from_numpy(x)).numpy() for x in xis])          # [n, 3, 4]
+    sys.modules["utils"].se3_exp = se3_exp                                        # diff_ba calls utils.se3_exp
+    CS = 8
+    R0 = rot(np.array([0.3, -0.2, 0.4])).astype(np.float32); t0 = np.array([0.2, -0.1, 0.5], np.float32)
+    sols = (rng.standard_normal((4, 7 + CS)) * 0.05).astype(np.float32)           # [rot3, trans3, scale, code]
+    code0 = (0.1 * rng.standard_normal(CS)).astype(np.float32)
+    upd = []
+    for sol in sols:
+        R1, t1, s1, c1 = DBA.update_variables(torch.from_numpy(sol).reshape(-1, 1), torch.from_numpy(R0),
+                                              torch.from_numpy(t0), torch.tensor([1.3]), torch.from_numpy(code0))
+        upd.append(np.concatenate([R1.numpy().reshape(-1), t1.numpy().reshape(-1), s1.numpy().reshape(-1),
+                                   c1.numpy().reshape(-1)]))
+    return dict(xi=xis, exp=exps, R0=R0, t0=t0, scale0=np.float32(1.3), code0=code0, sol=sols, updated=np.array(upd))
+
+
 GEO_CAUCHY = 0.03
 DEPTH_EPS = 1.0e-4
 MG_FACTOR = 0.1
@@ -179,6 +212,9 @@ def main():
     # photo_weight, num_photo_level, depth_eps, num_display_matches
     ba = DBA(MG_FACTOR, 0.1, 1.0e-3, GEO_CAUCHY, 0.1, 1.0, 1.0, 1.0, 1, DEPTH_EPS, 0)
     with torch.no_grad():
+        out = run_retract_cases(DBA, import_reference_se3_exp())
+        np.savez_compressed(os.path.join(HERE, "diffba_retract.npz"), **out)
+        print("diffba_retract", out["exp"].shape, out["updated"].shape)
         for name, kw in {"diffba_keypoints": dict(seed=21, N=40, CS=16),
                          "diffba_keypoints32": dict(seed=22, N=25, CS=32)}.items():
             out = run_keypoint_case(ba, make_keypoint_case(**kw))

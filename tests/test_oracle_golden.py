@@ -200,6 +200,31 @@ def test_reprojection_jacobians_match_diffba(orc, name, prec):
     assert rel(o["r"] / o["sw"], matched - proj) < (1e-4 if prec == "f32" else 1e-6)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_se3_exp_and_retraction_match_reference_python(orc, prec):
+    """a13 / a8 UpdateVariables: se3_exp (mapping_utils.h:316-346 <-> representation/utils/processing.py:596-633) on
+    twists from 1e-4 to ~4 rad, and the left-multiplicative pose update + additive scale / code of
+    DiffBundleAdjustment.update_variables (:830-842) -- oracle and the product's host helpers (sage_se3_exp,
+    sage_pose_retract).  Order: the Python twist is [omega, v], the C++ delta [v, omega]."""
+    from sage_slam_amd import capi
+    c = load("diffba_retract")
+    tol = 3e-6 if prec == "f32" else 1e-6                                       # the fixture is fp32 arithmetic
+    for xi, E in zip(c["xi"], c["exp"]):
+        R, t = orc.se3_exp(xi[:3], xi[3:], prec=prec)
+        # (translation: the fp32 reference forms (1 - cos a)/a and (a - sin a)/a by cancellation: its own error is
+        # ~eps/a relative to |t| -- 1e-4 at a = 1e-4 rad, 1e-6 above 0.1 rad)
+        tol_t = 3e-6 + 2e-8 / float(np.linalg.norm(xi[:3]))
+        assert rel(R.reshape(3, 3), E[:, :3]) < tol and rel(t, E[:, 3]) < tol_t
+        Rp, tp = capi.se3_exp(xi[:3], xi[3:])
+        assert rel(Rp.reshape(3, 3), E[:, :3]) < 3e-6 and rel(tp, E[:, 3]) < tol_t
+    pose0 = np.concatenate([c["R0"].reshape(-1), c["t0"]]).astype(np.float32)
+    for sol, upd in zip(c["sol"], c["updated"]):
+        out = capi.pose_retract(pose0, np.concatenate([sol[3:6], sol[0:3]]))    # [v, omega]
+        assert rel(out[:9], upd[:9]) < 3e-6 and rel(out[9:], upd[9:12]) < 1e-5
+        assert upd[12] == pytest.approx(float(c["scale0"]) + sol[6], rel=1e-6)  # s <- s + ds (camera_tracker.cpp:504)
+        assert np.allclose(upd[13:], c["code0"] + sol[7:], rtol=1e-6, atol=1e-7)
+
+
 def test_shuffle_restatement_matches_std_shuffle_golden(orc):
     """orc_shuffle_indices (MT19937 + libstdc++ 11 std::shuffle restated in C) against the permutations the literal
     reference call sequence (std::iota / std::mt19937::seed / std::shuffle, mapper.cpp:1326-1333) produced
