@@ -200,6 +200,23 @@ def run_retract_cases(DBA, se3_exp):
     return dict(xi=xis, exp=exps, R0=R0, t0=t0, scale0=np.float32(1.3), code0=code0, sol=sols, updated=np.array(upd))
 
 
+def run_pyramid_case(DBA, ba):
+    """generate_gaussian_pyramid (diff_ba.py:44-71): masked 3x3 binomial blur, stride 2, renormalised by the blurred mask
+    -- the Python twin of the keyframe pyramid of mapping_utils.h / mapper.cpp:1384-1426 (f1 producer)."""
+    rng = np.random.default_rng(41)
+    FS, H, W, L = 6, 32, 40, 3
+    feat = smooth(rng, FS, H, W).astype(np.float32)
+    mask = np.ones((H, W), np.float32)
+    mask[:, :6] = 0; mask[:3] = 0; mask[20:25, 30:] = 0
+    pyr, mpyr = DBA.generate_gaussian_pyramid(torch.from_numpy(feat).reshape(1, FS, H, W),
+                                              torch.from_numpy(mask).reshape(1, 1, H, W), True, L, ba.gauss_kernel)
+    out = dict(feat=feat, mask=mask, L=L)
+    for l, (f, m) in enumerate(zip(reversed(pyr), reversed(mpyr))):
+        out[f"level{l}"] = f.numpy()[0]
+        out[f"mask{l}"] = m.numpy()[0, 0]
+    return out
+
+
 GEO_CAUCHY = 0.03
 DEPTH_EPS = 1.0e-4
 MG_FACTOR = 0.1
@@ -212,6 +229,9 @@ def main():
     # photo_weight, num_photo_level, depth_eps, num_display_matches
     ba = DBA(MG_FACTOR, 0.1, 1.0e-3, GEO_CAUCHY, 0.1, 1.0, 1.0, 1.0, 1, DEPTH_EPS, 0)
     with torch.no_grad():
+        out = run_pyramid_case(DBA, ba)
+        np.savez_compressed(os.path.join(HERE, "diffba_pyramid.npz"), **out)
+        print("diffba_pyramid", [out[f"level{l}"].shape for l in range(out["L"])])
         out = run_retract_cases(DBA, import_reference_se3_exp())
         np.savez_compressed(os.path.join(HERE, "diffba_retract.npz"), **out)
         print("diffba_retract", out["exp"].shape, out["updated"].shape)

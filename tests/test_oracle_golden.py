@@ -225,6 +225,24 @@ def test_se3_exp_and_retraction_match_reference_python(orc, prec):
         assert np.allclose(upd[13:], c["code0"] + sol[7:], rtol=1e-6, atol=1e-7)
 
 
+def test_gaussian_pyramid_matches_reference_python(orc):
+    """f1 producer: the masked Gaussian pyramid (mapper.cpp:1384-1426 / mapping_utils.h) against
+    DiffBundleAdjustment.generate_gaussian_pyramid (diff_ba.py:44-71) on a feature map with masked bands: same 3x3
+    binomial weights, stride 2, renormalisation by the blurred mask."""
+    c = load("diffba_pyramid")
+    feat, mask, L = c["feat"], c["mask"], int(c["L"])
+    FS, H, W = feat.shape
+    cams = orc.camera_pyramid([0.9 * W, 0.9 * W, W / 2, H / 2, W, H], L)
+    offs = [0]
+    for cam in cams:
+        offs.append(offs[-1] + int(cam[4]) * int(cam[5]))
+    pyr, _ = orc.gaussian_pyramid_with_grad(feat, mask, L, np.array(offs[:-1], np.int32), offs[-1])
+    for l in range(L):
+        ref = c[f"level{l}"]
+        got = pyr[:, offs[l]:offs[l + 1]].reshape(ref.shape)
+        assert np.abs(got - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), l
+
+
 def test_shuffle_restatement_matches_std_shuffle_golden(orc):
     """orc_shuffle_indices (MT19937 + libstdc++ 11 std::shuffle restated in C) against the permutations the literal
     reference call sequence (std::iota / std::mt19937::seed / std::shuffle, mapper.cpp:1326-1333) produced
