@@ -120,8 +120,16 @@ def run_case(ba, c):
         camera_intrinsics=f32(c["intr"]).reshape(1, 4),
         guess_rotation=f32(c["R"]), guess_translation=f32(c["t"]),
         guess_code_hierarchy=f32(c["code"]), guess_scale=torch.tensor(c["scale"], dtype=torch.float32))
+    # error-only evaluation (compute_geometry_error :1995-2063; weight = geometry_term_weight of the constructor)
+    d0 = c["scale"] * (c["bias"] + c["basis"] @ c["code"])
+    ge_only = ba.compute_geometry_error(
+        tgt_valid_mask=f32(c["mask"]).reshape(1, 1, H, W), tgt_depth_map=f32(c["dmap"]).reshape(1, 1, H, W),
+        mean_squared_tgt_depth_value=torch.tensor(mean_sq, dtype=torch.float32), sampled_depths=f32(d0),
+        sampled_homo_2d_locations=f32(c["homo"]), camera_intrinsics=f32(c["intr"]).reshape(1, 4),
+        guess_rotation=f32(c["R"]), guess_translation=f32(c["t"]))
     out = {k: np.asarray(v, dtype=np.float32) if isinstance(v, np.ndarray) and v.dtype.kind == "f" else v
            for k, v in c.items()}
+    out.update(geo_error_only=np.float32(float(ge_only)), geo_term_weight=np.float32(GEO_WEIGHT))
     out.update(photo_A=A.detach().numpy(), photo_diff=diff.detach().numpy(), photo_valid=valid.detach().numpy(),
                geo_A=Ag.detach().numpy(), geo_diff=dg.detach().numpy(), geo_err=eg.detach().numpy(),
                geo_valid=vg.detach().numpy(), geo_mean_sq=np.float32(mean_sq),
@@ -162,6 +170,9 @@ def run_keypoint_case(ba, c):
     Jp = ba.jacobian_projected_2d_location_wrt_camera_pose(f32(X), fx, fy, mode="wh")
     Jd = ba.jacobian_projected_2d_location_wrt_src_depth(f32(c["R"] @ c["homo"]), f32(X), fx, fy, mode="wh")
     out = {k: (np.asarray(v, dtype=np.float32) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    mg_only = ba.compute_match_geom_error(f32(d0), f32(c["homo"]), f32(c["match_homo"]), f32(c["match_depths"]),
+                                          torch.tensor(c["mean_sq"], dtype=torch.float32), f32(c["R"]), f32(c["t"]))
+    out.update(mg_error_only=np.float32(float(mg_only)), mg_term_weight=np.float32(MG_WEIGHT))
     out.update(mg_A=A.detach().numpy(), mg_diff=diff.detach().numpy(), mg_err=err.detach().numpy(),
                mg_param_factor=np.float32(MG_FACTOR), proj_J_pose=Jp.detach().numpy(), proj_J_depth=Jd.detach().numpy())
     return out
@@ -220,6 +231,8 @@ def run_pyramid_case(DBA, ba):
 GEO_CAUCHY = 0.03
 DEPTH_EPS = 1.0e-4
 MG_FACTOR = 0.1
+MG_WEIGHT = 0.1
+GEO_WEIGHT = 0.1
 
 
 def main():
@@ -227,7 +240,7 @@ def main():
     # ctor args (diff_ba.py:16-18): match_geom_param_factor, match_geom_term_weight, code_term_weight,
     # geometry_cauchy_param_factor, geometry_term_weight, scale_term_weight, photo_pow_factor,
     # photo_weight, num_photo_level, depth_eps, num_display_matches
-    ba = DBA(MG_FACTOR, 0.1, 1.0e-3, GEO_CAUCHY, 0.1, 1.0, 1.0, 1.0, 1, DEPTH_EPS, 0)
+    ba = DBA(MG_FACTOR, MG_WEIGHT, 1.0e-3, GEO_CAUCHY, GEO_WEIGHT, 1.0, 1.0, 1.0, 1, DEPTH_EPS, 0)
     with torch.no_grad():
         out = run_pyramid_case(DBA, ba)
         np.savez_compressed(os.path.join(HERE, "diffba_pyramid.npz"), **out)

@@ -122,6 +122,12 @@ def test_geometric_rows_match_diffba(orc, name, prec):
     assert np.all(J[~valid] == 0)
     assert o["num_inliers"] == pytest.approx(valid.sum())
     assert o["error"] == pytest.approx(float(c["geo_err"].sum()) / valid.sum(), rel=1e-5)
+    # a5, the error-only operator, against compute_geometry_error (:1995-2063; weight * mean Cauchy error over the inliers)
+    wg = float(c["geo_term_weight"])
+    e_only, n_only = orc.geo_error(c["R"], c["t"], bias, basis, c["code"], c["dmap"], c["mask"], loc, homo,
+                                   float(c["scale"]), cams[0], float(c["depth_eps"]), loss, wg, prec=prec)
+    assert e_only == pytest.approx(float(c["geo_error_only"]), rel=2e-5)
+    assert n_only == pytest.approx(valid.sum())
 
 
 KP_CASES = ["diffba_keypoints", "diffba_keypoints32"]
@@ -172,6 +178,11 @@ def test_match_geometry_rows_match_diffba(orc, name, prec):
                                   weight=1.0, prec=prec, want_rows=True)
     assert rel(ot["J"][..., 0:3], A[..., 3:6]) < tol and rel(ot["J"][..., 6], A[..., 6]) < tol
     assert rel(ot["r"], diff) < tol
+    # error-only operator against compute_match_geom_error (:1822-1850): weight * mean fair error
+    e_only = orc.match_geom_error(2, "fair", c["R"], c["t"], dpts0=d0, dpts1=c["match_depths"], homo0=homo,
+                                  homo1=np.ascontiguousarray(c["match_homo"].T), loss_param=lp,
+                                  weight=float(c["mg_term_weight"]), prec=prec)
+    assert e_only == pytest.approx(float(c["mg_error_only"]), rel=2e-5)
 
 
 @pytest.mark.parametrize("name", KP_CASES)
