@@ -228,9 +228,47 @@ def run_pyramid_case(DBA, ba):
     return out
 
 
+def run_multilevel_photo_error(DBA, ba):
+    """compute_photo_error (diff_ba.py:1853-1939) over a 3-level pyramid: per level, project with that level's
+    intrinsics, grid_sample(align_corners=False), weight * sum / num_samples, summed over the levels.  The level
+    intrinsics handed over are the ones the C++ kernels' coordinate rule implies (u_l = (u_0 + .5) * fx_l / fx_0 - .5,
+    photometric_factor_kernels.cpp:142-160): fx_l = fx_0 * W_l / W_0, cx_l = (cx_0 + .5) * W_l / W_0 - .5.  All-valid
+    masks and positive depths, so the per-level inlier counts of the Python code equal the level-0 count the C++ uses."""
+    rng = np.random.default_rng(51)
+    FS, H, W, L, N = 8, 32, 40, 3, 60
+    fx0, fy0, cx0, cy0 = 0.9 * W, 0.85 * W, W / 2.0 - 0.3, H / 2.0 + 0.2
+    feat = smooth(rng, FS, H, W).astype(np.float32)
+    ones = np.ones((H, W), np.float32)
+    pyr, mpyr = DBA.generate_gaussian_pyramid(torch.from_numpy(feat).reshape(1, FS, H, W),
+                                              torch.from_numpy(ones).reshape(1, 1, H, W), True, L, ba.gauss_kernel)
+    pyr = list(reversed(pyr)); mpyr = list(reversed(mpyr))                        # fine -> coarse
+    px = rng.uniform(6, W - 7, N); py = rng.uniform(6, H - 7, N)
+    homo = np.stack([(px - cx0) / fx0, (py - cy0) / fy0, np.ones(N)], 0).astype(np.float32)
+    depths = (1.0 + 0.2 * rng.standard_normal(N)).astype(np.float32)
+    R = rot(np.array([0.02, -0.03, 0.015])).astype(np.float32); t = np.array([0.05, -0.02, 0.03], np.float32)
+    src = [rng.uniform(-1, 1, (FS, N)).astype(np.float32) for _ in range(L)]
+    intr, scales = [], []
+    for l in range(L):
+        hl, wl = pyr[l].shape[2:]
+        rx, ry = wl / W, hl / H
+        intr.append(torch.tensor([[fx0 * rx, fy0 * ry, (cx0 + 0.5) * rx - 0.5, (cy0 + 0.5) * ry - 0.5]], dtype=torch.float32))
+        scales.append(torch.tensor(0.5 ** l, dtype=torch.float32))
+    err = ba.compute_photo_error(torch.from_numpy(homo), torch.from_numpy(depths), [torch.from_numpy(x) for x in src],
+                                 intr, scales, pyr, mpyr, torch.from_numpy(R), torch.from_numpy(t))
+    weights = np.array([abs(PHOTO_WEIGHT * 10) * (0.5 ** l) ** PHOTO_POW for l in range(L)], np.float32)
+    out = dict(feat=feat, L=L, N=N, FS=FS, H=H, W=W, intr0=np.array([fx0, fy0, cx0, cy0], np.float32), homo=homo,
+               depths=depths, R=R, t=t, src=np.stack(src), weights=weights, error=np.float32(float(err)),
+               depth_eps=np.float32(DEPTH_EPS))
+    for l in range(L):
+        out[f"level{l}"] = pyr[l].numpy()[0]
+    return out
+
+
 GEO_CAUCHY = 0.03
 DEPTH_EPS = 1.0e-4
 MG_FACTOR = 0.1
+PHOTO_WEIGHT = 1.0
+PHOTO_POW = 1.0
 MG_WEIGHT = 0.1
 GEO_WEIGHT = 0.1
 
@@ -240,8 +278,11 @@ def main():
     # ctor args (diff_ba.py:16-18): match_geom_param_factor, match_geom_term_weight, code_term_weight,
     # geometry_cauchy_param_factor, geometry_term_weight, scale_term_weight, photo_pow_factor,
     # photo_weight, num_photo_level, depth_eps, num_display_matches
-    ba = DBA(MG_FACTOR, MG_WEIGHT, 1.0e-3, GEO_CAUCHY, GEO_WEIGHT, 1.0, 1.0, 1.0, 1, DEPTH_EPS, 0)
+    ba = DBA(MG_FACTOR, MG_WEIGHT, 1.0e-3, GEO_CAUCHY, GEO_WEIGHT, 1.0, PHOTO_POW, PHOTO_WEIGHT, 1, DEPTH_EPS, 0)
     with torch.no_grad():
+        out = run_multilevel_photo_error(DBA, ba)
+        np.savez_compressed(os.path.join(HERE, "diffba_photo_levels.npz"), **out)
+        print("diffba_photo_levels error", out["error"], "weights", out["weights"])
         out = run_pyramid_case(DBA, ba)
         np.savez_compressed(os.path.join(HERE, "diffba_pyramid.npz"), **out)
         print("diffba_pyramid", [out[f"level{l}"].shape for l in range(out["L"])])

@@ -236,6 +236,29 @@ def test_se3_exp_and_retraction_match_reference_python(orc, prec):
         assert np.allclose(upd[13:], c["code0"] + sol[7:], rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_multilevel_photometric_error_matches_reference_python(orc, prec):
+    """The multi-level coordinate rule and level weighting (a2/a3): compute_photo_error (diff_ba.py:1853-1939) over a
+    3-level pyramid -- each level projected with its own intrinsics and sampled with grid_sample(align_corners=False)
+    -- against the tracker error operator, whose levels all derive from the level-0 coordinates
+    (u_l = (u_0 + .5) fx_l/fx_0 - .5, photometric_factor_kernels.cpp:142-160).  The fixture's level intrinsics are the
+    ones that rule implies; masks all valid, so the per-level inlier counts (Python) equal the level-0 count (C++)."""
+    c = load("diffba_photo_levels")
+    L, N, FS, H, W = (int(c[k]) for k in ("L", "N", "FS", "H", "W"))
+    fx, fy, cx, cy = (float(v) for v in c["intr0"])
+    cams = orc.camera_pyramid([fx, fy, cx, cy, W, H], L, prec=prec)
+    offs = [0]
+    for cam in cams:
+        offs.append(offs[-1] + int(cam[4]) * int(cam[5]))
+    feat1 = np.concatenate([c[f"level{l}"].reshape(FS, -1) for l in range(L)], 1)
+    feat0s = np.ascontiguousarray(c["src"].transpose(0, 2, 1))                   # [L, N, FS]
+    e, n = orc.tracker_photo_error(c["R"], c["t"], np.ones((H, W)), c["depths"], np.ascontiguousarray(c["homo"].T),
+                                   feat0s, feat1, np.array(offs[:-1], np.int32), cams, float(c["depth_eps"]),
+                                   c["weights"], prec=prec)
+    assert n == N
+    assert e == pytest.approx(float(c["error"]), rel=3e-5 if prec == "f32" else 1e-5)
+
+
 def test_gaussian_pyramid_matches_reference_python(orc):
     """f1 producer: the masked Gaussian pyramid (mapper.cpp:1384-1426 / mapping_utils.h) against
     DiffBundleAdjustment.generate_gaussian_pyramid (diff_ba.py:44-71) on a feature map with masked bands: same 3x3
