@@ -384,6 +384,25 @@ def test_pipelined_lm_step_matches_classic(capi, monkeypatch):
     assert rel(p1, p0) < 1e-6 and rel(d1, d0) < 1e-5
 
 
+@pytest.mark.parametrize("use_photo,use_geo", [(True, False), (False, True)])
+def test_single_factor_windows(capi, use_photo, use_geo):
+    """windows with only one of the two factor types: the packed system is the corresponding part of the full one
+    (photometric + geometric = both), and the LM iteration runs"""
+    w = synth.make_window(K=5, H=32, W=40, FS=16, CS=32, L=3, seed=33)
+    both = capi.Window(w); both.linearize(); p_both = both.packed_host().astype(np.float64); both.close()
+    one = capi.Window(w, use_photo=use_photo, use_geo=use_geo); one.linearize()
+    other = capi.Window(w, use_photo=not use_photo, use_geo=not use_geo); other.linearize()
+    p_sum = one.packed_host().astype(np.float64) + other.packed_host().astype(np.float64)
+    assert rel(p_sum[:-4], p_both[:-4]) < 1e-12                                 # blocks and gradient add up
+    assert np.allclose(p_sum[-4:], p_both[-4:], rtol=1e-12)                     # error / inlier totals too
+    cfg = capi.lm_config_default(); cfg.max_inner_evals = 1
+    st = capi.SageLmState()
+    for _ in range(3):
+        one.lm_step(st, cfg)
+    assert np.isfinite(st.error) and st.candidate_error <= st.error * 1.5
+    one.close(); other.close()
+
+
 def test_long_window_lm(capi):
     """a window longer than the headline one (K = 150 keyframes, small images, padded B = 23 -> 24): the device
     scatter + two-halves host factorisation agree with the host block solve of the assembled system, and the LM
