@@ -616,6 +616,8 @@ static hipError_t geo_err_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   hipLaunchKernelGGL((geo_kernel<CS, false>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   if (lc.ev_stop)
     (void)hipEventRecord(lc.ev_stop, s);
+  if (lc.stage == 1) // the caller forms the per-edge statistics itself (window error pass)
+    return hipGetLastError();
   return launch_stats_finalize(s, lc, stats, 10.0f * weight, weight);
 }
 

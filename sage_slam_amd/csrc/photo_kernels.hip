@@ -822,6 +822,8 @@ static hipError_t photo_err_impl(hipStream_t s, const PhotoEdge *single, const P
     hipLaunchKernelGGL((photo_kernel<CS, FS, false, 0>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   if (lc.ev_stop)
     (void)hipEventRecord(lc.ev_stop, s);
+  if (lc.stage == 1) // the caller forms the per-edge statistics itself (window error pass)
+    return hipGetLastError();
   return launch_stats_finalize(s, lc, stats, 10.0f * wsum, 1.0f);
 }
 

@@ -931,27 +931,62 @@ __global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
   }
 }
 
-__global__ __launch_bounds__(256) void sum_stats_kernel(const float *stats_p, int np, const float *stats_g, int ng,
-                                                        double *out, double *mirror)
+// error pass of a window in ONE tail kernel: per-edge statistics of both factor types from the workgroup partials
+// (what stats_finalize_kernel does: photometric_factor_kernels.cpp:1049-1058, geometric :868-878) and their totals
+// (a wave-parallel sum in a fixed lane order) -- same summation orders, three launches and their gaps less on the step's critical path.
+struct ErrorTotalsSide
 {
-  // out = {sum err_photo, sum err_geo, sum n_photo, sum n_geo}; wave w sums one of the four in a fixed lane order
+  const int32_t *edge_first, *edge_tiles;
+  const float *partials; // [n_work][2]
+  float *stats;          // [n_edges][2]
+  float fallback, scale;
+  int n_edges;           // 0: factor type unused
+};
+
+__global__ __launch_bounds__(1024) void error_totals_kernel(const ErrorTotalsSide ph, const ErrorTotalsSide ge, double *out,
+                                                            double *mirror)
+{
+  for (int idx = threadIdx.x; idx < ph.n_edges + ge.n_edges; idx += blockDim.x)
+  {
+    const bool photo = idx < ph.n_edges;
+    const ErrorTotalsSide &sd = photo ? ph : ge;
+    const int e = photo ? idx : idx - ph.n_edges;
+    const int first = sd.edge_first[e], nt = sd.edge_tiles[e];
+    float se = 0.f, sn = 0.f;
+    for (int t = 0; t < nt; ++t)
+    {
+      se += sd.partials[(size_t)(first + t) * 2 + 0];
+      sn += sd.partials[(size_t)(first + t) * 2 + 1];
+    }
+    sd.stats[2 * e + 0] = sn > 0.f ? sd.scale * se / sn : sd.fallback;
+    sd.stats[2 * e + 1] = sn;
+  }
+  __threadfence_block();
+  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (wave >= 4)
+    return;
   const bool photo = (wave & 1) == 0;
   const int which = wave >> 1;
-  const float *st = photo ? stats_p : stats_g;
-  const int n = photo ? np : ng;
+  const ErrorTotalsSide &sd = photo ? ph : ge;
   double acc = 0.0;
-  if (st)
-    for (int e = lane; e < n; e += 64)
-      acc += (double)st[2 * e + which];
+  for (int e = lane; e < sd.n_edges; e += 64)
+    acc += (double)sd.stats[2 * e + which];
   for (int off = 32; off > 0; off >>= 1)
     acc += __shfl_down(acc, off);
   if (lane == 0)
   {
     out[which * 2 + (photo ? 0 : 1)] = acc;
-    if (mirror) // pinned host memory: the host reads the totals after a stream sync, without a copy of its own
+    if (mirror)
       mirror[which * 2 + (photo ? 0 : 1)] = acc;
   }
+}
+
+__global__ void copy_floats_kernel(const float *__restrict__ src, float *__restrict__ dst, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    dst[i] = src[i];
 }
 
 // sharded windows: the reduced totals (tail of the packed buffer, error buffer) -> pinned host mirror
@@ -1637,23 +1672,30 @@ extern "C" int sage_window_error(SageWindow *w, int which)
     w->dpt_set = which;
     w->dgrad_valid = false;
   }
+  ErrorTotalsSide ph{}, ge{};
   if (has && c.use_photo)
   {
     LaunchCommon lc = window_lc(w, true);
     prof_attach(w, 2, lc);
+    lc.stage = 1; // main kernel only: the per-edge statistics are formed by error_totals_kernel below
     SAGE_HIP(launch_photo_error(w->stream, c.CS, c.FS, nullptr, w->ptab[which].as<PhotoEdge>(), lc, c.pyr,
                                 c.photo_weights, c.eps, w->stats_p.as<float>()));
+    float wsum = 0.f;
+    for (int l = 0; l < c.pyr.levels; ++l)
+      wsum += c.photo_weights[l];
+    ph = ErrorTotalsSide{lc.edge_first, lc.edge_tiles, lc.partials, w->stats_p.as<float>(), 10.0f * wsum, 1.0f, w->n_edges};
   }
   if (has && c.use_geo)
   {
     LaunchCommon lc = window_lc(w, false);
     prof_attach(w, 3, lc);
+    lc.stage = 1;
     SAGE_HIP(launch_geo_error(w->stream, c.CS, nullptr, w->gtab[which].as<GeoEdge>(), lc, c.pyr.cam[0], c.eps,
                               c.geo_loss_param, c.geo_weight, w->stats_g.as<float>()));
+    ge = ErrorTotalsSide{lc.edge_first, lc.edge_tiles, lc.partials, w->stats_g.as<float>(), 10.0f * c.geo_weight,
+                         c.geo_weight, w->n_edges};
   }
-  hipLaunchKernelGGL(sum_stats_kernel, dim3(1), dim3(256), 0, w->stream,
-                     (has && c.use_photo) ? w->stats_p.as<float>() : nullptr, w->n_edges,
-                     (has && c.use_geo) ? w->stats_g.as<float>() : nullptr, w->n_edges, w->errbuf.as<double>(),
+  hipLaunchKernelGGL(error_totals_kernel, dim3(1), dim3(1024), 0, w->stream, ph, ge, w->errbuf.as<double>(),
                      w->world == 1 && w->h_err ? w->h_err + 4 : nullptr);
   SAGE_HIP(hipGetLastError());
   return SAGE_OK;
@@ -1873,8 +1915,11 @@ extern "C" int sage_window_accept(SageWindow *w)
   w->code[0] = w->code[1];
   w->scale[0] = w->scale[1];
   w->dpt_set = w->dpt_set == 1 ? 0 : -1; // depth maps evaluated at the candidate now belong to the current set
-  SAGE_HIP(hipMemcpyAsync(w->vars[0].p, w->vars[1].p, (size_t)w->K * w->VS * sizeof(float), hipMemcpyDeviceToDevice,
-                          w->stream));
+  // (a kernel, not hipMemcpyAsync: a device-to-device copy of 11 KB costs ~10 us of API time on the step's critical path)
+  const int nv = w->K * w->VS;
+  hipLaunchKernelGGL(copy_floats_kernel, dim3((nv + 255) / 256), dim3(256), 0, w->stream, w->vars[1].as<float>(),
+                     w->vars[0].as<float>(), nv);
+  SAGE_HIP(hipGetLastError());
   return SAGE_OK;
 }
 
