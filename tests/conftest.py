@@ -12,6 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The engine library is built in-tree and kept out of git: build it when a fresh checkout has none yet (hipcc
+    cross-compiles without a GPU).  The product itself never builds or falls back at run time."""
+    from sage_slam_amd import build as sage_build
+    lib = os.path.join(ROOT, "sage_slam_amd", "libsage_ba.so")
+    if not os.path.exists(lib) and os.path.exists(sage_build.HIPCC):
+        sage_build.build(verbose=False)
+
+
 @pytest.fixture(scope="session")
 def orc():
     """The CPU oracle (test infrastructure): built on demand with gcc."""
