@@ -882,9 +882,27 @@ namespace
 {
 #define SAGE_STOREU(p, v) __builtin_memcpy((p), &(v), sizeof(v8d))
 
+// The blocks of a row arrive by DMA straight into DRAM (no cache allocation on this platform): a row's first touch of
+// its ~4 fresh blocks (51 KB) would stall the core for ~2 us.  The contraction loops of row i therefore prefetch row
+// i+1's blocks, two cache lines per inner step.
+struct RowPrefetch // (plain aggregate: the multi-versioned callers must not need an out-of-line constructor)
+{
+  const char *p, *end;
+  inline __attribute__((always_inline)) void step()
+  {
+    if (p < end)
+    {
+      __builtin_prefetch(p, 0, 3);
+      __builtin_prefetch(p + 64, 0, 3);
+      p += 128;
+    }
+  }
+};
+
 // CT[c][8*V0 ..] -= sum_t Tj[t][c] * Ti[t][8*V0 ..]  for the 4 rows c0..c0+3 ; vectors V0..NV-1 only
 template <int NV, int V0>
-static inline __attribute__((always_inline)) void tn_sub_rows4(double *CT, const double *Tj, const double *Ti, int c0)
+static inline __attribute__((always_inline)) void tn_sub_rows4(double *CT, const double *Tj, const double *Ti, int c0,
+                                                               RowPrefetch &pf)
 {
   constexpr int BP = NV * 8;
   v8d acc[4][NV];
@@ -894,6 +912,7 @@ static inline __attribute__((always_inline)) void tn_sub_rows4(double *CT, const
   for (int t = 0; t < BP; ++t)
   {
     const double *ti = Ti + t * BP, *tj = Tj + t * BP + c0;
+    pf.step();
     v8d b[NV];
     for (int v = V0; v < NV; ++v)
       SAGE_LOADU(b[v], ti + 8 * v);
@@ -918,7 +937,8 @@ static inline __attribute__((always_inline)) void tn_sub_rows4(double *CT, const
 // CT -= Tj^T-contraction with Ti over the whole block; upper_only: only entries [c][r >= c] are needed (diagonal
 // block, symmetric) -> the vectors left of the diagonal are skipped
 template <int NV>
-static inline __attribute__((always_inline)) void tn_sub(double *CT, const double *Tj, const double *Ti, bool upper_only)
+static inline __attribute__((always_inline)) void tn_sub(double *CT, const double *Tj, const double *Ti, bool upper_only,
+                                                         RowPrefetch &pf)
 {
   constexpr int BP = NV * 8;
   for (int c0 = 0; c0 < BP; c0 += 4)
@@ -926,11 +946,11 @@ static inline __attribute__((always_inline)) void tn_sub(double *CT, const doubl
     const int v0 = upper_only ? c0 / 8 : 0;
     switch (v0)
     {
-    case 0: tn_sub_rows4<NV, 0>(CT, Tj, Ti, c0); break;
-    case 1: tn_sub_rows4<NV, (NV > 1 ? 1 : 0)>(CT, Tj, Ti, c0); break;
-    case 2: tn_sub_rows4<NV, (NV > 2 ? 2 : 0)>(CT, Tj, Ti, c0); break;
-    case 3: tn_sub_rows4<NV, (NV > 3 ? 3 : 0)>(CT, Tj, Ti, c0); break;
-    default: tn_sub_rows4<NV, (NV > 4 ? 4 : 0)>(CT, Tj, Ti, c0); break;
+    case 0: tn_sub_rows4<NV, 0>(CT, Tj, Ti, c0, pf); break;
+    case 1: tn_sub_rows4<NV, (NV > 1 ? 1 : 0)>(CT, Tj, Ti, c0, pf); break;
+    case 2: tn_sub_rows4<NV, (NV > 2 ? 2 : 0)>(CT, Tj, Ti, c0, pf); break;
+    case 3: tn_sub_rows4<NV, (NV > 3 ? 3 : 0)>(CT, Tj, Ti, c0, pf); break;
+    default: tn_sub_rows4<NV, (NV > 4 ? 4 : 0)>(CT, Tj, Ti, c0, pf); break;
     }
   }
 }
@@ -1116,6 +1136,7 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
   };
   if (phase == 0)
   {
+    static const bool getenv_no_prefetch = getenv("SAGE_SOLVE_NO_PREFETCH") != nullptr;
     for (int i = lo; i < hi; ++i)
     {
       if (E.before_row && E.before_row(E.user, i))
@@ -1124,6 +1145,15 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
         return -2;
       // the column ranges of row i, in ascending order
       const int r0[2] = {afirst(i), row_first[i]}, r1[2] = {afirst(i) + acnt(i), i};
+      RowPrefetch pf{nullptr, nullptr};
+      if (i + 1 < hi && !getenv_no_prefetch)
+      {
+        // row i+1's blocks are contiguous in the storage: [A range | B range]
+        const size_t b0 = (size_t)(acnt(i + 1) ? E.a_off[i + 1] : row_off[i + 1]);
+        const size_t nb = (size_t)acnt(i + 1) + (size_t)(i + 1 - row_first[i + 1] + 1);
+        pf.p = reinterpret_cast<const char *>(T + b0 * BB);
+        pf.end = pf.p + nb * BB * sizeof(double);
+      }
       for (int rg = 0; rg < 2; ++rg)
         for (int j = r0[rg]; j < r1[rg]; ++j)
         {
@@ -1131,13 +1161,13 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
           for (int rk = 0; rk <= rg; ++rk)
             for (int k = r0[rk]; k < std::min(r1[rk], j); ++k)
               if (has(j, k))
-                tn_sub<NV>(CT, blk(j, k), blk(i, k), false);
+                tn_sub<NV>(CT, blk(j, k), blk(i, k), false, pf);
           apply_inverse<NV>(CT, X + (size_t)j * BB);
         }
       double *S = blk(i, i);
       for (int rg = 0; rg < 2; ++rg)
         for (int k = r0[rg]; k < r1[rg]; ++k)
-          tn_sub<NV>(S, blk(i, k), blk(i, k), true);
+          tn_sub<NV>(S, blk(i, k), blk(i, k), true, pf);
       if (!factor_diag<NV>(S, X + (size_t)i * BB))
         return 1 + i;
       // forward substitution: y_i = L_ii^-1 (g_i - sum_k L_ik y_k)
