@@ -1206,26 +1206,42 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
     double z[BP];
     for (int t = 0; t < BP; ++t)
       z[t] = y[(size_t)i * BP + t];
+    // (explicit vectors: strict fp semantics keep the compiler from vectorising a dot product on its own, and the
+    // scalar loops made this sweep a tenth of the solve)
     for (int m = i + 1; m < K; ++m)
     {
       if (!has(m, i))
         continue;
       const double *Tm = blk(m, i), *xm = y + (size_t)m * BP;
+      v8d xv[NV];
+      for (int v = 0; v < NV; ++v)
+        SAGE_LOADU(xv[v], xm + 8 * v);
       for (int t = 0; t < BP; ++t)
       {
-        double acc = 0.0;
-        for (int r = 0; r < BP; ++r)
-          acc += Tm[t * BP + r] * xm[r];
-        z[t] -= acc;
+        v8d acc = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int v = 0; v < NV; ++v)
+        {
+          v8d a;
+          SAGE_LOADU(a, Tm + t * BP + 8 * v);
+          acc += a * xv[v];
+        }
+        z[t] -= ((acc[0] + acc[4]) + (acc[1] + acc[5])) + ((acc[2] + acc[6]) + (acc[3] + acc[7]));
       }
     }
     const double *Xi = X + (size_t)i * BB;
+    v8d zv[NV];
+    for (int v = 0; v < NV; ++v)
+      SAGE_LOADU(zv[v], z + 8 * v);
     for (int c = 0; c < BP; ++c)
     {
-      double acc = 0.0;
-      for (int t = c; t < BP; ++t)
-        acc += Xi[c * BP + t] * z[t];
-      y[(size_t)i * BP + c] = acc;
+      v8d acc = {0, 0, 0, 0, 0, 0, 0, 0};
+      for (int v = c / 8; v < NV; ++v) // X[c][t] = 0 for t < c (stored zeros inside the first vector)
+      {
+        v8d a;
+        SAGE_LOADU(a, Xi + c * BP + 8 * v);
+        acc += a * zv[v];
+      }
+      y[(size_t)i * BP + c] = ((acc[0] + acc[4]) + (acc[1] + acc[5])) + ((acc[2] + acc[6]) + (acc[3] + acc[7]));
     }
   }
   return 0;
