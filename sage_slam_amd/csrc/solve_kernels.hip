@@ -479,7 +479,9 @@ __device__ inline void se3_exp_dev(const float *omega, const float *v, float *R,
 
 // One workgroup.  Besides the candidate variables (device) it writes the host mirror -- candidate variables, delta and
 // |delta|^2 -- straight into pinned host memory (h_*: device-visible), so no copy follows the solve.
-__global__ __launch_bounds__(256) void solve_retract_kernel(const double *__restrict__ x, int K, int B, int Bp, int CS,
+// (1024 threads: in the hybrid path x lives in pinned host memory -- every read is a PCIe round trip, so the kernel's
+// time is the number of sequential reads per thread)
+__global__ __launch_bounds__(1024) void solve_retract_kernel(const double *__restrict__ x, int K, int B, int Bp, int CS,
                                                             int VS, const int32_t *__restrict__ pos,
                                                             const float *__restrict__ vars0,
                                                             float *__restrict__ vars1, float *__restrict__ h_vars,
@@ -522,14 +524,19 @@ __global__ __launch_bounds__(256) void solve_retract_kernel(const double *__rest
       h_vars[(size_t)k * VS + i] = o[i];
     }
   }
-  __shared__ double s_n[4];
+  __shared__ double s_n[16];
   for (int off = 32; off > 0; off >>= 1)
     nrm += __shfl_down(nrm, off);
   if ((tid & 63) == 0)
     s_n[tid >> 6] = nrm;
   __syncthreads();
   if (tid == 0)
-    h_tail[0] = (s_n[0] + s_n[1]) + (s_n[2] + s_n[3]);
+  {
+    double tot = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); ++w) // fixed order
+      tot += s_n[w];
+    h_tail[0] = tot;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -830,7 +837,7 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
   }
   char *h = reinterpret_cast<char *>(S->h_pinned);
   // (hybrid: the solution is read straight from the pinned buffer the host solved in)
-  hipLaunchKernelGGL(solve_retract_kernel, dim3(1), dim3(256), 0, stream,
+  hipLaunchKernelGGL(solve_retract_kernel, dim3(1), dim3(1024), 0, stream,
                      reinterpret_cast<const double *>(S->device_factor ? S->d_y : S->h_y), S->K,
                      S->B, S->Bp, CS, S->VS, S->plan.pos, vars0, vars1, reinterpret_cast<float *>(h + S->h_vars_off),
                      reinterpret_cast<double *>(h + S->h_delta_off), reinterpret_cast<double *>(h + S->h_tail_off));
@@ -912,7 +919,7 @@ int solver_pipe_factor(DeviceSolver *S, hipStream_t stream, int (*before_row)(vo
   if (bad)
     return SAGE_E_NOT_PSD;
   char *h = reinterpret_cast<char *>(S->h_pinned);
-  hipLaunchKernelGGL(solve_retract_kernel, dim3(1), dim3(256), 0, stream, reinterpret_cast<const double *>(S->h_y), S->K,
+  hipLaunchKernelGGL(solve_retract_kernel, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const double *>(S->h_y), S->K,
                      S->B, S->Bp, CS, S->VS, S->plan.pos, vars0, vars1, reinterpret_cast<float *>(h + S->h_vars_off),
                      reinterpret_cast<double *>(h + S->h_delta_off), reinterpret_cast<double *>(h + S->h_tail_off));
   const hipError_t e = hipGetLastError();
