@@ -992,6 +992,7 @@ template <int NV>
 static inline __attribute__((always_inline)) bool factor_diag(double *S, double *X)
 {
   constexpr int BP = NV * 8;
+  double rinv[BP];
   for (int p = 0; p < NV; ++p)
   {
     for (int c = 8 * p; c < 8 * p + 8; ++c)
@@ -1001,6 +1002,7 @@ static inline __attribute__((always_inline)) bool factor_diag(double *S, double 
       if (!(d > 0.0))
         return false;
       const double rs = 1.0 / std::sqrt(d);
+      rinv[c] = rs; // 1 / U[c][c]
       for (int r = 8 * p; r < c; ++r)
         row[r] = 0.0;
       const v8d rsv = {rs, rs, rs, rs, rs, rs, rs, rs};
@@ -1049,35 +1051,56 @@ static inline __attribute__((always_inline)) bool factor_diag(double *S, double 
       }
     }
   }
-  // X = U^-1 by back substitution on rows: X[c][:] = (e_c - sum_{t>c} U[c][t] X[t][:]) / U[c][c]
+  // X = U^-1 by back substitution on rows: X[c][:] = (e_c - sum_{t>c} U[c][t] X[t][:]) / U[c][c].  Two accumulator
+  // sets (even / odd t) keep 2 x NV independent FMA chains in flight -- one set is latency bound.  (All loops over the
+  // vectors have compile-time bounds: a run-time start index would move the accumulators from registers to the stack.)
   for (int c = BP - 1; c >= 0; --c)
   {
     double e[BP];
     for (int r = 0; r < BP; ++r)
       e[r] = 0.0;
     e[c] = 1.0;
-    v8d acc[NV];
+    v8d a0[NV], a1[NV];
     for (int v = 0; v < NV; ++v)
-      SAGE_LOADU(acc[v], e + 8 * v);
-    const double *u = S + c * BP;
-    for (int t = c + 1; t < BP; ++t)
     {
-      const double f = u[t];
-      const v8d fv = {f, f, f, f, f, f, f, f};
-      const double *xt = X + t * BP;
+      SAGE_LOADU(a0[v], e + 8 * v);
+      a1[v] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
+    }
+    const double *u = S + c * BP;
+    int t = c + 1;
+    for (; t + 1 < BP; t += 2)
+    {
+      const double f0 = u[t], f1 = u[t + 1];
+      const v8d fv0 = {f0, f0, f0, f0, f0, f0, f0, f0}, fv1 = {f1, f1, f1, f1, f1, f1, f1, f1};
+      const double *x0 = X + t * BP, *x1 = x0 + BP;
       for (int v = 0; v < NV; ++v)
       {
-        v8d x;
-        SAGE_LOADU(x, xt + 8 * v);
-        acc[v] -= fv * x;
+        v8d xa, xb;
+        SAGE_LOADU(xa, x0 + 8 * v);
+        SAGE_LOADU(xb, x1 + 8 * v);
+        a0[v] -= fv0 * xa;
+        a1[v] -= fv1 * xb;
       }
     }
-    const double inv = 1.0 / u[c];
+    if (t < BP)
+    {
+      const double f0 = u[t];
+      const v8d fv0 = {f0, f0, f0, f0, f0, f0, f0, f0};
+      const double *x0 = X + t * BP;
+      for (int v = 0; v < NV; ++v)
+      {
+        v8d xa;
+        SAGE_LOADU(xa, x0 + 8 * v);
+        a0[v] -= fv0 * xa;
+      }
+    }
+    const double inv = rinv[c];
     const v8d iv = {inv, inv, inv, inv, inv, inv, inv, inv};
     for (int v = 0; v < NV; ++v)
     {
-      acc[v] *= iv;
-      SAGE_STOREU(X + c * BP + 8 * v, acc[v]);
+      v8d r = a0[v] + a1[v];
+      r *= iv;
+      SAGE_STOREU(X + c * BP + 8 * v, r);
     }
   }
   return true;
@@ -1137,12 +1160,17 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
   if (phase == 0)
   {
     static const bool getenv_no_prefetch = getenv("SAGE_SOLVE_NO_PREFETCH") != nullptr;
+    static const bool prof = getenv("SAGE_CHOL_PROFILE") != nullptr;
+    unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_readcyclecounter();
+#define LAP(k) do { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); tp[k] += t_ - tl; tl = t_; } } while (0)
     for (int i = lo; i < hi; ++i)
     {
+      LAP(5);
       if (E.before_row && E.before_row(E.user, i))
         return -2;
       if (E.ready && !wait_row_tickets(E, i))
         return -2;
+      LAP(0);
       // the column ranges of row i, in ascending order
       const int r0[2] = {afirst(i), row_first[i]}, r1[2] = {afirst(i) + acnt(i), i};
       RowPrefetch pf{nullptr, nullptr};
@@ -1162,14 +1190,18 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
             for (int k = r0[rk]; k < std::min(r1[rk], j); ++k)
               if (has(j, k))
                 tn_sub<NV>(CT, blk(j, k), blk(i, k), false, pf);
+          LAP(1);
           apply_inverse<NV>(CT, X + (size_t)j * BB);
+          LAP(2);
         }
       double *S = blk(i, i);
       for (int rg = 0; rg < 2; ++rg)
         for (int k = r0[rg]; k < r1[rg]; ++k)
           tn_sub<NV>(S, blk(i, k), blk(i, k), true, pf);
+      LAP(1);
       if (!factor_diag<NV>(S, X + (size_t)i * BB))
         return 1 + i;
+      LAP(3);
       // forward substitution: y_i = L_ii^-1 (g_i - sum_k L_ik y_k)
       double w[BP];
       for (int r = 0; r < BP; ++r)
@@ -1197,7 +1229,11 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
       }
       for (int c = 0; c < BP; ++c)
         y[(size_t)i * BP + c] = yi[c];
+      LAP(4);
     }
+    if (prof)
+      fprintf(stderr, "[chol profile] rows %d..%d kcycles: wait %.0f gemm+syrk %.0f apply-inverse %.0f factor+inverse %.0f fwd-subst %.0f other %.0f\n",
+              lo, hi, tp[0] * 1e-3, tp[1] * 1e-3, tp[2] * 1e-3, tp[3] * 1e-3, tp[4] * 1e-3, tp[5] * 1e-3);
     return 0;
   }
   // back substitution: x_i = L_ii^-T (y_i - sum_{m>i, (m,i) stored} L_mi^T x_m)
