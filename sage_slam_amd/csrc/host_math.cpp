@@ -986,123 +986,177 @@ static inline __attribute__((always_inline)) void apply_inverse(double *CT, cons
   }
 }
 
+// One 8-row panel of the Cholesky factorisation below, everything with compile-time indices so that the panel's
+// diagonal block lives in eight registers: the pivot chain (sqrt, divide, seven multiplier broadcasts) never goes
+// through memory -- a scalar reload of a just-stored vector element does not forward and cost more than the sqrt.
+template <int NV, int P>
+static inline __attribute__((always_inline)) bool factor_panel(double *S, double *rinv)
+{
+  constexpr int BP = NV * 8;
+  v8d D[8];
+  for (int cc = 0; cc < 8; ++cc)
+    SAGE_LOADU(D[cc], S + (8 * P + cc) * BP + 8 * P);
+  double rsv[8];
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc)
+  {
+    const double d = D[cc][cc];
+    if (!(d > 0.0))
+      return false;
+    const double rs = 1.0 / std::sqrt(d);
+    rsv[cc] = rs;
+    rinv[8 * P + cc] = rs; // 1 / U[c][c]
+    const v8d rv = {rs, rs, rs, rs, rs, rs, rs, rs};
+    D[cc] *= rv;
+#pragma unroll
+    for (int c2 = cc + 1; c2 < 8; ++c2)
+    {
+      const double f = D[cc][c2];
+      const v8d fv = {f, f, f, f, f, f, f, f};
+      D[c2] -= fv * D[cc];
+    }
+  }
+  // U is upper triangular: clear what the updates left below the diagonal of the block, store the rows
+#pragma unroll
+  for (int cc = 0; cc < 8; ++cc)
+  {
+#pragma unroll
+    for (int r = 0; r < cc; ++r)
+      D[cc][r] = 0.0;
+    SAGE_STOREU(S + (8 * P + cc) * BP + 8 * P, D[cc]);
+  }
+  // the same eliminations on the panel's other columns (independent of the pivot chain)
+#pragma unroll
+  for (int v = P + 1; v < NV; ++v)
+  {
+    v8d R[8];
+    for (int cc = 0; cc < 8; ++cc)
+      SAGE_LOADU(R[cc], S + (8 * P + cc) * BP + 8 * v);
+#pragma unroll
+    for (int cc = 0; cc < 8; ++cc)
+    {
+      const v8d rv = {rsv[cc], rsv[cc], rsv[cc], rsv[cc], rsv[cc], rsv[cc], rsv[cc], rsv[cc]};
+      R[cc] *= rv;
+#pragma unroll
+      for (int c2 = cc + 1; c2 < 8; ++c2)
+      {
+        const double f = D[cc][c2];
+        const v8d fv = {f, f, f, f, f, f, f, f};
+        R[c2] -= fv * R[cc];
+      }
+    }
+    for (int cc = 0; cc < 8; ++cc)
+      SAGE_STOREU(S + (8 * P + cc) * BP + 8 * v, R[cc]);
+  }
+  // rank-8 update of the trailing rows
+  for (int c2 = 8 * P + 8; c2 < BP; ++c2)
+  {
+    double *row2 = S + c2 * BP;
+    v8d f[8];
+    for (int t = 0; t < 8; ++t)
+    {
+      const double ft = S[(8 * P + t) * BP + c2];
+      f[t] = v8d{ft, ft, ft, ft, ft, ft, ft, ft};
+    }
+    for (int v = c2 / 8; v < NV; ++v)
+    {
+      v8d acc;
+      SAGE_LOADU(acc, row2 + 8 * v);
+      for (int t = 0; t < 8; ++t)
+      {
+        v8d x;
+        SAGE_LOADU(x, S + (8 * P + t) * BP + 8 * v);
+        acc -= f[t] * x;
+      }
+      SAGE_STOREU(row2 + 8 * v, acc);
+    }
+  }
+  if constexpr (P + 1 < NV)
+    return factor_panel<NV, P + 1>(S, rinv);
+  else
+    return true;
+}
+
+// X = U^-1 by back substitution on rows: X[c][:] = (e_c - sum_{t>c} U[c][t] X[t][:]) / U[c][c].  X[t][:] is zero left
+// of column t, so a block of eight t only touches the vectors from its own on -- with the block index a template
+// parameter every vector loop has compile-time bounds (a run-time start index would move the accumulators from
+// registers to the stack).  Two accumulator sets (even / odd t) keep enough independent FMA chains in flight.
+template <int NV, int TB>
+static inline __attribute__((always_inline)) void inverse_accumulate(const double *u, const double *X, v8d *a0, v8d *a1)
+{
+  constexpr int BP = NV * 8;
+#pragma unroll
+  for (int tt = 0; tt < 8; tt += 2)
+  {
+    const int t = 8 * TB + tt;
+    const double f0 = u[t], f1 = u[t + 1];
+    const v8d fv0 = {f0, f0, f0, f0, f0, f0, f0, f0}, fv1 = {f1, f1, f1, f1, f1, f1, f1, f1};
+#pragma unroll
+    for (int v = TB; v < NV; ++v)
+    {
+      v8d xa, xb;
+      SAGE_LOADU(xa, X + t * BP + 8 * v);
+      SAGE_LOADU(xb, X + (t + 1) * BP + 8 * v);
+      a0[v] -= fv0 * xa;
+      a1[v] -= fv1 * xb;
+    }
+  }
+  if constexpr (TB + 1 < NV)
+    inverse_accumulate<NV, TB + 1>(u, X, a0, a1);
+}
+
+template <int NV, int CB>
+static inline __attribute__((always_inline)) void inverse_rows(const double *S, double *X, const double *rinv)
+{
+  constexpr int BP = NV * 8;
+  for (int cc = 7; cc >= 0; --cc)
+  {
+    const int c = 8 * CB + cc;
+    double e[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    e[cc] = 1.0;
+    v8d a0[NV], a1[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+      a0[v] = a1[v] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
+    SAGE_LOADU(a0[CB], e);
+    const double *u = S + c * BP;
+    for (int t = c + 1; t < 8 * CB + 8; ++t) // the rest of the row's own block
+    {
+      const double f = u[t];
+      const v8d fv = {f, f, f, f, f, f, f, f};
+#pragma unroll
+      for (int v = CB; v < NV; ++v)
+      {
+        v8d x;
+        SAGE_LOADU(x, X + t * BP + 8 * v);
+        a0[v] -= fv * x;
+      }
+    }
+    if constexpr (CB + 1 < NV)
+      inverse_accumulate<NV, CB + 1>(u, X, a0, a1);
+    const double inv = rinv[c];
+    const v8d iv = {inv, inv, inv, inv, inv, inv, inv, inv};
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+    {
+      v8d r = (a0[v] + a1[v]) * iv; // (zero for v < CB)
+      SAGE_STOREU(X + c * BP + 8 * v, r);
+    }
+  }
+  if constexpr (CB > 0)
+    inverse_rows<NV, CB - 1>(S, X, rinv);
+}
+
 // S (symmetric, entries [c][r >= c] valid) -> U = L^T in place (A = U^T U), X = U^-1 (upper triangular, zeros below).
-// Blocked by panels of 8 rows: scalar pivots inside the panel, one rank-8 register-accumulated update per trailing row.
+// Blocked by panels of 8 rows (factor_panel), one rank-8 register-accumulated update per trailing row.
 template <int NV>
 static inline __attribute__((always_inline)) bool factor_diag(double *S, double *X)
 {
   constexpr int BP = NV * 8;
   double rinv[BP];
-  for (int p = 0; p < NV; ++p)
-  {
-    for (int c = 8 * p; c < 8 * p + 8; ++c)
-    {
-      double *row = S + c * BP;
-      const double d = row[c];
-      if (!(d > 0.0))
-        return false;
-      const double rs = 1.0 / std::sqrt(d);
-      rinv[c] = rs; // 1 / U[c][c]
-      for (int r = 8 * p; r < c; ++r)
-        row[r] = 0.0;
-      const v8d rsv = {rs, rs, rs, rs, rs, rs, rs, rs};
-      for (int v = p; v < NV; ++v)
-      {
-        v8d x;
-        SAGE_LOADU(x, row + 8 * v);
-        x *= rsv;
-        SAGE_STOREU(row + 8 * v, x);
-      }
-      for (int c2 = c + 1; c2 < 8 * p + 8; ++c2)
-      {
-        const double f = row[c2];
-        const v8d fv = {f, f, f, f, f, f, f, f};
-        double *row2 = S + c2 * BP;
-        for (int v = p; v < NV; ++v)
-        {
-          v8d x, y2;
-          SAGE_LOADU(x, row + 8 * v);
-          SAGE_LOADU(y2, row2 + 8 * v);
-          y2 -= fv * x;
-          SAGE_STOREU(row2 + 8 * v, y2);
-        }
-      }
-    }
-    for (int c2 = 8 * p + 8; c2 < BP; ++c2)
-    {
-      double *row2 = S + c2 * BP;
-      v8d f[8];
-      for (int t = 0; t < 8; ++t)
-      {
-        const double ft = S[(8 * p + t) * BP + c2];
-        f[t] = v8d{ft, ft, ft, ft, ft, ft, ft, ft};
-      }
-      for (int v = c2 / 8; v < NV; ++v)
-      {
-        v8d acc;
-        SAGE_LOADU(acc, row2 + 8 * v);
-        for (int t = 0; t < 8; ++t)
-        {
-          v8d x;
-          SAGE_LOADU(x, S + (8 * p + t) * BP + 8 * v);
-          acc -= f[t] * x;
-        }
-        SAGE_STOREU(row2 + 8 * v, acc);
-      }
-    }
-  }
-  // X = U^-1 by back substitution on rows: X[c][:] = (e_c - sum_{t>c} U[c][t] X[t][:]) / U[c][c].  Two accumulator
-  // sets (even / odd t) keep 2 x NV independent FMA chains in flight -- one set is latency bound.  (All loops over the
-  // vectors have compile-time bounds: a run-time start index would move the accumulators from registers to the stack.)
-  for (int c = BP - 1; c >= 0; --c)
-  {
-    double e[BP];
-    for (int r = 0; r < BP; ++r)
-      e[r] = 0.0;
-    e[c] = 1.0;
-    v8d a0[NV], a1[NV];
-    for (int v = 0; v < NV; ++v)
-    {
-      SAGE_LOADU(a0[v], e + 8 * v);
-      a1[v] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
-    }
-    const double *u = S + c * BP;
-    int t = c + 1;
-    for (; t + 1 < BP; t += 2)
-    {
-      const double f0 = u[t], f1 = u[t + 1];
-      const v8d fv0 = {f0, f0, f0, f0, f0, f0, f0, f0}, fv1 = {f1, f1, f1, f1, f1, f1, f1, f1};
-      const double *x0 = X + t * BP, *x1 = x0 + BP;
-      for (int v = 0; v < NV; ++v)
-      {
-        v8d xa, xb;
-        SAGE_LOADU(xa, x0 + 8 * v);
-        SAGE_LOADU(xb, x1 + 8 * v);
-        a0[v] -= fv0 * xa;
-        a1[v] -= fv1 * xb;
-      }
-    }
-    if (t < BP)
-    {
-      const double f0 = u[t];
-      const v8d fv0 = {f0, f0, f0, f0, f0, f0, f0, f0};
-      const double *x0 = X + t * BP;
-      for (int v = 0; v < NV; ++v)
-      {
-        v8d xa;
-        SAGE_LOADU(xa, x0 + 8 * v);
-        a0[v] -= fv0 * xa;
-      }
-    }
-    const double inv = rinv[c];
-    const v8d iv = {inv, inv, inv, inv, inv, inv, inv, inv};
-    for (int v = 0; v < NV; ++v)
-    {
-      v8d r = a0[v] + a1[v];
-      r *= iv;
-      SAGE_STOREU(X + c * BP + 8 * v, r);
-    }
-  }
+  if (!factor_panel<NV, 0>(S, rinv))
+    return false;
+  inverse_rows<NV, NV - 1>(S, X, rinv);
   return true;
 }
 
