@@ -1526,7 +1526,7 @@ int plan_blocks(int K, const std::vector<std::pair<int, int>> &links, bool allow
   {
     // the helper's half runs a little slower than the caller's (it wakes from sleep for every solve): give it
     // `bias` rows less
-    static const int bias = getenv("SAGE_SPLIT_BIAS") ? atoi(getenv("SAGE_SPLIT_BIAS")) : 3;
+    static const int bias = getenv("SAGE_SPLIT_BIAS") ? atoi(getenv("SAGE_SPLIT_BIAS")) : 1;
     int best_m = -1, best_w = 0, best_cost = 2 * K;
     for (int m = K / 4; m <= (3 * K) / 4; ++m)
     {
