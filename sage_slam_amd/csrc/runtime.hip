@@ -1654,7 +1654,10 @@ extern "C" int sage_window_linearize(SageWindow *w)
       SAGE_HIP(hipStreamWaitEvent(w->stream, w->ev_join, 0));
   }
   AssembleParams ap = window_assemble_params(w);
-  hipLaunchKernelGGL(assemble_kernel, dim3(w->K + ap.nlinks + 1), dim3(1024), 0, w->stream, ap);
+  // four workgroups of 512 threads per output block: one element per thread (the kernel is a chain of dependent
+  // gathers per element -- 17 us; one 1024-thread workgroup per block with two elements per thread took 27 us)
+  ap.split = 4;
+  hipLaunchKernelGGL(assemble_kernel, dim3((w->K + ap.nlinks + 1) * ap.split), dim3(512), 0, w->stream, ap);
   SAGE_HIP(hipGetLastError());
   w->have_lin = true;
   return SAGE_OK;
