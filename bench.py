@@ -132,6 +132,9 @@ def main():
 
     from sage_slam_amd import capi, synth
     capi.lib()
+    # one process per GPU: stay on the NUMA node the GPU hangs off (the window solve reads freshly DMA'd pinned memory)
+    if os.environ.get("SAGE_BENCH_NO_BIND") != "1":
+        capi.bind_thread_to_device(dev_index)
     win_h = synth.make_window(K=args.keyframes, H=args.height, W=args.width, FS=args.fs, CS=args.cs, L=4, seed=0)
     win = capi.Window(win_h, rank=rank, world=world)
     packed = win.packed_tensor()

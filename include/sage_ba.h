@@ -161,6 +161,13 @@ int sage_gaussian_pyramid_with_grad(SageWorkspace *ws, float *pyr_dev, float *gr
 /* =====================================================================
  * Host-side helpers (pure CPU, no device needed)
  * ===================================================================== */
+/* Bind the CALLING thread to the CPUs of the NUMA node the HIP device hangs off (sysfs local_cpulist of its PCI
+ * function), intersected with the thread's current affinity mask.  The hybrid window solve reads 3 MB of freshly DMA'd
+ * normal equations per LM iteration and the pinned buffers live on the device's node: from the far socket of a
+ * two-socket host the iteration is ~10 % slower.  Opt-in (one process per GPU: call it once from the thread that
+ * drives the window); returns the number of CPUs bound to, 0 if the topology is not exposed, < 0 on error. */
+int sage_bind_thread_to_device(int device);
+
 /* se3_exp (core/mapping/mapping_utils.h:316-346): R[9], t[3] from omega[3], v[3]. */
 void sage_se3_exp(const float *omega, const float *v, float *R, float *t);
 /* left retraction T <- exp([v,w]) T (core/gtsam/gtsam_traits.h:45-70; camera_tracker.cpp:491-512);

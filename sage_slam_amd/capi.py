@@ -94,7 +94,7 @@ SYMBOLS = [
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_set_allreduce", "sage_sort_locations",
+    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_set_allreduce", "sage_sort_locations", "sage_bind_thread_to_device",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
@@ -679,6 +679,11 @@ def sample_locations(ws: "Workspace", vloc, vhomo, seed: int, num_samples: int):
 
 def _dptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def bind_thread_to_device(device: int = 0) -> int:
+    """``sage_bind_thread_to_device``: keep the calling thread on the GPU's NUMA node (returns the number of CPUs)."""
+    return int(lib().sage_bind_thread_to_device(int(device)))
 
 
 def sort_locations(ws, loc1d, homo, H, W):

@@ -5,6 +5,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cctype>
+#include <sched.h>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -1231,6 +1233,55 @@ extern "C" int sage_window_add_link(SageWindow *w, int a, int b)
     return SAGE_E_INVALID;
   w->links.emplace_back(std::min(a, b), std::max(a, b));
   return (int)w->links.size() - 1;
+}
+
+extern "C" int sage_bind_thread_to_device(int device)
+{
+  char bdf[64] = {0};
+  if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess)
+    return SAGE_E_INVALID;
+  for (char *p = bdf; *p; ++p)
+    *p = (char)tolower((unsigned char)*p);
+  char path[160];
+  snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
+  FILE *f = fopen(path, "r");
+  if (!f)
+    return 0;
+  char buf[4096] = {0};
+  const bool got = fgets(buf, sizeof(buf), f) != nullptr;
+  fclose(f);
+  if (!got)
+    return 0;
+  cpu_set_t allowed, want;
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
+    return 0;
+  CPU_ZERO(&want);
+  int n = 0;
+  for (const char *p = buf; *p;)
+  {
+    char *end;
+    const long a = strtol(p, &end, 10);
+    if (end == p)
+      break;
+    long b = a;
+    p = end;
+    if (*p == '-')
+    {
+      b = strtol(p + 1, &end, 10);
+      p = end;
+    }
+    for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+      if (CPU_ISSET(c, &allowed))
+      {
+        CPU_SET(c, &want);
+        ++n;
+      }
+    if (*p == ',')
+      ++p;
+  }
+  if (n == 0 || sched_setaffinity(0, sizeof(want), &want) != 0)
+    return 0;
+  return n;
 }
 
 extern "C" int sage_window_set_allreduce(SageWindow *w, SageAllReduceFn fn, void *user)

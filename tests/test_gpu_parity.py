@@ -5,6 +5,8 @@ Tolerances (north_star: fp32, pose/code deltas within 1e-4 rel-L2 of the referen
   * error, num_inliers        rel <= 1e-5 / exact
   * LM-damped deltas          rel-L2 <= 1e-4
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -432,6 +434,19 @@ def test_long_window_lm(capi):
         errs.append(st.error)
     assert errs[-1] < errs[0]
     win.close()
+
+
+def test_bind_thread_to_device():
+    """sage_bind_thread_to_device: the calling thread ends up on (a subset of) the CPUs it was allowed before; run in a
+    child process so that the test session's own affinity is left alone."""
+    import subprocess
+    import sys
+    code = ("import os, torch; from sage_slam_amd import capi; capi.lib(); a = os.sched_getaffinity(0); "
+            "n = capi.bind_thread_to_device(0); b = os.sched_getaffinity(0); "
+            "assert n >= 0 and b <= a and (n == 0 or len(b) == n), (n, len(a), len(b)); print('ok', n)")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
 
 
 def test_sort_locations(capi, ws):
