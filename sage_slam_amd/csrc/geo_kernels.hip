@@ -431,6 +431,7 @@ struct GeoFinalizeParams
   float *AtA, *Atb, *stats;
   float weight;
   int edge_base; // blockIdx.x = edge - edge_base
+  double *wide;  // optional [n_edges][D*D + D]: the results before rounding to fp32
 };
 
 template <int CS>
@@ -546,6 +547,8 @@ __global__ __launch_bounds__(kFinalizeBlock) void geo_finalize_kernel(const GeoF
       AtA[q] = (float)val;
     else
       Atb[q - D * D] = (float)val;
+    if (prm.wide)
+      prm.wide[(size_t)e * (D * D + D) + q] = val;
   }
 }
 
@@ -587,6 +590,7 @@ static hipError_t geo_lin_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   f.AtA = out.AtA;
   f.Atb = out.Atb;
   f.stats = out.stats;
+  f.wide = out.wide;
   f.weight = weight;
   f.edge_base = lc.stage == 2 ? lc.edge_base : 0;
   const int n_fin = lc.stage == 2 ? lc.edge_count : lc.n_edges;

@@ -580,6 +580,7 @@ struct PhotoFinalizeParams
   float *AtA, *Atb, *stats;
   float wsum;
   int edge_base; // blockIdx.x = edge - edge_base
+  double *wide;  // optional [n_edges][D*D + D]: the results before rounding to fp32
 };
 
 __device__ __forceinline__ double tile_elem(const double *s, int base, int tile, int row, int col)
@@ -698,6 +699,8 @@ __global__ __launch_bounds__(kFinalizeBlock) void photo_finalize_kernel(const Ph
       AtA[idx] = (float)val;
     else
       Atb[idx - D * D] = (float)val;
+    if (prm.wide)
+      prm.wide[(size_t)e * (D * D + D) + idx] = val;
   }
 }
 
@@ -799,6 +802,7 @@ static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const P
   f.AtA = out.AtA;
   f.Atb = out.Atb;
   f.stats = out.stats;
+  f.wide = out.wide;
   f.wsum = wsum;
   f.edge_base = lc.stage == 2 ? lc.edge_base : 0;
   const int n_fin = lc.stage == 2 ? lc.edge_count : lc.n_edges;

@@ -785,6 +785,7 @@ struct AssembleParams
 {
   const float *AtA_p, *Atb_p, *stats_p; // photo per-edge results
   const float *AtA_g, *Atb_g, *stats_g;
+  const double *wide_p, *wide_g; // optional: per-edge [D*D + D] results before their fp32 rounding (EdgeOut::wide)
   const int32_t *adj_start; // [K+1]
   const AdjEntry *adj;
   const LinkEdges *links; // [nlinks]
@@ -862,7 +863,11 @@ __global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
         const int cj = isg[s] ? 0 : edge_col(ae.type, ae.role, bj[s], p.CS);
         if (ci < 0 || cj < 0)
           continue;
-        acc[s] += isg[s] ? (double)b[(size_t)ae.edge * D + ci] : (double)A[(size_t)ae.edge * D * D + (size_t)ci * D + cj];
+        const double *Wd = ae.type == 0 ? p.wide_p : p.wide_g;
+        if (Wd)
+          acc[s] += Wd[(size_t)ae.edge * (D * D + D) + (isg[s] ? (size_t)D * D + ci : (size_t)ci * D + cj)];
+        else
+          acc[s] += isg[s] ? (double)b[(size_t)ae.edge * D + ci] : (double)A[(size_t)ae.edge * D * D + (size_t)ci * D + cj];
       }
     }
 #pragma unroll
@@ -894,15 +899,17 @@ __global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
             continue;
           const int D = type == 0 ? Dp : Dg;
           const float *A = type == 0 ? p.AtA_p : p.AtA_g;
+          const double *Wd = type == 0 ? p.wide_p : p.wide_g;
+          const size_t ws = (size_t)D * D + D;
           // edge a->b : a has role 0, b has role 1
           int ci = edge_col(type, 0, bi, p.CS), cj = edge_col(type, 1, bj, p.CS);
           if (ci >= 0 && cj >= 0)
-            acc += (double)A[(size_t)le.e_ab * D * D + (size_t)ci * D + cj];
+            acc += Wd ? Wd[(size_t)le.e_ab * ws + (size_t)ci * D + cj] : (double)A[(size_t)le.e_ab * D * D + (size_t)ci * D + cj];
           // edge b->a : b has role 0, a has role 1
           ci = edge_col(type, 1, bi, p.CS);
           cj = edge_col(type, 0, bj, p.CS);
           if (ci >= 0 && cj >= 0)
-            acc += (double)A[(size_t)le.e_ba * D * D + (size_t)ci * D + cj];
+            acc += Wd ? Wd[(size_t)le.e_ba * ws + (size_t)ci * D + cj] : (double)A[(size_t)le.e_ba * D * D + (size_t)ci * D + cj];
         }
       }
       lnk[(size_t)l * BB + idx] = acc;
@@ -1027,6 +1034,7 @@ struct SageWindow
   int n_edges = 0;                        // local directed edges per factor type (= 2 * local links)
   // device
   DevBuf vars[2];                       // [K][VS]: pose 12, scale 1, code CS
+  DevBuf wide_p, wide_g;                // per-edge results before their fp32 rounding (EdgeOut::wide)
   DevBuf sorted_loc, sorted_homo;       // raster-ordered copies of the keyframes' sampled locations
   std::vector<std::pair<const int64_t *, const float *>> user_samples; // the caller's arrays
   DevBuf dpt, dgrad, depth_items[2];    // per-keyframe depth maps of the set being evaluated
@@ -1181,7 +1189,7 @@ extern "C" void sage_window_destroy(SageWindow *w)
 {
   if (!w)
     return;
-  DevBuf *bufs[] = {&w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
+  DevBuf *bufs[] = {&w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
                     &w->pk, &w->f0s, &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
                     &w->work_g, &w->first_g, &w->tiles_g, &w->part_p, &w->part_g, &w->AtA_p, &w->Atb_p,
                     &w->stats_p, &w->AtA_g, &w->Atb_g, &w->stats_g, &w->adj_start, &w->adj, &w->link_edges,
@@ -1582,6 +1590,10 @@ extern "C" int sage_window_finalize(SageWindow *w)
       (rc = w->stats_p.reserve(ne * 2 * sizeof(float))) || (rc = w->AtA_g.reserve(ne * Dg * Dg * sizeof(float))) ||
       (rc = w->Atb_g.reserve(ne * Dg * sizeof(float))) || (rc = w->stats_g.reserve(ne * 2 * sizeof(float))))
     return rc;
+  if (!getenv("SAGE_NO_WIDE_EDGES") &&
+      ((rc = w->wide_p.reserve(ne * (Dp * Dp + Dp) * sizeof(double))) ||
+       (rc = w->wide_g.reserve(ne * (Dg * Dg + Dg) * sizeof(double)))))
+    return rc;
   // ---- adjacency for the assembly
   std::vector<int32_t> adj_start(K + 1, 0);
   std::vector<AdjEntry> adj;
@@ -1641,6 +1653,8 @@ static AssembleParams window_assemble_params(SageWindow *w)
   ap.Atb_p = w->Atb_p.as<float>();
   ap.stats_p = (has && c.use_photo) ? w->stats_p.as<float>() : nullptr;
   ap.AtA_g = (has && c.use_geo) ? w->AtA_g.as<float>() : nullptr;
+  ap.wide_p = (has && c.use_photo) ? w->wide_p.as<double>() : nullptr;
+  ap.wide_g = (has && c.use_geo) ? w->wide_g.as<double>() : nullptr;
   ap.Atb_g = w->Atb_g.as<float>();
   ap.stats_g = (has && c.use_geo) ? w->stats_g.as<float>() : nullptr;
   ap.adj_start = w->adj_start.as<int32_t>();
@@ -1685,7 +1699,7 @@ extern "C" int sage_window_linearize(SageWindow *w)
     // photometric finalize (9 us) sits between the last kernel and the assembly
     if (c.use_geo)
     {
-      EdgeOut out{w->AtA_g.as<float>(), w->Atb_g.as<float>(), w->stats_g.as<float>()};
+      EdgeOut out{w->AtA_g.as<float>(), w->Atb_g.as<float>(), w->stats_g.as<float>(), w->wide_g.as<double>()};
       LaunchCommon lc = window_lc(w, false);
       prof_attach(w, 1, lc);
       SAGE_HIP(launch_geo_linearize(gs, c.CS, nullptr, w->gtab[0].as<GeoEdge>(), lc, c.pyr.cam[0], c.eps,
@@ -1695,7 +1709,7 @@ extern "C" int sage_window_linearize(SageWindow *w)
     }
     if (c.use_photo)
     {
-      EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>()};
+      EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>(), w->wide_p.as<double>()};
       LaunchCommon lc = window_lc(w, true);
       prof_attach(w, 0, lc);
       SAGE_HIP(launch_photo_linearize(w->stream, c.CS, c.FS, nullptr, w->ptab[0].as<PhotoEdge>(), lc, c.pyr,
@@ -2279,7 +2293,7 @@ static int pipe_linearize(SageWindow *w)
   w->dgrad_valid = true;
   if (c.use_geo)
   {
-    EdgeOut out{w->AtA_g.as<float>(), w->Atb_g.as<float>(), w->stats_g.as<float>()};
+    EdgeOut out{w->AtA_g.as<float>(), w->Atb_g.as<float>(), w->stats_g.as<float>(), w->wide_g.as<double>()};
     LaunchCommon lc = window_lc(w, false);
     prof_attach(w, 1, lc);
     lc.stage = 1;
@@ -2296,7 +2310,7 @@ static int pipe_linearize(SageWindow *w)
                                   c.geo_loss_param, c.geo_weight, out));
   }
   {
-    EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>()};
+    EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>(), w->wide_p.as<double>()};
     LaunchCommon lc = window_lc(w, true);
     prof_attach(w, 0, lc);
     lc.stage = 1;
@@ -2337,7 +2351,7 @@ static int pipe_launch_chunk(SageWindow *w, int chunk)
   const SageWindowConfig &c = w->cfg;
   const SageWindow::PipeChunk &ch = w->pipe_chunks[chunk];
   std::atomic_thread_fence(std::memory_order_acquire);
-  EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>()};
+  EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>(), w->wide_p.as<double>()};
   const int ranges[2][2] = {{w->pipe_fin_lo, ch.need_lo + 1}, {ch.need_hi, w->pipe_fin_hi}};
   for (const auto &r : ranges)
     if (r[1] > r[0])

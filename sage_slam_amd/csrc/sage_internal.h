@@ -131,6 +131,10 @@ struct EdgeOut
   float *AtA;   // [n_edges][D*D]
   float *Atb;   // [n_edges][D]
   float *stats; // [n_edges][2] = {error, num_inliers}
+  // optional (window engine): the same results before their rounding to fp32, [n_edges][D*D + D] doubles per edge
+  // (AtA then Atb).  The assembly sums these, so the reference-layout fp32 outputs stay what the operator API returns
+  // while the window's normal equations skip one fp32 rounding per entry.
+  double *wide = nullptr;
 };
 
 // ---- launchers (implemented in the .hip files) ----
