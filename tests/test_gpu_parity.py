@@ -298,7 +298,8 @@ def test_window_step_noise_floor(capi, orc):
         assert rel(Hh, He) < 2 * rel(Ho, He) + 1e-8 and rel(gh, ge) < 2 * rel(go, ge) + 1e-8
         dh, do, de = (damped_delta(H, g, 1e-3) for H, g in ((Hh, gh), (Ho, go), (He, ge)))
         floor = rel(do, de)
-        print(f"seed {seed}: step hip-exact {rel(dh, de):.2e}  fp32-oracle-exact {floor:.2e}  H {rel(Hh, He):.1e}/{rel(Ho, He):.1e}")
+        print(f"seed {seed}: step hip-exact {rel(dh, de):.2e}  fp32-oracle-exact {floor:.2e}  hip-fp32-oracle {rel(dh, do):.2e}  "
+              f"H {rel(Hh, He):.1e}/{rel(Ho, He):.1e}  g {rel(gh, ge):.1e}/{rel(go, ge):.1e}")
         assert rel(dh, de) < max(TOL_DELTA, 3 * floor)
         win.close()
 
