@@ -2102,7 +2102,8 @@ extern "C" int sage_window_get_edge(const SageWindow *w, int type, int e, float 
 // 2.30 / 2.24 classic -- the host is done 0.28 ms after the last link instead of 0.44, but the photometric kernel
 // pays 0.09 ms for it (0.03 the write-through records and counters, 0.06 the small kernels squeezing in next to its
 // workgroups: 0.92 instead of 0.84 ms per launch).  Opt-in: 2-3 % of the step for 9 % of the dominant kernel's
-// roofline fraction is not a trade the default should make.
+// roofline fraction is not a trade the default should make -- and since the host factorisation got faster (0.29 ms)
+// the classic path is ahead again (2.13 vs 2.16 ms per step).
 // ------------------------------------------------------------------------------------------------
 static bool pipe_wanted(const SageWindow *w)
 {
