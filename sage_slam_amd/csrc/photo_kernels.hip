@@ -39,6 +39,7 @@ struct PhotoParams
   const int32_t *sig_total;
   unsigned *sig_flag_host;
   unsigned sig_epoch;
+  float geo_loss_param; // error kernel: > 0 -> also the geometric error of the edge (LaunchCommon::fused_geo_loss_param)
 };
 
 __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
@@ -107,6 +108,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   E.basis0 = uni(E.basis0); E.mask1 = uni(E.mask1); E.homo = uni(E.homo); E.loc = uni(E.loc);
   E.R0 = uni(E.R0); E.t0 = uni(E.t0); E.R1 = uni(E.R1); E.t1 = uni(E.t1); E.R10 = uni(E.R10); E.t10 = uni(E.t10);
   E.N = uni(E.N); E.loc_is_i64 = uni(E.loc_is_i64); E.f0s = uni(E.f0s);
+  E.dpt1_geo = uni(E.dpt1_geo);
   const int N = E.N;
 
   // ---- poses (wave-uniform) ----
@@ -138,6 +140,8 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   for (int t = 0; t < NT + 1; ++t)
     acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   float err_acc = 0.f, vm_acc = 0.f, sdd_acc = 0.f; // lane-local sums over the sub-tiles: error, inliers, sigma d^2
+  float gerr_acc = 0.f;                             // error kernel, fused geometric error
+  const bool fuse_geo = !JAC && prm.geo_loss_param > 0.f && E.dpt1_geo != nullptr;
   float *st_w = s_mem + wave * 64 * kPhotoStashLD; // this wave's stash
   __syncthreads();                                 // s_red zeroed
 
@@ -173,6 +177,19 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   const float q = (X[1] / X[2]) * fy0 + cy0;
   const float m = mask_lookup(E.mask1, p, q, W0, H0);
   const float vm = (pos && in_range) ? m : 0.0f; // sampled_valid_mask_1 (:237)
+  if (fuse_geo)
+  {
+    // geometric_factor_kernels.cpp:127-218 at the same warp: D1 bilinear at the level-0 coordinates (no half-pixel
+    // shift), rho = D1 - z, Cauchy error log(1 + (m rho)^2 / c) for the pixels in front of the camera
+    Taps tg;
+    make_taps(tg, p, q, W0, H0);
+    float Ds = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      Ds += tg.w[k] * E.dpt1_geo[tg.off[k]];
+    const float mr = m * (Ds - X[2]);
+    gerr_acc += (pos && in_range) ? logf(1.0f + mr * mr / prm.geo_loss_param) : 0.f;
+  }
 
   float G00 = 0.f, G01 = 0.f, G11 = 0.f, v0 = 0.f, v1 = 0.f, err = 0.f;
   if (PACKED)
@@ -462,20 +479,23 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
 
   if (!JAC)
   {
-    const float se = wave_sum(err_acc), sn = wave_sum(vm_acc);
+    const float se = wave_sum(err_acc), sn = wave_sum(vm_acc), sg = wave_sum(gerr_acc);
     if (lane == 63)
     {
-      s_red[wave * 2 + 0] = se;
-      s_red[wave * 2 + 1] = sn;
+      s_red[wave * 4 + 0] = se;
+      s_red[wave * 4 + 1] = sn;
+      s_red[wave * 4 + 2] = sg;
+      s_red[wave * 4 + 3] = sn; // the geometric edge counts the same pixels
     }
     __syncthreads();
-    if (tid < 2)
+    const int rec = prm.geo_loss_param > 0.f ? 4 : 2; // floats per workgroup record
+    if (tid < rec)
     {
       float a = 0.f;
 #pragma unroll
       for (int w = 0; w < kWaves; ++w)
-        a += s_red[w * 2 + tid];
-      prm.partials[(size_t)blockIdx.x * 2 + tid] = a;
+        a += s_red[w * 4 + tid];
+      prm.partials[(size_t)blockIdx.x * rec + tid] = a;
     }
     return;
   }
@@ -761,6 +781,7 @@ static PhotoParams make_params(const PhotoEdge *single, const PhotoEdge *table, 
   p.height = (int)pyr.cam[0].h;
   p.sig_group = lc.sig_group; p.sig_cnt = lc.sig_cnt; p.sig_total = lc.sig_total;
   p.sig_flag_host = lc.sig_flag_host; p.sig_epoch = lc.sig_epoch;
+  p.geo_loss_param = lc.fused_geo_loss_param;
   for (int l = 0; l < pyr.levels; ++l)
   {
     p.rx[l] = pyr.cam[l].fx / pyr.cam[0].fx; // same fp32 quotient the kernels used to form per pixel

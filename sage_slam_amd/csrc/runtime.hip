@@ -950,6 +950,7 @@ struct ErrorTotalsSide
   float *stats;          // [n_edges][2]
   float fallback, scale;
   int n_edges;           // 0: factor type unused
+  int stride, err_off, cnt_off; // record layout: floats per workgroup record, slots of the error sum / the inlier count
 };
 
 __global__ __launch_bounds__(1024) void error_totals_kernel(const ErrorTotalsSide ph, const ErrorTotalsSide ge, double *out,
@@ -964,8 +965,8 @@ __global__ __launch_bounds__(1024) void error_totals_kernel(const ErrorTotalsSid
     float se = 0.f, sn = 0.f;
     for (int t = 0; t < nt; ++t)
     {
-      se += sd.partials[(size_t)(first + t) * 2 + 0];
-      sn += sd.partials[(size_t)(first + t) * 2 + 1];
+      se += sd.partials[(size_t)(first + t) * sd.stride + sd.err_off];
+      sn += sd.partials[(size_t)(first + t) * sd.stride + sd.cnt_off];
     }
     sd.stats[2 * e + 0] = sn > 0.f ? sd.scale * se / sn : sd.fallback;
     sd.stats[2 * e + 1] = sn;
@@ -1495,6 +1496,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
         pe.gy1_pk = pe.feat1_pk + 2 * plane_f;
         pe.f0s = w->f0s.as<float>() + f0s_off[k0];
         pe.dpt0 = w->dpt.as<float>() + (size_t)k0 * HW;
+        pe.dpt1_geo = (c.use_photo && c.use_geo) ? w->dpt.as<float>() + (size_t)k1 * HW : nullptr;
         pe.basis0 = v0.basis; pe.mask1 = c.mask_dev; pe.homo = v0.homo; pe.loc = v0.loc1d; pe.loc_is_i64 = 1;
         pe.R0 = x0; pe.t0 = x0 + 9; pe.R1 = x1; pe.t1 = x1 + 9; pe.R10 = nullptr; pe.t10 = nullptr;
         pe.code0 = x0 + 13; pe.scale0 = x0 + 12; pe.N = v0.N;
@@ -1742,19 +1744,28 @@ extern "C" int sage_window_error(SageWindow *w, int which)
     w->dgrad_valid = false;
   }
   ErrorTotalsSide ph{}, ge{};
+  // both factor types: ONE kernel -- the photometric error kernel also evaluates the geometric edge at the same warp
+  // (PhotoEdge::dpt1_geo), which saves the geometric launch (39 us + a gap) of the error pass
+  static const bool no_fusion = getenv("SAGE_NO_ERROR_FUSION") != nullptr;
+  const bool fused = has && c.use_photo && c.use_geo && !no_fusion;
   if (has && c.use_photo)
   {
     LaunchCommon lc = window_lc(w, true);
     prof_attach(w, 2, lc);
     lc.stage = 1; // main kernel only: the per-edge statistics are formed by error_totals_kernel below
+    lc.fused_geo_loss_param = fused ? c.geo_loss_param : 0.f;
     SAGE_HIP(launch_photo_error(w->stream, c.CS, c.FS, nullptr, w->ptab[which].as<PhotoEdge>(), lc, c.pyr,
                                 c.photo_weights, c.eps, w->stats_p.as<float>()));
     float wsum = 0.f;
     for (int l = 0; l < c.pyr.levels; ++l)
       wsum += c.photo_weights[l];
-    ph = ErrorTotalsSide{lc.edge_first, lc.edge_tiles, lc.partials, w->stats_p.as<float>(), 10.0f * wsum, 1.0f, w->n_edges};
+    ph = ErrorTotalsSide{lc.edge_first, lc.edge_tiles, lc.partials, w->stats_p.as<float>(), 10.0f * wsum, 1.0f, w->n_edges,
+                         fused ? 4 : 2, 0, 1};
+    if (fused)
+      ge = ErrorTotalsSide{lc.edge_first, lc.edge_tiles, lc.partials, w->stats_g.as<float>(), 10.0f * c.geo_weight,
+                           c.geo_weight, w->n_edges, 4, 2, 3};
   }
-  if (has && c.use_geo)
+  if (has && c.use_geo && !fused)
   {
     LaunchCommon lc = window_lc(w, false);
     prof_attach(w, 3, lc);
@@ -1762,7 +1773,7 @@ extern "C" int sage_window_error(SageWindow *w, int which)
     SAGE_HIP(launch_geo_error(w->stream, c.CS, nullptr, w->gtab[which].as<GeoEdge>(), lc, c.pyr.cam[0], c.eps,
                               c.geo_loss_param, c.geo_weight, w->stats_g.as<float>()));
     ge = ErrorTotalsSide{lc.edge_first, lc.edge_tiles, lc.partials, w->stats_g.as<float>(), 10.0f * c.geo_weight,
-                         c.geo_weight, w->n_edges};
+                         c.geo_weight, w->n_edges, 2, 0, 1};
   }
   hipLaunchKernelGGL(error_totals_kernel, dim3(1), dim3(1024), 0, w->stream, ph, ge, w->errbuf.as<double>(),
                      w->world == 1 && w->h_err ? w->h_err + 4 : nullptr);

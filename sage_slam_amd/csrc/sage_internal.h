@@ -30,6 +30,9 @@ struct PhotoEdge
   // tracker calls cat_sampled_features_0, camera_tracker.cpp:1104-1123), built once per keyframe
   const float *f0s;
   const float *dpt0;    // [H,W]   s0*(bias0+basis0*code0): depth map of the SOURCE keyframe at the evaluated variables
+  // window error pass only: depth map of the DESTINATION keyframe -> the error kernel also forms the geometric edge's
+  // error (geometric_factor_kernels.cpp:127-218: same warp, same mask lookup) and no separate geometric launch runs
+  const float *dpt1_geo;
   const float *bias0;   // [H*W]
   const float *basis0;  // [H*W,CS]
   const float *mask1;   // [H,W]
@@ -116,6 +119,9 @@ struct LaunchCommon
   // 2 = finalize only, for the edges [edge_base, edge_base + edge_count)
   int32_t stage = 0, edge_base = 0, edge_count = 0;
   int32_t fin_block = kFinalizeBlock; // threads per workgroup of the finalize kernel
+  // photometric error launches: > 0 -> the kernel also evaluates the geometric error of every edge (PhotoEdge::dpt1_geo)
+  // with this Cauchy parameter; its partial record is then 4 floats {err_photo, n, err_geo, n} instead of 2
+  float fused_geo_loss_param = 0.f;
   // progress signalling of the photometric linearize (pipelined window solve, runtime.hip): work item i belongs to
   // group sig_group[i]; the last workgroup of a group to finish publishes sig_epoch in sig_flag_host[group] (pinned)
   const int32_t *sig_group = nullptr;

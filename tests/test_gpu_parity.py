@@ -543,6 +543,12 @@ def test_full_size_properties(capi, orc, cfg):
     assert capi.lib().sage_window_total_error(win.h, 0, C.byref(ed)) == 0
     # total_error(False) adds the CANDIDATE's priors; candidate == current before any solve
     assert ed.value == pytest.approx(e_lin, rel=2e-6)
+    # ... factor type by factor type (the error pass evaluates both in one kernel): [err_photo err_geo n_photo n_geo]
+    import torch
+    torch.cuda.synchronize()
+    et = win.error_tensor().cpu().numpy()
+    assert et[0] == pytest.approx(tail[0], rel=2e-6) and et[1] == pytest.approx(tail[1], rel=2e-6)
+    assert et[2] == tail[2] and et[3] == tail[3]
     # one edge against the oracle (the only oracle call at this size: a few seconds)
     o = oracle_photo(orc, w, 0, 1)
     h = win.get_edge(0, 0)
