@@ -2114,7 +2114,7 @@ extern "C" int sage_window_get_edge(const SageWindow *w, int type, int e, float 
 // pays 0.09 ms for it (0.03 the write-through records and counters, 0.06 the small kernels squeezing in next to its
 // workgroups: 0.92 instead of 0.84 ms per launch).  Opt-in: 2-3 % of the step for 9 % of the dominant kernel's
 // roofline fraction is not a trade the default should make -- and since the host factorisation got faster (0.29 ms)
-// the classic path is ahead again (2.13 vs 2.16 ms per step).
+// the two paths are within 1 % of each other (2.07 vs 2.09 ms per step with two chunks of pair rows).
 // ------------------------------------------------------------------------------------------------
 static bool pipe_wanted(const SageWindow *w)
 {
@@ -2190,7 +2190,7 @@ static int pipe_setup(SageWindow *w, const std::vector<int32_t> &group_of_work)
   }
   else
   {
-    const double frac[] = {0.40, 0.25, 0.15, 0.10};
+    const double frac[] = {0.70}; // (then the rest: with the 0.29 ms factorisation two chunks of pair rows measured best)
     int left = T;
     for (double f : frac)
     {
