@@ -51,6 +51,7 @@ extern "C" {
 #define SAGE_E_UNSUPPORTED (-2) /* combination not instantiated */
 #define SAGE_E_NOT_PSD (-3)     /* host solve: matrix not positive definite even after damping */
 #define SAGE_E_STATE (-4)       /* call order violated (e.g. solve before linearize) */
+#define SAGE_E_NO_OVERLAP (-5)  /* tracker LM: "no overlap between frame to track and keyframe" (camera_tracker.cpp:1515-1519; the reference returns false) */
 
 /* ---- cameras: replaces df::PinholeCamera<float> / df::CameraPyramid<float>
  *      (common/pinhole_camera.h:44-131, common/camera_pyramid.h:18-32) ---- */
@@ -199,6 +200,8 @@ typedef struct SageLmConfig
   float damp_inc_factor;
   float jac_update_err_inc_threshold; /* 1e-2 */
   int max_inner_evals;       /* window LM only: cap on candidate evaluations per iteration (0 = reference policy: retry until accepted or max_damp) */
+  float no_overlap_error;    /* tracker LM: > 0 -> stop with SAGE_E_NO_OVERLAP once the error at the current estimate is >= this
+                              * (TrackFrame without the match-geometry term: 9.9 * sum(photo weights), camera_tracker.cpp:1515); 0 = off */
 } SageLmConfig;
 void sage_lm_config_default(SageLmConfig *cfg);
 
@@ -219,19 +222,41 @@ int sage_track_lm(const SageLmConfig *cfg, int dof, SageTrackLinearizeFn lin, Sa
                   float *pose12, float *scale, float *final_error, int *iters,
                   SageLmTraceEntry *trace, int trace_cap, int *trace_len);
 
-/* product wiring of the two callbacks to the HIP kernels: track a frame against a keyframe on `ws`. */
+/* product wiring of the two callbacks to the HIP kernels: CameraTracker::TrackNewFrame (dof 6) / TrackFrame (dof 7)
+ * with the reference's term composition (camera_tracker.cpp:220-374):
+ *   dof 6: error / AtA / Atb = photometric (tracker_photo_*)            [use_photo]
+ *                            + reprojection (tracker_reproj_*)           [use_keypoints]      (:282-328, :220-248)
+ *   dof 7: photometric with scale (tracker_photo_*_with_scale)          [use_photo]
+ *                            + match geometry with scale                 [use_keypoints]      (:330-374, :250-280)
+ * dof 7 hands over UNSCALED depths (dpt_map_0 / dpt_scale_0, camera_tracker.cpp:1397,1418): every Jacobian and every
+ * candidate evaluation multiplies them by the scale being evaluated (guess_scale_0 * unscaled_*_dpts_0, :264,:273,:431,
+ * :453) -- the 7th variable moves the depths, not only the Jacobian column.  dof 6 hands over metric depths.
+ * The sums are fp32, term by term, like the reference's `AtA += photo_AtA` on fp32 tensors. */
 typedef struct SageTrackProblem
 {
   SageWorkspace *ws;
+  /* photometric term */
+  int32_t use_photo;
   const float *mask1_dev, *dpts0_dev, *homo_dev, *feat0s_dev, *feat1_dev, *grad1_dev;
   const float *weights_dev;
   SagePyramid pyr;
   float eps;
-  int N, FS;
-  float unscaled; /* reserved */
+  int32_t N, FS;
+  /* keypoint term: NK matched keypoints of frame 0 (depths: metric for dof 6, unscaled for dof 7) */
+  int32_t use_keypoints, NK;
+  const float *kp_dpts0_dev;          /* [NK]   */
+  const float *kp_homo0_dev;          /* [NK,3] */
+  const float *kp_matched_2d_dev;     /* dof 6: [NK,2] matched pixel locations in frame 1 (reprojection)       */
+  const float *kp_matched_dpts1_dev;  /* dof 7: [NK]   depths of the matched points in frame 1 (match geometry) */
+  const float *kp_matched_homo1_dev;  /* dof 7: [NK,3] */
+  float kp_loss_param;                /* reproj_loss_param_ / match_geom_loss_param                              */
+  float kp_weight;                    /* inlier_multiplier_ * {reproj,match_geom}_factor_weight                  */
 } SageTrackProblem;
+/* Returns SAGE_OK, or SAGE_E_NO_OVERLAP when TrackFrame's zero-overlap exit fires (cfg->no_overlap_error).  trace
+ * (optional) as in sage_track_lm. */
 int sage_track_frame(const SageLmConfig *cfg, int dof, const SageTrackProblem *prob,
-                     float *pose12, float *scale, float *final_error, int *iters);
+                     float *pose12, float *scale, float *final_error, int *iters,
+                     SageLmTraceEntry *trace, int trace_cap, int *trace_len);
 
 /* =====================================================================
  * Batched window engine (no reference counterpart; parity = sum of per-edge results)

@@ -38,7 +38,8 @@ class SageLmConfig(C.Structure):
     _fields_ = [("max_num_iters", C.c_int), ("min_grad_thresh", C.c_float), ("min_param_inc_thresh", C.c_float),
                 ("init_damp", C.c_float), ("min_damp", C.c_float), ("max_damp", C.c_float),
                 ("damp_dec_factor", C.c_float), ("damp_inc_factor", C.c_float),
-                ("jac_update_err_inc_threshold", C.c_float), ("max_inner_evals", C.c_int)]
+                ("jac_update_err_inc_threshold", C.c_float), ("max_inner_evals", C.c_int),
+                ("no_overlap_error", C.c_float)]
 
 
 class SageLmTraceEntry(C.Structure):
@@ -47,10 +48,13 @@ class SageLmTraceEntry(C.Structure):
 
 
 class SageTrackProblem(C.Structure):
-    _fields_ = [("ws", C.c_void_p), ("mask1_dev", C.c_void_p), ("dpts0_dev", C.c_void_p), ("homo_dev", C.c_void_p),
-                ("feat0s_dev", C.c_void_p), ("feat1_dev", C.c_void_p), ("grad1_dev", C.c_void_p),
-                ("weights_dev", C.c_void_p), ("pyr", SagePyramid), ("eps", C.c_float), ("N", C.c_int),
-                ("FS", C.c_int), ("unscaled", C.c_float)]
+    _fields_ = [("ws", C.c_void_p), ("use_photo", C.c_int32), ("mask1_dev", C.c_void_p), ("dpts0_dev", C.c_void_p),
+                ("homo_dev", C.c_void_p), ("feat0s_dev", C.c_void_p), ("feat1_dev", C.c_void_p),
+                ("grad1_dev", C.c_void_p), ("weights_dev", C.c_void_p), ("pyr", SagePyramid), ("eps", C.c_float),
+                ("N", C.c_int32), ("FS", C.c_int32), ("use_keypoints", C.c_int32), ("NK", C.c_int32),
+                ("kp_dpts0_dev", C.c_void_p), ("kp_homo0_dev", C.c_void_p), ("kp_matched_2d_dev", C.c_void_p),
+                ("kp_matched_dpts1_dev", C.c_void_p), ("kp_matched_homo1_dev", C.c_void_p),
+                ("kp_loss_param", C.c_float), ("kp_weight", C.c_float)]
 
 
 class SageKeyframeView(C.Structure):
@@ -244,6 +248,19 @@ def track_lm(cfg: SageLmConfig, dof: int, lin_fn, err_fn, pose12, scale: float, 
 
 
 # --------------------------------------------------------------------------- device side
+def track_frame(cfg: SageLmConfig, dof: int, prob: "SageTrackProblem", pose12, scale: float, trace_cap: int = 256):
+    """sage_track_frame: the tracker LM wired to the HIP kernels.  Returns (rc, pose12, scale, final_error, iters, trace)."""
+    L = lib()
+    p = _f32(pose12).copy()
+    sc = C.c_float(scale); fe = C.c_float(); it = C.c_int(); tl = C.c_int()
+    tr = (SageLmTraceEntry * trace_cap)()
+    rc = L.sage_track_frame(C.byref(cfg), dof, C.byref(prob), _fp(p), C.byref(sc), C.byref(fe), C.byref(it), tr,
+                            trace_cap, C.byref(tl))
+    trace = [dict(damp=tr[i].damp, error=tr[i].error, candidate_error=tr[i].candidate_error,
+                  accepted=tr[i].accepted, relinearized=tr[i].relinearized) for i in range(tl.value)]
+    return rc, p, sc.value, fe.value, it.value, trace
+
+
 class Workspace:
     """``SageWorkspace``: stream + scratch of one host thread."""
 

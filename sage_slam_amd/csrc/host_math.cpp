@@ -10,6 +10,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <limits>
 #include <cstdio>
 #include <cstdlib>
 #include <thread>
@@ -42,6 +43,8 @@ extern "C" const char *sage_error_string(int code)
     return "normal equations not positive definite";
   case SAGE_E_STATE:
     return "call order violated";
+  case SAGE_E_NO_OVERLAP:
+    return "tracker: no overlap between the frame to track and the keyframe";
   default:
     return code > 0 ? "HIP runtime error (hipError_t)" : "unknown error";
   }
@@ -321,14 +324,24 @@ extern "C" int sage_damped_solve_qr_f32(const float *A, const float *b, int n, f
     for (int i = k; i < n; ++i)
       rhs[i] -= s * v[i];
   }
+  // rank as Eigen's ColPivHouseholderQR::solve() determines it (the reference's solver, camera_tracker.cpp:1182-1183):
+  // pivots with |R_ii| <= eps * n * max|R_jj| do not count, only the leading rank x rank triangle is solved and the
+  // remaining components are zero -- a near-singular damped system gives a truncated step, not a division by a tiny pivot
+  float maxpiv = 0.f;
+  for (int i = 0; i < n; ++i)
+    maxpiv = std::max(maxpiv, std::fabs(M[(size_t)i * n + i]));
+  const float thr = maxpiv * (std::numeric_limits<float>::epsilon() * (float)n);
+  int rank = 0;
+  for (int i = 0; i < n; ++i)
+    rank += std::fabs(M[(size_t)i * n + i]) > thr ? 1 : 0;
   std::vector<float> y(n, 0.f);
-  for (int i = n - 1; i >= 0; --i)
+  for (int i = rank - 1; i >= 0; --i)
   {
     float s = rhs[i];
-    for (int j = i + 1; j < n; ++j)
+    for (int j = i + 1; j < rank; ++j)
       s -= M[(size_t)i * n + j] * y[j];
     const float d = M[(size_t)i * n + i];
-    y[i] = (d != 0.f) ? s / d : 0.f; // rank-deficient column -> minimum-norm-like zero (Eigen zeroes it)
+    y[i] = (d != 0.f) ? s / d : 0.f;
   }
   for (int i = 0; i < n; ++i)
     x[perm[i]] = y[i];
@@ -349,6 +362,7 @@ extern "C" void sage_lm_config_default(SageLmConfig *c)
   c->damp_inc_factor = 100.f;
   c->jac_update_err_inc_threshold = 1.0e-2f;
   c->max_inner_evals = 0;
+  c->no_overlap_error = 0.f;
 }
 
 namespace sage
@@ -451,12 +465,21 @@ extern "C" int sage_track_lm(const SageLmConfig *cfgp, int dof, SageTrackLineari
     // skip the Jacobian when the last step changed the error too little (:1159)
     if (std::fabs(curr_error - prev_error) / prev_error > cfg.jac_update_err_inc_threshold)
     {
-      if ((rc = lin(ctx, guess, guess_scale, AtA, Atb, &curr_error)) != 0)
+      float lin_error = 0.f;
+      if ((rc = lin(ctx, guess, guess_scale, AtA, Atb, &lin_error)) != 0)
         return rc;
+      if (curr_iter == 0) // update_error only on the first pass (:1166, :1491); later the accepted candidate's error stands
+        curr_error = lin_error;
       update_jac = true;
     }
     else
       update_jac = false;
+    // TrackFrame without the match-geometry term: "no overlap" ends the tracking with a failure (:1515-1519)
+    if (cfg.no_overlap_error > 0.f && curr_error >= cfg.no_overlap_error)
+    {
+      rc = SAGE_E_NO_OVERLAP;
+      break;
+    }
     curr_iter += 1;
     if ((rc = sage_damped_solve_qr_f32(AtA, Atb, dof, damp, sol)) != 0)
       return rc;
@@ -505,7 +528,7 @@ extern "C" int sage_track_lm(const SageLmConfig *cfgp, int dof, SageTrackLineari
     *iters = (int)curr_iter;
   if (trace_len)
     *trace_len = ntrace;
-  return SAGE_OK;
+  return rc;
 }
 
 // ---------------------------------------------------------------- envelope Cholesky (window solve)

@@ -435,4 +435,20 @@ hipError_t launch_sort_locations(hipStream_t s, const SortItem *items_dev, int K
   return hipGetLastError();
 }
 
+// out[i] = mult * in[i]: the tracker's `guess_scale_0 * unscaled_dpts_0` (camera_tracker.cpp:264,273,431,453), one fp32
+// multiply per sample like the reference's tensor expression
+__global__ void scale_array_kernel(float *__restrict__ out, const float *__restrict__ in, float mult, int n)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] = mult * in[i];
+}
+
+hipError_t launch_scale_array(hipStream_t s, float *out, const float *in, float mult, int n)
+{
+  if (n > 0)
+    hipLaunchKernelGGL(scale_array_kernel, dim3((n + 255) / 256), dim3(256), 0, s, out, in, mult, n);
+  return hipGetLastError();
+}
+
 } // namespace sage

@@ -709,57 +709,141 @@ struct TrackCtx
 {
   const SageTrackProblem *prob;
   int dof;
-  DevBuf pose, out; // pose: 12 floats; out: AtA(49)+Atb(7)
+  DevBuf pose, out;      // pose: 12 floats; out: 2 x (AtA(49)+Atb(7)) -- photometric and keypoint term
+  DevBuf dpts, kp_dpts;  // dof 7: scale * unscaled depths of the evaluation in flight
 };
 
+// depths the kernels of one evaluation read: dof 6 -> the caller's metric depths; dof 7 -> scale * unscaled
+// (camera_tracker.cpp:264, :273 candidate error; :431, :453 Jacobian)
+int track_depths(TrackCtx *c, float scale, const float **photo, const float **kp)
+{
+  const SageTrackProblem *p = c->prob;
+  *photo = p->dpts0_dev;
+  *kp = p->kp_dpts0_dev;
+  if (c->dof != 7)
+    return 0;
+  hipStream_t s = p->ws->stream;
+  if (p->use_photo)
+  {
+    SAGE_HIP(launch_scale_array(s, c->dpts.as<float>(), p->dpts0_dev, scale, p->N));
+    *photo = c->dpts.as<float>();
+  }
+  if (p->use_keypoints)
+  {
+    SAGE_HIP(launch_scale_array(s, c->kp_dpts.as<float>(), p->kp_dpts0_dev, scale, p->NK));
+    *kp = c->kp_dpts.as<float>();
+  }
+  return 0;
+}
+
+// CameraTracker::ComputeJacobianAndError (camera_tracker.cpp:282-328 dof 6, :330-374 dof 7)
 int track_lin_cb(void *vctx, const float *pose12, float scale, float *AtA, float *Atb, float *error)
 {
   TrackCtx *c = static_cast<TrackCtx *>(vctx);
   const SageTrackProblem *p = c->prob;
   hipStream_t s = p->ws->stream;
+  const int dof = c->dof;
   SAGE_HIP(hipMemcpyAsync(c->pose.p, pose12, 12 * sizeof(float), hipMemcpyHostToDevice, s));
-  float *dA = c->out.as<float>(), *db = dA + 49;
-  int rc = sage_tracker_photo_jac_error_calculate(p->ws, c->dof, dA, db, error, nullptr, c->pose.as<float>(),
-                                                  c->pose.as<float>() + 9, p->mask1_dev, p->dpts0_dev, p->homo_dev,
-                                                  p->feat0s_dev, p->feat1_dev, p->grad1_dev, &p->pyr, scale, p->eps,
-                                                  p->weights_dev, p->N, p->FS);
+  const float *R = c->pose.as<float>(), *t = R + 9;
+  const float *dp, *kdp;
+  int rc = track_depths(c, scale, &dp, &kdp);
   if (rc)
     return rc;
-  float host[56];
-  SAGE_HIP(hipMemcpy(host, dA, 56 * sizeof(float), hipMemcpyDeviceToHost));
-  std::memcpy(AtA, host, c->dof * c->dof * sizeof(float));
-  std::memcpy(Atb, host + 49, c->dof * sizeof(float));
+  float *dA = c->out.as<float>(), *db = dA + 49, *dA2 = dA + 56, *db2 = dA2 + 49;
+  float e_photo = 0.f, e_kp = 0.f;
+  if (p->use_photo &&
+      (rc = sage_tracker_photo_jac_error_calculate(p->ws, dof, dA, db, &e_photo, nullptr, R, t, p->mask1_dev, dp,
+                                                   p->homo_dev, p->feat0s_dev, p->feat1_dev, p->grad1_dev, &p->pyr,
+                                                   scale, p->eps, p->weights_dev, p->N, p->FS)))
+    return rc;
+  if (p->use_keypoints)
+  {
+    if (dof == 6)
+      rc = sage_tracker_reproj_jac_error_calculate(p->ws, dA2, db2, &e_kp, nullptr, R, t, kdp, p->kp_homo0_dev,
+                                                   p->kp_matched_2d_dev, &p->pyr.cam[0], p->eps, p->kp_loss_param,
+                                                   p->kp_weight, p->NK);
+    else
+      rc = sage_tracker_match_geom_jac_error_calculate(p->ws, dA2, db2, &e_kp, R, t, kdp, p->kp_matched_dpts1_dev,
+                                                       p->kp_homo0_dev, p->kp_matched_homo1_dev, scale,
+                                                       p->kp_loss_param, p->kp_weight, 1, p->NK);
+    if (rc)
+      return rc;
+  }
+  float host[112];
+  SAGE_HIP(hipMemcpy(host, dA, 112 * sizeof(float), hipMemcpyDeviceToHost));
+  // AtA = zeros; AtA += photo_AtA; AtA += keypoint_AtA  (fp32 tensor adds, :296-318 / :344-364)
+  for (int i = 0; i < dof * dof; ++i)
+    AtA[i] = (p->use_photo ? 0.f + host[i] : 0.f) + (p->use_keypoints ? host[56 + i] : 0.f);
+  for (int i = 0; i < dof; ++i)
+    Atb[i] = (p->use_photo ? 0.f + host[49 + i] : 0.f) + (p->use_keypoints ? host[56 + 49 + i] : 0.f);
+  *error = e_photo + e_kp;
   return 0;
 }
 
-int track_err_cb(void *vctx, const float *pose12, float /*scale*/, float *error)
+// CameraTracker::ComputeError (:220-248 dof 6, :250-280 dof 7)
+int track_err_cb(void *vctx, const float *pose12, float scale, float *error)
 {
   TrackCtx *c = static_cast<TrackCtx *>(vctx);
   const SageTrackProblem *p = c->prob;
   SAGE_HIP(hipMemcpyAsync(c->pose.p, pose12, 12 * sizeof(float), hipMemcpyHostToDevice, p->ws->stream));
-  return sage_tracker_photo_error_calculate(p->ws, error, nullptr, c->pose.as<float>(), c->pose.as<float>() + 9,
-                                            p->mask1_dev, p->dpts0_dev, p->homo_dev, p->feat0s_dev, p->feat1_dev,
-                                            &p->pyr, p->eps, p->weights_dev, p->N, p->FS);
+  const float *R = c->pose.as<float>(), *t = R + 9;
+  const float *dp, *kdp;
+  int rc = track_depths(c, scale, &dp, &kdp);
+  if (rc)
+    return rc;
+  float e_photo = 0.f, e_kp = 0.f;
+  if (p->use_photo &&
+      (rc = sage_tracker_photo_error_calculate(p->ws, &e_photo, nullptr, R, t, p->mask1_dev, dp, p->homo_dev,
+                                               p->feat0s_dev, p->feat1_dev, &p->pyr, p->eps, p->weights_dev, p->N,
+                                               p->FS)))
+    return rc;
+  if (p->use_keypoints)
+  {
+    if (c->dof == 6)
+      rc = sage_tracker_reproj_error_calculate(p->ws, &e_kp, nullptr, R, t, kdp, p->kp_homo0_dev, p->kp_matched_2d_dev,
+                                               &p->pyr.cam[0], p->eps, p->kp_loss_param, p->kp_weight, p->NK);
+    else
+      rc = sage_tracker_match_geom_error_calculate(p->ws, &e_kp, R, t, kdp, p->kp_matched_dpts1_dev, p->kp_homo0_dev,
+                                                   p->kp_matched_homo1_dev, p->kp_loss_param, p->kp_weight, p->NK);
+    if (rc)
+      return rc;
+  }
+  *error = e_photo + e_kp;
+  return 0;
 }
 } // namespace
 
 extern "C" int sage_track_frame(const SageLmConfig *cfg, int dof, const SageTrackProblem *prob, float *pose12,
-                                float *scale, float *final_error, int *iters)
+                                float *scale, float *final_error, int *iters, SageLmTraceEntry *trace, int trace_cap,
+                                int *trace_len)
 {
-  if (!cfg || !prob || !prob->ws || !pose12)
+  if (!cfg || !prob || !prob->ws || !pose12 || (dof != 6 && dof != 7) || (dof == 7 && !scale))
+    return SAGE_E_INVALID;
+  if (!prob->use_photo && !prob->use_keypoints) // "at least one factor should be enabled" (camera_tracker.cpp:1328)
+    return SAGE_E_INVALID;
+  if (prob->use_photo && (!prob->mask1_dev || !prob->dpts0_dev || !prob->homo_dev || !prob->feat0s_dev ||
+                          !prob->feat1_dev || !prob->grad1_dev || !prob->weights_dev || prob->N < 1))
+    return SAGE_E_INVALID;
+  if (prob->use_keypoints &&
+      (!prob->kp_dpts0_dev || !prob->kp_homo0_dev || prob->NK < 1 ||
+       (dof == 6 ? !prob->kp_matched_2d_dev : (!prob->kp_matched_dpts1_dev || !prob->kp_matched_homo1_dev))))
     return SAGE_E_INVALID;
   TrackCtx ctx;
   ctx.prob = prob;
   ctx.dof = dof;
   int rc;
-  if ((rc = ctx.pose.reserve(12 * sizeof(float))) || (rc = ctx.out.reserve(56 * sizeof(float))))
+  if ((rc = ctx.pose.reserve(12 * sizeof(float))) || (rc = ctx.out.reserve(112 * sizeof(float))))
     return rc;
-  // NOTE: with dof == 7 the reference rescales nothing on the device side: the scale only enters the Jacobian
-  // column (photometric_factor_kernels.cpp:856) and `s <- s + ds` (camera_tracker.cpp:487).
-  rc = sage_track_lm(cfg, dof, track_lin_cb, track_err_cb, &ctx, pose12, scale, final_error, iters, nullptr, 0,
-                     nullptr);
+  if (dof == 7 && ((prob->use_photo && (rc = ctx.dpts.reserve((size_t)prob->N * sizeof(float)))) ||
+                   (prob->use_keypoints && (rc = ctx.kp_dpts.reserve((size_t)prob->NK * sizeof(float))))))
+    return rc;
+  rc = sage_track_lm(cfg, dof, track_lin_cb, track_err_cb, &ctx, pose12, scale, final_error, iters, trace, trace_cap,
+                     trace_len);
+  (void)hipStreamSynchronize(prob->ws->stream);
   ctx.pose.release();
   ctx.out.release();
+  ctx.dpts.release();
+  ctx.kp_dpts.release();
   return rc;
 }
 

@@ -196,12 +196,14 @@ def _smooth_fields(rng, n, H, W, sigma, max_cycles=2.0, n_waves=4):
 def make_window(K: int, H: int, W: int, FS: int = 16, CS: int = 32, L: int = 4,
                 n_samples: int = 0, back_links: int = 3, seed: int = 0,
                 baseline: float = 0.025, pose_noise: float = 1.0, code_noise: float = 0.03,
-                border: int = 2, erode: int = 6) -> Window:
+                border: int = 2, erode: int = 6, loop_radius: float = 0.0) -> Window:
     """Build a K-keyframe window (SURVEY.md s8d "synthetic inputs").
 
     ``n_samples == 0`` -> dense sampling (all pixels of the eroded mask, row-major like
     ``torch.nonzero``); otherwise a seeded shuffle keeps the first ``n_samples``
-    (``core/mapping/mapper.cpp:1222-1237``)."""
+    (``core/mapping/mapper.cpp:1222-1237``).  ``loop_radius > 0``: the camera walks once around a circle of that
+    radius in the x-y plane (keyframe K-1 ends next to keyframe 0: loop closures have overlap) instead of along the
+    smooth arc."""
     rng = np.random.default_rng(seed)
     cam0 = Camera(0.9 * W, 0.9 * W, W / 2.0, H / 2.0, W, H)
     cams = camera_pyramid(cam0, L)
@@ -232,6 +234,9 @@ def make_window(K: int, H: int, W: int, FS: int = 16, CS: int = 32, L: int = 4,
         # smooth arc, small rotations that keep the plane in view
         s = k * baseline
         t_true = np.array([s, 0.15 * baseline * np.sin(0.7 * k), 0.05 * baseline * np.cos(0.3 * k)])
+        if loop_radius > 0:
+            th = 2 * np.pi * k / K
+            t_true = np.array([loop_radius * np.sin(th), loop_radius * (1 - np.cos(th)), 0.05 * baseline * np.cos(0.3 * k)])
         R_true = so3_exp(np.array([0.01 * np.sin(0.5 * k), -0.02 * np.sin(0.2 * k), 0.015 * np.sin(0.3 * k)]))
         dirs = rays @ R_true.T
         depth = (h - n @ t_true) / (dirs @ n)                                  # z-depth along the ray

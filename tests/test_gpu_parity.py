@@ -467,44 +467,7 @@ def test_sort_locations(capi, ws):
         capi.sort_locations(ws, torch.from_numpy(loc3).cuda(), torch.from_numpy(homo).cuda(), H, W)
 
 
-def test_track_frame_lm(capi, ws, orc):
-    """host LM (a8) wired to the HIP tracker kernels == the same policy driven by the oracle."""
-    import ctypes as C
-    import torch
-    w = synth.make_window(K=2, H=64, W=80, FS=16, CS=32, L=4, n_samples=3072, seed=31, pose_noise=0.0)
-    a, b = w.keyframes[0], w.keyframes[1]
-    pyr, mask, kfs = dev_window(capi, w)
-    feat0s = presample_source(orc, w, a)
-    dpts0 = (np.float32(a.scale_true) * (a.bias + a.basis @ a.code_true))[a.loc1d].astype(np.float32)
-    R10, t10 = synth.relative_pose(a.R_true, a.t_true, b.R_true, b.t_true)
-    pose0 = capi.pack_pose(synth.so3_exp(np.array([0.004, -0.003, 0.002])) @ R10, t10 + np.array([0.004, -0.003, 0.002], np.float32))
-    cfg = capi.lm_config_default()
-    wts = w.photo_weights
-
-    def lin(p, s):
-        o = orc.tracker_photo_jac_error(6, p[:9].reshape(3, 3), p[9:], w.mask, dpts0, a.homo, feat0s, b.feat_pyr,
-                                        b.grad_pyr, w.level_offsets, w.cams, w.eps, wts)
-        return o["AtA"], o["Atb"], o["error"]
-
-    def err(p, s):
-        return orc.tracker_photo_error(p[:9].reshape(3, 3), p[9:], w.mask, dpts0, a.homo, feat0s, b.feat_pyr,
-                                       w.level_offsets, w.cams, w.eps, wts)[0]
-
-    po, _, eo, ito, tro = capi.track_lm(cfg, 6, lin, err, pose0, 1.0)
-    prob = capi.SageTrackProblem()
-    f0 = torch.from_numpy(feat0s).cuda(); dp = torch.from_numpy(dpts0).cuda(); wd = torch.from_numpy(wts).cuda()
-    prob.ws = ws.h; prob.mask1_dev = mask.data_ptr(); prob.dpts0_dev = dp.data_ptr()
-    prob.homo_dev = kfs[0].homo.data_ptr(); prob.feat0s_dev = f0.data_ptr(); prob.feat1_dev = kfs[1].feat_pyr.data_ptr()
-    prob.grad1_dev = kfs[1].grad_pyr.data_ptr(); prob.weights_dev = wd.data_ptr(); prob.pyr = pyr
-    prob.eps = w.eps; prob.N = a.homo.shape[0]; prob.FS = w.FS
-    ph = pose0.copy(); sc = C.c_float(1.0); fe = C.c_float(); it = C.c_int()
-    rc = capi.lib().sage_track_frame(C.byref(cfg), 6, C.byref(prob), ph.ctypes.data_as(C.POINTER(C.c_float)),
-                                     C.byref(sc), C.byref(fe), C.byref(it))
-    assert rc == 0
-    assert it.value == ito
-    assert fe.value == pytest.approx(eo, rel=1e-3)
-    assert rel(ph, po) < 1e-4
-    assert eo < 0.5 * tro[0]["error"]      # the LM actually converged towards the true relative pose
+# (the tracker LM loops, dof 6 and 7 with the keypoint terms composed in: tests/test_gpu_tracker.py)
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -1,0 +1,217 @@
+"""a8: the tracker LM loops with the reference's term composition, HIP-wired (sage_track_frame) against the SAME policy
+(sage_track_lm) driven by the CPU oracle's kernels composed in Python exactly as CameraTracker::ComputeJacobianAndError /
+ComputeError do (camera_tracker.cpp:220-374):
+
+  TrackNewFrame (dof 6):  photometric + reprojection
+  TrackFrame    (dof 7):  photometric with scale + match geometry with scale; depths are handed over UNSCALED and every
+                          evaluation multiplies them by the scale being evaluated (:264, :273, :431, :453)
+
+BASELINE config 1 shape: 2 keyframes, 64x80x16 feature maps, 32-dim code, N = 3072 seeded samples.
+"""
+import numpy as np
+import pytest
+
+from sage_slam_amd import synth
+from tests.helpers import presample_source, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    from sage_slam_amd import capi as c
+    c.lib()
+    return c
+
+
+class Scene:
+    """frame 0 (tracked) -> frame 1 (reference keyframe) of a synthetic window, plus NK matched keypoints"""
+
+    def __init__(self, capi, orc, seed=31, NK=160, kp_noise_px=0.4, kp_noise_depth=0.002):
+        import torch
+        self.capi, self.orc = capi, orc
+        w = synth.make_window(K=2, H=64, W=80, FS=16, CS=32, L=4, n_samples=3072, seed=seed, pose_noise=0.0)
+        self.w = w
+        a, b = w.keyframes[0], w.keyframes[1]
+        self.a, self.b = a, b
+        self.feat0s = presample_source(orc, w, a)
+        self.unscaled = (a.bias + a.basis @ a.code_true)[a.loc1d].astype(np.float32)       # dpt_map_0 / dpt_scale_0
+        self.s_true = np.float32(a.scale_true)
+        self.R10, self.t10 = synth.relative_pose(a.R_true, a.t_true, b.R_true, b.t_true)
+        rng = np.random.default_rng(seed + 1)
+        cam = w.cams[0]
+        xs = rng.integers(10, w.W - 10, NK); ys = rng.integers(10, w.H - 10, NK)
+        loc = ys * w.W + xs
+        self.kp_homo0 = np.stack([(xs - cam.cx) / cam.fx, (ys - cam.cy) / cam.fy, np.ones(NK)], 1).astype(np.float32)
+        self.kp_unscaled = (a.bias + a.basis @ a.code_true)[loc].astype(np.float32)
+        X1 = (self.R10.astype(np.float64) @ (float(self.s_true) * self.kp_unscaled[:, None] * self.kp_homo0).T).T + self.t10
+        self.kp_matched_2d = (np.stack([X1[:, 0] / X1[:, 2] * cam.fx + cam.cx, X1[:, 1] / X1[:, 2] * cam.fy + cam.cy], 1)
+                              + rng.normal(0, kp_noise_px, (NK, 2))).astype(np.float32)
+        self.kp_dpts1 = (X1[:, 2] + rng.normal(0, kp_noise_depth, NK)).astype(np.float32)
+        self.kp_homo1 = np.stack([X1[:, 0] / X1[:, 2] + rng.normal(0, kp_noise_px / cam.fx, NK),
+                                  X1[:, 1] / X1[:, 2] + rng.normal(0, kp_noise_px / cam.fy, NK), np.ones(NK)], 1).astype(np.float32)
+        self.NK = NK
+        self.reproj_loss_param = 1e-4 * w.W * w.W           # reproj_loss_param_factor * width^2 (camera_tracker.cpp:1076)
+        self.mg_loss_param = 0.1 * float(np.mean(a.bias ** 2))
+        self.reproj_weight, self.mg_weight = 0.05, 3.0
+        # device side
+        self.ws = capi.Workspace()
+        self.pyr = capi.make_pyramid(w.cams[0], w.L)
+        dv = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        self.dev = dict(mask=dv(w.mask), homo=dv(a.homo), f0s=dv(self.feat0s), feat1=dv(b.feat_pyr), grad1=dv(b.grad_pyr),
+                        wts=dv(w.photo_weights), unscaled=dv(self.unscaled), metric=dv(self.s_true * self.unscaled),
+                        kp_homo0=dv(self.kp_homo0), kp_unscaled=dv(self.kp_unscaled),
+                        kp_metric=dv(self.s_true * self.kp_unscaled), kp_2d=dv(self.kp_matched_2d),
+                        kp_dpts1=dv(self.kp_dpts1), kp_homo1=dv(self.kp_homo1))
+
+    def problem(self, dof, use_photo, use_kp):
+        capi, d, w = self.capi, self.dev, self.w
+        p = capi.SageTrackProblem()
+        p.ws = self.ws.h
+        p.use_photo = int(use_photo)
+        p.mask1_dev = d["mask"].data_ptr(); p.homo_dev = d["homo"].data_ptr(); p.feat0s_dev = d["f0s"].data_ptr()
+        p.feat1_dev = d["feat1"].data_ptr(); p.grad1_dev = d["grad1"].data_ptr(); p.weights_dev = d["wts"].data_ptr()
+        p.dpts0_dev = (d["unscaled"] if dof == 7 else d["metric"]).data_ptr()
+        p.pyr = self.pyr; p.eps = w.eps; p.N = self.a.homo.shape[0]; p.FS = w.FS
+        p.use_keypoints = int(use_kp); p.NK = self.NK
+        p.kp_dpts0_dev = (d["kp_unscaled"] if dof == 7 else d["kp_metric"]).data_ptr()
+        p.kp_homo0_dev = d["kp_homo0"].data_ptr(); p.kp_matched_2d_dev = d["kp_2d"].data_ptr()
+        p.kp_matched_dpts1_dev = d["kp_dpts1"].data_ptr(); p.kp_matched_homo1_dev = d["kp_homo1"].data_ptr()
+        p.kp_loss_param = self.reproj_loss_param if dof == 6 else self.mg_loss_param
+        p.kp_weight = self.reproj_weight if dof == 6 else self.mg_weight
+        return p
+
+    def oracle_callbacks(self, dof, use_photo, use_kp):
+        """ComputeJacobianAndError / ComputeError restated over the oracle kernels: fp32 sums term by term"""
+        orc, w, a, b = self.orc, self.w, self.a, self.b
+        cam = w.cams[0]
+        F = np.float32
+
+        def depths(s):
+            if dof == 7:
+                return F(s) * self.unscaled, F(s) * self.kp_unscaled
+            return self.s_true * self.unscaled, self.s_true * self.kp_unscaled
+
+        def lin(p, s):
+            R, t = p[:9].reshape(3, 3), p[9:]
+            dp, kdp = depths(s)
+            A = np.zeros((dof, dof), F); g = np.zeros(dof, F); e = F(0)
+            if use_photo:
+                o = orc.tracker_photo_jac_error(dof, R, t, w.mask, dp, a.homo, self.feat0s, b.feat_pyr, b.grad_pyr,
+                                                w.level_offsets, w.cams, w.eps, w.photo_weights, scale0=s)
+                A = A + o["AtA"].astype(F); g = g + o["Atb"].astype(F); e = F(e + F(o["error"]))
+            if use_kp and dof == 6:
+                o = orc.tracker_reproj_jac_error(R, t, kdp, self.kp_homo0, self.kp_matched_2d, cam, w.eps,
+                                                 self.reproj_loss_param, self.reproj_weight)
+                A = A + o["AtA"].astype(F); g = g + o["Atb"].astype(F); e = F(e + F(o["error"]))
+            if use_kp and dof == 7:
+                o = orc.match_geom_jac_error(3, "fair", R, t, dpts0=kdp, dpts1=self.kp_dpts1, homo0=self.kp_homo0,
+                                             homo1=self.kp_homo1, scale0=s, loss_param=self.mg_loss_param,
+                                             weight=self.mg_weight)
+                A = A + o["AtA"].astype(F); g = g + o["Atb"].astype(F); e = F(e + F(o["error"]))
+            return A, g, float(e)
+
+        def err(p, s):
+            R, t = p[:9].reshape(3, 3), p[9:]
+            dp, kdp = depths(s)
+            e = F(0)
+            if use_photo:
+                e = F(e + F(orc.tracker_photo_error(R, t, w.mask, dp, a.homo, self.feat0s, b.feat_pyr, w.level_offsets,
+                                                    w.cams, w.eps, w.photo_weights)[0]))
+            if use_kp and dof == 6:
+                e = F(e + F(orc.tracker_reproj_error(R, t, kdp, self.kp_homo0, self.kp_matched_2d, cam, w.eps,
+                                                     self.reproj_loss_param, self.reproj_weight)[0]))
+            if use_kp and dof == 7:
+                e = F(e + F(orc.match_geom_error(2, "fair", R, t, dpts0=kdp, dpts1=self.kp_dpts1, homo0=self.kp_homo0,
+                                                 homo1=self.kp_homo1, loss_param=self.mg_loss_param,
+                                                 weight=self.mg_weight)))
+            return float(e)
+
+        return lin, err
+
+    def start_pose(self):
+        return self.capi.pack_pose(synth.so3_exp(np.array([0.004, -0.003, 0.002])) @ self.R10,
+                                   self.t10 + np.array([0.004, -0.003, 0.002], np.float32))
+
+    def close(self):
+        self.ws.close()
+
+
+@pytest.fixture(scope="module")
+def scene(capi, orc):
+    s = Scene(capi, orc)
+    yield s
+    s.close()
+
+
+@pytest.mark.parametrize("dof,use_photo,use_kp", [(6, True, False), (6, True, True), (6, False, True),
+                                                  (7, True, False), (7, True, True), (7, False, True)],
+                         ids=["new_photo", "new_photo+reproj", "new_reproj", "frame_photo", "frame_photo+matchgeom",
+                              "frame_matchgeom"])
+def test_track_frame_matches_oracle_wired_lm(capi, scene, dof, use_photo, use_kp):
+    cfg = capi.lm_config_default()
+    pose0 = scene.start_pose()
+    s0 = float(scene.s_true) * (0.96 if dof == 7 else 1.0)   # low: LMConvergence uses the SIGNED max increment
+    lin, err = scene.oracle_callbacks(dof, use_photo, use_kp)
+    po, so, eo, ito, tro = capi.track_lm(cfg, dof, lin, err, pose0, s0)
+    rc, ph, sh, eh, ith, trh = capi.track_frame(cfg, dof, scene.problem(dof, use_photo, use_kp), pose0, s0)
+    assert rc == 0
+    print(f"dof {dof} photo {use_photo} kp {use_kp}: iters {ith}/{ito}  error {tro[0]['error']:.5f} -> {eh:.5f}/{eo:.5f}  "
+          f"scale {s0:.5f} -> {sh:.5f}/{so:.5f} (true {float(scene.s_true):.5f})  pose rel {rel(ph, po):.1e}")
+    assert ith == ito and len(trh) == len(tro)
+    assert [t["accepted"] for t in trh] == [t["accepted"] for t in tro]
+    assert [t["relinearized"] for t in trh] == [t["relinearized"] for t in tro]
+    np.testing.assert_allclose([t["error"] for t in trh], [t["error"] for t in tro], rtol=2e-4)
+    np.testing.assert_allclose([t["candidate_error"] for t in trh], [t["candidate_error"] for t in tro], rtol=2e-4)
+    assert eh == pytest.approx(eo, rel=1e-3)
+    assert rel(ph, po) < 1e-4
+    if dof == 7:
+        assert sh == pytest.approx(so, rel=1e-4)
+        # the scale is a live variable of the cost (it used to drift without moving the depths): started 4 %
+        # low, the LM pulls it back towards the true scale
+        # (only the match-geometry term sees the scale; the photometric term trades s against t exactly)
+        if use_kp:
+            assert abs(sh / float(scene.s_true) - 1.0) < 0.5 * 0.04
+    assert eo < 0.7 * tro[0]["error"]                       # the LM actually descended
+    if dof == 6 or use_kp:                                  # (dof 7 photo-only may trade t against s)
+        assert np.linalg.norm(ph[9:] - scene.t10) < np.linalg.norm(pose0[9:] - scene.t10)
+
+
+def test_track_frame_scale_changes_the_cost(capi, scene):
+    """dof 7: two candidate scales give different errors through the product path (the error pass rescales the depths),
+    equal to the oracle at the same scaled depths."""
+    import ctypes as C
+    cfg = capi.lm_config_default(); cfg.max_num_iters = 1
+    prob = scene.problem(7, True, True)
+    errs = []
+    for s in (float(scene.s_true), 1.05 * float(scene.s_true)):
+        rc, _, _, _, _, tr = capi.track_frame(cfg, 7, prob, scene.start_pose(), s)
+        assert rc == 0 and len(tr) >= 1
+        lin, _ = scene.oracle_callbacks(7, True, True)
+        assert tr[0]["error"] == pytest.approx(lin(scene.start_pose(), s)[2], rel=2e-5)
+        errs.append(tr[0]["error"])
+    assert abs(errs[1] - errs[0]) > 1e-3 * errs[0]
+
+
+def test_track_frame_no_overlap_exit(capi, scene):
+    """TrackFrame without the match-geometry term: error >= 9.9 * sum(photo weights) ends the tracking with a failure
+    (camera_tracker.cpp:1515-1519); with the keypoint term enabled the reference keeps going."""
+    cfg = capi.lm_config_default()
+    cfg.no_overlap_error = 9.9 * float(np.sum(scene.w.photo_weights))
+    far = scene.start_pose().copy(); far[9:] += np.array([50.0, 0, 0], np.float32)     # warps everything out of the image
+    rc, p, s, e, it, tr = capi.track_frame(cfg, 7, scene.problem(7, True, False), far, float(scene.s_true))
+    assert rc == -5 and it == 0 and np.array_equal(p, far)                              # SAGE_E_NO_OVERLAP, pose untouched
+    assert e == pytest.approx(10.0 * float(np.sum(scene.w.photo_weights)))             # the zero-inlier fallback value
+    cfg.no_overlap_error = 0.0                                                          # use_match_geom: check is off
+    rc, p, s, e, it, tr = capi.track_frame(cfg, 7, scene.problem(7, True, True), far, float(scene.s_true))
+    assert rc == 0
+
+
+def test_track_frame_rejects_bad_problems(capi, scene):
+    cfg = capi.lm_config_default()
+    rc = capi.track_frame(cfg, 7, scene.problem(7, False, False), scene.start_pose(), 1.0)[0]
+    assert rc == -1                                                                     # "at least one factor should be enabled"
+    rc = capi.track_frame(cfg, 5, scene.problem(6, True, False), scene.start_pose(), 1.0)[0]
+    assert rc == -1

@@ -189,6 +189,114 @@ def test_tracker_lm_policy_with_oracle_backend(orc):
     assert calls["lin"] <= iters and calls["err"] >= len(trace)
 
 
+def test_damped_qr_solve_truncates_at_eigens_rank():
+    """colPivHouseholderQr().solve() (camera_tracker.cpp:1182-1183) only solves the leading rank x rank triangle, rank =
+    #pivots with |R_ii| > eps * n * max|R_jj|, and zeroes the other components: a (numerically) singular damped system
+    gives a truncated step, not a division by a tiny pivot."""
+    rng = np.random.default_rng(3)
+    n = 7
+    J = rng.normal(size=(40, n - 2))
+    M = np.concatenate([J, J[:, :1] + J[:, 1:2], np.zeros((40, 1))], 1)       # col 5 = col 0 + col 1, col 6 = 0
+    A = (M.T @ M).astype(np.float32)
+    b = (M.T @ rng.normal(size=40)).astype(np.float32)
+    x = capi.damped_solve_qr_f32(A, b, 0.0)                                     # no damping: rank 5 of 7
+    assert np.isfinite(x).all() and np.linalg.norm(x) < 1e3 * np.linalg.norm(b) / np.abs(A).max()
+    assert (x == 0).sum() >= 2                                                  # the truncated components are exactly zero
+    assert rel(A.astype(np.float64) @ x, b) < 1e-4                              # still solves the consistent system
+    # full-rank systems are untouched by the truncation
+    A2 = (J.T @ J).astype(np.float32); b2 = rng.normal(size=n - 2).astype(np.float32)
+    x2 = capi.damped_solve_qr_f32(A2, b2, 1e-4)
+    assert rel(x2, np.linalg.solve(A2.astype(np.float64) + 1e-4 * np.diag(np.diag(A2)), b2)) < 1e-4
+
+
+def test_tracker_lm_policy_details():
+    """(i) the Jacobian pass' error only initialises curr_error on the first iteration (update_error = curr_iter == 0,
+    camera_tracker.cpp:1166/:1491): afterwards the accepted candidate's error stands; (ii) the zero-overlap exit of
+    TrackFrame (:1515-1519) -> SAGE_E_NO_OVERLAP before any solve."""
+    import ctypes as C
+    cfg = capi.lm_config_default()
+    target = np.array([0.3, -0.2, 0.1], np.float32)
+    seen = []
+
+    def lin(p, s):
+        r = p[9:] - target
+        A = np.eye(6, dtype=np.float32); g = np.zeros(6, np.float32); g[:3] = -r
+        seen.append(len(seen))
+        # a Jacobian pass that reports a bogus error after the first iteration must not disturb the trajectory
+        return A, g, float(r @ r) if len(seen) == 1 else 1e9
+
+    def err(p, s):
+        r = p[9:] - target
+        return float(r @ r)
+
+    pose0 = capi.pack_pose(np.eye(3), np.zeros(3))
+    pose, _, e_final, iters, trace = capi.track_lm(cfg, 6, lin, err, pose0, 1.0)
+    assert len(seen) >= 2 and e_final < 1e-3 and all(t["error"] < 1e8 for t in trace)
+    cfg.no_overlap_error = 0.05
+    L = capi.lib()
+    p = pose0.copy(); fe = C.c_float(); it = C.c_int(); sc = C.c_float(1.0)
+    cb1 = capi.TRACK_LIN_FN(lambda ctx, pp, s, A, b, e: (e.__setitem__(0, 0.14), [A.__setitem__(i, 1.0 if i % 7 == 0 else 0.0) for i in range(36)],
+                                                       [b.__setitem__(i, 0.0) for i in range(6)], 0)[-1])
+    cb2 = capi.TRACK_ERR_FN(lambda ctx, pp, s, e: 1)
+    rc = L.sage_track_lm(C.byref(cfg), 6, cb1, cb2, None, p.ctypes.data_as(C.POINTER(C.c_float)), C.byref(sc),
+                         C.byref(fe), C.byref(it), None, 0, None)
+    assert rc == -5 and it.value == 0 and fe.value == pytest.approx(0.14) and np.array_equal(p, pose0)
+    assert b"overlap" in L.sage_error_string(-5)
+
+
+def test_tracker_lm_dof7_rescales_depths(orc):
+    """TrackFrame's 7th variable moves the depths of every evaluation (guess_scale_0 * unscaled_*_dpts_0,
+    camera_tracker.cpp:264,:273,:431,:453).  The photometric term alone cannot see the scale (s and t trade off exactly),
+    the match-geometry term can: the oracle-driven LM (photometric + match geometry, composed like
+    ComputeJacobianAndError :330-374) started 4 % low comes back to the true scale (low, not high: LMConvergence takes
+    the SIGNED maximum of the relative increments, :531-536, so a pure decrease counts as converged); with the depths
+    frozen at the initial scale (the r1 defect) the cost does not follow the variable and the scale runs away."""
+    w = synth.make_window(K=2, H=32, W=40, FS=16, CS=16, L=3, n_samples=400, seed=31, pose_noise=0.0)
+    a, b = w.keyframes[0], w.keyframes[1]
+    feat0s = presample_source(orc, w, a)
+    unscaled = (a.bias + a.basis @ a.code_true)[a.loc1d].astype(np.float32)
+    s_true = float(a.scale_true)
+    R10, t10 = synth.relative_pose(a.R_true, a.t_true, b.R_true, b.t_true)
+    rng = np.random.default_rng(5)
+    NK = 120
+    cam = w.cams[0]
+    xs = rng.integers(6, w.W - 6, NK); ys = rng.integers(6, w.H - 6, NK)
+    kp_homo0 = np.stack([(xs - cam.cx) / cam.fx, (ys - cam.cy) / cam.fy, np.ones(NK)], 1).astype(np.float32)
+    kp_unscaled = (a.bias + a.basis @ a.code_true)[ys * w.W + xs].astype(np.float32)
+    X1 = (R10.astype(np.float64) @ (s_true * kp_unscaled[:, None] * kp_homo0).T).T + t10
+    kp_dpts1 = X1[:, 2].astype(np.float32)
+    kp_homo1 = (X1 / X1[:, 2:3]).astype(np.float32)
+    c_mg, w_mg = 0.1 * float(np.mean(a.bias ** 2)), 3.0
+    pose0 = capi.pack_pose(R10, t10)
+    cfg = capi.lm_config_default()
+    F = np.float32
+
+    def make(frozen):
+        def sc(s):
+            return F(s_true * 0.96) if frozen else F(s)
+
+        def lin(p, s):
+            R, t = p[:9].reshape(3, 3), p[9:]
+            o = orc.tracker_photo_jac_error(7, R, t, w.mask, sc(s) * unscaled, a.homo, feat0s, b.feat_pyr,
+                                            b.grad_pyr, w.level_offsets, w.cams, w.eps, w.photo_weights, scale0=s)
+            m = orc.match_geom_jac_error(3, "fair", R, t, dpts0=sc(s) * kp_unscaled, dpts1=kp_dpts1, homo0=kp_homo0,
+                                         homo1=kp_homo1, scale0=s, loss_param=c_mg, weight=w_mg)
+            return o["AtA"].astype(F) + m["AtA"].astype(F), o["Atb"].astype(F) + m["Atb"].astype(F), o["error"] + m["error"]
+
+        def err(p, s):
+            R, t = p[:9].reshape(3, 3), p[9:]
+            return (orc.tracker_photo_error(R, t, w.mask, sc(s) * unscaled, a.homo, feat0s, b.feat_pyr, w.level_offsets,
+                                            w.cams, w.eps, w.photo_weights)[0]
+                    + orc.match_geom_error(2, "fair", R, t, dpts0=sc(s) * kp_unscaled, dpts1=kp_dpts1, homo0=kp_homo0,
+                                           homo1=kp_homo1, loss_param=c_mg, weight=w_mg))
+        return lin, err
+
+    _, s_live, e_live, _, tr_live = capi.track_lm(cfg, 7, *make(False), pose0, 0.96 * s_true)
+    assert abs(s_live / s_true - 1) < 0.01 and e_live < 0.8 * tr_live[0]["error"]
+    _, s_frozen, e_frozen, _, tr_frozen = capi.track_lm(cfg, 7, *make(True), pose0, 0.96 * s_true)
+    assert abs(s_frozen / s_true - 1) > 0.03               # the cost never sees the variable: it is not pulled back
+
+
 def test_synth_producers_match_oracle(orc):
     w = synth.make_window(K=1, H=32, W=40, FS=16, CS=16, L=3, seed=4)
     kf = w.keyframes[0]
