@@ -78,16 +78,25 @@ def window_vs_oracle(capi, orc, w, label):
     t0 = time.time()
     res32, res64 = {}, {}
     worst = [0.0, 0.0]
+    floor_hits = 0
     for l, (a, b) in enumerate(w.links):
         for d, (k0, k1) in enumerate(((a, b), (b, a))):
             for t, fn in ((0, oracle_photo), (1, oracle_geo)):
                 o32 = fn(orc, w, k0, k1, prec="f32")
+                o64 = fn(orc, w, k0, k1, prec="f64")
                 res32[(t, l, d)] = o32
-                res64[(t, l, d)] = fn(orc, w, k0, k1, prec="f64")
+                res64[(t, l, d)] = o64
                 he = win.get_edge(t, 2 * l + d)
                 ra, rb = rel(he["AtA"], o32["AtA"]), rel(he["Atb"], o32["Atb"])
                 worst = [max(worst[0], ra), max(worst[1], rb)]
-                assert ra < TOL_H and rb < TOL_H, (label, t, l, d, ra, rb)
+                assert ra < TOL_H, (label, t, l, d, ra)
+                # Atb is a sum of signed terms: near a minimum it cancels and the fp32 REFERENCE arithmetic itself is
+                # > 2e-5 away from the exact value on a few geometric edges (e.g. config 2, link 14: fp32 oracle vs fp64
+                # oracle 2.2e-5, one scale column).  There the bar is "at least as close to the exact value as the fp32
+                # oracle is" -- never looser than that
+                fl = rel(o32["Atb"], o64["Atb"])
+                floor_hits += fl >= 0.5 * TOL_H
+                assert rb < TOL_H or rel(he["Atb"], o64["Atb"]) <= fl, (label, t, l, d, rb, rel(he["Atb"], o64["Atb"]), fl)
                 assert he["num_inliers"] == o32["num_inliers"], (label, t, l, d)
                 assert he["error"] == pytest.approx(o32["error"], rel=1e-5)
     t_or = time.time() - t0
@@ -102,7 +111,7 @@ def window_vs_oracle(capi, orc, w, label):
     d32, d64 = damped_delta(H32, g32, DAMP), damped_delta(H64, g64, DAMP)
     r_h64, r_h32, r_3264 = rel(dh, d64), rel(dh, d32), rel(d32, d64)
     print(f"[{label}] K={K} {w.H}x{w.W}x{w.FS} CS={CS}: {4 * len(w.links)} edges, oracle {t_or:.0f} s; worst per-edge "
-          f"AtA {worst[0]:.1e} Atb {worst[1]:.1e}; packed {rel(packed[:-4], ref32[:-4]):.1e}; LM delta rel-L2: "
+          f"AtA {worst[0]:.1e} Atb {worst[1]:.1e} ({floor_hits} edges where the fp32 oracle's own Atb is >= 1e-5 from exact); packed {rel(packed[:-4], ref32[:-4]):.1e}; LM delta rel-L2: "
           f"hip-exact {r_h64:.2e}  hip-fp32oracle {r_h32:.2e}  fp32oracle-exact {r_3264:.2e}; cond(H_damped) "
           f"{np.linalg.cond(H64 + DAMP * np.diag(np.diag(H64))):.1e}")
     # pose / code / scale parts separately, for the record (the bar is on the whole vector)

@@ -294,3 +294,163 @@ def test_shuffle_restatement_matches_std_shuffle_golden(orc):
             h = ((h ^ v) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
         assert str(h) == c["fnv1a"], (c["seed"], c["n"])
         assert idx[:16].tolist() == c["head"]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# second batch (tests/golden/make_autograd_golden.py): world-frame pose blocks with T1 != I, code1 / scale1 columns,
+# multi-level Jacobian weighting, level-0-inlier normalisation with partially masked frames, f4 matching core
+# ---------------------------------------------------------------------------------------------------------------
+def _rot(w):
+    w = np.asarray(w, np.float64)
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def _hat(t):
+    return np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]], np.float64)
+
+
+def _adjoint_inv(R1, t1):
+    """Ad of T1^-1 = (R1^T, -R1^T t1) for twists ordered [v, omega]: a left perturbation delta0 of the WORLD pose T0 is
+    the left perturbation Ad(T1^-1) delta0 of T10 = T1^-1 T0 (and -Ad(T1^-1) delta1 for T1)."""
+    R = R1.T; t = -R1.T @ t1
+    A = np.zeros((6, 6))
+    A[:3, :3] = R; A[:3, 3:] = _hat(t) @ R; A[3:, 3:] = R
+    return A
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_world_frame_pose_blocks_for_general_T1_via_adjoint(orc, name):
+    """a1 / a4 with T1 != I (photometric_factor_kernels.cpp:258-297, geometric_factor_kernels.cpp:671-679): the
+    reference's Python rows are relative-pose rows; the C++ world-frame blocks must be those rows times Ad(T1^-1)
+    (pose0) and its negative (pose1), for any decomposition T0 = T1 T10."""
+    c = load(name)
+    H, W, N, FS, CS, cams, lo, feat1, grad1, homo = setup(c)
+    loc = c["loc"].astype(np.int64)
+    bias = np.zeros(H * W, np.float32); bias[loc] = c["bias"]
+    basis = np.zeros((H * W, CS), np.float32); basis[loc] = c["basis"]
+    feat0 = np.zeros((FS, H * W), np.float32); feat0[:, loc] = c["src_feats"]
+    R10, t10 = c["R"].astype(np.float64), c["t"].astype(np.float64)
+    for tw, t1 in (((0.3, -0.2, 0.25), (0.4, -0.3, 0.2)), ((-1.1, 0.7, 0.4), (-2.0, 1.0, 0.5))):
+        R1 = _rot(tw); t1 = np.array(t1)
+        R0 = R1 @ R10; t0 = R1 @ t10 + t1
+        Ad = _adjoint_inv(R1, t1)
+        # photometric
+        o = orc.photo_jac_error(R10, t10, R0, t0, R1, t1, bias, basis, c["code"], c["mask"], loc, homo, feat0, feat1,
+                                grad1, lo, float(c["scale"]), cams, float(c["depth_eps"]), np.ones(1, np.float32),
+                                prec="f64", want_rows=True)
+        A = c["photo_A"].reshape(N, FS, 7 + CS).astype(np.float64)
+        valid = c["photo_valid"].reshape(N) > 0.5
+        Jrel = np.concatenate([A[..., 3:6], A[..., 0:3]], -1)                   # [v, omega]
+        J = o["J"][0]
+        assert rel(J[valid][..., 0:6], Jrel[valid] @ Ad) < 2e-5
+        assert rel(J[valid][..., 6:12], -(Jrel[valid] @ Ad)) < 2e-5
+        assert rel(J[valid][..., 12:12 + CS], A[valid][..., 7:]) < 2e-5          # code / scale columns do not see T1
+        # geometric
+        loss = float(c["geo_cauchy_factor"]) * float(c["geo_mean_sq"])
+        dgrad = np.stack([c["dgx"], c["dgy"]], 0)
+        basis1 = np.zeros((H, W, CS))
+        g = orc.geo_jac_error(R10, t10, R0, t0, R1, t1, bias, basis, c["code"], c["dmap"], dgrad, basis1, c["mask"],
+                              loc, homo, float(c["scale"]), 1.0, cams[0], float(c["depth_eps"]), loss, 1.0,
+                              prec="f64", want_rows=True)
+        Ag = c["geo_A"].astype(np.float64)
+        Grel = np.concatenate([Ag[:, 3:6], Ag[:, 0:3]], -1)
+        assert rel(g["J"][:, 0:6], Grel @ Ad) < 5e-6
+        assert rel(g["J"][:, 6:12], -(Grel @ Ad)) < 5e-6
+
+
+def _central_grad_hw(img):
+    p = np.pad(img, ((1, 1), (1, 1)), mode="edge")
+    return np.stack([0.5 * (p[1:-1, 2:] - p[1:-1, :-2]), 0.5 * (p[2:, 1:-1] - p[:-2, 1:-1])], 0)
+
+
+@pytest.mark.parametrize("name", ["diffba_autograd_geo_allvalid", "diffba_autograd_geo_band"])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_geometric_gradient_matches_reference_autograd(orc, name, prec):
+    """dE/dx of the reference's compute_geometry_error (autograd, fp64) == -2 Atb of the geometric factor for ALL column
+    blocks: both world poses (T1 != I), code0, code1 (-s1 * bilinear(basis1), geometric_factor_kernels.cpp:696),
+    scale0, scale1 (-D/s1, :688), with the caller-side D1 / grad D1 precompute of geometric_factor.cpp:317-347 and the
+    weight / n_inliers normalisation (:931-947) on a partially masked frame."""
+    c = load(name)
+    H, W, N, CS = (int(c[k]) for k in ("H", "W", "N", "CS"))
+    fx, fy, cx, cy = (float(v) for v in c["intr"])
+    cam = np.array([[fx, fy, cx, cy, W, H]])
+    loc = c["loc"].astype(np.int64)
+    bias0 = np.zeros(H * W); bias0[loc] = c["bias0"]
+    basis0 = np.zeros((H * W, CS)); basis0[loc] = c["basis0"]
+    R0, t0, R1, t1 = c["R0"], c["t0"], c["R1"], c["t1"]
+    R10, t10 = R1.T @ R0, R1.T @ (t0 - t1)
+    s0, s1 = float(c["s0"]), float(c["s1"])
+    unscaled1 = c["bias1"] + c["basis1"] @ c["code1"]
+    D1 = s1 * unscaled1
+    gD1 = s1 * _central_grad_hw(unscaled1)
+    loss = float(c["cauchy_factor"]) * float(c["mean_sq"])
+    o = orc.geo_jac_error(R10, t10, R0, t0, R1, t1, bias0, basis0, c["code0"], D1, gD1, c["basis1"], c["mask"], loc,
+                          np.ascontiguousarray(c["homo"].T), s0, s1, cam[0], float(c["depth_eps"]), loss,
+                          float(c["weight"]), prec=prec)
+    tol = 1e-6 if prec == "f64" else 2e-4
+    assert o["error"] == pytest.approx(float(c["E"]), rel=1e-7 if prec == "f64" else 2e-5)
+    g = -2.0 * o["Atb"].astype(np.float64)
+    assert rel(g[0:6], c["g_pose0"]) < tol and rel(g[6:12], c["g_pose1"]) < tol
+    assert rel(g[12:12 + CS], c["g_code0"]) < tol
+    assert rel(g[12 + CS:12 + 2 * CS], c["g_code1"]) < tol                       # code1 columns
+    assert g[12 + 2 * CS] == pytest.approx(float(c["g_s0"]), rel=tol)
+    assert g[13 + 2 * CS] == pytest.approx(float(c["g_s1"]), rel=tol)            # scale1 column
+    if "band" in name:
+        assert 0 < o["num_inliers"] < N                                          # the band really masks samples
+
+
+@pytest.mark.parametrize("name", ["diffba_autograd_photo_allvalid", "diffba_autograd_photo_band"])
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+def test_multilevel_photometric_gradient_matches_reference_autograd(orc, name, prec):
+    """dE/dx of the reference's 3-level compute_photo_error (autograd, fp64) == -2 Atb of a1: the level weights inside
+    the Jacobian reduction (photometric_factor_kernels.cpp:1143-1150), the 1/n_inliers(level 0) normalisation (:1139)
+    with a masked band, the level coordinate rule in the Jacobian (fx_l, :241-245), both world-pose blocks with
+    T1 != I (:258-297), code and scale columns (:324-335)."""
+    c = load(name)
+    H, W, N, CS, FS, L = (int(c[k]) for k in ("H", "W", "N", "CS", "FS", "L"))
+    fx, fy, cx, cy = (float(v) for v in c["intr0"])
+    cams = orc.camera_pyramid([fx, fy, cx, cy, W, H], L, prec=prec)
+    offs = [0]
+    for cam in cams:
+        offs.append(offs[-1] + int(cam[4]) * int(cam[5]))
+    feat0 = np.concatenate([c[f"feat0_level{l}"].reshape(FS, -1) for l in range(L)], 1)
+    feat1 = np.concatenate([c[f"feat1_level{l}"].reshape(FS, -1) for l in range(L)], 1)
+    grads = []
+    for l in range(L):
+        lv = c[f"feat1_level{l}"]
+        grads.append(np.stack([_central_grad_hw(lv[ch]) for ch in range(FS)], 1).reshape(2, FS, -1))   # [2,FS,HW_l]
+    grad1 = np.concatenate(grads, 2)
+    loc = c["loc"].astype(np.int64)
+    bias0 = np.zeros(H * W); bias0[loc] = c["bias0"]
+    basis0 = np.zeros((H * W, CS)); basis0[loc] = c["basis0"]
+    R0, t0, R1, t1 = c["R0"], c["t0"], c["R1"], c["t1"]
+    R10, t10 = R1.T @ R0, R1.T @ (t0 - t1)
+    o = orc.photo_jac_error(R10, t10, R0, t0, R1, t1, bias0, basis0, c["code0"], c["mask"], loc,
+                            np.ascontiguousarray(c["homo"].T), feat0, feat1, grad1, np.array(offs[:-1], np.int32),
+                            float(c["s0"]), cams, float(c["depth_eps"]), c["weights"], prec=prec)
+    tol = 2e-6 if prec == "f64" else 3e-4
+    assert o["error"] == pytest.approx(float(c["E"]), rel=1e-6 if prec == "f64" else 3e-5)
+    g = -2.0 * o["Atb"].astype(np.float64)
+    assert rel(g[0:6], c["g_pose0"]) < tol and rel(g[6:12], c["g_pose1"]) < tol
+    # (the code / scale gradients are 3e-4 of the pose gradient's magnitude here: sums that cancel -> fp32 noise 1e-3)
+    assert rel(g[12:12 + CS], c["g_code0"]) < (tol if prec == "f64" else 2e-3)
+    assert g[12 + CS] == pytest.approx(float(c["g_s0"]), rel=tol if prec == "f64" else 2e-3)
+    if "band" in name:
+        assert 0 < o["num_inliers"] < N
+
+
+def test_cycle_match_matches_the_reference_tensor_expression(orc):
+    """f4: the oracle's matching core against the literal torch expression of match_geometry_factor.cpp:62-97 /
+    camera_tracker.cpp:608-633 (evaluated by the same ATen ops; torch_cycle_match.npz), incl. exactly tied descriptors:
+    torch::max returns the FIRST maximal index."""
+    z = np.load(os.path.join(GOLD, "torch_cycle_match.npz"))
+    for k in ("c0", "c1", "c2"):
+        d0, d1, kp = z[f"{k}_desc0"], z[f"{k}_desc1"], z[f"{k}_kp"]
+        C_, H, W = d0.shape
+        raw, cyc, flags = orc.cycle_match(d0, d1, kp, H, W, float(z[f"{k}_thresh"]))
+        assert np.array_equal(raw, z[f"{k}_raw"]), k
+        assert np.array_equal(cyc, z[f"{k}_cyc"]), k
+        assert np.array_equal(flags, z[f"{k}_inlier"]), k
+        assert np.array_equal(np.nonzero(flags)[0], z[f"{k}_inlier_idx"]), k
