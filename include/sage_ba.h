@@ -177,6 +177,12 @@ void sage_pose_retract(const float *pose, const float *delta6, float *out);
 /* Higham nearest-PSD of a symmetric-ish n x n matrix in double (the algorithm
  * core/mapping/mapping_utils.h:104-128 intends; see DESIGN.md for the reference's V^T S V slip). */
 int sage_nearest_psd(const double *M, int n, double *out);
+/* NearestPsd AS THE REFERENCE WROTE IT (mapping_utils.h:104-128): H = V^T diag(sigma) V with the V of Eigen 3.3.9's
+ * two-sided Jacobi SVD (its rotation sequence is restated, because the expression depends on V's sign and order
+ * conventions), then the LDLT / minimum-eigenvalue bump loop.  Reproduces the reference (fixtures generated with the
+ * vendored Eigen) wherever the reference itself is reproducible: see DESIGN.md s6 -- on the gauge-deficient systems
+ * the dense factors actually produce, a 1e-15 relative change of the input moves the reference's result by 20 %. */
+int sage_nearest_psd_reference(const double *M, int n, double *out);
 /* solve (A + damp*diag(A)) x = b, column-pivoted Householder QR in fp32 (camera_tracker.cpp:1182-1183). */
 int sage_damped_solve_qr_f32(const float *A, const float *b, int n, float damp, float *x);
 

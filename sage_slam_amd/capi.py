@@ -90,7 +90,7 @@ SYMBOLS = [
     "sage_photometric_jac_error_calculate", "sage_photometric_error_calculate",
     "sage_tracker_photo_jac_error_calculate", "sage_tracker_photo_error_calculate",
     "sage_geometric_jac_error_calculate", "sage_geometric_error_calculate", "sage_depth_and_grad",
-    "sage_gaussian_pyramid_with_grad", "sage_se3_exp", "sage_pose_retract", "sage_nearest_psd",
+    "sage_gaussian_pyramid_with_grad", "sage_se3_exp", "sage_pose_retract", "sage_nearest_psd", "sage_nearest_psd_reference",
     "sage_damped_solve_qr_f32", "sage_block_solve", "sage_lm_config_default", "sage_track_lm", "sage_track_frame",
     "sage_window_create", "sage_window_destroy", "sage_window_add_keyframe", "sage_window_add_link",
     "sage_window_set_shard", "sage_window_finalize", "sage_window_num_keyframes", "sage_window_num_links",
@@ -185,6 +185,14 @@ def nearest_psd(M):
     out = np.zeros_like(M)
     _chk(lib().sage_nearest_psd(M.ctypes.data_as(C.POINTER(C.c_double)), M.shape[0],
                                 out.ctypes.data_as(C.POINTER(C.c_double))), "sage_nearest_psd")
+    return out
+
+
+def nearest_psd_reference(M):
+    M = np.ascontiguousarray(M, np.float64)
+    out = np.zeros_like(M)
+    _chk(lib().sage_nearest_psd_reference(M.ctypes.data_as(C.POINTER(C.c_double)), M.shape[0],
+                                          out.ctypes.data_as(C.POINTER(C.c_double))), "sage_nearest_psd_reference")
     return out
 
 

@@ -261,6 +261,197 @@ extern "C" int sage_nearest_psd(const double *M, int n, double *out)
   return SAGE_OK;
 }
 
+// ---------------------------------------------------------------- NearestPsd exactly as the reference wrote it
+namespace sage
+{
+// Two-sided Jacobi SVD of a square real matrix the way Eigen 3.3.9's JacobiSVD runs it (the reference's
+// `Eigen::JacobiSVD<T> svd(B, ComputeThinV)`, mapping_utils.h:111): work = B / max|B|; sweeps over (p, q < p) while any
+// off-diagonal pair exceeds max(DBL_MIN, 2 eps * max diagonal); each pair: a left rotation that symmetrises the 2x2
+// block, then a symmetric Jacobi rotation on both sides; |diagonal| = singular values sorted descending with the columns
+// of V swapped alongside.  Only V (what `matrixV()` returns) and sigma are produced.  The point of restating the
+// procedure instead of calling any SVD: the reference's  H = V^T diag(sigma) V  is NOT invariant under the sign / order
+// conventions of V, so it can only be reproduced by walking the same rotations.
+static void eigen_jacobi_svd_v(const std::vector<double> &B, int n, std::vector<double> &V, std::vector<double> &sv)
+{
+  double scale = 0.0;
+  for (double v : B)
+    scale = std::max(scale, std::fabs(v));
+  if (scale == 0.0)
+    scale = 1.0;
+  std::vector<double> Wk(B);
+  for (double &v : Wk)
+    v /= scale;
+  V.assign((size_t)n * n, 0.0);
+  for (int i = 0; i < n; ++i)
+    V[(size_t)i * n + i] = 1.0;
+  auto W = [&](int i, int j) -> double & { return Wk[(size_t)i * n + j]; };
+  const double tiny = std::numeric_limits<double>::min(), prec = 2.0 * std::numeric_limits<double>::epsilon();
+  double max_diag = 0.0;
+  for (int i = 0; i < n; ++i)
+    max_diag = std::max(max_diag, std::fabs(W(i, i)));
+  bool finished = false;
+  while (!finished)
+  {
+    finished = true;
+    for (int p = 1; p < n; ++p)
+      for (int q = 0; q < p; ++q)
+      {
+        const double thr = std::max(tiny, prec * max_diag);
+        if (!(std::fabs(W(p, q)) > thr || std::fabs(W(q, p)) > thr))
+          continue;
+        finished = false;
+        // 2x2 block [[W(p,p), W(p,q)], [W(q,p), W(q,q)]]: rot1 makes it symmetric ...
+        double m00 = W(p, p), m01 = W(p, q), m10 = W(q, p), m11 = W(q, q);
+        double c1, s1;
+        {
+          const double t = m00 + m11, d = m10 - m01;
+          if (std::fabs(d) < tiny)
+          {
+            s1 = 0.0;
+            c1 = 1.0;
+          }
+          else
+          {
+            const double u = t / d, tmp = std::sqrt(1.0 + u * u);
+            s1 = 1.0 / tmp;
+            c1 = u / tmp;
+          }
+        }
+        {
+          const double a0 = c1 * m00 + s1 * m10, a1 = c1 * m01 + s1 * m11;
+          const double b0 = -s1 * m00 + c1 * m10, b1 = -s1 * m01 + c1 * m11;
+          m00 = a0; m01 = a1; m10 = b0; m11 = b1;
+        }
+        // ... j_right diagonalises the symmetric block (makeJacobi(x = m00, y = m01, z = m11))
+        double cr, sr;
+        {
+          const double deno = 2.0 * std::fabs(m01);
+          if (deno < tiny)
+          {
+            cr = 1.0;
+            sr = 0.0;
+          }
+          else
+          {
+            const double tau = (m00 - m11) / deno, w = std::sqrt(tau * tau + 1.0);
+            const double t = tau > 0.0 ? 1.0 / (tau + w) : 1.0 / (tau - w);
+            const double sign_t = t > 0.0 ? 1.0 : -1.0, nn = 1.0 / std::sqrt(t * t + 1.0);
+            sr = -sign_t * (m01 / std::fabs(m01)) * std::fabs(t) * nn;
+            cr = nn;
+          }
+        }
+        // j_left = rot1 * j_right^T
+        const double cl = c1 * cr + s1 * sr, sl = -c1 * sr + s1 * cr;
+        for (int k = 0; k < n; ++k) // rows p, q from the left
+        {
+          const double x = W(p, k), y = W(q, k);
+          W(p, k) = cl * x + sl * y;
+          W(q, k) = -sl * x + cl * y;
+        }
+        for (int k = 0; k < n; ++k) // columns p, q from the right (work matrix and V)
+        {
+          const double x = W(k, p), y = W(k, q);
+          W(k, p) = cr * x - sr * y;
+          W(k, q) = sr * x + cr * y;
+          const double vx = V[(size_t)k * n + p], vy = V[(size_t)k * n + q];
+          V[(size_t)k * n + p] = cr * vx - sr * vy;
+          V[(size_t)k * n + q] = sr * vx + cr * vy;
+        }
+        max_diag = std::max(max_diag, std::max(std::fabs(W(p, p)), std::fabs(W(q, q))));
+      }
+  }
+  sv.resize(n);
+  for (int i = 0; i < n; ++i)
+    sv[i] = std::fabs(W(i, i)) * scale; // (negative diagonals flip columns of U, which the reference never asks for)
+  for (int i = 0; i < n; ++i)
+  {
+    int pos = i;
+    for (int j = i + 1; j < n; ++j)
+      if (sv[j] > sv[pos])
+        pos = j;
+    if (sv[pos] == 0.0)
+      break;
+    if (pos != i)
+    {
+      std::swap(sv[i], sv[pos]);
+      for (int k = 0; k < n; ++k)
+        std::swap(V[(size_t)k * n + i], V[(size_t)k * n + pos]);
+    }
+  }
+}
+
+// Eigen::LDLT::isPositive(): the pivoted LDL^T (largest remaining |diagonal| first) meets no negative pivot
+static bool eigen_ldlt_is_positive(const std::vector<double> &M, int n)
+{
+  std::vector<double> A(M);
+  auto a = [&](int i, int j) -> double & { return A[(size_t)i * n + j]; };
+  for (int k = 0; k < n; ++k)
+  {
+    int piv = k;
+    for (int i = k + 1; i < n; ++i)
+      if (std::fabs(a(i, i)) > std::fabs(a(piv, piv)))
+        piv = i;
+    if (piv != k)
+    {
+      for (int j = 0; j < n; ++j)
+        std::swap(a(k, j), a(piv, j));
+      for (int i = 0; i < n; ++i)
+        std::swap(a(i, k), a(i, piv));
+    }
+    const double d = a(k, k);
+    if (d < 0.0)
+      return false;
+    if (d == 0.0)
+      continue;
+    for (int i = k + 1; i < n; ++i)
+    {
+      const double l = a(i, k) / d;
+      for (int j = k + 1; j < n; ++j)
+        a(i, j) -= l * a(k, j);
+    }
+  }
+  return true;
+}
+} // namespace sage
+
+extern "C" int sage_nearest_psd_reference(const double *M, int n, double *out)
+{
+  if (!M || !out || n < 1)
+    return SAGE_E_INVALID;
+  std::vector<double> B((size_t)n * n), V, sv;
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      B[(size_t)i * n + j] = (M[(size_t)i * n + j] + M[(size_t)j * n + i]) / 2;
+  sage::eigen_jacobi_svd_v(B, n, V, sv);
+  // H = V^T diag(sigma) V  (mapping_utils.h:112, as written): H_ij = sum_k sigma_k V_ki V_kj
+  std::vector<double> A3((size_t)n * n);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+    {
+      double h = 0.0;
+      for (int k = 0; k < n; ++k)
+        h += V[(size_t)k * n + i] * sv[k] * V[(size_t)k * n + j];
+      A3[(size_t)i * n + j] = (B[(size_t)i * n + j] + h) / 2;
+    }
+  std::vector<double> S(A3);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      A3[(size_t)i * n + j] = (S[(size_t)i * n + j] + S[(size_t)j * n + i]) / 2;
+  int k = 1;
+  const double spacing = 1e-15;
+  for (int it = 0; it < 60 && !sage::eigen_ldlt_is_positive(A3, n); ++it)
+  {
+    std::vector<double> t2(A3), w2, V2;
+    sage::sym_eig(t2, n, w2, V2);
+    const double mn = *std::min_element(w2.begin(), w2.end());
+    for (int i = 0; i < n; ++i)
+      A3[(size_t)i * n + i] += -mn * k + spacing;
+    k *= 2;
+  }
+  std::memcpy(out, A3.data(), sizeof(double) * n * n);
+  return SAGE_OK;
+}
+
 extern "C" int sage_damped_solve_qr_f32(const float *A, const float *b, int n, float damp, float *x)
 {
   if (!A || !b || !x || n < 1 || n > 64)

