@@ -183,6 +183,18 @@ int sage_nearest_psd(const double *M, int n, double *out);
  * vendored Eigen) wherever the reference itself is reproducible: see DESIGN.md s6 -- on the gauge-deficient systems
  * the dense factors actually produce, a 1e-15 relative change of the input moves the reference's result by 20 %. */
 int sage_nearest_psd_reference(const double *M, int n, double *out);
+/* a6 / a7: the HessianFactor blocks of one per-edge system, as PhotometricFactor::linearize
+ * (core/gtsam/photometric_factor.cpp:142-218: keys {p0, p1, c0, s0}, block sizes {6, 6, CS, 1}) and
+ * GeometricFactor::linearize (core/gtsam/geometric_factor.cpp:120-218: keys {p0, p1, c0, c1, s0, s1}, sizes
+ * {6, 6, CS, CS, 1, 1}) cut them: AtA (fp32, row-major D x D, HOST) is widened to double, passed through NearestPsd
+ * (psd_mode 0: none, 1: sage_nearest_psd, 2: sage_nearest_psd_reference = as the reference wrote it) and split into
+ * the upper-triangular blocks G_ij, i <= j, in the order the reference pushes them (G11 G12 .. G1n G22 ..), each
+ * block row-major, concatenated in G_out (sage_factor_block_count doubles); g_out receives Atb widened (D doubles: the
+ * g_i are its consecutive segments).  type 0 = photometric (D = 13 + CS), 1 = geometric (D = 14 + 2 CS).
+ * dims_out (optional, 6 ints) receives the key dimensions, *nkeys_out their number. */
+int sage_factor_block_count(int type, int CS);
+int sage_factor_hessian_blocks(int type, int CS, const float *AtA_host, const float *Atb_host, int psd_mode,
+                               double *G_out, double *g_out, int32_t *dims_out, int32_t *nkeys_out);
 /* solve (A + damp*diag(A)) x = b, column-pivoted Householder QR in fp32 (camera_tracker.cpp:1182-1183). */
 int sage_damped_solve_qr_f32(const float *A, const float *b, int n, float damp, float *x);
 

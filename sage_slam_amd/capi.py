@@ -90,7 +90,7 @@ SYMBOLS = [
     "sage_photometric_jac_error_calculate", "sage_photometric_error_calculate",
     "sage_tracker_photo_jac_error_calculate", "sage_tracker_photo_error_calculate",
     "sage_geometric_jac_error_calculate", "sage_geometric_error_calculate", "sage_depth_and_grad",
-    "sage_gaussian_pyramid_with_grad", "sage_se3_exp", "sage_pose_retract", "sage_nearest_psd", "sage_nearest_psd_reference",
+    "sage_gaussian_pyramid_with_grad", "sage_se3_exp", "sage_pose_retract", "sage_nearest_psd", "sage_nearest_psd_reference", "sage_factor_block_count", "sage_factor_hessian_blocks",
     "sage_damped_solve_qr_f32", "sage_block_solve", "sage_lm_config_default", "sage_track_lm", "sage_track_frame",
     "sage_window_create", "sage_window_destroy", "sage_window_add_keyframe", "sage_window_add_link",
     "sage_window_set_shard", "sage_window_finalize", "sage_window_num_keyframes", "sage_window_num_links",
@@ -194,6 +194,27 @@ def nearest_psd_reference(M):
     _chk(lib().sage_nearest_psd_reference(M.ctypes.data_as(C.POINTER(C.c_double)), M.shape[0],
                                           out.ctypes.data_as(C.POINTER(C.c_double))), "sage_nearest_psd_reference")
     return out
+
+
+def factor_hessian_blocks(type_: int, CS: int, AtA, Atb, psd_mode: int = 1):
+    """sage_factor_hessian_blocks -> (dict {(i, j): G_ij}, [g_i], dims): the HessianFactor blocks of a per-edge system."""
+    L = lib()
+    A = _f32(AtA); b = _f32(Atb)
+    n = L.sage_factor_block_count(type_, CS)
+    if n < 0:
+        raise SageError(n, "sage_factor_block_count")
+    G = np.zeros(n, np.float64); g = np.zeros(b.size, np.float64)
+    dims = (C.c_int32 * 6)(); nk = C.c_int32()
+    _chk(L.sage_factor_hessian_blocks(type_, CS, _fp(A), _fp(b), psd_mode, G.ctypes.data_as(C.POINTER(C.c_double)),
+                                      g.ctypes.data_as(C.POINTER(C.c_double)), dims, C.byref(nk)),
+         "sage_factor_hessian_blocks")
+    dims = [int(dims[i]) for i in range(nk.value)]
+    blocks, o = {}, 0
+    for i in range(nk.value):
+        for j in range(i, nk.value):
+            blocks[(i, j)] = G[o:o + dims[i] * dims[j]].reshape(dims[i], dims[j]); o += dims[i] * dims[j]
+    offs = np.concatenate([[0], np.cumsum(dims)])
+    return blocks, [g[offs[i]:offs[i + 1]] for i in range(nk.value)], dims
 
 
 def damped_solve_qr_f32(A, b, damp):

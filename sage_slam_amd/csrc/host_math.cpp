@@ -452,6 +452,76 @@ extern "C" int sage_nearest_psd_reference(const double *M, int n, double *out)
   return SAGE_OK;
 }
 
+// ---------------------------------------------------------------- HessianFactor blocks (a6 / a7)
+static int factor_dims(int type, int CS, int dims[6])
+{
+  if (CS < 1 || (type != 0 && type != 1))
+    return 0;
+  if (type == 0)
+  {
+    const int d[4] = {6, 6, CS, 1};
+    std::copy(d, d + 4, dims);
+    return 4;
+  }
+  const int d[6] = {6, 6, CS, CS, 1, 1};
+  std::copy(d, d + 6, dims);
+  return 6;
+}
+
+extern "C" int sage_factor_block_count(int type, int CS)
+{
+  int dims[6];
+  const int nk = factor_dims(type, CS, dims);
+  if (!nk)
+    return SAGE_E_INVALID;
+  int total = 0;
+  for (int i = 0; i < nk; ++i)
+    for (int j = i; j < nk; ++j)
+      total += dims[i] * dims[j];
+  return total;
+}
+
+extern "C" int sage_factor_hessian_blocks(int type, int CS, const float *AtA, const float *Atb, int psd_mode,
+                                          double *G_out, double *g_out, int32_t *dims_out, int32_t *nkeys_out)
+{
+  int dims[6];
+  const int nk = factor_dims(type, CS, dims);
+  if (!nk || !AtA || !Atb || !G_out || !g_out || psd_mode < 0 || psd_mode > 2)
+    return SAGE_E_INVALID;
+  int D = 0, off[6];
+  for (int i = 0; i < nk; ++i)
+  {
+    off[i] = D;
+    D += dims[i];
+  }
+  std::vector<double> M((size_t)D * D), C((size_t)D * D);
+  for (size_t i = 0; i < M.size(); ++i)
+    M[i] = (double)AtA[i]; // AtA_.cast<double>() (photometric_factor.cpp:305, :142)
+  int rc = SAGE_OK;
+  if (psd_mode == 1)
+    rc = sage_nearest_psd(M.data(), D, C.data());
+  else if (psd_mode == 2)
+    rc = sage_nearest_psd_reference(M.data(), D, C.data());
+  else
+    C = M;
+  if (rc)
+    return rc;
+  double *o = G_out;
+  for (int i = 0; i < nk; ++i)
+    for (int j = i; j < nk; ++j)
+      for (int r = 0; r < dims[i]; ++r)
+        for (int c = 0; c < dims[j]; ++c)
+          *o++ = C[(size_t)(off[i] + r) * D + off[j] + c];
+  for (int i = 0; i < D; ++i)
+    g_out[i] = (double)Atb[i];
+  if (dims_out)
+    for (int i = 0; i < nk; ++i)
+      dims_out[i] = dims[i];
+  if (nkeys_out)
+    *nkeys_out = nk;
+  return SAGE_OK;
+}
+
 extern "C" int sage_damped_solve_qr_f32(const float *A, const float *b, int n, float damp, float *x)
 {
   if (!A || !b || !x || n < 1 || n > 64)

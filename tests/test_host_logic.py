@@ -104,6 +104,28 @@ def test_nearest_psd_as_written_matches_eigen_fixture():
     assert rel(hb, ha) < 1e-12                                          # the intended projection is stable there
 
 
+@pytest.mark.parametrize("type_,CS", [(0, 16), (0, 32), (1, 16), (1, 32)])
+def test_factor_hessian_blocks_follow_the_reference_partition(type_, CS):
+    """a6 / a7: block partition of PhotometricFactor::linearize (photometric_factor.cpp:142-218, keys {p0,p1,c0,s0}) and
+    GeometricFactor::linearize (geometric_factor.cpp:120-218, keys {p0,p1,c0,c1,s0,s1}): G_ij = corrected_AtA.block(off_i,
+    off_j, d_i, d_j) for i <= j in push order, g_i = Atb segments, after NearestPsd on the double-widened AtA."""
+    rng = np.random.default_rng(CS + type_)
+    dims = [6, 6, CS, 1] if type_ == 0 else [6, 6, CS, CS, 1, 1]
+    D = sum(dims)
+    J = rng.normal(size=(3 * D, D)).astype(np.float32)
+    AtA = (J.T @ J).astype(np.float32); Atb = rng.normal(size=D).astype(np.float32)
+    offs = np.concatenate([[0], np.cumsum(dims)])
+    for mode, fn in ((0, lambda M: M), (1, capi.nearest_psd), (2, capi.nearest_psd_reference)):
+        blocks, gs, d = capi.factor_hessian_blocks(type_, CS, AtA, Atb, mode)
+        assert d == dims and len(blocks) == len(dims) * (len(dims) + 1) // 2
+        Cm = fn(AtA.astype(np.float64))
+        for (i, j), G in blocks.items():
+            assert np.array_equal(G, Cm[offs[i]:offs[i + 1], offs[j]:offs[j + 1]]), (mode, i, j)
+        for i, g in enumerate(gs):
+            assert np.array_equal(g, Atb[offs[i]:offs[i + 1]].astype(np.float64))
+    assert list(blocks.keys()) == [(i, j) for i in range(len(dims)) for j in range(i, len(dims))]   # G11 G12 .. G22 ..
+
+
 def test_damped_qr_solve():
     rng = np.random.default_rng(2)
     for n in (6, 7):
