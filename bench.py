@@ -95,6 +95,124 @@ def cpu_baseline(win, budget_s: float = 20.0):
                 lm_iters_per_sec=(1.0 / (t_used / n_edges * 2 * len(w.links))))
 
 
+def edge_mode(capi, synth, torch):
+    """Latency of the drop-in path: what ISAM2 / the tracker call one factor at a time -- reference
+    defaults N = 3072 samples of a 64x80x16 keyframe, CS 16 and 32, samples in the reference's shuffled order
+    (mapper.cpp:1326-1340) and raster-sorted (sage_sort_locations) -- and one full BASELINE config-1 tracker frame
+    (<= 40 LM iterations, TrackNewFrame = photometric + reprojection, TrackFrame = photometric + match geometry with
+    scale).  Every call ends with the host reading `error` (stream synchronise), like the reference's .item<float>().
+    The CPU port (oracle) runs the same calls on the host cores beside it."""
+    import ctypes as C
+    from oracle import oracle as orc
+    from tests.helpers import presample_source
+    orc.build()
+    L = capi.lib()
+    H, W, FS, NS, REP = 64, 80, 16, 3072, 200
+    ws = capi.Workspace()
+    res = {}
+    f = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).cuda()
+
+    def timeit(fn, rep=REP):
+        for _ in range(10):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(rep):
+            fn()
+        torch.cuda.synchronize()
+        return 1e6 * (time.perf_counter() - t0) / rep
+
+    # ctypes overhead of a call of this arity (NULL workspace -> SAGE_E_INVALID before anything runs)
+    noop = lambda: L.sage_photometric_jac_error_calculate(None, *([None] * 19), C.c_float(1), None, C.c_float(0), None, 0, 16, 32)
+    res["ctypes_noop_us"] = timeit(noop, 2000)
+    for CS in (16, 32):
+        w = synth.make_window(K=2, H=H, W=W, FS=FS, CS=CS, L=4, n_samples=NS, seed=0)
+        a, b = w.keyframes
+        pyr = capi.make_pyramid(w.cams[0], w.L)
+        mask = f(w.mask)
+        R10, t10 = synth.relative_pose(a.R, a.t, b.R, b.t)
+        small = f(np.concatenate([np.asarray(x, np.float32).reshape(-1) for x in (R10, t10, a.R, a.t, b.R, b.t, a.code)]))
+        base = small.data_ptr()
+        sp = lambda off: C.c_void_p(base + 4 * off)
+        kb = capi.DeviceKeyframe(b, H, W)
+        dpt1, dgrad1 = capi.depth_and_grad(ws, kb.bias, kb.basis, b.code, b.scale, H, W, CS)
+        wts = np.ascontiguousarray(w.photo_weights, np.float32)
+        wp = wts.ctypes.data_as(C.POINTER(C.c_float))
+        for order in ("shuffled", "sorted"):
+            ka = capi.DeviceKeyframe(a, H, W)
+            if order == "sorted":
+                lo, ho, ok = capi.sort_locations(ws, ka.loc1d, ka.homo, H, W)
+                ka.loc1d, ka.homo = lo, ho
+                ka.loc1d_i32 = lo.to(torch.int32)
+            Dp, Dg = 13 + CS, 14 + 2 * CS
+            AtA = torch.empty(Dg * Dg, device="cuda"); Atb = torch.empty(Dg, device="cuda")
+            err = C.c_float(); nin = C.c_float()
+            d = capi.dptr
+            calls = {
+                "photometric_jac_error": lambda: L.sage_photometric_jac_error_calculate(
+                    ws.h, d(AtA), d(Atb), C.byref(err), C.byref(nin), sp(0), sp(9), sp(12), sp(21), sp(24), sp(33),
+                    d(ka.bias), d(ka.basis), sp(36), d(mask), d(ka.loc1d), d(ka.homo), d(ka.feat_pyr), d(kb.feat_pyr),
+                    d(kb.grad_pyr), C.c_float(a.scale), C.byref(pyr), C.c_float(w.eps), wp, ka.N, FS, CS),
+                "photometric_error": lambda: L.sage_photometric_error_calculate(
+                    ws.h, C.byref(err), C.byref(nin), sp(0), sp(9), d(ka.bias), d(ka.basis), sp(36), d(mask),
+                    d(ka.loc1d), d(ka.homo), d(ka.feat_pyr), d(kb.feat_pyr), C.c_float(a.scale), C.byref(pyr),
+                    C.c_float(w.eps), wp, ka.N, FS, CS),
+                "geometric_jac_error": lambda: L.sage_geometric_jac_error_calculate(
+                    ws.h, d(AtA), d(Atb), C.byref(err), C.byref(nin), sp(0), sp(9), sp(12), sp(21), sp(24), sp(33),
+                    d(ka.bias), d(ka.basis), sp(36), d(dpt1), d(dgrad1), d(kb.basis), d(mask), d(ka.loc1d_i32),
+                    d(ka.homo), C.c_float(a.scale), C.c_float(b.scale), C.byref(pyr.cam[0]), C.c_float(w.eps),
+                    C.c_float(w.geo_loss_param), C.c_float(w.geo_weight), ka.N, CS),
+                "geometric_error": lambda: L.sage_geometric_error_calculate(
+                    ws.h, C.byref(err), C.byref(nin), sp(0), sp(9), d(ka.bias), d(ka.basis), sp(36), d(dpt1), d(mask),
+                    d(ka.loc1d_i32), d(ka.homo), C.c_float(a.scale), C.byref(pyr.cam[0]), C.c_float(w.eps),
+                    C.c_float(w.geo_loss_param), C.c_float(w.geo_weight), ka.N, CS),
+            }
+            for name, fn in calls.items():
+                assert fn() == 0, name
+                res[f"{name}_CS{CS}_{order}_us"] = timeit(fn)
+        # the same four calls through the CPU port (default OpenMP threads), CS as above, once per CS
+        t = {}
+        for name, fn in {
+            "photometric_jac_error": lambda: orc.photo_jac_error(R10, t10, a.R, a.t, b.R, b.t, a.bias, a.basis, a.code, w.mask, a.loc1d, a.homo, a.feat_pyr, b.feat_pyr, b.grad_pyr, w.level_offsets, a.scale, w.cams, w.eps, w.photo_weights),
+            "geometric_jac_error": lambda: orc.geo_jac_error(R10, t10, a.R, a.t, b.R, b.t, a.bias, a.basis, a.code, *synth.depth_and_grad(b, H, W), b.basis.reshape(H, W, CS), w.mask, a.loc1d, a.homo, a.scale, b.scale, w.cams[0], w.eps, w.geo_loss_param, w.geo_weight),
+        }.items():
+            fn()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                fn()
+            res[f"cpu_port_{name}_CS{CS}_us"] = 1e6 * (time.perf_counter() - t0) / 5
+    # ---- one tracker frame (config 1: CS 32) ----
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tests.test_gpu_tracker import Scene
+    sc = Scene(capi, orc)
+    cfg = capi.lm_config_default()
+    for name, dof, up, uk in (("TrackNewFrame_photo+reproj", 6, True, True), ("TrackNewFrame_photo", 6, True, False),
+                              ("TrackFrame_photo+matchgeom", 7, True, True)):
+        prob = sc.problem(dof, up, uk)
+        s0 = float(sc.s_true) * (0.96 if dof == 7 else 1.0)
+        rc, _, _, _, iters, tr = capi.track_frame(cfg, dof, prob, sc.start_pose(), s0)
+        assert rc == 0
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            capi.track_frame(cfg, dof, prob, sc.start_pose(), s0)
+        ms = 1e3 * (time.perf_counter() - t0) / 20
+        lin, errf = sc.oracle_callbacks(dof, up, uk)
+        t0 = time.perf_counter()
+        capi.track_lm(cfg, dof, lin, errf, sc.start_pose(), s0)
+        cpu_ms = 1e3 * (time.perf_counter() - t0)
+        res[name] = dict(ms_per_frame=ms, lm_iterations=iters, candidate_evaluations=len(tr), cpu_port_ms_per_frame=cpu_ms)
+    sc.close()
+    ws.close()
+    key = "photometric_jac_error_CS32_sorted_us"
+    return {"metric": "us per drop-in operator call (photometric linearize, N=3072, 64x80x16, CS 32, raster-sorted samples)",
+            "value": res[key], "unit": "us/call", "n_gpus": 1, "steps": REP, "warmup": 10, "ms_per_step": res[key] / 1e3,
+            "higher_is_better": False, "scaling": "n/a", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 1: 2-keyframe tracker BA / per-edge operator API at the reference defaults "
+                                   "(64x80x16 feature maps, N = 3072 samples, CS 16 and 32)"},
+            "edge": res}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -106,7 +224,29 @@ def main():
     ap.add_argument("--fs", type=int, default=16)
     ap.add_argument("--cs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", type=int, default=0,
+                    help="BASELINE.json configuration 1..5 (1 = tracker frame -> --mode edge; 3 = the headline window = default)")
+    ap.add_argument("--mode", choices=["window", "edge"], default="window",
+                    help="edge: latency of the drop-in per-edge operator API and of a full tracker frame (config 1)")
     args = ap.parse_args()
+    loops = []
+    synth_kw = {}
+    if args.config == 1:
+        args.mode = "edge"
+    elif args.config == 2:
+        args.keyframes, args.height, args.width, args.fs, args.cs = 16, 128, 160, 16, 32
+    elif args.config == 4:
+        args.keyframes, args.height, args.width, args.fs, args.cs = 16, 256, 320, 32, 32
+    elif args.config == 5:
+        args.keyframes, args.height, args.width, args.fs, args.cs = 512, 64, 80, 16, 32
+        synth_kw = dict(n_samples=3072, loop_radius=0.12)
+        loops = [(0, 511), (2, 509), (1, 510), (0, 256), (100, 130)]
+
+    # the driver reads ONE JSON line from stdout: libraries that print banners to fd 1 (RCCL prints its version block at
+    # communicator teardown) are sent to stderr; the JSON line goes out through the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -135,7 +275,14 @@ def main():
     # one process per GPU: stay on the NUMA node the GPU hangs off (the window solve reads freshly DMA'd pinned memory)
     if os.environ.get("SAGE_BENCH_NO_BIND") != "1":
         capi.bind_thread_to_device(dev_index)
-    win_h = synth.make_window(K=args.keyframes, H=args.height, W=args.width, FS=args.fs, CS=args.cs, L=4, seed=0)
+    if args.mode == "edge":
+        out = edge_mode(capi, synth, torch)
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        return
+    win_h = synth.make_window(K=args.keyframes, H=args.height, W=args.width, FS=args.fs, CS=args.cs, L=4, seed=0,
+                              **synth_kw)
+    for lk in loops:
+        win_h.links.append(lk)
     win = capi.Window(win_h, rank=rank, world=world)
     packed = win.packed_tensor()
     errt = win.error_tensor()
@@ -159,8 +306,32 @@ def main():
     # SAGE_BENCH_PY_STEPS=1 (dev knob): drive the sharded window from Python call by call instead of through
     # sage_window_lm_step + the all-reduce hook
     py_steps = os.environ.get("SAGE_BENCH_PY_STEPS") == "1"
+    rccl_comm = None
+    collective = "none"
     if dist is not None and not py_steps:
-        win.set_allreduce(dist)
+        if one_dev or os.environ.get("SAGE_BENCH_TORCH_ALLREDUCE") == "1":
+            win.set_allreduce(dist)                      # torch.distributed hook (gloo on one device / dev knob)
+            collective = "torch.distributed.all_reduce hook"
+        else:
+            # native RCCL: rank 0 draws the unique id, torch.distributed only ferries its 128 bytes; from here on the
+            # two all-reduces of an LM iteration are ncclAllReduce calls issued by the C++ host on the window's stream.
+            # Every rank first probes that the engine found an RCCL to bind; the ranks agree (MIN) before committing.
+            try:
+                uid = capi.rccl_unique_id()
+                have = 1
+            except Exception:
+                uid, have = bytes(128), 0
+            flag = torch.tensor([have], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                t = torch.tensor(list(uid), dtype=torch.uint8, device="cuda")
+                dist.broadcast(t, 0)
+                rccl_comm = capi.rccl_comm_create(bytes(t.cpu().tolist()), rank, world)
+                win.use_rccl(rccl_comm)
+                collective = "native ncclAllReduce (RCCL) on the window's stream"
+            else:
+                win.set_allreduce(dist)
+                collective = "torch.distributed.all_reduce hook (no librccl found by the engine)"
 
     def lm_step():
         nonlocal damp
@@ -228,7 +399,7 @@ def main():
         ach = px_launch * bytes_photo_px / (ms_photo * 1e-3) / 1e9 if ms_photo > 0 else 0.0
         ach_geo = px_launch * bytes_geo_px / (ms_geo * 1e-3) / 1e9 if ms_geo > 0 else 0.0
         out = {
-            "metric": "M residuals/sec (+ LM iters/sec), 64-keyframe feature-metric BA @128x160",
+            "metric": f"M residuals/sec (+ LM iters/sec), {args.keyframes}-keyframe feature-metric BA @{args.height}x{args.width}",
             "value": residuals_per_step * args.steps / elapsed / 1e6,
             "unit": "Mresiduals/s",
             "lm_iters_per_sec": args.steps / elapsed,
@@ -241,6 +412,7 @@ def main():
                                    f"{len(win_h.links)} links = {n_dir} photometric + {n_dir} geometric directed edges",
                        "residuals_per_step": residuals_per_step,
                        "parallelism": f"edge-shard x{world}" if world > 1 else "single GPU",
+                       "collective": collective,
                        "lm": "1 linearize + 1 solve (device scatter/retract, host block Cholesky) + 1 error pass per step",
                        "accepted_steps": int(sum(1 for h in hist[args.warmup:] if h[2])),
                        "error_first_last": [hist[0][0], hist[-1][1]]},
@@ -259,8 +431,10 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(win_h)
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     win.close()
+    if rccl_comm is not None:
+        capi.rccl_comm_destroy(rccl_comm)
     if dist is not None:
         dist.destroy_process_group()
 

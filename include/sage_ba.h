@@ -475,6 +475,18 @@ int sage_sample_locations(SageWorkspace *ws, const int64_t *valid_loc1d_dev, con
 typedef int (*SageAllReduceFn)(double *dev_buf, size_t n, void *user);
 int sage_window_set_allreduce(SageWindow *w, SageAllReduceFn fn, void *user);
 
+/* Native collective: RCCL (backend of record on MI355X: ring / tree over xGMI) bound at run time.  One process per GPU:
+ *   rank 0:  sage_rccl_unique_id(id);   broadcast the 128 bytes by any means (MPI, a socket, torch.distributed);
+ *   every rank, with its GPU current:   sage_rccl_comm_create(id, rank, world, &comm);
+ *   sage_window_use_rccl(win, comm)     -> the window's two all-reduces per LM iteration become
+ *        ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, comm, <the window's stream>)   -- no Python, no torch in the loop.
+ * `comm` may equally be an ncclComm_t the host application already owns.  SAGE_E_UNSUPPORTED when no librccl is found. */
+#define SAGE_RCCL_ID_BYTES 128
+int sage_rccl_unique_id(unsigned char *id128);
+int sage_rccl_comm_create(const unsigned char *id128, int rank, int world, void **comm_out);
+void sage_rccl_comm_destroy(void *comm);
+int sage_window_use_rccl(SageWindow *w, void *nccl_comm);
+
 /* one full LM iteration: linearize -> (all-reduce) -> solve -> error at candidate -> (all-reduce) -> accept/reject
  * (policy of camera_tracker.cpp:1156-1279).  Sharded windows need sage_window_set_allreduce first. */
 typedef struct SageLmState

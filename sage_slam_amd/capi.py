@@ -98,7 +98,7 @@ SYMBOLS = [
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_set_allreduce", "sage_sort_locations", "sage_bind_thread_to_device",
+    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_set_allreduce", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_sort_locations", "sage_bind_thread_to_device",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
@@ -561,6 +561,10 @@ class Window:
         self._allreduce_cb = ALLREDUCE_FN(hook)    # keep the trampoline alive as long as the window
         _chk(lib().sage_window_set_allreduce(self.h, self._allreduce_cb, None), "sage_window_set_allreduce")
 
+    def use_rccl(self, comm):
+        """native RCCL all-reduce on the window's stream (sage_window_use_rccl); comm from rccl_comm_create()."""
+        _chk(lib().sage_window_use_rccl(self.h, C.c_void_p(comm)), "sage_window_use_rccl")
+
     def lm_step(self, state: SageLmState, cfg: SageLmConfig):
         _chk(lib().sage_window_lm_step(self.h, C.byref(state), C.byref(cfg)), "sage_window_lm_step")
         return state
@@ -626,6 +630,24 @@ def _tensor_from_ptr(ptr: int, n: int):
 
 # --------------------------------------------------------------------------- host-side window algebra
 # (pure numpy; used by the multi-process CPU tests of the sharded reduction and by parity tests)
+def rccl_unique_id() -> bytes:
+    buf = (C.c_ubyte * 128)()
+    _chk(lib().sage_rccl_unique_id(buf), "sage_rccl_unique_id")
+    return bytes(buf)
+
+
+def rccl_comm_create(uid: bytes, rank: int, world: int) -> int:
+    """ncclCommInitRank on the current device -> opaque communicator handle (int)."""
+    buf = (C.c_ubyte * 128).from_buffer_copy(uid)
+    comm = C.c_void_p()
+    _chk(lib().sage_rccl_comm_create(buf, rank, world, C.byref(comm)), "sage_rccl_comm_create")
+    return comm.value
+
+
+def rccl_comm_destroy(comm: int):
+    lib().sage_rccl_comm_destroy(C.c_void_p(comm))
+
+
 def shard_links(nlinks: int, rank: int, world: int) -> List[int]:
     """link ownership rule of ``sage_window_set_shard``: rank r owns the contiguous range
     [r*n/world, (r+1)*n/world) of the link list."""

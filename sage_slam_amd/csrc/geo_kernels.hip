@@ -145,8 +145,10 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
     {
     const int tile = wi.tile + h;
     const int n = tile * kTile + wq * 64 + lane;
-    const bool in_range = n < N;
-    const int my_loc = in_range ? gload_loc(E.loc, E.loc_is_i64, n) : 0;
+    bool in_range = n < N;
+    int my_loc = in_range ? gload_loc(E.loc, E.loc_is_i64, n) : 0;
+    in_range = in_range && (unsigned)my_loc < (unsigned)(W * H); // a location outside the image is dropped, not read
+    my_loc = in_range ? my_loc : 0;
     // depth of the source pixel: s0*(bias + basis.code), read from the keyframe's depth map (:514-521)
     const float d0 = in_range ? E.dpt0[my_loc] : 1.0f;
 

@@ -150,8 +150,12 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   {
   const int tile = wi.tile + sub;
   const int n = tile * kTile + tid;
-  const bool in_range = n < N;
-  const int my_loc = in_range ? load_loc(E.loc, E.loc_is_i64, n) : 0;
+  bool in_range = n < N;
+  int my_loc = in_range ? load_loc(E.loc, E.loc_is_i64, n) : 0;
+  // a location outside the image is dropped here (the window engine and sage_sort_locations reject it up front; the
+  // reference's tensor index() would throw): no out-of-bounds read of the depth map / basis rows
+  in_range = in_range && (unsigned)my_loc < (unsigned)(W0 * H0);
+  my_loc = in_range ? my_loc : 0;
   // depth of the source pixel: s0*(bias + basis.code), read from the keyframe's depth map (:1094-1095)
   const float d = in_range ? E.dpt0[my_loc] : 1.0f;
 
@@ -206,7 +210,10 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         dof[k] = (lo + (uint32_t)td.off[k]) * 16u;
-      float g00 = 0.f, g01 = 0.f, g11 = 0.f, a0 = 0.f, a1 = 0.f, ee = 0.f; // level accumulators (:200-236)
+      // level accumulators (:200-236) as channel PAIRS: every update below is one v_pk_fma_f32 on naturally aligned
+      // register pairs of the interpolated quads; the level's fx_l / fy_l scaling (h = (fx_l gx, fy_l gy)) is applied once
+      // to the five sums instead of to every channel
+      f32x2 q00 = {0.f, 0.f}, q01 = q00, q11 = q00, qa0 = q00, qa1 = q00, qee = q00;
       for (int g = 0; g < NG; ++g)
       {
         const uint32_t soff = (uint32_t)g * plane * 4u;
@@ -234,31 +241,35 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
             gy += td.w[k] * B.ty[k];
           }
         }
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
+        const f32x4 d4 = B.f0 - f1;
+        const f32x2 dl = {d4[0], d4[1]}, dh = {d4[2], d4[3]};
+        qee += dl * dl;
+        qee += dh * dh;
+        if (JAC)
         {
-          const float diff = B.f0[c] - f1[c];
-          ee += diff * diff;
-          if (JAC)
-          {
-            const float hx = fxl * gx[c], hy = fyl * gy[c];
-            g00 += hx * hx;
-            g01 += hx * hy;
-            g11 += hy * hy;
-            a0 += hx * diff;
-            a1 += hy * diff;
-          }
+          const f32x2 xl = {gx[0], gx[1]}, xh = {gx[2], gx[3]}, yl = {gy[0], gy[1]}, yh = {gy[2], gy[3]};
+          q00 += xl * xl;
+          q00 += xh * xh;
+          q01 += xl * yl;
+          q01 += xh * yh;
+          q11 += yl * yl;
+          q11 += yh * yh;
+          qa0 += xl * dl;
+          qa0 += xh * dh;
+          qa1 += yl * dl;
+          qa1 += yh * dh;
         }
       }
       const float wl = prm.w[l];
-      err += wl * ee;
+      err += wl * (qee[0] + qee[1]);
       if (JAC)
       {
-        G00 += wl * g00;
-        G01 += wl * g01;
-        G11 += wl * g11;
-        v0 += wl * a0;
-        v1 += wl * a1;
+        const float wx = wl * fxl, wy = wl * fyl;
+        G00 += (wx * fxl) * (q00[0] + q00[1]);
+        G01 += (wx * fyl) * (q01[0] + q01[1]);
+        G11 += (wy * fyl) * (q11[0] + q11[1]);
+        v0 += wx * (qa0[0] + qa0[1]);
+        v1 += wy * (qa1[0] + qa1[1]);
       }
     }
   }
@@ -500,22 +511,17 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     return;
   }
 
-  // ---- cross-wave sum in a fixed order (deterministic), (NT+1)*256 floats in the (now idle) stash memory ----
-  for (int w = 0; w < kWaves; ++w)
-  {
-    __syncthreads();
-    if (wave == w)
-    {
+  // ---- cross-wave sum in a fixed order (deterministic): every wave dumps its tiles into its own slice of the (now idle)
+  //      stash memory, one barrier, then all threads add the four slices as ((w0 + w1) + w2) + w3 on their way out to the
+  //      partial record (a round of barriers per wave used to cost ~8 % of a one-sub-tile workgroup) ----
+  constexpr int SLICE = (NT + 1) * 256;
+  static_assert(!JAC || kWaves * SLICE <= STASH, "cross-wave sum slices must fit the stash");
+  __syncthreads(); // the other waves may still be reading their stash (phase D)
 #pragma unroll
-      for (int t = 0; t < NT + 1; ++t)
+  for (int t = 0; t < NT + 1; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-        {
-          float *qd = s_mem + t * 256 + r * 64 + lane;
-          *qd = (w == 0) ? acc[t][r] : *qd + acc[t][r];
-        }
-    }
-  }
+    for (int r = 0; r < 4; ++r)
+      s_mem[wave * SLICE + t * 256 + r * 64 + lane] = acc[t][r];
   {
     const float se = wave_sum(err_acc), sn = wave_sum(vm_acc), sd = wave_sum(sdd_acc);
     if (lane == 63)
@@ -526,12 +532,16 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     }
   }
   __syncthreads();
+  auto tsum = [&](int idx) { // element idx of the summed tiles
+    return ((s_mem[idx] + s_mem[SLICE + idx]) + s_mem[2 * SLICE + idx]) + s_mem[3 * SLICE + idx];
+  };
+  static_assert(kWaves == 4, "tsum adds four slices");
   float *out = prm.partials + (size_t)blockIdx.x * photo_partial_floats(CS);
   if (tid < kPhotoScalars)
   {
     // scalar slots of the partial record (layout unchanged): [0..20] Q^T G Q (upper triangle), [21..26] Q^T G q6 d,
     // [27] sigma d^2, [28..33] Q^T v, [34] q6^T v d, [35] error, [36] inliers.  Pose tile element (row r of A, col c of B):
-    auto yy = [&](int r, int c) { return s_mem[YY * 256 + (r & 3) * 64 + ((r >> 2) * 16 + c)]; };
+    auto yy = [&](int r, int c) { return tsum(YY * 256 + (r & 3) * 64 + ((r >> 2) * 16 + c)); };
     float a = 0.f;
     if (tid < 21)
     {
@@ -561,10 +571,10 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   }
   if (prm.sig_cnt)
     for (int idx = tid; idx < NT * 256; idx += kBlock)
-      __hip_atomic_store(out + kPhotoScalars + idx, s_mem[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(out + kPhotoScalars + idx, tsum(idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   else
     for (int idx = tid; idx < NT * 256; idx += kBlock)
-      out[kPhotoScalars + idx] = s_mem[idx];
+      out[kPhotoScalars + idx] = tsum(idx);
   if (prm.sig_cnt)
   {
     // this workgroup's partial record is complete: agent-scope release, then count it; the

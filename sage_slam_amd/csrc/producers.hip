@@ -43,6 +43,50 @@ __global__ __launch_bounds__(256) void depth_kernel(float *dpt, const float *__r
     dpt[px] = s * (bias[px] + part);
 }
 
+// per-edge operator path with N << H*W samples: only the sampled pixels' depths, written at their map positions
+// (dpt[loc[n]]), same arithmetic and lane cooperation as depth_kernel.  Locations outside [0, HW) are skipped.
+template <int CS>
+__global__ __launch_bounds__(256) void depth_samples_kernel(float *dpt, const float *__restrict__ bias,
+                                                            const float *__restrict__ basis,
+                                                            const float *__restrict__ code, float scale,
+                                                            const void *__restrict__ loc, int loc_is_i64, int N, int HW)
+{
+  constexpr int F4 = CS / 4;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n = gid / F4, c4 = gid % F4;
+  long long px = -1;
+  if (n < N)
+    px = loc_is_i64 ? reinterpret_cast<const long long *>(loc)[n] : (long long)reinterpret_cast<const int *>(loc)[n];
+  const bool ok = px >= 0 && px < HW;
+  float part = 0.f;
+  if (ok)
+  {
+    const f32x4 b = *reinterpret_cast<const f32x4 *>(basis + (size_t)px * CS + c4 * 4);
+    part = b[0] * code[c4 * 4 + 0] + b[1] * code[c4 * 4 + 1] + b[2] * code[c4 * 4 + 2] + b[3] * code[c4 * 4 + 3];
+  }
+#pragma unroll
+  for (int o = F4 / 2; o > 0; o >>= 1)
+    part += __shfl_xor(part, o, 64);
+  if (ok && c4 == 0)
+    dpt[px] = scale * (bias[px] + part);
+}
+
+hipError_t launch_depth_samples(hipStream_t s, int CS, float *dpt, const float *bias, const float *basis,
+                                const float *code, float scale, const void *loc, int loc_is_i64, int N, int HW)
+{
+  if (N <= 0)
+    return hipSuccess;
+  if (CS == 32)
+    hipLaunchKernelGGL((depth_samples_kernel<32>), dim3((N * 8 + 255) / 256), dim3(256), 0, s, dpt, bias, basis, code,
+                       scale, loc, loc_is_i64, N, HW);
+  else if (CS == 16)
+    hipLaunchKernelGGL((depth_samples_kernel<16>), dim3((N * 4 + 255) / 256), dim3(256), 0, s, dpt, bias, basis, code,
+                       scale, loc, loc_is_i64, N, HW);
+  else
+    return hipErrorInvalidValue;
+  return hipGetLastError();
+}
+
 // batched variant over keyframes (blockIdx.y = keyframe): one launch per LM pass for the whole window
 constexpr int kDepthUnroll = 4;
 template <int CS>

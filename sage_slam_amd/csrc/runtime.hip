@@ -14,6 +14,9 @@
 #include <cstring>
 #include <vector>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h> // types only: the library is bound at run time (sage_rccl_*), CPU-only hosts never load it
+
 #include "host_math.h"
 #include "sage_ba.h"
 #include "sage_internal.h"
@@ -206,6 +209,24 @@ static int ws_fetch_stats(SageWorkspace *ws, float *error_host, float *num_inlie
   return SAGE_OK;
 }
 
+// source depths of a per-edge operator call: the kernels read them from a map indexed by loc1d.  With few samples only
+// those pixels are formed (N*CS reads instead of H*W*CS); the photometric kernels also range-check loc1d against H*W
+// (PhotoEdge::HW), so a bad location reads nothing -- the reference's tensor index() would throw on it.
+static int operator_depths(SageWorkspace *ws, int CS, const float *bias0, const float *basis0, const float *code0,
+                           float scale0, const void *loc, int loc_is_i64, int N, int H, int W)
+{
+  int rc;
+  if ((rc = ws->dpt0.reserve((size_t)H * W * sizeof(float))))
+    return rc;
+  if ((long long)N * 2 <= (long long)H * W)
+    SAGE_HIP(launch_depth_samples(ws->stream, CS, ws->dpt0.as<float>(), bias0, basis0, code0, scale0, loc, loc_is_i64,
+                                  N, H * W));
+  else
+    SAGE_HIP(launch_depth_and_grad(ws->stream, CS, ws->dpt0.as<float>(), nullptr, bias0, basis0, code0, nullptr,
+                                   scale0, H, W));
+  return SAGE_OK;
+}
+
 static bool supported(int CS, int FS)
 {
   return (CS == 16 || CS == 32) && (FS == 16 || FS == 32);
@@ -231,11 +252,8 @@ extern "C" int sage_photometric_jac_error_calculate(
   if (rc)
     return rc;
   // depth map of the source keyframe at (code0, scale0): the kernel reads its sample depths from it
-  const int pH = (int)pyr->cam[0].h, pW = (int)pyr->cam[0].w;
-  if ((rc = ws->dpt0.reserve((size_t)pH * pW * sizeof(float))))
+  if ((rc = operator_depths(ws, CS, bias0, basis0, code0, scale0, loc1d, 1, N, (int)pyr->cam[0].h, (int)pyr->cam[0].w)))
     return rc;
-  SAGE_HIP(launch_depth_and_grad(ws->stream, CS, ws->dpt0.as<float>(), nullptr, bias0, basis0, code0, nullptr, scale0,
-                                 pH, pW));
   PhotoEdge e{};
   e.dpt0 = ws->dpt0.as<float>();
   e.feat0 = feat0; e.feat1 = feat1; e.grad1 = grad1; e.bias0 = bias0; e.basis0 = basis0; e.mask1 = mask1;
@@ -263,11 +281,8 @@ extern "C" int sage_photometric_error_calculate(
   if (rc)
     return rc;
   // depth map of the source keyframe at (code0, scale0): the kernel reads its sample depths from it
-  const int pH = (int)pyr->cam[0].h, pW = (int)pyr->cam[0].w;
-  if ((rc = ws->dpt0.reserve((size_t)pH * pW * sizeof(float))))
+  if ((rc = operator_depths(ws, CS, bias0, basis0, code0, scale0, loc1d, 1, N, (int)pyr->cam[0].h, (int)pyr->cam[0].w)))
     return rc;
-  SAGE_HIP(launch_depth_and_grad(ws->stream, CS, ws->dpt0.as<float>(), nullptr, bias0, basis0, code0, nullptr, scale0,
-                                 pH, pW));
   PhotoEdge e{};
   e.dpt0 = ws->dpt0.as<float>();
   e.feat0 = feat0; e.feat1 = feat1; e.grad1 = nullptr; e.bias0 = bias0; e.basis0 = basis0; e.mask1 = mask1;
@@ -365,11 +380,8 @@ extern "C" int sage_geometric_jac_error_calculate(
   if (rc)
     return rc;
   // depth map of the source keyframe at (code0, scale0): the kernel reads its sample depths from it
-  const int gH = (int)cam->h, gW = (int)cam->w;
-  if ((rc = ws->dpt0.reserve((size_t)gH * gW * sizeof(float))))
+  if ((rc = operator_depths(ws, CS, bias0, basis0, code0, scale0, loc1d, 0, N, (int)cam->h, (int)cam->w)))
     return rc;
-  SAGE_HIP(launch_depth_and_grad(ws->stream, CS, ws->dpt0.as<float>(), nullptr, bias0, basis0, code0, nullptr, scale0,
-                                 gH, gW));
   GeoEdge e{};
   e.dpt0 = ws->dpt0.as<float>();
   e.bias0 = bias0; e.basis0 = basis0; e.dpt1 = dpt1; e.dgrad1 = dgrad1; e.basis1 = basis1; e.mask1 = mask1;
@@ -395,11 +407,8 @@ extern "C" int sage_geometric_error_calculate(
   int rc = ws_prepare(ws, N, 2, &lc);
   if (rc)
     return rc;
-  const int gH = (int)cam->h, gW = (int)cam->w;
-  if ((rc = ws->dpt0.reserve((size_t)gH * gW * sizeof(float))))
+  if ((rc = operator_depths(ws, CS, bias0, basis0, code0, scale0, loc1d, 0, N, (int)cam->h, (int)cam->w)))
     return rc;
-  SAGE_HIP(launch_depth_and_grad(ws->stream, CS, ws->dpt0.as<float>(), nullptr, bias0, basis0, code0, nullptr, scale0,
-                                 gH, gW));
   GeoEdge e{};
   e.dpt0 = ws->dpt0.as<float>();
   e.bias0 = bias0; e.basis0 = basis0; e.dpt1 = dpt1; e.mask1 = mask1; e.homo = homo; e.loc = loc1d;
@@ -1153,6 +1162,7 @@ struct SageWindow
   DeviceSolver *last_solver = nullptr;   // the solver whose pinned mirror holds the pending candidate
   SageAllReduceFn allreduce = nullptr;  // sharded windows: caller-provided sum all-reduce (see sage_ba.h)
   void *allreduce_user = nullptr;
+  void *rccl_hook = nullptr;            // sage_window_use_rccl: owned {comm, stream} record behind `allreduce`
   double *h_err = nullptr;              // pinned [8]: {linearize tail[4], error pass totals[4]} written by the kernels
   DevBuf pk;                            // engine-internal channel-group pyramids [K][3 (f,gx,gy)][FS/4][P][4]
   DevBuf f0s;                           // per keyframe: pre-sampled source features [L][FS/4][N][4]
@@ -1281,6 +1291,7 @@ extern "C" void sage_window_destroy(SageWindow *w)
                     &w->packed, &w->errbuf};
   for (DevBuf *b : bufs)
     b->release();
+  std::free(w->rccl_hook); // (the communicator itself belongs to the caller)
   solver_destroy(w->solver);
   if (w->pipe_flags)
     (void)hipHostFree(w->pipe_flags);
@@ -1383,6 +1394,125 @@ extern "C" int sage_window_set_allreduce(SageWindow *w, SageAllReduceFn fn, void
     return SAGE_E_INVALID;
   w->allreduce = fn;
   w->allreduce_user = user;
+  return SAGE_OK;
+}
+
+// =====================================================================================================
+// native RCCL: the all-reduce of a sharded window as an ncclAllReduce on the window's own stream (xGMI), no Python
+// and no torch in the loop.  RCCL is bound with dlopen so that the library loads on hosts without it; when the
+// process already has an RCCL mapped (PyTorch-ROCm bundles one) that instance is reused.
+// =====================================================================================================
+namespace
+{
+struct RcclApi
+{
+  void *handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+RcclApi &rccl()
+{
+  static RcclApi api = [] {
+    RcclApi a;
+    const char *already[] = {"librccl.so", "librccl.so.1"};
+    for (const char *n : already)
+      if (!a.handle)
+        a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+    const char *fresh[] = {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"};
+    for (const char *n : fresh)
+      if (!a.handle)
+        a.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+    if (!a.handle)
+      return a;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.handle, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.handle, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.handle, "ncclCommDestroy"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.handle, "ncclAllReduce"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.handle, "ncclGetErrorString"));
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
+    return a;
+  }();
+  return api;
+}
+
+struct RcclHook
+{
+  ncclComm_t comm;
+  hipStream_t stream;
+};
+
+int rccl_allreduce_cb(double *buf, size_t n, void *user)
+{
+  RcclHook *h = static_cast<RcclHook *>(user);
+  const ncclResult_t r = rccl().AllReduce(buf, buf, n, ncclDouble, ncclSum, h->comm, h->stream);
+  if (r != ncclSuccess)
+  {
+    fprintf(stderr, "[sage] ncclAllReduce: %s\n", rccl().GetErrorString ? rccl().GetErrorString(r) : "error");
+    return 1;
+  }
+  return 0;
+}
+} // namespace
+
+extern "C" int sage_rccl_unique_id(unsigned char *id128)
+{
+  if (!id128)
+    return SAGE_E_INVALID;
+  if (!rccl().ok)
+    return SAGE_E_UNSUPPORTED;
+  ncclUniqueId id;
+  if (rccl().GetUniqueId(&id) != ncclSuccess)
+    return SAGE_E_STATE;
+  static_assert(sizeof(id) == SAGE_RCCL_ID_BYTES, "ncclUniqueId size");
+  std::memcpy(id128, &id, sizeof(id));
+  return SAGE_OK;
+}
+
+extern "C" int sage_rccl_comm_create(const unsigned char *id128, int rank, int world, void **comm_out)
+{
+  if (!id128 || !comm_out || world < 1 || rank < 0 || rank >= world)
+    return SAGE_E_INVALID;
+  if (!rccl().ok)
+    return SAGE_E_UNSUPPORTED;
+  ncclUniqueId id;
+  std::memcpy(&id, id128, sizeof(id));
+  ncclComm_t c = nullptr;
+  const ncclResult_t r = rccl().CommInitRank(&c, world, id, rank);
+  if (r != ncclSuccess)
+  {
+    fprintf(stderr, "[sage] ncclCommInitRank: %s\n", rccl().GetErrorString ? rccl().GetErrorString(r) : "error");
+    return SAGE_E_STATE;
+  }
+  *comm_out = c;
+  return SAGE_OK;
+}
+
+extern "C" void sage_rccl_comm_destroy(void *comm)
+{
+  if (comm && rccl().ok)
+    (void)rccl().CommDestroy(static_cast<ncclComm_t>(comm));
+}
+
+extern "C" int sage_window_use_rccl(SageWindow *w, void *nccl_comm)
+{
+  if (!w || !nccl_comm)
+    return SAGE_E_INVALID;
+  if (!rccl().ok)
+    return SAGE_E_UNSUPPORTED;
+  std::free(w->rccl_hook);
+  RcclHook *h = static_cast<RcclHook *>(std::malloc(sizeof(RcclHook)));
+  if (!h)
+    return SAGE_E_STATE;
+  h->comm = static_cast<ncclComm_t>(nccl_comm);
+  h->stream = w->stream;
+  w->rccl_hook = h;
+  w->allreduce = rccl_allreduce_cb;
+  w->allreduce_user = h;
   return SAGE_OK;
 }
 
@@ -1647,7 +1777,12 @@ extern "C" int sage_window_finalize(SageWindow *w)
     long long total = 0;
     for (int n : Nedge)
       total += (n + kTile - 1) / kTile;
-    int tpb = total >= 8192 ? 8 : 0; // measured on the headline window: 2..16 are within noise, 8 halves the partials of 4
+    // sub-tiles a workgroup accumulates in fp32 (MFMA chains of 64 fmaf per sub-tile and accumulator) before its partial
+    // record goes out to the double-precision sums: the LM step's distance from the exact step grows with the chain
+    // length (K = 64 headline window, scripts/tpb_noise_probe.py: 8 -> 2.1e-4, 4 -> 1.2e-4, 2 -> 7.6e-5, 1 -> 4.9e-5
+    // rel-L2; the fp32 oracle itself sits at 5.5e-5), the kernel time with the workgroup prologues (8: 0.86 ms,
+    // 2: 0.88 ms, 1: 0.96 ms).  2 keeps the step within the 1e-4 parity bar with margin at +2 % kernel time.
+    int tpb = total >= 4096 ? 2 : 1;
     if (const char *e = getenv("SAGE_PHOTO_TPB"))
       tpb = std::max(1, atoi(e));
     std::vector<int> edge_order;
@@ -1942,15 +2077,17 @@ extern "C" int sage_window_total_error(SageWindow *w, int from_linearize, double
     return SAGE_E_STATE;
   double t[4];
   int rcs = sync_candidate(w);
-  if (rcs)
+  if (rcs && rcs != SAGE_E_NOT_PSD)
     return rcs;
+  // a failed factorisation only invalidates the CANDIDATE: the error at the linearisation point is still served
+  const int rc_out = from_linearize ? SAGE_OK : rcs;
   if (w->world == 1 && w->h_err)
   {
     // single-rank window: the kernels mirrored the totals into pinned host memory
     SAGE_HIP(hipStreamSynchronize(w->stream));
     const double *m = w->h_err + (from_linearize ? 0 : 4);
     *err = m[0] + m[1] + prior_error(w, from_linearize ? 0 : 1);
-    return SAGE_OK;
+    return rc_out;
   }
   if (from_linearize)
   {
@@ -1961,7 +2098,7 @@ extern "C" int sage_window_total_error(SageWindow *w, int from_linearize, double
     SAGE_HIP(hipMemcpyAsync(t, w->errbuf.p, 4 * sizeof(double), hipMemcpyDeviceToHost, w->stream));
   SAGE_HIP(hipStreamSynchronize(w->stream));
   *err = t[0] + t[1] + prior_error(w, from_linearize ? 0 : 1);
-  return SAGE_OK;
+  return rc_out;
 }
 
 extern "C" int sage_window_solve(SageWindow *w, double damp, double *step_norm)
@@ -2639,18 +2776,26 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
         return SAGE_E_STATE;
       hipLaunchKernelGGL(mirror_totals_kernel, dim3(1), dim3(64), 0, w->stream,
                          w->packed.as<double>() + sage_window_packed_count(w) - 4, w->errbuf.as<double>(), w->h_err);
-      if ((rc = sync_candidate(w)))
+      // a non-positive pivot of the damped system is a REJECTED evaluation (raise the damping), not a hard error; every
+      // rank factors the same reduced system, so all of them take this branch together and the number of collectives
+      // per iteration stays the same on every rank
+      rc = sync_candidate(w);
+      if (rc && rc != SAGE_E_NOT_PSD)
         return rc;
+      const bool not_psd = rc == SAGE_E_NOT_PSD;
       SAGE_HIP(hipStreamSynchronize(w->stream));
       if (evals == 0)
         st->error = w->h_err[0] + w->h_err[1] + prior_error(w, 0);
-      st->candidate_error = w->h_err[4] + w->h_err[5] + prior_error(w, 1);
+      st->candidate_error = not_psd ? INFINITY : w->h_err[4] + w->h_err[5] + prior_error(w, 1);
     }
     else
     {
       if (evals == 0 && (rc = sage_window_total_error(w, 1, &st->error)))
         return rc;
-      if ((rc = sage_window_total_error(w, 0, &st->candidate_error)))
+      rc = sage_window_total_error(w, 0, &st->candidate_error);
+      if (rc == SAGE_E_NOT_PSD)
+        st->candidate_error = INFINITY;
+      else if (rc)
         return rc;
     }
     ++evals;

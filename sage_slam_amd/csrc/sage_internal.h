@@ -206,6 +206,8 @@ hipError_t launch_valid_locations(hipStream_t s, const float *mask, const SageCa
                                   int *n_out_dev);
 hipError_t launch_gather_locations(hipStream_t s, const long long *vloc, const float *vhomo, const long long *index_dev,
                                    int n, long long *loc1d, float *homo);
+hipError_t launch_depth_samples(hipStream_t s, int CS, float *dpt, const float *bias, const float *basis,
+                                const float *code, float scale, const void *loc, int loc_is_i64, int N, int HW);
 hipError_t launch_scale_array(hipStream_t s, float *out, const float *in, float mult, int n);
 hipError_t launch_gaussian_pyramid_with_grad(hipStream_t s, float *pyr, float *grad, const float *feat,
                                              const float *mask, const SagePyramid &p, int FS, float *scratch_mask);
