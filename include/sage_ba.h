@@ -475,6 +475,29 @@ int sage_sample_locations(SageWorkspace *ws, const int64_t *valid_loc1d_dev, con
 typedef int (*SageAllReduceFn)(double *dev_buf, size_t n, void *user);
 int sage_window_set_allreduce(SageWindow *w, SageAllReduceFn fn, void *user);
 
+/* ---- domain-decomposed solve of a link-sharded window (host, double; csrc/shard_solve.cpp) ---------------------------
+ * Link ranges are contiguous (sage_window_set_shard), so a rank's slice of the normal equations is complete for the
+ * keyframes only its own links touch: it eliminates those locally (sage_shard_eliminate) and contributes the Schur
+ * complement on the keyframes it shares with other ranks to the separator buffer -- the ONE all-reduced payload of an
+ * LM iteration (sage_shard_sep_count doubles; 1.2 MB instead of the 3.0 MB packed system at K = 64 on 8 ranks).  After
+ * the sum every rank factors the (identical) separator system and back-substitutes its own keyframes
+ * (sage_shard_solve).  packed_local_host: this rank's UN-reduced packed normal equations in the layout of
+ * sage_window_packed_dev; diag_add / g_add: the K*B diagonal priors of sage_block_solve, applied by the keyframe's
+ * designated owner (the lowest rank touching it).  The separator buffer ends with 8 doubles: [0..3] the rank's error
+ * / inlier totals at the linearisation point (tail of the packed buffer), [4..7] free for the caller (prior errors).
+ * delta (K*B doubles): entries of the keyframes this rank touches are written, the others left alone. */
+typedef struct SageShardPlan SageShardPlan;
+int sage_shard_plan_create(int K, int nlinks, const int32_t *links, int B, int rank, int world, SageShardPlan **out);
+void sage_shard_plan_destroy(SageShardPlan *p);
+size_t sage_shard_sep_count(const SageShardPlan *p);
+int sage_shard_num_separators(const SageShardPlan *p);
+int sage_shard_num_interior(const SageShardPlan *p);
+int sage_shard_keyframe_owner(const SageShardPlan *p, int kf);
+int sage_shard_keyframe_is_local(const SageShardPlan *p, int kf);
+int sage_shard_eliminate(SageShardPlan *p, const double *packed_local_host, double damp, const double *diag_add,
+                         const double *g_add, double *sep_out);
+int sage_shard_solve(SageShardPlan *p, const double *sep_reduced, double *delta);
+
 /* Native collective: RCCL (backend of record on MI355X: ring / tree over xGMI) bound at run time.  One process per GPU:
  *   rank 0:  sage_rccl_unique_id(id);   broadcast the 128 bytes by any means (MPI, a socket, torch.distributed);
  *   every rank, with its GPU current:   sage_rccl_comm_create(id, rank, world, &comm);

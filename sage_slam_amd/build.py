@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libsage_ba.so")
 SOURCES = ["photo_kernels.hip", "geo_kernels.hip", "track_kernels.hip", "producers.hip", "keypoint_kernels.hip", "solve_kernels.hip", "runtime.hip",
-           "host_math.cpp"]
+           "host_math.cpp", "shard_solve.cpp"]
 HEADERS = ["sage_device.h", "sage_internal.h", "host_math.h", os.path.join(ROOT, "include", "sage_ba.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HOSTCXX = os.environ.get("HOSTCXX", "/opt/rocm/lib/llvm/bin/clang++")

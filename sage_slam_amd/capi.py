@@ -98,7 +98,7 @@ SYMBOLS = [
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_set_allreduce", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_sort_locations", "sage_bind_thread_to_device",
+    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_sort_locations", "sage_bind_thread_to_device",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
@@ -630,6 +630,50 @@ def _tensor_from_ptr(ptr: int, n: int):
 
 # --------------------------------------------------------------------------- host-side window algebra
 # (pure numpy; used by the multi-process CPU tests of the sharded reduction and by parity tests)
+class ShardPlan:
+    """sage_shard_* : domain-decomposed solve of a link-sharded window (host, double)."""
+
+    def __init__(self, K, links, B, rank, world):
+        L = lib()
+        L.sage_shard_sep_count.restype = C.c_size_t
+        L.sage_shard_sep_count.argtypes = [C.c_void_p]
+        lk = np.ascontiguousarray(np.asarray(links, np.int32).reshape(-1))
+        self.h = C.c_void_p()
+        _chk(L.sage_shard_plan_create(K, len(links), lk.ctypes.data_as(C.POINTER(C.c_int32)), B, rank, world,
+                                      C.byref(self.h)), "sage_shard_plan_create")
+        self.K, self.B = K, B
+        self.sep_count = int(L.sage_shard_sep_count(self.h))
+        self.n_sep = L.sage_shard_num_separators(self.h)
+        self.n_interior = L.sage_shard_num_interior(self.h)
+
+    def owner(self, kf):
+        return lib().sage_shard_keyframe_owner(self.h, kf)
+
+    def is_local(self, kf):
+        return bool(lib().sage_shard_keyframe_is_local(self.h, kf))
+
+    def eliminate(self, packed_local, damp, diag_add=None, g_add=None):
+        p = np.ascontiguousarray(packed_local, np.float64)
+        out = np.zeros(self.sep_count, np.float64)
+        dp = lambda a: None if a is None else np.ascontiguousarray(a, np.float64).ctypes.data_as(C.POINTER(C.c_double))
+        self._keep = (diag_add, g_add)
+        _chk(lib().sage_shard_eliminate(self.h, p.ctypes.data_as(C.POINTER(C.c_double)), C.c_double(damp), dp(diag_add),
+                                        dp(g_add), out.ctypes.data_as(C.POINTER(C.c_double))), "sage_shard_eliminate")
+        return out
+
+    def solve(self, sep_reduced):
+        s = np.ascontiguousarray(sep_reduced, np.float64)
+        delta = np.zeros(self.K * self.B, np.float64)
+        _chk(lib().sage_shard_solve(self.h, s.ctypes.data_as(C.POINTER(C.c_double)),
+                                    delta.ctypes.data_as(C.POINTER(C.c_double))), "sage_shard_solve")
+        return delta
+
+    def close(self):
+        if self.h:
+            lib().sage_shard_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 def rccl_unique_id() -> bytes:
     buf = (C.c_ubyte * 128)()
     _chk(lib().sage_rccl_unique_id(buf), "sage_rccl_unique_id")

@@ -1,0 +1,420 @@
+// shard_solve.cpp -- domain-decomposed damped solve of a link-sharded window (multi-GPU).
+//
+// No reference counterpart (the reference is one GPU, ISAM2 on the host).  Link ranges are contiguous
+// (sage_window_set_shard), so every rank's slice of the block-sparse normal equations is COMPLETE for the keyframes that
+// only its own links touch ("interior" keyframes): it eliminates them locally and only the Schur complement on the
+// keyframes shared with other ranks ("separators": ~3 per range boundary of a temporal window) crosses xGMI:
+//
+//   A = H + P + damp*diag(H + P)        H = sum_r H^(r) (per-rank edge sums), P = diagonal priors (owned by one rank each)
+//   rank r:   C^(r) = A^(r)_SS - A_SI A_II^-1 A_IS ,  c^(r) = b^(r)_S - A_SI A_II^-1 b_I          (I = its interior)
+//   all-reduce (sum, double) of the separator buffer [blocks of C | c | 8 tail doubles]
+//   every rank: (sum_r C^(r)) d_S = sum_r c^(r)   (block-envelope Cholesky over the separators, identical on all ranks)
+//   rank r:   d_I = A_II^-1 (b_I - A_IS d_S)
+//
+// Payload at K = 64, 8 ranks, B = 39: 96 blocks + rhs = 1.2 MB instead of the 3.0 MB packed system; per-rank
+// factorisation: 8 interior keyframes + the 21-keyframe separator system instead of all 64 keyframes.
+// The result equals the single-rank solve of the summed system to rounding (tests/test_shard_schur.py, world 2/4/8;
+// tests/test_sharded_reduce_gloo.py over gloo).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "host_math.h"
+#include "sage_ba.h"
+
+struct SageShardPlan
+{
+  int K = 0, B = 0, rank = 0, world = 1, nlinks = 0;
+  std::vector<std::pair<int, int>> links;
+  std::vector<int> link_lo;        // [world + 1] link range of every rank
+  std::vector<int> kf_owner;       // designated owner (lowest rank touching the keyframe; -1: untouched)
+  std::vector<int> kf_ntouch;      // number of ranks touching the keyframe
+  std::vector<int> sep_all;        // separator keyframes (touched by >= 2 ranks), ascending
+  std::vector<int> sep_index;      // keyframe -> index in sep_all, or -1
+  std::vector<int> interior;       // this rank's interior keyframes, ascending
+  std::vector<int> sep_local;      // indices into sep_all of the separators this rank touches
+  std::vector<int> local_links;    // links this rank owns
+  // separator buffer: upper-triangular block pairs (i <= j, indices into sep_all) that SOME rank couples
+  std::map<std::pair<int, int>, int> pair_block; // -> block index
+  int n_pair_blocks = 0;
+  size_t sep_doubles = 0;
+  // state between eliminate() and solve()
+  sage::EnvelopeMatrix LI;         // Cholesky factor of the damped interior matrix
+  std::vector<double> LS;          // [nS_local*B][nI*B]  rows of L^-1 A_IS^T  (i.e. A_SI L^-T)
+  std::vector<double> y;           // L^-1 b_I
+  std::vector<int> int_pos;        // keyframe -> position among interior, or -1
+  bool have_factor = false;
+};
+
+namespace
+{
+inline int touch_rank_range(const SageShardPlan &p, int link)
+{
+  // rank owning `link` (ranges are contiguous and ordered)
+  int r = (int)(std::upper_bound(p.link_lo.begin(), p.link_lo.end(), link) - p.link_lo.begin()) - 1;
+  return std::min(std::max(r, 0), p.world - 1);
+}
+} // namespace
+
+extern "C" int sage_shard_plan_create(int K, int nlinks, const int32_t *links, int B, int rank, int world,
+                                      SageShardPlan **out)
+{
+  if (!out || K < 1 || B < 1 || nlinks < 0 || (nlinks > 0 && !links) || world < 1 || rank < 0 || rank >= world)
+    return SAGE_E_INVALID;
+  SageShardPlan *p = new SageShardPlan;
+  p->K = K; p->B = B; p->rank = rank; p->world = world; p->nlinks = nlinks;
+  p->links.resize(nlinks);
+  for (int l = 0; l < nlinks; ++l)
+  {
+    const int a = links[2 * l], b = links[2 * l + 1];
+    if (a < 0 || b <= a || b >= K)
+    {
+      delete p;
+      return SAGE_E_INVALID;
+    }
+    p->links[l] = {a, b};
+  }
+  p->link_lo.resize(world + 1);
+  for (int r = 0; r <= world; ++r)
+    p->link_lo[r] = (int)((long long)nlinks * r / world); // the rule of sage_window_set_shard
+  std::vector<std::vector<char>> touch(world, std::vector<char>(K, 0));
+  for (int l = 0; l < nlinks; ++l)
+  {
+    const int r = touch_rank_range(*p, l);
+    touch[r][p->links[l].first] = touch[r][p->links[l].second] = 1;
+  }
+  p->kf_owner.assign(K, -1);
+  p->kf_ntouch.assign(K, 0);
+  for (int k = 0; k < K; ++k)
+    for (int r = 0; r < world; ++r)
+      if (touch[r][k])
+      {
+        if (p->kf_owner[k] < 0)
+          p->kf_owner[k] = r;
+        p->kf_ntouch[k] += 1;
+      }
+  // keyframes no link touches (isolated): give them to rank 0 as interior unknowns (prior-only rows)
+  p->sep_index.assign(K, -1);
+  p->int_pos.assign(K, -1);
+  for (int k = 0; k < K; ++k)
+  {
+    if (p->kf_ntouch[k] >= 2)
+    {
+      p->sep_index[k] = (int)p->sep_all.size();
+      p->sep_all.push_back(k);
+    }
+    else
+    {
+      const int owner = p->kf_owner[k] < 0 ? 0 : p->kf_owner[k];
+      if (p->kf_owner[k] < 0)
+        p->kf_owner[k] = 0;
+      if (owner == rank)
+      {
+        p->int_pos[k] = (int)p->interior.size();
+        p->interior.push_back(k);
+      }
+    }
+  }
+  for (int l = p->link_lo[rank]; l < p->link_lo[rank + 1]; ++l)
+    p->local_links.push_back(l);
+  for (size_t s = 0; s < p->sep_all.size(); ++s)
+    if (touch[rank][p->sep_all[s]])
+      p->sep_local.push_back((int)s);
+  // coupled separator pairs: every rank couples all the separators it touches with each other (Schur fill through its
+  // interior); identical on every rank
+  for (int r = 0; r < world; ++r)
+  {
+    std::vector<int> sl;
+    for (size_t s = 0; s < p->sep_all.size(); ++s)
+      if (touch[r][p->sep_all[s]])
+        sl.push_back((int)s);
+    for (size_t i = 0; i < sl.size(); ++i)
+      for (size_t j = i; j < sl.size(); ++j)
+        p->pair_block.emplace(std::make_pair(sl[i], sl[j]), 0);
+  }
+  int nb = 0;
+  for (auto &kv : p->pair_block)
+    kv.second = nb++;
+  p->n_pair_blocks = nb;
+  p->sep_doubles = (size_t)nb * B * B + p->sep_all.size() * (size_t)B + 8;
+  *out = p;
+  return SAGE_OK;
+}
+
+extern "C" void sage_shard_plan_destroy(SageShardPlan *p) { delete p; }
+extern "C" size_t sage_shard_sep_count(const SageShardPlan *p) { return p ? p->sep_doubles : 0; }
+extern "C" int sage_shard_num_separators(const SageShardPlan *p) { return p ? (int)p->sep_all.size() : 0; }
+extern "C" int sage_shard_num_interior(const SageShardPlan *p) { return p ? (int)p->interior.size() : 0; }
+extern "C" int sage_shard_keyframe_owner(const SageShardPlan *p, int kf)
+{
+  return (p && kf >= 0 && kf < p->K) ? p->kf_owner[kf] : -1;
+}
+extern "C" int sage_shard_keyframe_is_local(const SageShardPlan *p, int kf)
+{
+  if (!p || kf < 0 || kf >= p->K)
+    return 0;
+  if (p->int_pos[kf] >= 0)
+    return 1;
+  const int s = p->sep_index[kf];
+  return s >= 0 && std::find(p->sep_local.begin(), p->sep_local.end(), s) != p->sep_local.end();
+}
+
+// this rank's damped contribution: element (r, c) of block (kr, kc) of  A^(r) = H^(r) + P^(r) + damp * diag(...)
+namespace
+{
+struct LocalSystem
+{
+  const SageShardPlan &p;
+  const double *diag, *lnk, *g;
+  const double *dadd, *gadd;
+  double damp;
+  int B, BB;
+  LocalSystem(const SageShardPlan &pl, const double *packed, double dmp, const double *da, const double *ga)
+      : p(pl), dadd(da), gadd(ga), damp(dmp), B(pl.B), BB(pl.B * pl.B)
+  {
+    diag = packed;
+    lnk = diag + (size_t)p.K * BB;
+    g = lnk + (size_t)p.nlinks * BB;
+  }
+  bool owns_prior(int k) const { return p.kf_owner[k] == p.rank; }
+  double diag_elem(int k, int r, int c) const // symmetrised like the full solve (0.5 (D + D^T)) + prior + damping
+  {
+    double v = 0.5 * (diag[(size_t)k * BB + r * B + c] + diag[(size_t)k * BB + c * B + r]);
+    if (r == c)
+    {
+      const double pr = (dadd && owns_prior(k)) ? dadd[(size_t)k * B + r] : 0.0;
+      v = (v + pr) * (1.0 + damp);
+    }
+    return v;
+  }
+  double rhs(int k, int r) const
+  {
+    return g[(size_t)k * B + r] + ((gadd && owns_prior(k)) ? gadd[(size_t)k * B + r] : 0.0);
+  }
+};
+} // namespace
+
+extern "C" int sage_shard_eliminate(SageShardPlan *p, const double *packed_local, double damp, const double *diag_add,
+                                    const double *g_add, double *sep_out)
+{
+  if (!p || !packed_local || !sep_out)
+    return SAGE_E_INVALID;
+  const int B = p->B, BB = B * B, K = p->K;
+  const LocalSystem S(*p, packed_local, damp, diag_add, g_add);
+  const int nI = (int)p->interior.size(), nS = (int)p->sep_local.size();
+  const int NI = nI * B, NS = nS * B;
+  std::fill(sep_out, sep_out + p->sep_doubles, 0.0);
+  double *sep_rhs = sep_out + (size_t)p->n_pair_blocks * BB;
+  // tail: this rank's error / inlier totals at the linearisation point ride along
+  const double *tail = packed_local + (size_t)(K + p->nlinks) * BB + (size_t)K * B;
+  double *sep_tail = sep_rhs + p->sep_all.size() * (size_t)B;
+  for (int i = 0; i < 4; ++i)
+    sep_tail[i] = tail[i];
+  // local separator position of a keyframe (or -1)
+  std::vector<int> spos(K, -1);
+  for (int i = 0; i < nS; ++i)
+    spos[p->sep_all[p->sep_local[i]]] = i;
+  // ---- interior matrix in envelope form: first[] from the links among interior keyframes
+  std::vector<int> first_blk(nI);
+  for (int i = 0; i < nI; ++i)
+    first_blk[i] = i;
+  for (int l : p->local_links)
+  {
+    const int a = p->int_pos[p->links[l].first], b = p->int_pos[p->links[l].second];
+    if (a >= 0 && b >= 0)
+      first_blk[std::max(a, b)] = std::min(first_blk[std::max(a, b)], std::min(a, b));
+  }
+  std::vector<int> first(NI);
+  for (int i = 0; i < nI; ++i)
+    for (int r = 0; r < B; ++r)
+      first[i * B + r] = first_blk[i] * B;
+  p->LI.init(NI, first);
+  for (int i = 0; i < nI; ++i)
+  {
+    const int k = p->interior[i];
+    for (int r = 0; r < B; ++r)
+      for (int c = 0; c <= r; ++c)
+        p->LI.at(i * B + r, i * B + c) = S.diag_elem(k, r, c);
+  }
+  // A_SS (local contribution), A_SI
+  std::vector<double> ASS((size_t)NS * NS, 0.0), ASI((size_t)NS * std::max(NI, 1), 0.0), bS(NS, 0.0), bI(NI, 0.0);
+  for (int i = 0; i < nS; ++i)
+  {
+    const int k = p->sep_all[p->sep_local[i]];
+    for (int r = 0; r < B; ++r)
+    {
+      for (int c = 0; c < B; ++c)
+        ASS[(size_t)(i * B + r) * NS + i * B + c] = S.diag_elem(k, r, c);
+      bS[i * B + r] = S.rhs(k, r);
+    }
+  }
+  for (int i = 0; i < nI; ++i)
+    for (int r = 0; r < B; ++r)
+      bI[i * B + r] = S.rhs(p->interior[i], r);
+  for (int l : p->local_links)
+  {
+    const int a = p->links[l].first, b = p->links[l].second; // block rows = a, cols = b
+    const double *blk = S.lnk + (size_t)l * BB;
+    const int ia = p->int_pos[a], ib = p->int_pos[b], sa = spos[a], sb = spos[b];
+    for (int r = 0; r < B; ++r)
+      for (int c = 0; c < B; ++c)
+      {
+        const double v = blk[r * B + c]; // A[a*B + r][b*B + c]
+        if (ia >= 0 && ib >= 0)
+        {
+          if (ib > ia)
+            p->LI.at(ib * B + c, ia * B + r) += v;
+          else
+            p->LI.at(ia * B + r, ib * B + c) += v;
+        }
+        else if (sa >= 0 && sb >= 0)
+        {
+          ASS[(size_t)(sa * B + r) * NS + sb * B + c] += v;
+          ASS[(size_t)(sb * B + c) * NS + sa * B + r] += v;
+        }
+        else if (sa >= 0 && ib >= 0)
+          ASI[(size_t)(sa * B + r) * NI + ib * B + c] += v;
+        else if (ia >= 0 && sb >= 0)
+          ASI[(size_t)(sb * B + c) * NI + ia * B + r] += v;
+        else
+          return SAGE_E_STATE; // a link of this rank touching a keyframe that is neither interior nor its separator
+      }
+  }
+  // ---- eliminate the interior
+  p->have_factor = false;
+  if (NI > 0)
+  {
+    if (!p->LI.cholesky_inplace(B, 1))
+      return SAGE_E_NOT_PSD;
+    // forward substitutions: y = L^-1 b_I ; rows of LS = L^-1 (A_SI row)^T
+    auto forward = [&](double *v) {
+      for (int r = 0; r < NI; ++r)
+      {
+        const int fr = p->LI.first[r];
+        const double *Lr = &p->LI.data[p->LI.rowptr[r]];
+        double acc = v[r];
+        for (int c = fr; c < r; ++c)
+          acc -= Lr[c - fr] * v[c];
+        v[r] = acc / Lr[r - fr];
+      }
+    };
+    p->y = bI;
+    forward(p->y.data());
+    p->LS = ASI;
+    for (int s = 0; s < NS; ++s)
+      forward(&p->LS[(size_t)s * NI]);
+    // C = A_SS - LS LS^T ; c = b_S - LS y
+    for (int i = 0; i < NS; ++i)
+    {
+      const double *li = &p->LS[(size_t)i * NI];
+      for (int j = i; j < NS; ++j)
+      {
+        const double *lj = &p->LS[(size_t)j * NI];
+        double acc = 0.0;
+        for (int k = 0; k < NI; ++k)
+          acc += li[k] * lj[k];
+        ASS[(size_t)i * NS + j] -= acc;
+        if (j != i)
+          ASS[(size_t)j * NS + i] -= acc;
+      }
+      double acc = 0.0;
+      for (int k = 0; k < NI; ++k)
+        acc += li[k] * p->y[k];
+      bS[i] -= acc;
+    }
+  }
+  else
+  {
+    p->LS.clear();
+    p->y.clear();
+  }
+  p->have_factor = true;
+  // ---- scatter into the separator buffer (upper-triangular block pairs)
+  for (int i = 0; i < nS; ++i)
+  {
+    for (int j = i; j < nS; ++j)
+    {
+      const auto it = p->pair_block.find({p->sep_local[i], p->sep_local[j]});
+      if (it == p->pair_block.end())
+        return SAGE_E_STATE;
+      double *dst = sep_out + (size_t)it->second * BB;
+      for (int r = 0; r < B; ++r)
+        for (int c = 0; c < B; ++c)
+          dst[r * B + c] = ASS[(size_t)(i * B + r) * NS + j * B + c];
+    }
+    for (int r = 0; r < B; ++r)
+      sep_rhs[(size_t)p->sep_local[i] * B + r] = bS[i * B + r];
+  }
+  return SAGE_OK;
+}
+
+extern "C" int sage_shard_solve(SageShardPlan *p, const double *sep_reduced, double *delta)
+{
+  if (!p || !sep_reduced || !delta || !p->have_factor)
+    return SAGE_E_STATE;
+  const int B = p->B, BB = B * B;
+  const int nSa = (int)p->sep_all.size(), NSa = nSa * B;
+  const double *sep_rhs = sep_reduced + (size_t)p->n_pair_blocks * BB;
+  std::vector<double> dS(NSa, 0.0);
+  if (NSa > 0)
+  {
+    // block envelope of the separator system: first coupled separator of every separator
+    std::vector<int> first_blk(nSa);
+    for (int j = 0; j < nSa; ++j)
+      first_blk[j] = j;
+    for (const auto &kv : p->pair_block)
+      first_blk[kv.first.second] = std::min(first_blk[kv.first.second], kv.first.first);
+    std::vector<int> first(NSa);
+    for (int j = 0; j < nSa; ++j)
+      for (int r = 0; r < B; ++r)
+        first[j * B + r] = first_blk[j] * B;
+    sage::EnvelopeMatrix M;
+    M.init(NSa, first);
+    for (const auto &kv : p->pair_block)
+    {
+      const int i = kv.first.first, j = kv.first.second; // i <= j: block (i, j) -> lower triangle entry (j, i)^T
+      const double *blk = sep_reduced + (size_t)kv.second * BB;
+      for (int r = 0; r < B; ++r)
+        for (int c = 0; c < B; ++c)
+        {
+          const int R = j * B + c, Cc = i * B + r; // element A[i*B + r][j*B + c] = A[R][Cc]
+          if (Cc <= R)
+            M.at(R, Cc) = blk[r * B + c];
+        }
+    }
+    if (!M.cholesky_inplace(B, 1))
+      return SAGE_E_NOT_PSD;
+    for (int i = 0; i < NSa; ++i)
+      dS[i] = sep_rhs[i];
+    M.solve_inplace(dS);
+  }
+  // ---- back-substitute the interior: d_I = L^-T (y - LS^T d_S(local))
+  const int nI = (int)p->interior.size(), nS = (int)p->sep_local.size(), NI = nI * B;
+  std::vector<double> v(p->y);
+  for (int s = 0; s < nS; ++s)
+    for (int r = 0; r < B; ++r)
+    {
+      const double d = dS[(size_t)p->sep_local[s] * B + r];
+      const double *ls = &p->LS[(size_t)(s * B + r) * std::max(NI, 1)];
+      for (int k = 0; k < NI; ++k)
+        v[k] -= ls[k] * d;
+    }
+  for (int r = NI - 1; r >= 0; --r)
+  {
+    const int fr = p->LI.first[r];
+    const double *Lr = &p->LI.data[p->LI.rowptr[r]];
+    const double x = v[r] / Lr[r - fr];
+    v[r] = x;
+    for (int c = fr; c < r; ++c)
+      v[c] -= Lr[c - fr] * x;
+  }
+  for (int i = 0; i < nI; ++i)
+    for (int r = 0; r < B; ++r)
+      delta[(size_t)p->interior[i] * B + r] = v[i * B + r];
+  for (int s = 0; s < nS; ++s)
+    for (int r = 0; r < B; ++r)
+      delta[(size_t)p->sep_all[p->sep_local[s]] * B + r] = dS[(size_t)p->sep_local[s] * B + r];
+  return SAGE_OK;
+}

@@ -67,3 +67,75 @@ def test_two_rank_shard_equals_single_rank(orc, tmp_path):
     assert np.array_equal(d0, d1)                        # every rank solves the identical reduced system
     assert rel(p0, full) < 1e-14 and rel(d0, ref) < 1e-9
     assert np.abs(ref).max() > 0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# domain-decomposed solve (sage_shard_*, csrc/shard_solve.cpp): the all-reduced payload is the separator Schur system,
+# every rank back-substitutes its own keyframes; world 2, 4 and 8 over gloo, per-edge values from the oracle
+# ---------------------------------------------------------------------------------------------------------------
+SCHUR_WINDOW = dict(K=12, H=16, W=20, FS=16, CS=16, L=2, seed=5, back_links=3, border=1, erode=2)
+
+
+def _schur_priors(w):
+    K, CS, B = len(w.keyframes), w.CS, 7 + w.CS
+    dadd = np.zeros(K * B); gadd = np.zeros(K * B)
+    for k, kf in enumerate(w.keyframes):
+        dadd[k * B + 6:k * B + 6 + CS] = 1e-3
+        gadd[k * B + 6:k * B + 6 + CS] = 1e-3 * (0 - kf.code.astype(np.float64))
+    dadd[:6] += 1e4
+    dadd[6 + CS] += 1e4 / float(w.keyframes[0].scale) ** 2
+    return dadd, gadd
+
+
+def _schur_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    orc.set_threads(1)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    w = synth.make_window(**SCHUR_WINDOW)
+    K, CS, B = len(w.keyframes), w.CS, 7 + w.CS
+    dadd, gadd = _schur_priors(w)
+    owned = capi.shard_links(len(w.links), rank, world)
+    packed_local = capi.assemble_packed(K, w.links, CS, _edge_results(orc, w, owned))   # NOT reduced
+    plan = capi.ShardPlan(K, w.links, B, rank, world)
+    sep = plan.eliminate(packed_local, 1e-3, dadd, gadd)
+    t = torch.from_numpy(sep.copy())
+    dist.all_reduce(t)                                   # the one data-path collective: the separator system
+    delta = plan.solve(t.numpy())
+    local = np.array([plan.is_local(k) for k in range(K)])
+    np.save(os.path.join(out_dir, f"sdelta_{rank}.npy"), delta)
+    np.save(os.path.join(out_dir, f"slocal_{rank}.npy"), local)
+    np.save(os.path.join(out_dir, f"stail_{rank}.npy"), t.numpy()[-8:])
+    if rank == 0:
+        np.save(os.path.join(out_dir, "spayload.npy"), np.array([plan.sep_count, packed_local.size, plan.n_sep]))
+    plan.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_schur_sharded_solve_over_gloo(orc, tmp_path, world):
+    import torch.multiprocessing as mp
+    mp.spawn(_schur_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    w = synth.make_window(**SCHUR_WINDOW)
+    K, CS, B = len(w.keyframes), w.CS, 7 + w.CS
+    dadd, gadd = _schur_priors(w)
+    full = capi.assemble_packed(K, w.links, CS, _edge_results(orc, w, range(len(w.links))))
+    ref = capi.block_solve(full[:-4], K, w.links, B, 1e-3, dadd, gadd)
+    merged = np.full(K * B, np.nan)
+    for r in range(world):
+        d = np.load(tmp_path / f"sdelta_{r}.npy"); loc = np.load(tmp_path / f"slocal_{r}.npy")
+        for k in np.nonzero(loc)[0]:
+            seg = d[k * B:(k + 1) * B]
+            if not np.isnan(merged[k * B]):
+                assert np.array_equal(merged[k * B:(k + 1) * B], seg)   # shared keyframes: bit-identical across ranks
+            merged[k * B:(k + 1) * B] = seg
+    assert not np.isnan(merged).any()                    # every keyframe is solved by some rank
+    nsep_doubles, packed_doubles, nsep = np.load(tmp_path / "spayload.npy")
+    print(f"world {world}: {int(nsep)} separator keyframes, payload {nsep_doubles * 8 / 1e3:.0f} kB vs packed "
+          f"{packed_doubles * 8 / 1e3:.0f} kB, delta vs single-rank {rel(merged, ref):.2e}")
+    assert rel(merged, ref) < 1e-9
+    assert np.allclose(np.load(tmp_path / "stail_0.npy")[:4], full[-4:], rtol=1e-12)     # error totals ride along
