@@ -34,6 +34,7 @@ struct GeoParams
   float eps, loss_param;
   int tiles_per_block;
   int width, height; // cam.w / cam.h as integers: scalar (SGPR) values for the buffer descriptors
+  int n_work, xcd_chunk; // xcd_chunk > 0: XCD-aware work order (xcd_work_index)
 };
 
 __device__ __forceinline__ int gload_loc(const void *loc, int is64, int n)
@@ -107,7 +108,10 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wq = wave; // quarter of the 256-pixel sub-tile this wave owns
-  WorkItem wi = prm.work[blockIdx.x];
+  const int bid = uni(xcd_work_index((int)blockIdx.x, prm.n_work, prm.xcd_chunk));
+  if (bid < 0)
+    return;
+  WorkItem wi = prm.work[bid];
   wi.edge = uni(wi.edge);
   wi.tile = uni(wi.tile);
   GeoEdge E = prm.table ? prm.table[wi.edge] : prm.single;
@@ -377,7 +381,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
 #pragma unroll
       for (int w = 0; w < NW; ++w)
         a += s_red[w * 2 + tid];
-      prm.partials[(size_t)blockIdx.x * 2 + tid] = a;
+      prm.partials[(size_t)bid * 2 + tid] = a;
     }
     return;
   }
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
     }
   }
   __syncthreads();
-  float *out = prm.partials + (size_t)blockIdx.x * geo_partial_floats(CS);
+  float *out = prm.partials + (size_t)bid * geo_partial_floats(CS);
   if (tid < kGeoScalars)
   {
     float a = 0.f;
@@ -572,11 +576,13 @@ static hipError_t geo_lin_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   p.tiles_per_block = lc.tiles_per_block;
   p.width = (int)cam.w;
   p.height = (int)cam.h;
+  p.n_work = lc.n_work;
+  p.xcd_chunk = lc.xcd_order ? (lc.n_work + 7) / 8 : 0;
   if (lc.stage != 2)
   {
     if (lc.ev_start)
       (void)hipEventRecord(lc.ev_start, s);
-    hipLaunchKernelGGL((geo_kernel<CS, true>), dim3(lc.n_work), dim3(kGeoLinBlock), 0, s, p);
+    hipLaunchKernelGGL((geo_kernel<CS, true>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kGeoLinBlock), 0, s, p);
     if (lc.ev_stop)
       (void)hipEventRecord(lc.ev_stop, s);
   }
@@ -617,9 +623,11 @@ static hipError_t geo_err_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   p.tiles_per_block = lc.tiles_per_block;
   p.width = (int)cam.w;
   p.height = (int)cam.h;
+  p.n_work = lc.n_work;
+  p.xcd_chunk = lc.xcd_order ? (lc.n_work + 7) / 8 : 0;
   if (lc.ev_start)
     (void)hipEventRecord(lc.ev_start, s);
-  hipLaunchKernelGGL((geo_kernel<CS, false>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+  hipLaunchKernelGGL((geo_kernel<CS, false>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
   if (lc.ev_stop)
     (void)hipEventRecord(lc.ev_stop, s);
   if (lc.stage == 1) // the caller forms the per-edge statistics itself (window error pass)

@@ -40,6 +40,7 @@ struct PhotoParams
   unsigned *sig_flag_host;
   unsigned sig_epoch;
   float geo_loss_param; // error kernel: > 0 -> also the geometric error of the edge (LaunchCommon::fused_geo_loss_param)
+  int n_work, xcd_chunk; // xcd_chunk > 0: XCD-aware work order (xcd_work_index)
 };
 
 __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
@@ -99,7 +100,10 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   __shared__ float s_red[kWaves * kPhotoScalars];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  WorkItem wi = prm.work[blockIdx.x];
+  const int bid = uni(xcd_work_index((int)blockIdx.x, prm.n_work, prm.xcd_chunk));
+  if (bid < 0)
+    return;
+  WorkItem wi = prm.work[bid];
   wi.edge = uni(wi.edge);
   wi.tile = uni(wi.tile);
   PhotoEdge E = prm.table ? prm.table[wi.edge] : prm.single;
@@ -506,7 +510,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
 #pragma unroll
       for (int w = 0; w < kWaves; ++w)
         a += s_red[w * 4 + tid];
-      prm.partials[(size_t)blockIdx.x * rec + tid] = a;
+      prm.partials[(size_t)bid * rec + tid] = a;
     }
     return;
   }
@@ -536,7 +540,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     return ((s_mem[idx] + s_mem[SLICE + idx]) + s_mem[2 * SLICE + idx]) + s_mem[3 * SLICE + idx];
   };
   static_assert(kWaves == 4, "tsum adds four slices");
-  float *out = prm.partials + (size_t)blockIdx.x * photo_partial_floats(CS);
+  float *out = prm.partials + (size_t)bid * photo_partial_floats(CS);
   if (tid < kPhotoScalars)
   {
     // scalar slots of the partial record (layout unchanged): [0..20] Q^T G Q (upper triangle), [21..26] Q^T G q6 d,
@@ -585,7 +589,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     __syncthreads();
     if (tid == 0)
     {
-      const int g = prm.sig_group[blockIdx.x];
+      const int g = prm.sig_group[bid];
       if (atomicAdd(&prm.sig_cnt[g], 1) == prm.sig_total[g] - 1)
       { // (every record of the group is in memory already; the host only reads this flag, kernels launched after it
         // start with fresh caches)
@@ -792,6 +796,8 @@ static PhotoParams make_params(const PhotoEdge *single, const PhotoEdge *table, 
   p.sig_group = lc.sig_group; p.sig_cnt = lc.sig_cnt; p.sig_total = lc.sig_total;
   p.sig_flag_host = lc.sig_flag_host; p.sig_epoch = lc.sig_epoch;
   p.geo_loss_param = lc.fused_geo_loss_param;
+  p.n_work = lc.n_work;
+  p.xcd_chunk = lc.xcd_order ? (lc.n_work + 7) / 8 : 0;
   for (int l = 0; l < pyr.levels; ++l)
   {
     p.rx[l] = pyr.cam[l].fx / pyr.cam[0].fx; // same fp32 quotient the kernels used to form per pixel
@@ -815,9 +821,9 @@ static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const P
     if (lc.ev_start)
       (void)hipEventRecord(lc.ev_start, s);
     if (lc.packed)
-      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
     else
-      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 0>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 0>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
     if (lc.ev_stop)
       (void)hipEventRecord(lc.ev_stop, s);
   }
@@ -852,9 +858,9 @@ static hipError_t photo_err_impl(hipStream_t s, const PhotoEdge *single, const P
   if (lc.ev_start)
     (void)hipEventRecord(lc.ev_start, s);
   if (lc.packed)
-    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 1>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 1>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
   else
-    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 0>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 0>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
   if (lc.ev_stop)
     (void)hipEventRecord(lc.ev_stop, s);
   if (lc.stage == 1) // the caller forms the per-edge statistics itself (window error pass)

@@ -1862,6 +1862,8 @@ static LaunchCommon window_lc(SageWindow *w, bool photo)
   lc.partials = photo ? w->part_p.as<float>() : w->part_g.as<float>();
   lc.tiles_per_block = photo ? w->tpb_p : w->tpb_g;
   lc.packed = photo;
+  static const int xcd = [] { const char *e = getenv("SAGE_XCD_ORDER"); return e ? atoi(e) : 1; }();
+  lc.xcd_order = xcd != 0 && lc.n_work >= 64 && !w->pipe_enabled; // (the pipelined launch orders links itself)
   return lc;
 }
 

@@ -129,6 +129,10 @@ struct LaunchCommon
   const int32_t *sig_total = nullptr;
   unsigned *sig_flag_host = nullptr;
   unsigned sig_epoch = 0;
+  // XCD-aware work order (window launches): workgroup b runs work item (b % 8) * ceil(n_work / 8) + b / 8, so that the
+  // workgroups the dispatcher deals round-robin to one XCD walk a CONTIGUOUS eighth of the work list (consecutive
+  // sub-tile runs of the same edges, edges sharing a destination keyframe) and find each other's lines in that XCD's L2
+  bool xcd_order = false;
 };
 
 // per-edge results, reference layouts

@@ -16,6 +16,9 @@
 // The result equals the single-rank solve of the summed system to rounding (tests/test_shard_schur.py, world 2/4/8;
 // tests/test_sharded_reduce_gloo.py over gloo).
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <map>
@@ -36,20 +39,40 @@ struct SageShardPlan
   std::vector<int> interior;       // this rank's interior keyframes, ascending
   std::vector<int> sep_local;      // indices into sep_all of the separators this rank touches
   std::vector<int> local_links;    // links this rank owns
-  // separator buffer: upper-triangular block pairs (i <= j, indices into sep_all) that SOME rank couples
-  std::map<std::pair<int, int>, int> pair_block; // -> block index
+  // separator buffer = the packed layout of sage_block_solve over the separator keyframes: [diag blocks | blocks of the
+  // coupled pairs i < j (rows i, cols j) | rhs | 8 tail doubles]; pair_block maps (i <= j) -> block index
+  std::map<std::pair<int, int>, int> pair_block;
+  std::vector<int32_t> sep_pairs;  // flat (i, j), i < j, in block order: the "links" of the separator system
   int n_pair_blocks = 0;
   size_t sep_doubles = 0;
   // state between eliminate() and solve()
   sage::EnvelopeMatrix LI;         // Cholesky factor of the damped interior matrix
   std::vector<double> LS;          // [nS_local*B][nI*B]  rows of L^-1 A_IS^T  (i.e. A_SI L^-T)
   std::vector<double> y;           // L^-1 b_I
+  std::vector<int> ls_first;       // first non-zero column of every row of LS
   std::vector<int> int_pos;        // keyframe -> position among interior, or -1
   bool have_factor = false;
 };
 
 namespace
 {
+__attribute__((target_clones("avx512f", "avx2", "default"))) double sdot(const double *a, const double *b, int len)
+{
+#pragma clang fp reassociate(on)
+  double acc = 0.0;
+#pragma clang loop vectorize(enable) interleave_count(4)
+  for (int k = 0; k < len; ++k)
+    acc += a[k] * b[k];
+  return acc;
+}
+
+__attribute__((target_clones("avx512f", "avx2", "default"))) void saxpy(double *y, const double *x, double a, int len)
+{
+#pragma clang loop vectorize(enable) interleave_count(4)
+  for (int k = 0; k < len; ++k)
+    y[k] -= a * x[k];
+}
+
 inline int touch_rank_range(const SageShardPlan &p, int link)
 {
   // rank owning `link` (ranges are contiguous and ordered)
@@ -119,6 +142,35 @@ extern "C" int sage_shard_plan_create(int K, int nlinks, const int32_t *links, i
   }
   for (int l = p->link_lo[rank]; l < p->link_lo[rank + 1]; ++l)
     p->local_links.push_back(l);
+  {
+    // elimination order of the interior: keyframes far from the separators first, their neighbours last (BFS distance
+    // over this rank's links).  A temporal chain is eliminated from its middle outwards: the separator rows of A_SI
+    // L^-T then only fill the last few block columns instead of the whole chain.
+    std::vector<int> dist(K, -1), queue;
+    for (int k = 0; k < K; ++k)
+      if (p->sep_index[k] >= 0 && touch[rank][k])
+      {
+        dist[k] = 0;
+        queue.push_back(k);
+      }
+    for (size_t q = 0; q < queue.size(); ++q)
+      for (int l : p->local_links)
+      {
+        const int a = p->links[l].first, b = p->links[l].second;
+        const int o = a == queue[q] ? b : (b == queue[q] ? a : -1);
+        if (o >= 0 && dist[o] < 0)
+        {
+          dist[o] = dist[queue[q]] + 1;
+          queue.push_back(o);
+        }
+      }
+    std::stable_sort(p->interior.begin(), p->interior.end(), [&](int x, int y) {
+      const int dx = dist[x] < 0 ? K + 1 : dist[x], dy = dist[y] < 0 ? K + 1 : dist[y];
+      return dx > dy;
+    });
+    for (size_t i = 0; i < p->interior.size(); ++i)
+      p->int_pos[p->interior[i]] = (int)i;
+  }
   for (size_t s = 0; s < p->sep_all.size(); ++s)
     if (touch[rank][p->sep_all[s]])
       p->sep_local.push_back((int)s);
@@ -134,9 +186,20 @@ extern "C" int sage_shard_plan_create(int K, int nlinks, const int32_t *links, i
       for (size_t j = i; j < sl.size(); ++j)
         p->pair_block.emplace(std::make_pair(sl[i], sl[j]), 0);
   }
-  int nb = 0;
+  int nb = (int)p->sep_all.size(); // diagonal blocks first
   for (auto &kv : p->pair_block)
-    kv.second = nb++;
+  {
+    if (kv.first.first == kv.first.second)
+      kv.second = kv.first.first;
+    else
+    {
+      kv.second = nb++;
+      p->sep_pairs.push_back(kv.first.first);
+      p->sep_pairs.push_back(kv.first.second);
+    }
+  }
+  for (int s = 0; s < (int)p->sep_all.size(); ++s) // (every separator is touched by >= 2 ranks, so (s, s) exists)
+    p->pair_block.emplace(std::make_pair(s, s), s);
   p->n_pair_blocks = nb;
   p->sep_doubles = (size_t)nb * B * B + p->sep_all.size() * (size_t)B + 8;
   *out = p;
@@ -203,6 +266,9 @@ extern "C" int sage_shard_eliminate(SageShardPlan *p, const double *packed_local
     return SAGE_E_INVALID;
   const int B = p->B, BB = B * B, K = p->K;
   const LocalSystem S(*p, packed_local, damp, diag_add, g_add);
+  static const bool dbg = getenv("SAGE_DEBUG_TIMING") != nullptr;
+  auto tnow = [] { return std::chrono::steady_clock::now(); };
+  const auto t0 = tnow();
   const int nI = (int)p->interior.size(), nS = (int)p->sep_local.size();
   const int NI = nI * B, NS = nS * B;
   std::fill(sep_out, sep_out + p->sep_doubles, 0.0);
@@ -284,27 +350,35 @@ extern "C" int sage_shard_eliminate(SageShardPlan *p, const double *packed_local
   }
   // ---- eliminate the interior
   p->have_factor = false;
+  const auto t1 = tnow();
+  auto t2 = t1, t3 = t1;
   if (NI > 0)
   {
     if (!p->LI.cholesky_inplace(B, 1))
       return SAGE_E_NOT_PSD;
+    t2 = tnow();
     // forward substitutions: y = L^-1 b_I ; rows of LS = L^-1 (A_SI row)^T
+    // v <- L^-1 v, skipping the leading zeros of v (a separator row of A_SI only touches the interior keyframes next
+    // to it, which the elimination order puts last); returns the index of the first non-zero
     auto forward = [&](double *v) {
-      for (int r = 0; r < NI; ++r)
+      int z = 0;
+      while (z < NI && v[z] == 0.0)
+        ++z;
+      for (int r = z; r < NI; ++r)
       {
-        const int fr = p->LI.first[r];
-        const double *Lr = &p->LI.data[p->LI.rowptr[r]];
-        double acc = v[r];
-        for (int c = fr; c < r; ++c)
-          acc -= Lr[c - fr] * v[c];
-        v[r] = acc / Lr[r - fr];
+        const int fr = std::max(p->LI.first[r], z);
+        const double *Lr = &p->LI.data[p->LI.rowptr[r]] - p->LI.first[r];
+        v[r] = (v[r] - sdot(Lr + fr, v + fr, r - fr)) / Lr[r];
       }
+      return z;
     };
     p->y = bI;
     forward(p->y.data());
     p->LS = ASI;
-    for (int s = 0; s < NS; ++s)
-      forward(&p->LS[(size_t)s * NI]);
+    p->ls_first.assign(NS, 0);
+    for (int s2 = 0; s2 < NS; ++s2)
+      p->ls_first[s2] = forward(&p->LS[(size_t)s2 * NI]);
+    t3 = tnow();
     // C = A_SS - LS LS^T ; c = b_S - LS y
     for (int i = 0; i < NS; ++i)
     {
@@ -312,17 +386,14 @@ extern "C" int sage_shard_eliminate(SageShardPlan *p, const double *packed_local
       for (int j = i; j < NS; ++j)
       {
         const double *lj = &p->LS[(size_t)j * NI];
-        double acc = 0.0;
-        for (int k = 0; k < NI; ++k)
-          acc += li[k] * lj[k];
+        const int z = std::max(p->ls_first[i], p->ls_first[j]);
+        const double acc = z < NI ? sdot(li + z, lj + z, NI - z) : 0.0;
         ASS[(size_t)i * NS + j] -= acc;
         if (j != i)
           ASS[(size_t)j * NS + i] -= acc;
       }
-      double acc = 0.0;
-      for (int k = 0; k < NI; ++k)
-        acc += li[k] * p->y[k];
-      bS[i] -= acc;
+      const int z = p->ls_first[i];
+      bS[i] -= z < NI ? sdot(li + z, p->y.data() + z, NI - z) : 0.0;
     }
   }
   else
@@ -331,6 +402,12 @@ extern "C" int sage_shard_eliminate(SageShardPlan *p, const double *packed_local
     p->y.clear();
   }
   p->have_factor = true;
+  if (dbg)
+  {
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    fprintf(stderr, "[sage shard eliminate] build %.3f chol(I) %.3f forward(S rows) %.3f schur %.3f ms (NI %d NS %d)\n",
+            ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, tnow()), NI, NS);
+  }
   // ---- scatter into the separator buffer (upper-triangular block pairs)
   for (int i = 0; i < nS; ++i)
   {
@@ -360,35 +437,12 @@ extern "C" int sage_shard_solve(SageShardPlan *p, const double *sep_reduced, dou
   std::vector<double> dS(NSa, 0.0);
   if (NSa > 0)
   {
-    // block envelope of the separator system: first coupled separator of every separator
-    std::vector<int> first_blk(nSa);
-    for (int j = 0; j < nSa; ++j)
-      first_blk[j] = j;
-    for (const auto &kv : p->pair_block)
-      first_blk[kv.first.second] = std::min(first_blk[kv.first.second], kv.first.first);
-    std::vector<int> first(NSa);
-    for (int j = 0; j < nSa; ++j)
-      for (int r = 0; r < B; ++r)
-        first[j * B + r] = first_blk[j] * B;
-    sage::EnvelopeMatrix M;
-    M.init(NSa, first);
-    for (const auto &kv : p->pair_block)
-    {
-      const int i = kv.first.first, j = kv.first.second; // i <= j: block (i, j) -> lower triangle entry (j, i)^T
-      const double *blk = sep_reduced + (size_t)kv.second * BB;
-      for (int r = 0; r < B; ++r)
-        for (int c = 0; c < B; ++c)
-        {
-          const int R = j * B + c, Cc = i * B + r; // element A[i*B + r][j*B + c] = A[R][Cc]
-          if (Cc <= R)
-            M.at(R, Cc) = blk[r * B + c];
-        }
-    }
-    if (!M.cholesky_inplace(B, 1))
-      return SAGE_E_NOT_PSD;
-    for (int i = 0; i < NSa; ++i)
-      dS[i] = sep_rhs[i];
-    M.solve_inplace(dS);
+    // the reduced buffer IS a packed block system over the separator keyframes (diag | coupled pairs | rhs): the
+    // fixed-block AVX-512 factorisation of the window solve takes it as it is (no damping, no priors: both are inside)
+    const int rc = sage_block_solve(sep_reduced, nSa, (int)p->sep_pairs.size() / 2, p->sep_pairs.data(), B, 0.0, nullptr,
+                                    nullptr, dS.data());
+    if (rc)
+      return rc;
   }
   // ---- back-substitute the interior: d_I = L^-T (y - LS^T d_S(local))
   const int nI = (int)p->interior.size(), nS = (int)p->sep_local.size(), NI = nI * B;
@@ -397,9 +451,9 @@ extern "C" int sage_shard_solve(SageShardPlan *p, const double *sep_reduced, dou
     for (int r = 0; r < B; ++r)
     {
       const double d = dS[(size_t)p->sep_local[s] * B + r];
-      const double *ls = &p->LS[(size_t)(s * B + r) * std::max(NI, 1)];
-      for (int k = 0; k < NI; ++k)
-        v[k] -= ls[k] * d;
+      const int row = s * B + r, z = NI > 0 ? p->ls_first[row] : 0;
+      if (z < NI)
+        saxpy(v.data() + z, &p->LS[(size_t)row * NI] + z, d, NI - z);
     }
   for (int r = NI - 1; r >= 0; --r)
   {
@@ -407,8 +461,7 @@ extern "C" int sage_shard_solve(SageShardPlan *p, const double *sep_reduced, dou
     const double *Lr = &p->LI.data[p->LI.rowptr[r]];
     const double x = v[r] / Lr[r - fr];
     v[r] = x;
-    for (int c = fr; c < r; ++c)
-      v[c] -= Lr[c - fr] * x;
+    saxpy(v.data() + fr, Lr, x, r - fr);
   }
   for (int i = 0; i < nI; ++i)
     for (int r = 0; r < B; ++r)
