@@ -35,6 +35,7 @@ struct GeoParams
   int tiles_per_block;
   int width, height; // cam.w / cam.h as integers: scalar (SGPR) values for the buffer descriptors
   int n_work, xcd_chunk; // xcd_chunk > 0: XCD-aware work order (xcd_work_index)
+  const int32_t *order;  // optional launch order (LaunchCommon::order)
 };
 
 __device__ __forceinline__ int gload_loc(const void *loc, int is64, int n)
@@ -108,9 +109,11 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wq = wave; // quarter of the 256-pixel sub-tile this wave owns
-  const int bid = uni(xcd_work_index((int)blockIdx.x, prm.n_work, prm.xcd_chunk));
+  int bid = uni(xcd_work_index((int)blockIdx.x, prm.n_work, prm.xcd_chunk));
   if (bid < 0)
     return;
+  if (prm.order)
+    bid = uni(prm.order[bid]);
   WorkItem wi = prm.work[bid];
   wi.edge = uni(wi.edge);
   wi.tile = uni(wi.tile);
@@ -578,6 +581,7 @@ static hipError_t geo_lin_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   p.height = (int)cam.h;
   p.n_work = lc.n_work;
   p.xcd_chunk = lc.xcd_order ? (lc.n_work + 7) / 8 : 0;
+  p.order = lc.order;
   if (lc.stage != 2)
   {
     if (lc.ev_start)
@@ -625,6 +629,7 @@ static hipError_t geo_err_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   p.height = (int)cam.h;
   p.n_work = lc.n_work;
   p.xcd_chunk = lc.xcd_order ? (lc.n_work + 7) / 8 : 0;
+  p.order = lc.order;
   if (lc.ev_start)
     (void)hipEventRecord(lc.ev_start, s);
   hipLaunchKernelGGL((geo_kernel<CS, false>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);

@@ -41,6 +41,11 @@ struct PhotoParams
   unsigned sig_epoch;
   float geo_loss_param; // error kernel: > 0 -> also the geometric error of the edge (LaunchCommon::fused_geo_loss_param)
   int n_work, xcd_chunk; // xcd_chunk > 0: XCD-aware work order (xcd_work_index)
+  const int32_t *order;  // optional launch order (LaunchCommon::order)
+  // linearize: a workgroup writes one partial record per `flush` sub-tiles (record index = rec_first[edge] + tile / flush);
+  // flush == tiles_per_block is the plain "one record per work item"
+  const int32_t *rec_first;
+  int flush;
 };
 
 __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
@@ -100,9 +105,11 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   __shared__ float s_red[kWaves * kPhotoScalars];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int bid = uni(xcd_work_index((int)blockIdx.x, prm.n_work, prm.xcd_chunk));
+  int bid = uni(xcd_work_index((int)blockIdx.x, prm.n_work, prm.xcd_chunk));
   if (bid < 0)
     return;
+  if (prm.order)
+    bid = uni(prm.order[bid]);
   WorkItem wi = prm.work[bid];
   wi.edge = uni(wi.edge);
   wi.tile = uni(wi.tile);
@@ -143,6 +150,14 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
 #pragma unroll
   for (int t = 0; t < NT + 1; ++t)
     acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef SAGE_PHOTO_TWO_LEVEL
+  // second-level sums: the MFMA chains run over SAGE_PHOTO_TWO_LEVEL sub-tiles, their results are added here (a handful
+  // of adds per record instead of hundreds of chained fmaf) -- only touched between sub-tiles, so they can live in scratch
+  f32x4 acc2[NT + 1];
+#pragma unroll
+  for (int t = 0; t < NT + 1; ++t)
+    acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
   float err_acc = 0.f, vm_acc = 0.f, sdd_acc = 0.f; // lane-local sums over the sub-tiles: error, inliers, sigma d^2
   float gerr_acc = 0.f;                             // error kernel, fused geometric error
   const bool fuse_geo = !JAC && prm.geo_loss_param > 0.f && E.dpt1_geo != nullptr;
@@ -150,6 +165,8 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   __syncthreads();                                 // s_red zeroed
 
   const int nsub = min(prm.tiles_per_block, (N + kTile - 1) / kTile - wi.tile);
+  const int flush = JAC ? max(1, prm.flush) : 1;
+  const int rec_base = (JAC && prm.rec_first) ? uni(prm.rec_first[wi.edge]) + wi.tile / flush : bid;
   for (int sub = 0; sub < nsub; ++sub)
   {
   const int tile = wi.tile + sub;
@@ -490,31 +507,32 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     }
   }
   __builtin_amdgcn_wave_barrier(); // the stash is rewritten by the next sub-tile
-  } // sub-tile loop
-
-  if (!JAC)
+  // ---- flush: one partial record per `flush` sub-tiles.  The fp32 accumulation chains (64 fmaf per sub-tile and
+  //      accumulator) are what the LM step's distance from the exact step grows with (DESIGN s4); the workgroup keeps
+  //      walking its run of sub-tiles (pose / descriptor prologue amortised, vertically adjacent bands stay in its L1/L2)
+  const bool last_sub = sub + 1 == nsub;
+#ifdef SAGE_PHOTO_TWO_LEVEL
+  if (JAC && (last_sub || ((sub + 1) % SAGE_PHOTO_TWO_LEVEL) == 0))
   {
-    const float se = wave_sum(err_acc), sn = wave_sum(vm_acc), sg = wave_sum(gerr_acc);
-    if (lane == 63)
-    {
-      s_red[wave * 4 + 0] = se;
-      s_red[wave * 4 + 1] = sn;
-      s_red[wave * 4 + 2] = sg;
-      s_red[wave * 4 + 3] = sn; // the geometric edge counts the same pixels
-    }
-    __syncthreads();
-    const int rec = prm.geo_loss_param > 0.f ? 4 : 2; // floats per workgroup record
-    if (tid < rec)
-    {
-      float a = 0.f;
 #pragma unroll
-      for (int w = 0; w < kWaves; ++w)
-        a += s_red[w * 4 + tid];
-      prm.partials[(size_t)bid * rec + tid] = a;
+    for (int t = 0; t < NT + 1; ++t)
+    {
+      acc2[t] += acc[t];
+      acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    return;
+    if (last_sub || ((sub + 1) % flush) == 0)
+    {
+#pragma unroll
+      for (int t = 0; t < NT + 1; ++t)
+      {
+        acc[t] = acc2[t];
+        acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
   }
-
+#endif
+  if (last_sub || ((sub + 1) % flush) == 0)
+  {
   // ---- cross-wave sum in a fixed order (deterministic): every wave dumps its tiles into its own slice of the (now idle)
   //      stash memory, one barrier, then all threads add the four slices as ((w0 + w1) + w2) + w3 on their way out to the
   //      partial record (a round of barriers per wave used to cost ~8 % of a one-sub-tile workgroup) ----
@@ -540,7 +558,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     return ((s_mem[idx] + s_mem[SLICE + idx]) + s_mem[2 * SLICE + idx]) + s_mem[3 * SLICE + idx];
   };
   static_assert(kWaves == 4, "tsum adds four slices");
-  float *out = prm.partials + (size_t)bid * photo_partial_floats(CS);
+  float *out = prm.partials + (size_t)(rec_base + sub / flush) * photo_partial_floats(CS);
   if (tid < kPhotoScalars)
   {
     // scalar slots of the partial record (layout unchanged): [0..20] Q^T G Q (upper triangle), [21..26] Q^T G q6 d,
@@ -579,6 +597,42 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   else
     for (int idx = tid; idx < NT * 256; idx += kBlock)
       out[kPhotoScalars + idx] = tsum(idx);
+    if (!last_sub)
+    {
+      __syncthreads(); // the slices are about to become stash memory again
+#pragma unroll
+      for (int t = 0; t < NT + 1; ++t)
+        acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+      err_acc = 0.f;
+      vm_acc = 0.f;
+      sdd_acc = 0.f;
+    }
+  }
+  } // sub-tile loop
+
+  if (!JAC)
+  {
+    const float se = wave_sum(err_acc), sn = wave_sum(vm_acc), sg = wave_sum(gerr_acc);
+    if (lane == 63)
+    {
+      s_red[wave * 4 + 0] = se;
+      s_red[wave * 4 + 1] = sn;
+      s_red[wave * 4 + 2] = sg;
+      s_red[wave * 4 + 3] = sn; // the geometric edge counts the same pixels
+    }
+    __syncthreads();
+    const int rec = prm.geo_loss_param > 0.f ? 4 : 2; // floats per workgroup record
+    if (tid < rec)
+    {
+      float a = 0.f;
+#pragma unroll
+      for (int w = 0; w < kWaves; ++w)
+        a += s_red[w * 4 + tid];
+      prm.partials[(size_t)bid * rec + tid] = a;
+    }
+    return;
+  }
+
   if (prm.sig_cnt)
   {
     // this workgroup's partial record is complete: agent-scope release, then count it; the
@@ -798,6 +852,9 @@ static PhotoParams make_params(const PhotoEdge *single, const PhotoEdge *table, 
   p.geo_loss_param = lc.fused_geo_loss_param;
   p.n_work = lc.n_work;
   p.xcd_chunk = lc.xcd_order ? (lc.n_work + 7) / 8 : 0;
+  p.order = lc.order;
+  p.rec_first = lc.flush > 0 ? lc.edge_first : nullptr;
+  p.flush = lc.flush > 0 ? lc.flush : lc.tiles_per_block;
   for (int l = 0; l < pyr.levels; ++l)
   {
     p.rx[l] = pyr.cam[l].fx / pyr.cam[0].fx; // same fp32 quotient the kernels used to form per pixel

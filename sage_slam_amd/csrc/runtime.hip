@@ -77,19 +77,26 @@ int pick_tiles_per_block(long long total_tiles)
 struct WorkList
 {
   std::vector<WorkItem> work;
-  std::vector<int32_t> edge_first, edge_tiles;
+  std::vector<int32_t> edge_first, edge_tiles; // per edge: first work item, number of work items
+  std::vector<int32_t> rec_first, rec_count;   // per edge: first partial record, number of partial records
   int tiles_per_block = 1;
+  int flush = 1; // sub-tiles per partial record (== tiles_per_block unless the photometric linearize asks for less)
+  int n_records = 0;
   // `order`: optional sequence of the edges (a permutation of 0..N.size()-1) the work items are laid out in; every
   // edge's items stay contiguous
-  void build(const std::vector<int> &N, int tpb_override = 0, const std::vector<int> *order = nullptr)
+  void build(const std::vector<int> &N, int tpb_override = 0, const std::vector<int> *order = nullptr, int flush_ = 0)
   {
     long long total = 0;
     for (int n : N)
       total += (n + kTile - 1) / kTile;
     tiles_per_block = tpb_override > 0 ? tpb_override : pick_tiles_per_block(total);
+    flush = (flush_ > 0 && flush_ < tiles_per_block && tiles_per_block % flush_ == 0) ? flush_ : tiles_per_block;
     work.clear();
     edge_first.assign(N.size(), 0);
     edge_tiles.assign(N.size(), 0);
+    rec_first.assign(N.size(), 0);
+    rec_count.assign(N.size(), 0);
+    n_records = 0;
     for (size_t i = 0; i < N.size(); ++i)
     {
       const size_t e = order ? (size_t)(*order)[i] : i;
@@ -98,6 +105,9 @@ struct WorkList
       for (int t = 0; t < tiles; t += tiles_per_block)
         work.push_back(WorkItem{(int32_t)e, t});
       edge_tiles[e] = (int32_t)work.size() - edge_first[e];
+      rec_first[e] = n_records;
+      rec_count[e] = (tiles + flush - 1) / flush;
+      n_records += rec_count[e];
     }
   }
 };
@@ -1163,11 +1173,14 @@ struct SageWindow
   SageAllReduceFn allreduce = nullptr;  // sharded windows: caller-provided sum all-reduce (see sage_ba.h)
   void *allreduce_user = nullptr;
   void *rccl_hook = nullptr;            // sage_window_use_rccl: owned {comm, stream} record behind `allreduce`
+  DevBuf order_p, order_g;              // launch order of the photometric / geometric work lists (build_launch_order)
   double *h_err = nullptr;              // pinned [8]: {linearize tail[4], error pass totals[4]} written by the kernels
   DevBuf pk;                            // engine-internal channel-group pyramids [K][3 (f,gx,gy)][FS/4][P][4]
   DevBuf f0s;                           // per keyframe: pre-sampled source features [L][FS/4][N][4]
   DevBuf ptab[2], gtab[2];              // edge tables per variable set
   DevBuf work_p, first_p, tiles_p, work_g, first_g, tiles_g;
+  DevBuf rec_first_p, rec_count_p;      // photometric linearize: partial RECORDS per edge (flush_p sub-tiles each)
+  int flush_p = 0, n_rec_p = 0;
   DevBuf part_p, part_g;
   DevBuf AtA_p, Atb_p, stats_p, AtA_g, Atb_g, stats_g;
   DevBuf adj_start, adj, link_edges, packed, errbuf;
@@ -1284,7 +1297,7 @@ extern "C" void sage_window_destroy(SageWindow *w)
 {
   if (!w)
     return;
-  DevBuf *bufs[] = {&w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
+  DevBuf *bufs[] = {&w->rec_first_p, &w->rec_count_p, &w->order_p, &w->order_g, &w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
                     &w->pk, &w->f0s, &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
                     &w->work_g, &w->first_g, &w->tiles_g, &w->part_p, &w->part_g, &w->AtA_p, &w->Atb_p,
                     &w->stats_p, &w->AtA_g, &w->Atb_g, &w->stats_g, &w->adj_start, &w->adj, &w->link_edges,
@@ -1555,6 +1568,52 @@ static int pipe_setup(SageWindow *w, const std::vector<int32_t> &group_of_work);
 static bool pipe_wanted(const SageWindow *w);
 static std::vector<int> pipe_link_sequence(int nl, int *mid = nullptr);
 
+// Launch order of a window work list.  The list itself is edge-major (an edge's sub-tile runs are contiguous: its
+// partial records must be).  mode 1: the edges of the links that share their newer keyframe (3 links = 6 directed edges
+// in a temporal window: 3 INTO that keyframe, sharing their destination pyramids, 3 OUT of it, sharing source samples,
+// basis rows and pre-sampled features) are walked BAND BY BAND -- run t of every edge of the group before run t + 1 --
+// so the ~770 workgroups in flight work on one or two keyframe groups (tens of MB: L2/MALL resident) instead of on 24
+// edges' worth of keyframes.  mode 2: additionally transposes blocks of 8 bands x (edges of the group) so that the
+// workgroups of one band go to the same XCD (ids congruent mod 8).
+static std::vector<int32_t> build_launch_order(const SageWindow *w, const WorkList &wl, int mode)
+{
+  std::vector<int32_t> order;
+  const int n_edges = (int)wl.edge_first.size();
+  if (mode <= 0 || n_edges == 0)
+    return order;
+  order.reserve(wl.work.size());
+  int e0 = 0;
+  while (e0 < n_edges)
+  {
+    // group: consecutive local edges whose links have the same newer keyframe
+    const int kb = w->links[w->local_links[e0 / 2]].second;
+    int e1 = e0;
+    while (e1 < n_edges && w->links[w->local_links[e1 / 2]].second == kb)
+      ++e1;
+    int max_runs = 0;
+    for (int e = e0; e < e1; ++e)
+      max_runs = std::max(max_runs, (int)wl.edge_tiles[e]);
+    const int ne = e1 - e0;
+    if (mode == 1)
+    {
+      for (int t = 0; t < max_runs; ++t)
+        for (int e = e0; e < e1; ++e)
+          if (t < wl.edge_tiles[e])
+            order.push_back(wl.edge_first[e] + t);
+    }
+    else
+    {
+      for (int t0 = 0; t0 < max_runs; t0 += 8)
+        for (int j = 0; j < ne; ++j)       // position 8 * j + i  <-  (band t0 + i, edge j): XCD i gets band t0 + i
+          for (int i = 0; i < 8; ++i)
+            if (t0 + i < wl.edge_tiles[e0 + j])
+              order.push_back(wl.edge_first[e0 + j] + t0 + i);
+    }
+    e0 = e1;
+  }
+  return order;
+}
+
 extern "C" int sage_window_finalize(SageWindow *w)
 {
   if (!w || w->finalized || w->K < 1)
@@ -1767,6 +1826,14 @@ extern "C" int sage_window_finalize(SageWindow *w)
   }
   w->n_work_g = (int)wl.work.size();
   w->tpb_g = wl.tiles_per_block;
+  static const int order_mode = [] { const char *e = getenv("SAGE_WORK_ORDER"); return e ? atoi(e) : 0; }();
+  {
+    const std::vector<int32_t> og = build_launch_order(w, wl, order_mode);
+    if (!og.empty() && og.size() == wl.work.size() && (rc = upload(w->order_g, og, w->stream)))
+      return rc;
+    if (og.empty())
+      w->order_g.release();
+  }
   if ((rc = upload(w->work_g, wl.work, w->stream)) || (rc = upload(w->first_g, wl.edge_first, w->stream)) ||
       (rc = upload(w->tiles_g, wl.edge_tiles, w->stream)))
     return rc;
@@ -1777,12 +1844,15 @@ extern "C" int sage_window_finalize(SageWindow *w)
     long long total = 0;
     for (int n : Nedge)
       total += (n + kTile - 1) / kTile;
-    // sub-tiles a workgroup accumulates in fp32 (MFMA chains of 64 fmaf per sub-tile and accumulator) before its partial
-    // record goes out to the double-precision sums: the LM step's distance from the exact step grows with the chain
-    // length (K = 64 headline window, scripts/tpb_noise_probe.py: 8 -> 2.1e-4, 4 -> 1.2e-4, 2 -> 7.6e-5, 1 -> 4.9e-5
-    // rel-L2; the fp32 oracle itself sits at 5.5e-5), the kernel time with the workgroup prologues (8: 0.86 ms,
-    // 2: 0.88 ms, 1: 0.96 ms).  2 keeps the step within the 1e-4 parity bar with margin at +2 % kernel time.
-    int tpb = total >= 4096 ? 2 : 1;
+    // run length of a workgroup (sub-tiles it walks: prologue amortisation, vertical L1/L2 reuse between its bands) and,
+    // separately, the number of sub-tiles it accumulates in fp32 before a partial record goes out to the double sums
+    // (MFMA chains of 64 fmaf per sub-tile and accumulator): the LM step's distance from the exact step grows with the
+    // chain length (K = 64 window, scripts/tpb_noise_probe.py: 8 -> 2.1e-4, 4 -> 1.2e-4, 2 -> 7.6e-5, 1 -> 4.9e-5 rel-L2;
+    // the fp32 oracle itself sits at 5.5e-5).  Records every 2 sub-tiles keep the step inside the 1e-4 parity bar.
+    int tpb = total >= 8192 ? 8 : (total >= 4096 ? 2 : 1);
+    int flush = 2;
+    if (const char *e = getenv("SAGE_PHOTO_FLUSH"))
+      flush = std::max(1, atoi(e));
     if (const char *e = getenv("SAGE_PHOTO_TPB"))
       tpb = std::max(1, atoi(e));
     std::vector<int> edge_order;
@@ -1792,20 +1862,30 @@ extern "C" int sage_window_finalize(SageWindow *w)
         edge_order.push_back(2 * li); // both directed edges of a link stay together
         edge_order.push_back(2 * li + 1);
       }
-    wp.build(Nedge, tpb, edge_order.empty() ? nullptr : &edge_order);
+    wp.build(Nedge, tpb, edge_order.empty() ? nullptr : &edge_order, flush);
     wp_group_of_work.resize(wp.work.size());
     for (size_t i = 0; i < wp.work.size(); ++i)
       wp_group_of_work[i] = wp.work[i].edge / 2; // group = local link of the edge
     w->n_work_p = (int)wp.work.size();
     w->tpb_p = wp.tiles_per_block;
+    {
+      const std::vector<int32_t> op = build_launch_order(w, wp, edge_order.empty() ? order_mode : 0);
+      if (!op.empty() && op.size() == wp.work.size() && (rc = upload(w->order_p, op, w->stream)))
+        return rc;
+      if (op.empty())
+        w->order_p.release();
+    }
+    w->flush_p = wp.flush;
+    w->n_rec_p = wp.n_records;
     if ((rc = upload(w->work_p, wp.work, w->stream)) || (rc = upload(w->first_p, wp.edge_first, w->stream)) ||
-        (rc = upload(w->tiles_p, wp.edge_tiles, w->stream)))
+        (rc = upload(w->tiles_p, wp.edge_tiles, w->stream)) || (rc = upload(w->rec_first_p, wp.rec_first, w->stream)) ||
+        (rc = upload(w->rec_count_p, wp.rec_count, w->stream)))
       return rc;
   }
   SAGE_HIP(hipStreamSynchronize(w->stream));
   const size_t Dp = 13 + CS, Dg = 14 + 2 * CS;
   const size_t ne = std::max(1, w->n_edges);
-  if ((rc = w->part_p.reserve(std::max<size_t>(1, w->n_work_p) * photo_partial_floats(CS) * sizeof(float))) ||
+  if ((rc = w->part_p.reserve(std::max<size_t>(1, std::max(w->n_work_p, w->n_rec_p)) * photo_partial_floats(CS) * sizeof(float))) ||
       (rc = w->part_g.reserve(std::max<size_t>(1, w->n_work_g) * geo_partial_floats(CS) * sizeof(float))) ||
       (rc = w->AtA_p.reserve(ne * Dp * Dp * sizeof(float))) || (rc = w->Atb_p.reserve(ne * Dp * sizeof(float))) ||
       (rc = w->stats_p.reserve(ne * 2 * sizeof(float))) || (rc = w->AtA_g.reserve(ne * Dg * Dg * sizeof(float))) ||
@@ -1851,7 +1931,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
   return SAGE_OK;
 }
 
-static LaunchCommon window_lc(SageWindow *w, bool photo)
+static LaunchCommon window_lc(SageWindow *w, bool photo, bool photo_linearize = false)
 {
   LaunchCommon lc{};
   lc.work = (photo ? w->work_p : w->work_g).as<WorkItem>();
@@ -1862,12 +1942,21 @@ static LaunchCommon window_lc(SageWindow *w, bool photo)
   lc.partials = photo ? w->part_p.as<float>() : w->part_g.as<float>();
   lc.tiles_per_block = photo ? w->tpb_p : w->tpb_g;
   lc.packed = photo;
+  if (photo_linearize && w->flush_p > 0)
+  {
+    // the linearize (and its per-edge finalize) count partial RECORDS, the error pass work items
+    lc.edge_first = w->rec_first_p.as<int32_t>();
+    lc.edge_tiles = w->rec_count_p.as<int32_t>();
+    lc.flush = w->flush_p;
+  }
   // opt-in, measured NEGATIVE on the K = 64 headline window (r02): giving every XCD a contiguous eighth of the work list
   // makes the eight L2s work on eight different edge sets at once -- L2 hit rate 59 % -> 25 %, HBM fetch 2.3 -> 5.5 GB per
   // launch, photometric linearize 0.88 -> 1.03 ms.  With the dispatcher's round-robin all XCDs walk the same edges
   // together and the MALL serves the duplicates.
   static const int xcd = [] { const char *e = getenv("SAGE_XCD_ORDER"); return e ? atoi(e) : 0; }();
   lc.xcd_order = xcd != 0 && lc.n_work >= 64 && !w->pipe_enabled; // (the pipelined launch orders links itself)
+  if (!w->pipe_enabled)
+    lc.order = photo ? (w->order_p.p ? w->order_p.as<int32_t>() : nullptr) : (w->order_g.p ? w->order_g.as<int32_t>() : nullptr);
   return lc;
 }
 
@@ -1937,7 +2026,7 @@ extern "C" int sage_window_linearize(SageWindow *w)
     if (c.use_photo)
     {
       EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>(), w->wide_p.as<double>()};
-      LaunchCommon lc = window_lc(w, true);
+      LaunchCommon lc = window_lc(w, true, true);
       prof_attach(w, 0, lc);
       SAGE_HIP(launch_photo_linearize(w->stream, c.CS, c.FS, nullptr, w->ptab[0].as<PhotoEdge>(), lc, c.pyr,
                                       c.photo_weights, c.eps, out));
@@ -2550,7 +2639,7 @@ static int pipe_linearize(SageWindow *w)
   }
   {
     EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>(), w->wide_p.as<double>()};
-    LaunchCommon lc = window_lc(w, true);
+    LaunchCommon lc = window_lc(w, true, true);
     prof_attach(w, 0, lc);
     lc.stage = 1;
     lc.sig_group = w->pipe_group.as<int32_t>();
@@ -2595,7 +2684,7 @@ static int pipe_launch_chunk(SageWindow *w, int chunk)
   for (const auto &r : ranges)
     if (r[1] > r[0])
     {
-      LaunchCommon lf = window_lc(w, true);
+      LaunchCommon lf = window_lc(w, true, true);
       lf.stage = 2;
       lf.fin_block = 256;
       lf.edge_base = 2 * r[0];

@@ -133,6 +133,12 @@ struct LaunchCommon
   // workgroups the dispatcher deals round-robin to one XCD walk a CONTIGUOUS eighth of the work list (consecutive
   // sub-tile runs of the same edges, edges sharing a destination keyframe) and find each other's lines in that XCD's L2
   bool xcd_order = false;
+  // launch order (window launches, optional): workgroup b runs work item order[b] (a permutation of 0..n_work-1); the
+  // partial record stays indexed by the WORK ITEM, so every edge's records remain contiguous for its finalize
+  const int32_t *order = nullptr;
+  // photometric linearize: > 0 -> one partial record per `flush` sub-tiles (edge_first / edge_tiles then count RECORDS:
+  // record = edge_first[edge] + tile / flush); 0 -> one record per work item
+  int32_t flush = 0;
 };
 
 // per-edge results, reference layouts

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """LM-delta noise of the K-keyframe window against the exact (fp64-oracle) step as a function of the fp32 accumulation
 run length of the two linearize kernels (SAGE_PHOTO_TPB / SAGE_GEO_TPB = sub-tiles a workgroup sums before it writes a
-partial record; the partials are summed in double).  usage: python scripts/tpb_noise_probe.py [K]"""
+partial record; the partials are summed in double).  (SAGE_PHOTO_TPB = sub-tiles a workgroup walks, SAGE_PHOTO_FLUSH = sub-tiles per partial record).
+usage: python scripts/tpb_noise_probe.py [K]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -27,8 +28,8 @@ for prec in res:
     H, g = add_priors(*capi.unpack_dense(capi.assemble_packed(K, w.links, CS, res[prec]), K, w.links, CS)[:2], w, CS)
     D[prec] = damped_delta(H, g, 1e-3)
 print(f"fp32 oracle vs exact: {rel(D['f32'], D['f64']):.2e}")
-for pt, gt in ((8, 16), (4, 8), (2, 4), (2, 2), (1, 2), (1, 1)):
-    os.environ["SAGE_PHOTO_TPB"] = str(pt); os.environ["SAGE_GEO_TPB"] = str(gt)
+for pt, fl in ((8, 8), (8, 4), (8, 2), (8, 1), (2, 2), (1, 1)):
+    os.environ["SAGE_PHOTO_TPB"] = str(pt); os.environ["SAGE_PHOTO_FLUSH"] = str(fl); gt = 16
     win = capi.Window(w)
     win.set_profiling(True)
     for _ in range(5):
@@ -36,6 +37,6 @@ for pt, gt in ((8, 16), (4, 8), (2, 4), (2, 2), (1, 2), (1, 1)):
     win.solve(1e-3)
     dh = win.delta()
     kt = [win.kernel_time(i) for i in range(2)]
-    print(f"photo tpb {pt:2d} geo tpb {gt:2d}: hip-exact {rel(dh, D['f64']):.2e}  hip-fp32oracle {rel(dh, D['f32']):.2e}   "
+    print(f"photo run {pt:2d} sub-tiles, record every {fl:2d}: hip-exact {rel(dh, D['f64']):.2e}  hip-fp32oracle {rel(dh, D['f32']):.2e}   "
           f"photo lin {kt[0][0] / max(1, kt[0][1]):.3f} ms  geo lin {kt[1][0] / max(1, kt[1][1]):.3f} ms", flush=True)
     win.close()
