@@ -497,6 +497,15 @@ int sage_shard_keyframe_is_local(const SageShardPlan *p, int kf);
 int sage_shard_eliminate(SageShardPlan *p, const double *packed_local_host, double damp, const double *diag_add,
                          const double *g_add, double *sep_out);
 int sage_shard_solve(SageShardPlan *p, const double *sep_reduced, double *delta);
+/* The same decomposition inside ONE process: keyframe k belongs to domain k*ndomains/K, the newer endpoint of every
+ * link that crosses a domain boundary is a separator (the first 3 keyframes of a domain in a temporal window, the far
+ * end of a loop closure).  packed_host is then the ASSEMBLED system (domain 0 contributes the separator blocks).
+ * sage_block_solve_domains = sage_block_solve computed that way on `ndomains` host threads: for long windows and for
+ * loop closures, whose envelope rows would otherwise span the whole window. */
+int sage_shard_plan_create_domains(int K, int nlinks, const int32_t *links, int B, int domain, int ndomains,
+                                   SageShardPlan **out);
+int sage_block_solve_domains(const double *packed_host, int K, int nlinks, const int32_t *links, int B, double damp,
+                             const double *diag_add, const double *g_add, int ndomains, double *delta);
 
 /* Native collective: RCCL (backend of record on MI355X: ring / tree over xGMI) bound at run time.  One process per GPU:
  *   rank 0:  sage_rccl_unique_id(id);   broadcast the 128 bytes by any means (MPI, a socket, torch.distributed);
@@ -518,6 +527,12 @@ typedef struct SageLmState
   int accepted, iters;
 } SageLmState;
 int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmConfig *cfg);
+/* Sharded windows with the domain-decomposed solve (sage_shard_*: chosen at sage_window_finalize for world > 1 when
+ * SAGE_SHARD_SCHUR=1, or by default from K >= 256 keyframes): sage_window_lm_step all-reduces the separator system
+ * instead of the packed normal equations, and a rank only updates the keyframes its own links touch.  Call this (a
+ * collective: every rank, through the window's all-reduce) before reading variables of other keyframes with
+ * sage_window_get_keyframe; a no-op for windows that solve the whole system on every rank. */
+int sage_window_sync_variables(SageWindow *w);
 
 #ifdef __cplusplus
 }

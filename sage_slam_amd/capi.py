@@ -98,7 +98,7 @@ SYMBOLS = [
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_sort_locations", "sage_bind_thread_to_device",
+    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_sort_locations", "sage_bind_thread_to_device",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
@@ -235,6 +235,20 @@ def block_solve(packed, K, links, B, damp, diag_add=None, g_add=None):
                                 C.c_double(damp), dp(da), dp(ga), delta.ctypes.data_as(C.POINTER(C.c_double))),
          "sage_block_solve")
     return delta
+
+
+def block_solve_domains(packed, K, links, B, damp, ndomains, diag_add=None, g_add=None):
+    """sage_block_solve by domain decomposition on `ndomains` host threads (long windows, loop closures)."""
+    p = np.ascontiguousarray(packed, np.float64)
+    lk = np.ascontiguousarray(np.asarray(links, np.int32).reshape(-1))
+    out = np.zeros(K * B, np.float64)
+    dp = lambda a: None if a is None else np.ascontiguousarray(a, np.float64).ctypes.data_as(C.POINTER(C.c_double))
+    da = None if diag_add is None else np.ascontiguousarray(diag_add, np.float64)
+    ga = None if g_add is None else np.ascontiguousarray(g_add, np.float64)
+    _chk(lib().sage_block_solve_domains(p.ctypes.data_as(C.POINTER(C.c_double)), K, len(links),
+                                        lk.ctypes.data_as(C.POINTER(C.c_int32)), B, C.c_double(damp), dp(da), dp(ga),
+                                        ndomains, out.ctypes.data_as(C.POINTER(C.c_double))), "sage_block_solve_domains")
+    return out
 
 
 def lm_config_default() -> SageLmConfig:
@@ -560,6 +574,9 @@ class Window:
 
         self._allreduce_cb = ALLREDUCE_FN(hook)    # keep the trampoline alive as long as the window
         _chk(lib().sage_window_set_allreduce(self.h, self._allreduce_cb, None), "sage_window_set_allreduce")
+
+    def sync_variables(self):
+        _chk(lib().sage_window_sync_variables(self.h), "sage_window_sync_variables")
 
     def use_rccl(self, comm):
         """native RCCL all-reduce on the window's stream (sage_window_use_rccl); comm from rccl_comm_create()."""

@@ -1633,6 +1633,62 @@ __attribute__((target_clones("avx512f", "avx2", "default"))) static int block_ch
 {
   return block_chol_pass<3>(E, T, X, y, phase, lo, hi);
 }
+// Separator rows of a partial factorisation (domain decomposition, shard_solve.cpp): the rows [nI, K) get L_ij for
+// their columns j < nI; their blocks (i, j), nI <= j <= i, end as the Schur complement C_ij = A_ij - sum_{k<nI} L_ik L_jk^T
+// (not factorised) and y_i as c_i = b_i - sum_{k<nI} L_ik y_k.  No A ranges in this storage.
+template <int NV>
+static inline __attribute__((always_inline)) void block_schur_rows(const BlockEnvelope &E, double *T, double *X, double *y,
+                                                                   int nI)
+{
+  constexpr int BP = NV * 8, BB = BP * BP;
+  const int K = E.K;
+  const int32_t *row_first = E.row_first, *row_off = E.row_off;
+  auto has = [&](int i, int j) { return j >= row_first[i] && j <= i; };
+  auto blk = [&](int i, int j) { return T + (size_t)(row_off[i] + j - row_first[i]) * BB; };
+  RowPrefetch pf{nullptr, nullptr};
+  for (int i = nI; i < K; ++i)
+  {
+    const int f = row_first[i];
+    for (int j = f; j < i; ++j)
+    {
+      double *CT = blk(i, j);
+      for (int k = f; k < std::min(j, nI); ++k)
+        if (has(j, k))
+          tn_sub<NV>(CT, blk(j, k), blk(i, k), false, pf);
+      if (j < nI)
+        apply_inverse<NV>(CT, X + (size_t)j * BB);
+    }
+    double *S = blk(i, i);
+    for (int k = f; k < std::min(i, nI); ++k)
+      tn_sub<NV>(S, blk(i, k), blk(i, k), true, pf);
+    double w[BP];
+    for (int r = 0; r < BP; ++r)
+      w[r] = y[(size_t)i * BP + r];
+    for (int k = f; k < std::min(i, nI); ++k)
+    {
+      const double *Tk = blk(i, k), *yk = y + (size_t)k * BP;
+      for (int t = 0; t < BP; ++t)
+      {
+        const double fk = yk[t];
+        for (int r = 0; r < BP; ++r)
+          w[r] -= fk * Tk[t * BP + r];
+      }
+    }
+    for (int r = 0; r < BP; ++r)
+      y[(size_t)i * BP + r] = w[r];
+  }
+}
+__attribute__((target_clones("avx512f", "avx2", "default"))) static void block_schur_40(const BlockEnvelope &E, double *T,
+                                                                                        double *X, double *y, int nI)
+{
+  block_schur_rows<5>(E, T, X, y, nI);
+}
+__attribute__((target_clones("avx512f", "avx2", "default"))) static void block_schur_24(const BlockEnvelope &E, double *T,
+                                                                                        double *X, double *y, int nI)
+{
+  block_schur_rows<3>(E, T, X, y, nI);
+}
+
 static int block_chol_range(const BlockEnvelope &E, double *T, double *X, double *y, int phase, int lo, int hi)
 {
   return E.Bp == 40 ? block_chol_40(E, T, X, y, phase, lo, hi) : block_chol_24(E, T, X, y, phase, lo, hi);
@@ -1910,6 +1966,27 @@ int plan_blocks(int K, const std::vector<std::pair<int, int>> &links, bool allow
     src = (int)l | (perm[i] == a ? 0x40000000 : 0);
   }
   return SAGE_OK;
+}
+
+int block_chol_partial(const BlockEnvelope &E, double *T, double *X, double *y, int nI)
+{
+  if ((E.Bp != 40 && E.Bp != 24) || E.a_cnt)
+    return -1;
+  const int rc = block_chol_range(E, T, X, y, 0, 0, nI); // interior rows: factor + forward substitution
+  if (rc)
+    return rc;
+  if (E.Bp == 40)
+    block_schur_40(E, T, X, y, nI);
+  else
+    block_schur_24(E, T, X, y, nI);
+  return 0;
+}
+
+int block_chol_partial_back(const BlockEnvelope &E, double *T, double *X, double *y, int nI)
+{
+  if ((E.Bp != 40 && E.Bp != 24) || E.a_cnt)
+    return -1;
+  return block_chol_range(E, T, X, y, 1, 0, nI); // x_i for the interior rows, y[nI..K) holding the separators' x
 }
 
 int block_chol_solve_tr(const BlockEnvelope &E, double *T, double *X, double *y)

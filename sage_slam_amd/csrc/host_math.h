@@ -55,6 +55,12 @@ struct BlockEnvelope
 // right-hand side on entry and the solution on return.  Returns 0, or 1 + the block column of the first non-positive
 // pivot, -1 for an unsupported Bp, -2 when a block's ticket did not arrive within two seconds.
 int block_chol_solve_tr(const BlockEnvelope &env, double *T, double *X, double *y);
+// Partial factorisation for domain decomposition (shard_solve.cpp; storage as above, no A ranges): rows [0, nI) are
+// factorised and forward-substituted; the separator rows [nI, K) receive L_ij for j < nI, their blocks (i, j >= nI) end
+// as the Schur complement C_ij^T = (A_ij - sum_{k<nI} L_ik L_jk^T)^T and y_i as c_i = b_i - sum_{k<nI} L_ik y_k.
+// block_chol_partial_back: x of the rows [0, nI) given x of the separators in y[nI..K).  Returns as block_chol_solve_tr.
+int block_chol_partial(const BlockEnvelope &env, double *T, double *X, double *y, int nI);
+int block_chol_partial_back(const BlockEnvelope &env, double *T, double *X, double *y, int nI);
 // Wake the helper thread ahead of a block_chol_solve_tr call with n1 > 0 (it then spins for the job for a few
 // milliseconds at most); call it when the system is about to be produced, e.g. before waiting on the D2H copy.
 void block_chol_arm();

@@ -150,14 +150,6 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
 #pragma unroll
   for (int t = 0; t < NT + 1; ++t)
     acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#ifdef SAGE_PHOTO_TWO_LEVEL
-  // second-level sums: the MFMA chains run over SAGE_PHOTO_TWO_LEVEL sub-tiles, their results are added here (a handful
-  // of adds per record instead of hundreds of chained fmaf) -- only touched between sub-tiles, so they can live in scratch
-  f32x4 acc2[NT + 1];
-#pragma unroll
-  for (int t = 0; t < NT + 1; ++t)
-    acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#endif
   float err_acc = 0.f, vm_acc = 0.f, sdd_acc = 0.f; // lane-local sums over the sub-tiles: error, inliers, sigma d^2
   float gerr_acc = 0.f;                             // error kernel, fused geometric error
   const bool fuse_geo = !JAC && prm.geo_loss_param > 0.f && E.dpt1_geo != nullptr;
@@ -511,26 +503,6 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   //      accumulator) are what the LM step's distance from the exact step grows with (DESIGN s4); the workgroup keeps
   //      walking its run of sub-tiles (pose / descriptor prologue amortised, vertically adjacent bands stay in its L1/L2)
   const bool last_sub = sub + 1 == nsub;
-#ifdef SAGE_PHOTO_TWO_LEVEL
-  if (JAC && (last_sub || ((sub + 1) % SAGE_PHOTO_TWO_LEVEL) == 0))
-  {
-#pragma unroll
-    for (int t = 0; t < NT + 1; ++t)
-    {
-      acc2[t] += acc[t];
-      acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (last_sub || ((sub + 1) % flush) == 0)
-    {
-#pragma unroll
-      for (int t = 0; t < NT + 1; ++t)
-      {
-        acc[t] = acc2[t];
-        acc2[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-    }
-  }
-#endif
   if (last_sub || ((sub + 1) % flush) == 0)
   {
   // ---- cross-wave sum in a fixed order (deterministic): every wave dumps its tiles into its own slice of the (now idle)

@@ -1174,6 +1174,10 @@ struct SageWindow
   void *allreduce_user = nullptr;
   void *rccl_hook = nullptr;            // sage_window_use_rccl: owned {comm, stream} record behind `allreduce`
   DevBuf order_p, order_g;              // launch order of the photometric / geometric work lists (build_launch_order)
+  // sharded windows, domain-decomposed solve (shard_solve.cpp): the all-reduced payload is the separator system
+  SageShardPlan *shard = nullptr;
+  DevBuf sepbuf;                        // device copy of the separator buffer (what the collective sums)
+  std::vector<double> h_sep;
   double *h_err = nullptr;              // pinned [8]: {linearize tail[4], error pass totals[4]} written by the kernels
   DevBuf pk;                            // engine-internal channel-group pyramids [K][3 (f,gx,gy)][FS/4][P][4]
   DevBuf f0s;                           // per keyframe: pre-sampled source features [L][FS/4][N][4]
@@ -1305,6 +1309,8 @@ extern "C" void sage_window_destroy(SageWindow *w)
   for (DevBuf *b : bufs)
     b->release();
   std::free(w->rccl_hook); // (the communicator itself belongs to the caller)
+  sage_shard_plan_destroy(w->shard);
+  w->sepbuf.release();
   solver_destroy(w->solver);
   if (w->pipe_flags)
     (void)hipHostFree(w->pipe_flags);
@@ -1927,6 +1933,29 @@ extern "C" int sage_window_finalize(SageWindow *w)
   }
   if ((rc = pipe_setup(w, wp_group_of_work)))
     return rc;
+  if (w->world > 1)
+  {
+    // domain-decomposed solve for sharded windows: on by request (SAGE_SHARD_SCHUR=1) or for long windows, where the
+    // replicated factorisation of all K keyframes dominates the iteration (DESIGN s7: K = 512 on 8 ranks: 5x less solve)
+    const char *e = getenv("SAGE_SHARD_SCHUR");
+    const bool want = e ? atoi(e) != 0 : w->K >= 256;
+    if (want)
+    {
+      std::vector<int32_t> lk(2 * w->links.size());
+      for (size_t l = 0; l < w->links.size(); ++l)
+      {
+        lk[2 * l] = w->links[l].first;
+        lk[2 * l + 1] = w->links[l].second;
+      }
+      if ((rc = sage_shard_plan_create(w->K, (int)w->links.size(), lk.data(), w->B, w->rank, w->world, &w->shard)))
+        return rc;
+      const size_t ns = sage_shard_sep_count(w->shard);
+      w->h_sep.assign(ns, 0.0);
+      if ((rc = w->sepbuf.reserve(ns * sizeof(double))))
+        return rc;
+      w->host_packed.resize(sage_window_packed_count(w));
+    }
+  }
   w->finalized = true;
   return SAGE_OK;
 }
@@ -2839,6 +2868,171 @@ static int pipe_solve(SageWindow *w, double damp)
   return SAGE_OK;
 }
 
+// ---- sharded windows, domain-decomposed solve -------------------------------------------------------------------
+// priors (a9) as diagonal / gradient additions over all K keyframes; the shard plan applies them on the owner rank only
+static void window_priors(const SageWindow *w, std::vector<double> &dadd, std::vector<double> &gadd)
+{
+  const SageWindowConfig &c = w->cfg;
+  const int K = w->K, B = w->B, CS = c.CS;
+  dadd.assign((size_t)K * B, 0.0);
+  gadd.assign((size_t)K * B, 0.0);
+  for (int k = 0; k < K; ++k)
+    for (int i = 0; i < CS; ++i)
+    {
+      dadd[k * B + 6 + i] += c.code_prior_weight;
+      gadd[k * B + 6 + i] += c.code_prior_weight * (0.0 - (double)w->code[0][(size_t)k * CS + i]);
+    }
+  if (c.scale_prior_weight > 0)
+  {
+    const double s = w->scale[0][0];
+    dadd[6 + CS] += c.scale_prior_weight / (s * s);
+    gadd[6 + CS] += c.scale_prior_weight / s * (std::log((double)w->scale_init[0]) - std::log(s));
+  }
+  if (c.pose_prior_weight > 0)
+  {
+    double loc[6];
+    pose_local(&w->pose[0][0], &w->pose_init[0], loc);
+    for (int i = 0; i < 6; ++i)
+    {
+      dadd[i] += c.pose_prior_weight;
+      gadd[i] += c.pose_prior_weight * loc[i];
+    }
+  }
+}
+
+// prior error terms of the keyframes THIS rank owns (the other ranks' copies of their variables are stale here)
+static double prior_error_owned(const SageWindow *w, int set)
+{
+  const SageWindowConfig &c = w->cfg;
+  double e = 0;
+  for (int k = 0; k < w->K; ++k)
+  {
+    if (sage_shard_keyframe_owner(w->shard, k) != w->rank)
+      continue;
+    double s2 = 0;
+    for (int i = 0; i < c.CS; ++i)
+      s2 += (double)w->code[set][(size_t)k * c.CS + i] * w->code[set][(size_t)k * c.CS + i];
+    e += c.code_prior_weight * s2 / c.CS;
+    if (k == 0 && c.scale_prior_weight > 0)
+    {
+      const double d = std::log((double)w->scale_init[0]) - std::log((double)w->scale[set][0]);
+      e += c.scale_prior_weight * d * d;
+    }
+    if (k == 0 && c.pose_prior_weight > 0)
+    {
+      double loc[6];
+      pose_local(&w->pose[set][0], &w->pose_init[0], loc);
+      for (int i = 0; i < 6; ++i)
+        e += c.pose_prior_weight * loc[i] * loc[i];
+    }
+  }
+  return e;
+}
+
+__global__ void add_to_double_kernel(double *p, double v) { p[0] += v; }
+
+// local elimination -> all-reduce of the separator system -> separator solve + back substitution of this rank's
+// keyframes -> candidate variables of those keyframes.  *lin_error (optional) receives the total error at the
+// linearisation point (edge totals ride in the payload tail, prior terms are contributed by their owners).
+// Returns SAGE_E_NOT_PSD consistently on every rank (a rank whose local elimination fails poisons the payload).
+static int schur_solve(SageWindow *w, double damp, double *lin_error)
+{
+  const SageWindowConfig &c = w->cfg;
+  const int K = w->K, B = w->B, CS = c.CS;
+  const size_t np = sage_window_packed_count(w), ns = w->h_sep.size();
+  SAGE_HIP(hipMemcpyAsync(w->host_packed.data(), w->packed.p, np * sizeof(double), hipMemcpyDeviceToHost, w->stream));
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  std::vector<double> dadd, gadd;
+  window_priors(w, dadd, gadd);
+  int rc = sage_shard_eliminate(w->shard, w->host_packed.data(), damp, dadd.data(), gadd.data(), w->h_sep.data());
+  if (rc == SAGE_E_NOT_PSD)
+    std::fill(w->h_sep.begin(), w->h_sep.end(), NAN); // every rank will see it after the sum
+  else if (rc)
+    return rc;
+  else
+    w->h_sep[ns - 4] = prior_error_owned(w, 0);
+  SAGE_HIP(hipMemcpyAsync(w->sepbuf.p, w->h_sep.data(), ns * sizeof(double), hipMemcpyHostToDevice, w->stream));
+  if (w->allreduce(w->sepbuf.as<double>(), ns, w->allreduce_user))
+    return SAGE_E_STATE;
+  SAGE_HIP(hipMemcpyAsync(w->h_sep.data(), w->sepbuf.p, ns * sizeof(double), hipMemcpyDeviceToHost, w->stream));
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  if (lin_error)
+    *lin_error = w->h_sep[ns - 8] + w->h_sep[ns - 7] + w->h_sep[ns - 4];
+  if (std::isnan(w->h_sep[ns - 8]) || std::isnan(w->h_sep[0]))
+    return SAGE_E_NOT_PSD;
+  w->delta.assign((size_t)K * B, 0.0);
+  rc = sage_shard_solve(w->shard, w->h_sep.data(), w->delta.data());
+  if (rc)
+    return rc; // SAGE_E_NOT_PSD of the separator system: identical on every rank
+  // candidate = retract(current, delta) for the keyframes this rank touches; the others keep their (stale) values
+  w->pose[1] = w->pose[0];
+  w->code[1] = w->code[0];
+  w->scale[1] = w->scale[0];
+  for (int k = 0; k < K; ++k)
+  {
+    if (!sage_shard_keyframe_is_local(w->shard, k))
+      continue;
+    float d6[6];
+    for (int i = 0; i < 6; ++i)
+      d6[i] = (float)w->delta[(size_t)k * B + i];
+    sage_pose_retract(&w->pose[0][(size_t)k * 12], d6, &w->pose[1][(size_t)k * 12]);
+    for (int i = 0; i < CS; ++i)
+      w->code[1][(size_t)k * CS + i] = w->code[0][(size_t)k * CS + i] + (float)w->delta[(size_t)k * B + 6 + i];
+    w->scale[1][k] = w->scale[0][k] + (float)w->delta[(size_t)k * B + 6 + CS];
+  }
+  w->cand_pending = false;
+  return upload_vars(w, 1);
+}
+
+// after a Schur-mode run every rank holds current variables only for the keyframes it touches: sum the owners' copies
+extern "C" int sage_window_sync_variables(SageWindow *w)
+{
+  if (!w || !w->finalized)
+    return SAGE_E_STATE;
+  if (!w->shard)
+    return SAGE_OK; // every rank solves the whole system: nothing to exchange
+  if (!w->allreduce)
+    return SAGE_E_STATE;
+  const int K = w->K, CS = w->cfg.CS, VS = 13 + CS;
+  std::vector<double> buf((size_t)K * VS, 0.0);
+  for (int k = 0; k < K; ++k)
+    if (sage_shard_keyframe_owner(w->shard, k) == w->rank)
+    {
+      double *b = &buf[(size_t)k * VS];
+      for (int i = 0; i < 12; ++i)
+        b[i] = w->pose[0][(size_t)k * 12 + i];
+      b[12] = w->scale[0][k];
+      for (int i = 0; i < CS; ++i)
+        b[13 + i] = w->code[0][(size_t)k * CS + i];
+    }
+  DevBuf d;
+  int rc = d.reserve(buf.size() * sizeof(double));
+  if (rc)
+    return rc;
+  SAGE_HIP(hipMemcpyAsync(d.p, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice, w->stream));
+  if (w->allreduce(d.as<double>(), buf.size(), w->allreduce_user))
+  {
+    d.release();
+    return SAGE_E_STATE;
+  }
+  SAGE_HIP(hipMemcpyAsync(buf.data(), d.p, buf.size() * sizeof(double), hipMemcpyDeviceToHost, w->stream));
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  d.release();
+  for (int s = 0; s < 2; ++s)
+    for (int k = 0; k < K; ++k)
+    {
+      const double *b = &buf[(size_t)k * VS];
+      for (int i = 0; i < 12; ++i)
+        w->pose[s][(size_t)k * 12 + i] = (float)b[i];
+      w->scale[s][k] = (float)b[12];
+      for (int i = 0; i < CS; ++i)
+        w->code[s][(size_t)k * CS + i] = (float)b[13 + i];
+    }
+  if ((rc = upload_vars(w, 0)) || (rc = upload_vars(w, 1)))
+    return rc;
+  return SAGE_OK;
+}
+
 extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmConfig *cfg)
 {
   if (!w || !st || !cfg)
@@ -2853,15 +3047,68 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
   const bool pipelined = w->pipe_enabled && !sharded && w->n_edges > 0;
   if ((rc = pipelined ? pipe_linearize(w) : sage_window_linearize(w)))
     return rc;
-  if (sharded && w->allreduce(w->packed.as<double>(), sage_window_packed_count(w), w->allreduce_user))
+  const bool schur = sharded && w->shard != nullptr;
+  if (sharded && !schur && w->allreduce(w->packed.as<double>(), sage_window_packed_count(w), w->allreduce_user))
     return SAGE_E_STATE;
   int evals = 0;
   st->accepted = 0;
-  while (true)
+  while (schur)
+  {
+    // domain-decomposed iteration: the collectives are the separator system and the 4-double error totals
+    double lin_error = 0;
+    rc = schur_solve(w, st->damp, &lin_error);
+    if (rc && rc != SAGE_E_NOT_PSD)
+      return rc;
+    if (evals == 0)
+      st->error = lin_error;
+    if (rc == SAGE_E_NOT_PSD)
+      st->candidate_error = INFINITY;
+    else
+    {
+      if ((rc = sage_window_error(w, 1)))
+        return rc;
+      hipLaunchKernelGGL(add_to_double_kernel, dim3(1), dim3(1), 0, w->stream, w->errbuf.as<double>(),
+                         prior_error_owned(w, 1));
+      if (w->allreduce(w->errbuf.as<double>(), 4, w->allreduce_user))
+        return SAGE_E_STATE;
+      double t4[4];
+      SAGE_HIP(hipMemcpyAsync(t4, w->errbuf.p, sizeof(t4), hipMemcpyDeviceToHost, w->stream));
+      SAGE_HIP(hipStreamSynchronize(w->stream));
+      st->candidate_error = t4[0] + t4[1];
+    }
+    ++evals;
+    if (st->candidate_error < st->error)
+    {
+      st->accepted = 1;
+      break;
+    }
+    const bool give_up = st->damp >= cfg->max_damp || (cfg->max_inner_evals > 0 && evals >= cfg->max_inner_evals);
+    st->damp = clampd(st->damp * cfg->damp_inc_factor);
+    if (give_up)
+      break;
+  }
+  while (!schur)
   {
     // everything of one evaluation is enqueued before the host looks at a number: the error at the linearisation
     // point (tail of the packed buffer) is read together with the candidate's
-    if ((rc = (pipelined && evals == 0) ? pipe_solve(w, st->damp) : sage_window_solve(w, st->damp, nullptr)))
+    rc = (pipelined && evals == 0) ? pipe_solve(w, st->damp) : sage_window_solve(w, st->damp, nullptr);
+    if (rc == SAGE_E_NOT_PSD)
+    {
+      // the damped system has a non-positive pivot: a rejected evaluation (every rank factors the same system and
+      // takes this branch together; no error pass, no collective)
+      if (evals == 0 && (rc = sage_window_total_error(w, 1, &st->error)))
+        return rc;
+      st->candidate_error = INFINITY;
+      ++evals;
+      if (st->damp >= cfg->max_damp || (cfg->max_inner_evals > 0 && evals >= cfg->max_inner_evals))
+      {
+        st->damp = clampd(st->damp * cfg->damp_inc_factor);
+        break;
+      }
+      st->damp = clampd(st->damp * cfg->damp_inc_factor);
+      continue;
+    }
+    if (rc)
       return rc;
     if ((rc = sage_window_error(w, 1)))
       return rc;

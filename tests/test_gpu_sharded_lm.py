@@ -65,3 +65,59 @@ def test_sharded_lm_step_matches_single_rank(tmp_path):
     # fp32 per-edge sums are reduced in double; only the order of the double additions differs between 1 and 2 ranks
     np.testing.assert_allclose(t0[:, :2], single[:, :2], rtol=1e-6)
     assert t0[-1, 1] < t0[0, 0]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# domain-decomposed solve wired into sage_window_lm_step (SAGE_SHARD_SCHUR=1): the all-reduced payload is the separator
+# system, a rank only updates the keyframes it touches; same trajectory as the single-rank window, and after
+# sage_window_sync_variables every rank holds the single-rank variables
+# ---------------------------------------------------------------------------------------------------------------
+def _make_long():
+    from sage_slam_amd import synth
+    return synth.make_window(K=14, H=32, W=40, FS=16, CS=16, L=2, n_samples=500, seed=8)
+
+
+def _all_vars(win, K):
+    out = []
+    for k in range(K):
+        pose, code, scale = win.get_keyframe(k)
+        out.append(np.concatenate([pose, code, [scale]]))
+    return np.array(out)
+
+
+def _schur_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["SAGE_SHARD_SCHUR"] = "1"
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from sage_slam_amd import capi
+    w = _make_long()
+    win = capi.Window(w, rank=rank, world=world)
+    win.set_allreduce(dist)
+    np.save(os.path.join(out_dir, f"strace_{rank}.npy"), _run(win, capi, 4))
+    win.sync_variables()
+    np.save(os.path.join(out_dir, f"svars_{rank}.npy"), _all_vars(win, len(w.keyframes)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_schur_sharded_lm_step_matches_single_rank(tmp_path, world):
+    import torch.multiprocessing as mp
+    from sage_slam_amd import capi
+    mp.spawn(_schur_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    traces = [np.load(tmp_path / f"strace_{r}.npy") for r in range(world)]
+    for t in traces[1:]:
+        assert np.array_equal(t, traces[0])        # the reduced totals are identical on every rank
+    w = _make_long()
+    ref = capi.Window(w)
+    single = _run(ref, capi, 4)
+    assert np.array_equal(single[:, 2], traces[0][:, 2])
+    np.testing.assert_allclose(traces[0][:, :2], single[:, :2], rtol=1e-6)
+    assert traces[0][0, 2] == 1 and traces[0][-1, 1] < traces[0][0, 0]
+    v_ref = _all_vars(ref, len(w.keyframes))
+    for r in range(world):
+        v = np.load(tmp_path / f"svars_{r}.npy")
+        assert np.abs(v - v_ref).max() < 2e-5 * max(1.0, np.abs(v_ref).max())
