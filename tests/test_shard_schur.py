@@ -81,3 +81,20 @@ def test_schur_sharded_solve_equals_single_rank(world, K, CS, loops):
     assert np.allclose(sep_sum[-8:-4], full[-4:])
     for p in plans:
         p.close()
+
+
+@pytest.mark.parametrize("K,CS,loops", [(64, 32, []), (40, 16, [(0, 39), (3, 30)]), (30, 32, [(2, 27)])])
+@pytest.mark.parametrize("ndomains", [1, 2, 4])
+def test_block_solve_domains_equals_block_solve(K, CS, loops, ndomains):
+    """sage_block_solve_domains: the same decomposition inside one process (keyframe-range domains on host threads,
+    ONE assembled system; the far end of a long-range link is a separator whatever the domains are)."""
+    B = 7 + CS
+    links = [(j, i) for i in range(K) for j in range(max(0, i - 3), i)] + loops
+    per_link = random_window_system(K, links, B, seed=3 * K + ndomains)
+    full = packed_of(K, links, B, per_link, range(len(links)))
+    rng = np.random.default_rng(2)
+    dadd = np.full(K * B, 1e-3); gadd = 1e-3 * rng.normal(size=K * B)
+    dadd[:6] += 1e4
+    ref = capi.block_solve(full[:-4], K, links, B, 1e-3, dadd, gadd)
+    d = capi.block_solve_domains(full, K, links, B, 1e-3, ndomains, dadd, gadd)
+    assert rel(d, ref) < 1e-9
