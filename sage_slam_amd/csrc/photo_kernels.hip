@@ -508,9 +508,10 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   // ---- cross-wave sum in a fixed order (deterministic): every wave dumps its tiles into its own slice of the (now idle)
   //      stash memory, one barrier, then all threads add the four slices as ((w0 + w1) + w2) + w3 on their way out to the
   //      partial record (a round of barriers per wave used to cost ~8 % of a one-sub-tile workgroup) ----
-  constexpr int SLICE = (NT + 1) * 256;
-  static_assert(!JAC || kWaves * SLICE <= STASH, "cross-wave sum slices must fit the stash");
-  __syncthreads(); // the other waves may still be reading their stash (phase D)
+  // (every wave dumps into ITS OWN stash region -- it is done with it, the other waves' phase D is not disturbed: no
+  //  barrier before the dump)
+  constexpr int SLICE = 64 * kPhotoStashLD; // distance between the waves' regions
+  static_assert(!JAC || (NT + 1) * 256 <= SLICE, "a wave's tiles must fit its own stash region");
 #pragma unroll
   for (int t = 0; t < NT + 1; ++t)
 #pragma unroll
