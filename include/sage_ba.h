@@ -312,6 +312,9 @@ int sage_window_add_keyframe(SageWindow *w, const SageKeyframeView *view, const 
                              const float *code, float scale);
 /* a link contributes both directed edges of every enabled factor type (mapper.cpp:346-374). */
 int sage_window_add_link(SageWindow *w, int kf_a, int kf_b);
+/* the Cauchy parameter of ONE link's two geometric edges (before finalize; 0 = the window's geo_loss_param): the mapper
+ * derives it per link from the newer keyframe, geo_loss_param_factor * kf->avg_squared_dpt_bias (mapper.cpp:367-373) */
+int sage_window_set_link_geo_loss(SageWindow *w, int link, float loss_param);
 /* edge sharding for multi-GPU: this process evaluates the contiguous range [rank*n/world, (rank+1)*n/world) of the
  * n links (in the order they were added). Default (0,1). */
 int sage_window_set_shard(SageWindow *w, int rank, int world);
@@ -354,6 +357,27 @@ int sage_window_get_delta(const SageWindow *w, double *delta);
  * type 0 = photometric (D=13+CS), 1 = geometric (D=14+2CS); edge index e in [0, 2*nlinks): link e/2,
  * direction e%2 (0: a->b, 1: b->a). */
 int sage_window_get_edge(const SageWindow *w, int type, int e, float *AtA, float *Atb, float *err, float *n_in);
+
+/* f2 (core/gtsam/photometric_factor.cpp:72-219, geometric_factor.cpp:41-233, mapper.cpp:544-551): the
+ * batched per-Values prepass behind the gtsam factors.  ISAM2 calls linearize(values) / error(values) factor by factor
+ * with the same Values; the adapter's factor hands the window's values over and the engine evaluates the WHOLE window
+ * once per distinct Values:
+ *   sage_window_prepass(win, pose12[K][12], codes[K][CS], scales[K], jacobians, &recomputed)
+ *       values bit-identical to the cached ones and the cache holds what is asked for -> nothing is launched
+ *       (*recomputed = 0); otherwise they become the window's current variables, ONE sage_window_linearize
+ *       (jacobians != 0) or ONE sage_window_error (jacobians == 0) runs, and the per-edge results are copied to the host
+ *       cache (*recomputed = 1).  A cached linearisation also answers error() at the same values.
+ *   sage_window_factor(win, type, e, psd_mode, G, g, f, dims, nkeys)
+ *       the HessianFactor of directed edge e (as sage_window_get_edge numbers them) from the cache: blocks and g as
+ *       sage_factor_hessian_blocks cuts them (NearestPsd per psd_mode), *f = the factor's error_ (the constant term the
+ *       reference passes to gtsam::HessianFactor).  SAGE_E_STATE when the cache holds no linearisation.
+ *   sage_window_factor_error(win, type, e, &err)     PhotometricFactor::error / GeometricFactor::error from the cache.
+ * Host pointers throughout; type 0 = photometric, 1 = geometric. */
+int sage_window_prepass(SageWindow *w, const float *pose12, const float *codes, const float *scales, int jacobians,
+                        int *recomputed);
+int sage_window_factor(const SageWindow *w, int type, int e, int psd_mode, double *G_out, double *g_out, double *f_out,
+                       int *dims_out, int *nkeys_out);
+int sage_window_factor_error(const SageWindow *w, int type, int e, double *err_out);
 
 /* kernel timing with HIP events on the engine's own stream (bench.py's roofline): when enabled every launch of
  * the four hot kernels is bracketed by an event pair.  which: 0 photometric linearize, 1 geometric linearize,

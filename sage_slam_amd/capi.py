@@ -92,13 +92,13 @@ SYMBOLS = [
     "sage_geometric_jac_error_calculate", "sage_geometric_error_calculate", "sage_depth_and_grad",
     "sage_gaussian_pyramid_with_grad", "sage_se3_exp", "sage_pose_retract", "sage_nearest_psd", "sage_nearest_psd_reference", "sage_factor_block_count", "sage_factor_hessian_blocks",
     "sage_damped_solve_qr_f32", "sage_block_solve", "sage_lm_config_default", "sage_track_lm", "sage_track_frame",
-    "sage_window_create", "sage_window_destroy", "sage_window_add_keyframe", "sage_window_add_link",
+    "sage_window_create", "sage_window_destroy", "sage_window_add_keyframe", "sage_window_add_link", "sage_window_set_link_geo_loss",
     "sage_window_set_shard", "sage_window_finalize", "sage_window_num_keyframes", "sage_window_num_links",
     "sage_window_block_size", "sage_window_packed_count", "sage_window_packed_dev",
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_sort_locations", "sage_bind_thread_to_device",
+    "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_sort_locations", "sage_bind_thread_to_device",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
@@ -510,6 +510,9 @@ class Window:
             r = L.sage_window_add_link(self.h, a, b)
             if r < 0:
                 raise SageError(r, "sage_window_add_link")
+            gl = getattr(win, "link_geo_loss", None)     # optional per-link Cauchy parameters (mapper.cpp:367-373)
+            if gl is not None and gl[r] > 0:
+                _chk(L.sage_window_set_link_geo_loss(self.h, r, C.c_float(gl[r])), "sage_window_set_link_geo_loss")
         _chk(L.sage_window_set_shard(self.h, rank, world), "sage_window_set_shard")
         _chk(L.sage_window_finalize(self.h), "sage_window_finalize")
         self.K = L.sage_window_num_keyframes(self.h)
@@ -608,6 +611,37 @@ class Window:
         _chk(lib().sage_window_get_edge(self.h, type_, e, _fp(A), _fp(b), C.byref(err), C.byref(nin)),
              "sage_window_get_edge")
         return dict(AtA=A, Atb=b, error=err.value, num_inliers=nin.value)
+
+    def prepass(self, poses12, codes, scales, jacobians: bool = True) -> bool:
+        """f2: evaluate the whole window once at these values (or hit the cache). Returns True when kernels ran."""
+        P = _f32(np.asarray(poses12).reshape(-1)); Cd = _f32(np.asarray(codes).reshape(-1)); S = _f32(np.asarray(scales).reshape(-1))
+        K = self.K
+        assert P.size == K * 12 and Cd.size == K * self.win.CS and S.size == K
+        rec = C.c_int32()
+        _chk(lib().sage_window_prepass(self.h, _fp(P), _fp(Cd), _fp(S), int(jacobians), C.byref(rec)), "sage_window_prepass")
+        return bool(rec.value)
+
+    def factor(self, type_, e, psd_mode: int = 1):
+        """f2: the HessianFactor of directed edge e from the prepass cache -> (blocks, gs, f, dims)."""
+        L = lib(); CS = self.win.CS
+        n = L.sage_factor_block_count(type_, CS)
+        D = 13 + CS if type_ == 0 else 14 + 2 * CS
+        G = np.zeros(n, np.float64); g = np.zeros(D, np.float64); f = C.c_double()
+        dims = (C.c_int32 * 6)(); nk = C.c_int32()
+        _chk(L.sage_window_factor(self.h, type_, e, psd_mode, G.ctypes.data_as(C.POINTER(C.c_double)),
+                                  g.ctypes.data_as(C.POINTER(C.c_double)), C.byref(f), dims, C.byref(nk)), "sage_window_factor")
+        dims = [int(dims[i]) for i in range(nk.value)]
+        blocks, o = {}, 0
+        for i in range(nk.value):
+            for j in range(i, nk.value):
+                blocks[(i, j)] = G[o:o + dims[i] * dims[j]].reshape(dims[i], dims[j]); o += dims[i] * dims[j]
+        offs = np.concatenate([[0], np.cumsum(dims)])
+        return blocks, [g[offs[i]:offs[i + 1]] for i in range(nk.value)], f.value, dims
+
+    def factor_error(self, type_, e) -> float:
+        v = C.c_double()
+        _chk(lib().sage_window_factor_error(self.h, type_, e, C.byref(v)), "sage_window_factor_error")
+        return v.value
 
     def set_profiling(self, on: bool):
         _chk(lib().sage_window_set_profiling(self.h, int(on)), "sage_window_set_profiling")

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
   E.R0 = uni(E.R0); E.t0 = uni(E.t0); E.R1 = uni(E.R1); E.t1 = uni(E.t1); E.R10 = uni(E.R10); E.t10 = uni(E.t10);
   E.N = uni(E.N); E.loc_is_i64 = uni(E.loc_is_i64);
   const int N = E.N;
+  const float loss_param = E.loss_param > 0.f ? E.loss_param : prm.loss_param; // per-link parameter (mapper.cpp:369)
 
   const Pose p0 = JAC ? load_pose2(E.R0, E.t0) : Pose{};
   const Pose p1 = JAC ? load_pose2(E.R1, E.t1) : Pose{};
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
     const float vm = (pos && in_range) ? m : 0.f;
     const float rho = Ds - X[2];
     const float mr = m * rho;
-    const float err = (pos && in_range) ? logf(1.0f + mr * mr / prm.loss_param) : 0.f; // :600
+    const float err = (pos && in_range) ? logf(1.0f + mr * mr / loss_param) : 0.f; // :600
     err_acc += err;
     vm_acc += vm;
     if (JAC)
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
       y[8] = rho;
     }
     // sqrt_cauchy_weight = m / sqrt(rho^2 + c)  (:690);  omega = its square
-    const float om = live ? (m * m) / (rho * rho + prm.loss_param) : 0.f;
+    const float om = live ? (m * m) / (rho * rho + loss_param) : 0.f;
     if (!live)
     {
 #pragma unroll

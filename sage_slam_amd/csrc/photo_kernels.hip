@@ -153,6 +153,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   float err_acc = 0.f, vm_acc = 0.f, sdd_acc = 0.f; // lane-local sums over the sub-tiles: error, inliers, sigma d^2
   float gerr_acc = 0.f;                             // error kernel, fused geometric error
   const bool fuse_geo = !JAC && prm.geo_loss_param > 0.f && E.dpt1_geo != nullptr;
+  const float geo_loss = E.geo_loss > 0.f ? E.geo_loss : prm.geo_loss_param; // per-link parameter (mapper.cpp:369)
   float *st_w = s_mem + wave * 64 * kPhotoStashLD; // this wave's stash
   __syncthreads();                                 // s_red zeroed
 
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     for (int k = 0; k < 4; ++k)
       Ds += tg.w[k] * E.dpt1_geo[tg.off[k]];
     const float mr = m * (Ds - X[2]);
-    gerr_acc += (pos && in_range) ? logf(1.0f + mr * mr / prm.geo_loss_param) : 0.f;
+    gerr_acc += (pos && in_range) ? logf(1.0f + mr * mr / geo_loss) : 0.f;
   }
 
   float G00 = 0.f, G01 = 0.f, G11 = 0.f, v0 = 0.f, v1 = 0.f, err = 0.f;

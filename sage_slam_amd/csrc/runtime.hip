@@ -1131,6 +1131,7 @@ struct SageWindow
   std::vector<SageKeyframeView> views;
   // host variables: [set][kf] ; set 0 = current, 1 = candidate
   std::vector<float> pose[2], code[2], scale[2];
+  std::vector<float> link_geo_loss; // per link: the geometric factors' Cauchy parameter, 0 = cfg.geo_loss_param
   std::vector<float> code_init, scale_init, pose_init;
   std::vector<float> code_added; // codes as added (code_init is the zero prior mean)
   std::vector<std::pair<int, int>> links; // (a, b) with a < b
@@ -1197,6 +1198,14 @@ struct SageWindow
   bool cand_pending = false;
   double residuals_per_lin = 0, bytes_per_lin = 0;
   bool have_lin = false;
+  // f2: per-Values factor cache (sage_window_prepass): host copies of every local edge's results and the values
+  // (all K keyframes) they were evaluated at
+  struct FactorCache
+  {
+    bool lin = false, err = false;
+    std::vector<float> pose, code, scale;         // the key: [K][12], [K][CS], [K]
+    std::vector<float> Ap, bp, sp, Ag, bg, sg;    // per local directed edge: AtA, Atb, (error, n_inliers)
+  } fc;
   // optional kernel timing (HIP events on `stream`)
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[4];
@@ -1355,7 +1364,16 @@ extern "C" int sage_window_add_link(SageWindow *w, int a, int b)
   if (!w || w->finalized || a == b || a < 0 || b < 0 || a >= w->K || b >= w->K)
     return SAGE_E_INVALID;
   w->links.emplace_back(std::min(a, b), std::max(a, b));
+  w->link_geo_loss.push_back(0.f);
   return (int)w->links.size() - 1;
+}
+
+extern "C" int sage_window_set_link_geo_loss(SageWindow *w, int link, float loss_param)
+{
+  if (!w || w->finalized || link < 0 || link >= (int)w->links.size() || !(loss_param >= 0.f))
+    return w && w->finalized ? SAGE_E_STATE : SAGE_E_INVALID;
+  w->link_geo_loss[link] = loss_param;
+  return SAGE_OK;
 }
 
 extern "C" int sage_bind_thread_to_device(int device)
@@ -1776,6 +1794,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
         pe.f0s = w->f0s.as<float>() + f0s_off[k0];
         pe.dpt0 = w->dpt.as<float>() + (size_t)k0 * HW;
         pe.dpt1_geo = (c.use_photo && c.use_geo) ? w->dpt.as<float>() + (size_t)k1 * HW : nullptr;
+        pe.geo_loss = w->link_geo_loss[l];
         pe.basis0 = v0.basis; pe.mask1 = c.mask_dev; pe.homo = v0.homo; pe.loc = v0.loc1d; pe.loc_is_i64 = 1;
         pe.R0 = x0; pe.t0 = x0 + 9; pe.R1 = x1; pe.t1 = x1 + 9; pe.R10 = nullptr; pe.t10 = nullptr;
         pe.code0 = x0 + 13; pe.scale0 = x0 + 12; pe.N = v0.N;
@@ -1787,6 +1806,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
         ge.homo = v0.homo; ge.loc = v0.loc1d; ge.loc_is_i64 = 1;
         ge.R0 = x0; ge.t0 = x0 + 9; ge.R1 = x1; ge.t1 = x1 + 9; ge.R10 = nullptr; ge.t10 = nullptr;
         ge.code0 = x0 + 13; ge.scale0 = x0 + 12; ge.scale1 = x1 + 12; ge.N = v0.N;
+        ge.loss_param = w->link_geo_loss[l];
         gt[e] = ge;
         if (s == 0)
         {
@@ -2439,6 +2459,134 @@ extern "C" int sage_window_get_edge(const SageWindow *w, int type, int e, float 
   if (n_in)
     *n_in = s2[1];
   return SAGE_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// f2: the batched per-Values prepass behind the gtsam factors.  ISAM2 asks every factor of the window for
+// linearize(values) / error(values) one at a time with the SAME Values; the reference answers each with its own kernel
+// launches, .item() syncs and a NearestPsd (photometric_factor.cpp:72-219, geometric_factor.cpp:41-233).  Here the first
+// factor that sees new values triggers ONE sage_window_linearize (or sage_window_error) for the whole window and one
+// device-to-host copy of the per-edge results; every other factor is served from the host cache.
+static int local_edge_index(const SageWindow *w, int e)
+{
+  const int l = e / 2, dir = e % 2;
+  for (size_t i = 0; i < w->local_links.size(); ++i)
+    if (w->local_links[i] == l)
+      return 2 * (int)i + dir;
+  return -1;
+}
+
+extern "C" int sage_window_prepass(SageWindow *w, const float *pose12, const float *codes, const float *scales,
+                                   int jacobians, int *recomputed)
+{
+  if (!w || !w->finalized || !pose12 || !codes || !scales)
+    return SAGE_E_INVALID;
+  const int K = w->K, CS = w->cfg.CS;
+  SageWindow::FactorCache &fc = w->fc;
+  const size_t np = (size_t)K * 12, nc = (size_t)K * CS;
+  const bool same = fc.pose.size() == np && std::memcmp(fc.pose.data(), pose12, np * sizeof(float)) == 0 &&
+                    std::memcmp(fc.code.data(), codes, nc * sizeof(float)) == 0 &&
+                    std::memcmp(fc.scale.data(), scales, (size_t)K * sizeof(float)) == 0;
+  if (recomputed)
+    *recomputed = 0;
+  if (same && (fc.lin || (!jacobians && fc.err)))
+    return SAGE_OK; // a cached linearisation also carries the errors (a1 returns the same error as a2)
+  int rc;
+  if (!same)
+  {
+    (void)sync_candidate(w);
+    fc.lin = fc.err = false;
+    fc.pose.assign(pose12, pose12 + np);
+    fc.code.assign(codes, codes + nc);
+    fc.scale.assign(scales, scales + K);
+  }
+  // the window's CURRENT variables become the requested values (both sets: a later solve starts from them)
+  if (std::memcmp(w->pose[0].data(), pose12, np * sizeof(float)) != 0 ||
+      std::memcmp(w->code[0].data(), codes, nc * sizeof(float)) != 0 ||
+      std::memcmp(w->scale[0].data(), scales, (size_t)K * sizeof(float)) != 0)
+  {
+    (void)sync_candidate(w);
+    for (int s = 0; s < 2; ++s)
+    {
+      w->pose[s].assign(pose12, pose12 + np);
+      w->code[s].assign(codes, codes + nc);
+      w->scale[s].assign(scales, scales + K);
+    }
+    if ((rc = upload_vars(w, 0)) || (rc = upload_vars(w, 1)))
+      return rc;
+    w->have_lin = false;
+  }
+  const size_t ne = (size_t)w->n_edges, Dp = 13 + CS, Dg = 14 + 2 * CS;
+  if (jacobians)
+  {
+    if ((rc = sage_window_linearize(w)))
+      return rc;
+  }
+  else if ((rc = sage_window_error(w, 0)))
+    return rc;
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  auto pull = [&](std::vector<float> &dst, const DevBuf &src, size_t n) -> hipError_t {
+    dst.resize(n);
+    return n ? hipMemcpy(dst.data(), src.p, n * sizeof(float), hipMemcpyDeviceToHost) : hipSuccess;
+  };
+  if (w->cfg.use_photo)
+  {
+    if (jacobians)
+    {
+      SAGE_HIP(pull(fc.Ap, w->AtA_p, ne * Dp * Dp));
+      SAGE_HIP(pull(fc.bp, w->Atb_p, ne * Dp));
+    }
+    SAGE_HIP(pull(fc.sp, w->stats_p, ne * 2));
+  }
+  if (w->cfg.use_geo)
+  {
+    if (jacobians)
+    {
+      SAGE_HIP(pull(fc.Ag, w->AtA_g, ne * Dg * Dg));
+      SAGE_HIP(pull(fc.bg, w->Atb_g, ne * Dg));
+    }
+    SAGE_HIP(pull(fc.sg, w->stats_g, ne * 2));
+  }
+  fc.lin = jacobians != 0;
+  fc.err = true;
+  if (recomputed)
+    *recomputed = 1;
+  return SAGE_OK;
+}
+
+extern "C" int sage_window_factor_error(const SageWindow *w, int type, int e, double *err_out)
+{
+  if (!w || !w->finalized || (type != 0 && type != 1) || !err_out)
+    return SAGE_E_INVALID;
+  const SageWindow::FactorCache &fc = w->fc;
+  if (!fc.err)
+    return SAGE_E_STATE;
+  const int le = local_edge_index(w, e);
+  const std::vector<float> &st = type == 0 ? fc.sp : fc.sg;
+  if (le < 0 || (size_t)le * 2 + 1 >= st.size())
+    return SAGE_E_INVALID;
+  *err_out = (double)st[(size_t)le * 2];
+  return SAGE_OK;
+}
+
+extern "C" int sage_window_factor(const SageWindow *w, int type, int e, int psd_mode, double *G_out, double *g_out,
+                                  double *f_out, int *dims_out, int *nkeys_out)
+{
+  if (!w || !w->finalized || (type != 0 && type != 1))
+    return SAGE_E_INVALID;
+  const SageWindow::FactorCache &fc = w->fc;
+  if (!fc.lin)
+    return SAGE_E_STATE;
+  const int le = local_edge_index(w, e);
+  const int CS = w->cfg.CS;
+  const size_t D = type == 0 ? 13 + CS : 14 + 2 * CS;
+  const std::vector<float> &A = type == 0 ? fc.Ap : fc.Ag, &b = type == 0 ? fc.bp : fc.bg, &st = type == 0 ? fc.sp : fc.sg;
+  if (le < 0 || ((size_t)le + 1) * D * D > A.size())
+    return SAGE_E_INVALID;
+  if (f_out)
+    *f_out = (double)st[(size_t)le * 2];
+  return sage_factor_hessian_blocks(type, CS, A.data() + (size_t)le * D * D, b.data() + (size_t)le * D, psd_mode, G_out,
+                                    g_out, dims_out, nkeys_out);
 }
 
 // ------------------------------------------------------------------------------------------------

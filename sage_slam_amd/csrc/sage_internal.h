@@ -33,6 +33,7 @@ struct PhotoEdge
   // window error pass only: depth map of the DESTINATION keyframe -> the error kernel also forms the geometric edge's
   // error (geometric_factor_kernels.cpp:127-218: same warp, same mask lookup) and no separate geometric launch runs
   const float *dpt1_geo;
+  float geo_loss; // > 0: the geometric edge's own Cauchy parameter (GeoEdge::loss_param), else the launch's
   const float *bias0;   // [H*W]
   const float *basis0;  // [H*W,CS]
   const float *mask1;   // [H,W]
@@ -66,6 +67,8 @@ struct GeoEdge
   float scale0_val, scale1_val;
   int32_t N;
   int32_t loc_is_i64;
+  float loss_param; // > 0: this edge's Cauchy parameter (the mapper's geo_loss_param_factor * avg_squared_dpt_bias of the
+                    // link's newer keyframe, mapper.cpp:369), else the launch's
 };
 
 // Tracker edge (a3): relative pose only, pre-sampled source features.
