@@ -228,6 +228,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", type=int, default=0,
                     help="BASELINE.json configuration 1..5 (1 = tracker frame -> --mode edge; 3 = the headline window = default)")
+    ap.add_argument("--lm-variant", choices=["classic", "candidate"], default="classic",
+                    help="classic: linearize, solve, error pass at the candidate (SURVEY s8d's definition of an LM iteration, "
+                         "the default and the number quoted as `value`); candidate: SageLmConfig.linearize_at_candidate -- the "
+                         "candidate is evaluated by the linearize kernels, an accepted iteration has no separate error pass")
     ap.add_argument("--mode", choices=["window", "edge"], default="window",
                     help="edge: latency of the drop-in per-edge operator API and of a full tracker frame (config 1)")
     args = ap.parse_args()
@@ -289,6 +293,7 @@ def main():
     packed = win.packed_tensor()
     errt = win.error_tensor()
     cfg = capi.lm_config_default()
+    cfg.linearize_at_candidate = 1 if args.lm_variant == "candidate" else 0
     damp = float(cfg.init_damp)
 
     # totals over the whole job (all ranks): every link has 2 photometric + 2 geometric directed edges
@@ -415,7 +420,10 @@ def main():
                        "residuals_per_step": residuals_per_step,
                        "parallelism": f"edge-shard x{world}" if world > 1 else "single GPU",
                        "collective": collective,
-                       "lm": "1 linearize + 1 solve (device scatter/retract, host block Cholesky) + 1 error pass per step",
+                       "lm": ("1 linearize + 1 solve (device scatter/retract, host block Cholesky) + 1 error pass per step"
+                              if args.lm_variant == "classic" else
+                              "linearize-at-candidate: per evaluation 1 solve + 1 linearize at the candidate (error and "
+                              "system from one pass); no separate error pass; +1 linearize after every restart"),
                        "accepted_steps": int(sum(1 for h in hist[args.warmup:] if h[2])),
                        "error_first_last": [hist[0][0], hist[-1][1]]},
             "roofline": {"bound": "hbm", "kernel": "photo_kernel<CS,FS,true> (fused photometric linearize)",

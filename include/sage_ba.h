@@ -220,6 +220,11 @@ typedef struct SageLmConfig
   int max_inner_evals;       /* window LM only: cap on candidate evaluations per iteration (0 = reference policy: retry until accepted or max_damp) */
   float no_overlap_error;    /* tracker LM: > 0 -> stop with SAGE_E_NO_OVERLAP once the error at the current estimate is >= this
                               * (TrackFrame without the match-geometry term: 9.9 * sum(photo weights), camera_tracker.cpp:1515); 0 = off */
+  int linearize_at_candidate;/* window LM only (sage_window_lm_step), default 0.  1: the candidate is evaluated by the LINEARIZE
+                              * kernels (error and normal equations from one pass, the system at the current estimate kept
+                              * aside): an accepted iteration costs one linearize + one solve and no separate error pass, a
+                              * rejected one costs a linearize instead of an error pass.  Same accept / reject rule and the
+                              * same iterates as the default sequence (the two kernels' errors agree to fp32 rounding). */
 } SageLmConfig;
 void sage_lm_config_default(SageLmConfig *cfg);
 

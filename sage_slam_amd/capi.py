@@ -39,7 +39,7 @@ class SageLmConfig(C.Structure):
                 ("init_damp", C.c_float), ("min_damp", C.c_float), ("max_damp", C.c_float),
                 ("damp_dec_factor", C.c_float), ("damp_inc_factor", C.c_float),
                 ("jac_update_err_inc_threshold", C.c_float), ("max_inner_evals", C.c_int),
-                ("no_overlap_error", C.c_float)]
+                ("no_overlap_error", C.c_float), ("linearize_at_candidate", C.c_int)]
 
 
 class SageLmTraceEntry(C.Structure):

@@ -624,6 +624,7 @@ extern "C" void sage_lm_config_default(SageLmConfig *c)
   c->jac_update_err_inc_threshold = 1.0e-2f;
   c->max_inner_evals = 0;
   c->no_overlap_error = 0.f;
+  c->linearize_at_candidate = 0;
 }
 
 namespace sage

@@ -1198,6 +1198,11 @@ struct SageWindow
   bool cand_pending = false;
   double residuals_per_lin = 0, bytes_per_lin = 0;
   bool have_lin = false;
+  // linearize-at-candidate LM (SageLmConfig::linearize_at_candidate): which variables the packed system belongs to
+  uint64_t vars_epoch = 1, lin_epoch = 0; // lin_epoch == vars_epoch: `packed` is the linearisation at the current variables
+  bool spec_err_valid = false;
+  double spec_error = 0.0;                // total error at that linearisation point (priors included)
+  DevBuf packed_save;                     // the current system while the candidate's is being formed in `packed`
   // f2: per-Values factor cache (sage_window_prepass): host copies of every local edge's results and the values
   // (all K keyframes) they were evaluated at
   struct FactorCache
@@ -1276,6 +1281,8 @@ static int upload_vars(SageWindow *w, int set)
 {
   if (w->dpt_set == set)
     w->dpt_set = -1;
+  if (set == 0)
+    ++w->vars_epoch; // whatever was linearised is no longer the system at the current variables
   std::vector<float> buf;
   upload_vars_host(w, set, buf);
   SAGE_HIP(hipMemcpyAsync(w->vars[set].p, buf.data(), buf.size() * sizeof(float), hipMemcpyHostToDevice, w->stream));
@@ -1310,7 +1317,7 @@ extern "C" void sage_window_destroy(SageWindow *w)
 {
   if (!w)
     return;
-  DevBuf *bufs[] = {&w->rec_first_p, &w->rec_count_p, &w->order_p, &w->order_g, &w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
+  DevBuf *bufs[] = {&w->packed_save, &w->rec_first_p, &w->rec_count_p, &w->order_p, &w->order_g, &w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
                     &w->pk, &w->f0s, &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
                     &w->work_g, &w->first_g, &w->tiles_g, &w->part_p, &w->part_g, &w->AtA_p, &w->Atb_p,
                     &w->stats_p, &w->AtA_g, &w->Atb_g, &w->stats_g, &w->adj_start, &w->adj, &w->link_edges,
@@ -2037,7 +2044,8 @@ static AssembleParams window_assemble_params(SageWindow *w)
   return ap;
 }
 
-extern "C" int sage_window_linearize(SageWindow *w)
+// linearize every local edge at variable set `set` (0 = current estimate, 1 = candidate) and assemble the packed system
+static int window_linearize_set(SageWindow *w, int set)
 {
   if (!w || !w->finalized)
     return SAGE_E_STATE;
@@ -2048,10 +2056,10 @@ extern "C" int sage_window_linearize(SageWindow *w)
     // depth maps of every keyframe at the current variables: both factor types read their sample depths from them
     // (an accepted candidate's maps from the error pass are still valid: only the gradients are missing then)
     static const bool no_reuse = getenv("SAGE_NO_DEPTH_REUSE") != nullptr;
-    const bool have_depth = w->dpt_set == 0 && !no_reuse;
-    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[0].as<DepthItem>(), w->n_depth, H, W, !have_depth,
+    const bool have_depth = w->dpt_set == set && !no_reuse;
+    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[set].as<DepthItem>(), w->n_depth, H, W, !have_depth,
                                 !(have_depth && w->dgrad_valid)));
-    w->dpt_set = 0;
+    w->dpt_set = set;
     w->dgrad_valid = true;
     const bool fork = w->two_streams && c.use_photo && c.use_geo;
     hipStream_t gs = fork ? w->stream2 : w->stream;
@@ -2067,7 +2075,7 @@ extern "C" int sage_window_linearize(SageWindow *w)
       EdgeOut out{w->AtA_g.as<float>(), w->Atb_g.as<float>(), w->stats_g.as<float>(), w->wide_g.as<double>()};
       LaunchCommon lc = window_lc(w, false);
       prof_attach(w, 1, lc);
-      SAGE_HIP(launch_geo_linearize(gs, c.CS, nullptr, w->gtab[0].as<GeoEdge>(), lc, c.pyr.cam[0], c.eps,
+      SAGE_HIP(launch_geo_linearize(gs, c.CS, nullptr, w->gtab[set].as<GeoEdge>(), lc, c.pyr.cam[0], c.eps,
                                     c.geo_loss_param, c.geo_weight, out));
       if (fork)
         SAGE_HIP(hipEventRecord(w->ev_join, gs));
@@ -2077,7 +2085,7 @@ extern "C" int sage_window_linearize(SageWindow *w)
       EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>(), w->wide_p.as<double>()};
       LaunchCommon lc = window_lc(w, true, true);
       prof_attach(w, 0, lc);
-      SAGE_HIP(launch_photo_linearize(w->stream, c.CS, c.FS, nullptr, w->ptab[0].as<PhotoEdge>(), lc, c.pyr,
+      SAGE_HIP(launch_photo_linearize(w->stream, c.CS, c.FS, nullptr, w->ptab[set].as<PhotoEdge>(), lc, c.pyr,
                                       c.photo_weights, c.eps, out));
     }
     if (fork)
@@ -2090,8 +2098,12 @@ extern "C" int sage_window_linearize(SageWindow *w)
   hipLaunchKernelGGL(assemble_kernel, dim3((w->K + ap.nlinks + 1) * ap.split), dim3(512), 0, w->stream, ap);
   SAGE_HIP(hipGetLastError());
   w->have_lin = true;
+  w->lin_epoch = set == 0 ? w->vars_epoch : 0; // (a candidate's system becomes current only through lm_step's accept)
+  w->spec_err_valid = false;
   return SAGE_OK;
 }
+
+extern "C" int sage_window_linearize(SageWindow *w) { return window_linearize_set(w, 0); }
 
 extern "C" int sage_window_error(SageWindow *w, int which)
 {
@@ -2359,6 +2371,7 @@ extern "C" int sage_window_accept(SageWindow *w)
   w->pose[0] = w->pose[1];
   w->code[0] = w->code[1];
   w->scale[0] = w->scale[1];
+  ++w->vars_epoch;
   w->dpt_set = w->dpt_set == 1 ? 0 : -1; // depth maps evaluated at the candidate now belong to the current set
   // (a kernel, not hipMemcpyAsync: a device-to-device copy of 11 KB costs ~10 us of API time on the step's critical path)
   const int nv = w->K * w->VS;
@@ -2831,6 +2844,8 @@ static int pipe_linearize(SageWindow *w)
   w->pipe_fin_lo = 0;
   w->pipe_fin_hi = nl;
   w->have_lin = true;
+  w->lin_epoch = w->vars_epoch;
+  w->spec_err_valid = false;
   return SAGE_OK;
 }
 
@@ -3181,6 +3196,115 @@ extern "C" int sage_window_sync_variables(SageWindow *w)
   return SAGE_OK;
 }
 
+__global__ void copy_doubles_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    dst[i] = src[i];
+}
+
+// SageLmConfig::linearize_at_candidate: one LM iteration in which the candidate is evaluated by the linearize kernels.
+// `packed` holds the system at the current estimate (kept from the previous accepted iteration); per evaluation: damped
+// solve -> candidate; the current system is set aside (device copy, 3 MB); linearize at the candidate (its finalize
+// kernels deliver the error); accepted: the candidate's system IS the next iteration's, nothing is re-evaluated;
+// rejected: the saved system comes back and the damping goes up.  Decisions, damping schedule and iterates are those of
+// the default sequence; sage_window_get_edge afterwards returns the per-edge results of the LAST evaluation.
+static int lm_step_at_candidate(SageWindow *w, SageLmState *st, const SageLmConfig *cfg, bool sharded)
+{
+  int rc;
+  auto clampd = [&](double d) { return std::min(std::max((double)cfg->min_damp, d), (double)cfg->max_damp); };
+  const size_t np = sage_window_packed_count(w);
+  auto reduce_packed = [&]() -> int {
+    return (sharded && w->allreduce(w->packed.as<double>(), np, w->allreduce_user)) ? SAGE_E_STATE : SAGE_OK;
+  };
+  if (!(w->have_lin && w->lin_epoch == w->vars_epoch))
+  {
+    if ((rc = window_linearize_set(w, 0)) || (rc = reduce_packed()))
+      return rc;
+  }
+  if (!w->spec_err_valid)
+  {
+    if (sharded)
+    { // (the single-rank mirror h_err is not maintained for reduced totals: read the tail of the reduced buffer)
+      double t[4];
+      SAGE_HIP(hipMemcpyAsync(t, w->packed.as<double>() + np - 4, sizeof(t), hipMemcpyDeviceToHost, w->stream));
+      SAGE_HIP(hipStreamSynchronize(w->stream));
+      w->spec_error = t[0] + t[1] + prior_error(w, 0);
+    }
+    else if ((rc = sage_window_total_error(w, 1, &w->spec_error)))
+      return rc;
+    w->spec_err_valid = true;
+  }
+  st->error = w->spec_error;
+  if ((rc = w->packed_save.reserve(np * sizeof(double))))
+    return rc;
+  int evals = 0;
+  st->accepted = 0;
+  const bool mirror = !sharded && w->h_err != nullptr; // single-rank windows: totals mirrored into pinned host memory
+  for (;;)
+  {
+    rc = sage_window_solve(w, st->damp, nullptr);
+    bool not_psd = rc == SAGE_E_NOT_PSD;
+    if (rc && !not_psd)
+      return rc;
+    bool replaced = false;
+    double cur_tot[4] = {0, 0, 0, 0};
+    st->candidate_error = INFINITY;
+    if (!not_psd)
+    {
+      const uint64_t lin_epoch = w->lin_epoch;
+      if (mirror)
+        std::memcpy(cur_tot, w->h_err, sizeof(cur_tot)); // (the stream drained at the end of the previous evaluation)
+      hipLaunchKernelGGL(copy_doubles_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, w->stream,
+                         w->packed.as<double>(), w->packed_save.as<double>(), np);
+      SAGE_HIP(hipGetLastError());
+      if ((rc = window_linearize_set(w, 1)) || (rc = reduce_packed()))
+        return rc;
+      replaced = true;
+      w->lin_epoch = lin_epoch; // (not the current variables' system unless accepted below)
+      w->spec_err_valid = true; // spec_error still is the error at the current estimate
+      double t[4];
+      if (!mirror)
+        SAGE_HIP(hipMemcpyAsync(t, w->packed.as<double>() + np - 4, sizeof(t), hipMemcpyDeviceToHost, w->stream));
+      rc = sync_candidate(w); // a non-positive pivot of the factorisation shows up here
+      if (rc && rc != SAGE_E_NOT_PSD)
+        return rc;
+      not_psd = rc == SAGE_E_NOT_PSD;
+      SAGE_HIP(hipStreamSynchronize(w->stream));
+      if (mirror)
+        std::memcpy(t, w->h_err, sizeof(t));
+      if (!not_psd)
+        st->candidate_error = t[0] + t[1] + prior_error(w, 1);
+    }
+    ++evals;
+    if (st->candidate_error < st->error)
+    {
+      st->accepted = 1;
+      if ((rc = sage_window_accept(w)))
+        return rc;
+      w->lin_epoch = w->vars_epoch; // `packed` is the system at the (new) current estimate
+      w->spec_error = st->candidate_error;
+      st->damp = clampd(st->damp / cfg->damp_dec_factor);
+      break;
+    }
+    if (replaced)
+    {
+      // rejected: the system at the current estimate comes back
+      hipLaunchKernelGGL(copy_doubles_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, w->stream,
+                         w->packed_save.as<double>(), w->packed.as<double>(), np);
+      SAGE_HIP(hipGetLastError());
+      if (mirror)
+        std::memcpy(w->h_err, cur_tot, sizeof(cur_tot));
+    }
+    const bool give_up = st->damp >= cfg->max_damp || (cfg->max_inner_evals > 0 && evals >= cfg->max_inner_evals);
+    st->damp = clampd(st->damp * cfg->damp_inc_factor);
+    if (give_up)
+      break;
+  }
+  st->iters += 1;
+  return SAGE_OK;
+}
+
 extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmConfig *cfg)
 {
   if (!w || !st || !cfg)
@@ -3193,9 +3317,11 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
     st->damp = cfg->init_damp;
   auto clampd = [&](double d) { return std::min(std::max((double)cfg->min_damp, d), (double)cfg->max_damp); };
   const bool pipelined = w->pipe_enabled && !sharded && w->n_edges > 0;
+  const bool schur = sharded && w->shard != nullptr;
+  if (cfg->linearize_at_candidate && !pipelined && !schur && w->n_edges > 0)
+    return lm_step_at_candidate(w, st, cfg, sharded);
   if ((rc = pipelined ? pipe_linearize(w) : sage_window_linearize(w)))
     return rc;
-  const bool schur = sharded && w->shard != nullptr;
   if (sharded && !schur && w->allreduce(w->packed.as<double>(), sage_window_packed_count(w), w->allreduce_user))
     return SAGE_E_STATE;
   int evals = 0;

@@ -387,6 +387,45 @@ def test_pipelined_lm_step_matches_classic(capi, monkeypatch):
     assert rel(p1, p0) < 1e-6 and rel(d1, d0) < 1e-5
 
 
+@pytest.mark.parametrize("dec,inner", [(10.0, 0), (1.0e5, 0), (1.0e5, 1)])
+def test_linearize_at_candidate_lm_matches_classic(capi, dec, inner):
+    """SageLmConfig.linearize_at_candidate: the candidate is evaluated by the linearize kernels (error + system from one
+    pass, the current system set aside and restored on a rejection).  Same accept / reject sequence, errors, damping and
+    iterates as the classic sequence -- also through REJECTED evaluations (damp_dec_factor 1e5 drops the damping to its
+    floor after every accepted step, so Gauss-Newton overshoots near the optimum) and through the give-up exit
+    (max_inner_evals = 1); the system left in `packed` is the one at the current estimate."""
+    w = synth.make_window(K=8, H=48, W=64, FS=16, CS=32, L=3, n_samples=1500, seed=14)
+
+    def run(at_candidate):
+        win = capi.Window(w)
+        cfg = capi.lm_config_default()
+        cfg.damp_dec_factor = dec; cfg.max_inner_evals = inner
+        cfg.linearize_at_candidate = 1 if at_candidate else 0
+        st = capi.SageLmState()
+        tr = []
+        for _ in range(9):
+            win.lm_step(st, cfg)
+            tr.append((st.error, st.candidate_error, st.accepted, st.damp))
+        vars_ = np.concatenate([np.concatenate([*win.get_keyframe(k)[:2], [win.get_keyframe(k)[2]]]) for k in range(8)])
+        p_left = win.packed_host().astype(np.float64)
+        win.linearize()                                   # the system at the final estimate, classic kernels
+        p_final = win.packed_host().astype(np.float64)
+        win.close()
+        return np.array(tr), vars_, p_left, p_final
+
+    t0, v0, _, pf0 = run(False)
+    t1, v1, pl1, pf1 = run(True)
+    print("accepted:", t0[:, 2], "rejections:", int((1 - t0[:, 2]).sum()))
+    assert np.array_equal(t0[:, 2], t1[:, 2])
+    fin = np.isfinite(t0[:, 1])
+    np.testing.assert_allclose(t1[:, 0], t0[:, 0], rtol=2e-6)
+    np.testing.assert_allclose(t1[fin, 1], t0[fin, 1], rtol=2e-6)
+    np.testing.assert_allclose(t1[:, 3], t0[:, 3], rtol=1e-12)
+    assert rel(v1, v0) < 1e-5
+    assert rel(pf1, pf0) < 1e-5
+    assert rel(pl1, pf1) < 1e-12                         # what the variant keeps IS the linearisation at the current estimate
+
+
 @pytest.mark.parametrize("use_photo,use_geo", [(True, False), (False, True)])
 def test_single_factor_windows(capi, use_photo, use_geo):
     """windows with only one of the two factor types: the packed system is the corresponding part of the full one
