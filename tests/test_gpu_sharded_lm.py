@@ -18,9 +18,10 @@ def _make():
     return synth.make_window(K=6, H=48, W=64, FS=16, CS=32, L=3, n_samples=900, seed=5)
 
 
-def _run(win, capi, steps):
+def _run(win, capi, steps, at_candidate=False):
     cfg = capi.lm_config_default()
     cfg.max_inner_evals = 1
+    cfg.linearize_at_candidate = 1 if at_candidate else 0
     st = capi.SageLmState()
     trace = []
     for _ in range(steps):
@@ -49,6 +50,9 @@ def _worker(rank, world, port, out_dir):
     win.set_allreduce(dist)
     np.save(os.path.join(out_dir, f"trace_{rank}.npy"), _run(win, capi, 4))
     np.save(os.path.join(out_dir, f"vars_{rank}.npy"), win.delta())
+    # the linearize-at-candidate variant through the same hook (reduced candidate systems, restored on a rejection)
+    win.reset()
+    np.save(os.path.join(out_dir, f"trace_c_{rank}.npy"), _run(win, capi, 6, at_candidate=True))
     dist.destroy_process_group()
 
 
@@ -65,6 +69,13 @@ def test_sharded_lm_step_matches_single_rank(tmp_path):
     # fp32 per-edge sums are reduced in double; only the order of the double additions differs between 1 and 2 ranks
     np.testing.assert_allclose(t0[:, :2], single[:, :2], rtol=1e-6)
     assert t0[-1, 1] < t0[0, 0]
+    c0, c1 = (np.load(tmp_path / f"trace_c_{r}.npy") for r in range(world))
+    assert np.array_equal(c0, c1)
+    single6 = _run(capi.Window(_make()), capi, 6)
+    assert np.array_equal(single6[:, 2], c0[:, 2])
+    fin = np.isfinite(single6[:, 1])
+    np.testing.assert_allclose(c0[:, 0], single6[:, 0], rtol=2e-6)
+    np.testing.assert_allclose(c0[fin, 1], single6[fin, 1], rtol=2e-6)
 
 
 # ---------------------------------------------------------------------------------------------------------------
