@@ -627,9 +627,8 @@ extern "C" int sage_shard_solve(SageShardPlan *p, const double *sep_reduced, dou
 {
   if (!p || !sep_reduced || !delta || !p->have_factor)
     return SAGE_E_STATE;
-  const int B = p->B, BB = B * B;
+  const int B = p->B;
   const int nSa = (int)p->sep_all.size(), NSa = nSa * B;
-  const double *sep_rhs = sep_reduced + (size_t)p->n_pair_blocks * BB;
   std::vector<double> dS(NSa, 0.0);
   if (NSa > 0)
   {
