@@ -356,6 +356,42 @@ def test_window_sample_order_is_internal(capi):
         capi.Window(wb)
 
 
+def test_window_with_ragged_sample_counts(capi, orc):
+    """keyframes of one window with different numbers of samples (N = min(pho_num_samples, #valid) differs per keyframe
+    in the reference, mapper.cpp:1326-1344): 1 sample, a count below one wave, a ragged multiple of the 256-pixel
+    sub-tile and the dense list -- packed system == sum of the oracle's edges, error pass == sum of its errors."""
+    import copy
+    w = synth.make_window(K=4, H=48, W=64, FS=16, CS=32, L=3, seed=31, back_links=2)
+    rng = np.random.default_rng(3)
+    w = copy.deepcopy(w)
+    for kf, n in zip(w.keyframes, (1, 37, 1000, None)):
+        if n is None:
+            continue
+        sel = np.sort(rng.choice(kf.loc1d.size, size=n, replace=False))
+        kf.loc1d = np.ascontiguousarray(kf.loc1d[sel]); kf.homo = np.ascontiguousarray(kf.homo[sel])
+    win = capi.Window(w)
+    win.linearize()
+    packed = win.packed_host().astype(np.float64)
+    res = {}
+    for l, (a, b) in enumerate(w.links):
+        for d, (k0, k1) in enumerate(((a, b), (b, a))):
+            res[(0, l, d)] = oracle_photo(orc, w, k0, k1)
+            res[(1, l, d)] = oracle_geo(orc, w, k0, k1)
+            for t in (0, 1):
+                he = win.get_edge(t, 2 * l + d)
+                assert he["num_inliers"] == res[(t, l, d)]["num_inliers"], (t, l, d)
+                assert rel(he["AtA"], res[(t, l, d)]["AtA"]) < TOL_H, (t, l, d)
+    ref = capi.assemble_packed(len(w.keyframes), w.links, 32, res)
+    assert rel(packed[:-4], ref[:-4]) < TOL_H
+    assert packed[-4:] == pytest.approx(ref[-4:], rel=2e-5)
+    win.error(0)
+    import torch
+    torch.cuda.synchronize()
+    tot = win.error_tensor().cpu().numpy()
+    assert tot[:2] == pytest.approx(ref[-4:-2], rel=2e-5)
+    win.close()
+
+
 def test_pipelined_lm_step_matches_classic(capi, monkeypatch):
     """SAGE_PIPELINE=1: the LM iteration that post-processes finished row chunks while the photometric kernel is still
     running, and factors rows as they arrive, walks the same trajectory as the classic sequence (same per-edge
