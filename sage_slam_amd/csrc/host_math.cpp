@@ -1123,7 +1123,7 @@ bool EnvelopeMatrix::cholesky_inplace(int block, int threads)
     for (auto &th : pool)
       th.join();
   }
-  if (getenv("SAGE_DEBUG_TIMING"))
+  if (sage::env_flag("SAGE_DEBUG_TIMING"))
     fprintf(stderr, "[sage cholesky] gemm(S) %.3f gemm(trsm) %.3f diag-gemm %.3f diag-chol+inv %.3f ms\n", t_gemm1,
             t_gemm2, t_diag, t_scalar);
   return ok.load();
@@ -1498,8 +1498,8 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
   };
   if (phase == 0)
   {
-    static const bool getenv_no_prefetch = getenv("SAGE_SOLVE_NO_PREFETCH") != nullptr;
-    static const bool prof = getenv("SAGE_CHOL_PROFILE") != nullptr;
+    static const bool getenv_no_prefetch = sage::env_flag("SAGE_SOLVE_NO_PREFETCH");
+    static const bool prof = sage::env_flag("SAGE_CHOL_PROFILE");
     unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_readcyclecounter();
 #define LAP(k) do { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); tp[k] += t_ - tl; tl = t_; } } while (0)
     for (int i = lo; i < hi; ++i)
@@ -1759,7 +1759,7 @@ static CholHelper *chol_helper()
 {
   // deliberately leaked: the thread may still be parked on the condition variable when the process exits
   static CholHelper *h = [] {
-    if (getenv("SAGE_SOLVE_NO_HELPER") || std::thread::hardware_concurrency() < 2)
+    if (sage::env_flag("SAGE_SOLVE_NO_HELPER") || std::thread::hardware_concurrency() < 2)
       return (CholHelper *)nullptr;
     CholHelper *p = new CholHelper;
     p->th = std::thread([p] { p->loop(); });
@@ -1809,7 +1809,7 @@ static std::vector<int> read_cpu_list(const char *path)
 // of one cache and one NUMA node -- on a two-socket host a helper on the far socket takes ~35 % longer for its half.
 static void place_helper_near(CholHelper *h, int cpu)
 {
-  if (cpu < 0 || cpu == h->near_cpu || getenv("SAGE_SOLVE_NO_AFFINITY"))
+  if (cpu < 0 || cpu == h->near_cpu || sage::env_flag("SAGE_SOLVE_NO_AFFINITY"))
     return;
   h->near_cpu = cpu;
   char path[128];
@@ -2017,7 +2017,7 @@ int block_chol_solve_tr(const BlockEnvelope &E, double *T, double *X, double *y)
       h->posted.fetch_add(1, std::memory_order_release);
     }
   }
-  static const bool dbg = getenv("SAGE_DEBUG_TIMING") != nullptr;
+  static const bool dbg = sage::env_flag("SAGE_DEBUG_TIMING");
   double tp[6] = {0, 0, 0, 0, 0, 0};
   if (dbg)
     tp[0] = mono_seconds();
@@ -2100,7 +2100,7 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
       return SAGE_E_INVALID;
     first_blk[b] = std::min(first_blk[b], a);
   }
-  static const bool force_envelope = getenv("SAGE_SOLVE_ENVELOPE") != nullptr;
+  static const bool force_envelope = sage::env_flag("SAGE_SOLVE_ENVELOPE");
   if ((Bp == 40 || Bp == 24) && !force_envelope)
   {
     // fixed-size transposed-block path (the one the window engine runs on the device-scattered storage), with the
@@ -2111,12 +2111,12 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
       lk[l] = {links[2 * l], links[2 * l + 1]};
     sage::BlockPlan bp;
     {
-      const int rcp = sage::plan_blocks(K, lk, getenv("SAGE_SOLVE_NO_SPLIT") == nullptr, bp);
+      const int rcp = sage::plan_blocks(K, lk, !sage::env_flag("SAGE_SOLVE_NO_SPLIT"), bp);
       if (rcp == SAGE_E_UNSUPPORTED) // duplicate links accumulate on this path: plan without them
       {
         std::sort(lk.begin(), lk.end());
         lk.erase(std::unique(lk.begin(), lk.end()), lk.end());
-        const int rcq = sage::plan_blocks(K, lk, getenv("SAGE_SOLVE_NO_SPLIT") == nullptr, bp);
+        const int rcq = sage::plan_blocks(K, lk, !sage::env_flag("SAGE_SOLVE_NO_SPLIT"), bp);
         if (rcq != SAGE_OK)
           return rcq;
       }
@@ -2162,7 +2162,7 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
         for (int j = 0; j < B; ++j)
           D[row_is_a ? j * Bp + i : i * Bp + j] += lnk[(size_t)l * BB + i * B + j];
     }
-    static const bool dbg2 = getenv("SAGE_DEBUG_TIMING") != nullptr;
+    static const bool dbg2 = sage::env_flag("SAGE_DEBUG_TIMING");
     const auto t0 = std::chrono::steady_clock::now();
     sage::BlockEnvelope env;
     env.K = K; env.Bp = Bp; env.row_first = bp.row_first.data(); env.row_off = bp.row_off.data();
@@ -2182,7 +2182,7 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
   for (int k = 0; k < K; ++k)
     for (int i = 0; i < Bp; ++i)
       first[k * Bp + i] = first_blk[k] * Bp;
-  static const bool dbg = getenv("SAGE_DEBUG_TIMING") != nullptr;
+  static const bool dbg = sage::env_flag("SAGE_DEBUG_TIMING");
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto t_a = tnow();
   sage::EnvelopeMatrix M;

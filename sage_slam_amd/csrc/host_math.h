@@ -1,12 +1,20 @@
 // host_math.h -- internal host-side dense helpers (double precision).
 #pragma once
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <utility>
 #include <vector>
 
 namespace sage
 {
+// boolean environment switch ("Environment switches"): set and neither empty nor "0"
+inline bool env_flag(const char *name)
+{
+  const char *e = getenv(name);
+  return e && e[0] && !(e[0] == '0' && e[1] == 0);
+}
+
 void sym_eig(std::vector<double> &A, int n, std::vector<double> &w, std::vector<double> &V);
 void rotation_to_angle_axis_as_reference(const float *R, float eps, float *out);
 

@@ -1305,7 +1305,7 @@ extern "C" int sage_window_create(const SageWindowConfig *cfg, void *hip_stream,
   w->stream = reinterpret_cast<hipStream_t>(hip_stream);
   w->B = 7 + cfg->CS;
   w->VS = ((13 + cfg->CS + 3) / 4) * 4;
-  if (getenv("SAGE_TWO_STREAMS") && hipStreamCreateWithFlags(&w->stream2, hipStreamNonBlocking) == hipSuccess &&
+  if (sage::env_flag("SAGE_TWO_STREAMS") && hipStreamCreateWithFlags(&w->stream2, hipStreamNonBlocking) == hipSuccess &&
       hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) == hipSuccess &&
       hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) == hipSuccess)
     w->two_streams = true;
@@ -1749,7 +1749,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
       return rc;
     if (he != hipSuccess)
       return (int)he;
-    static const bool no_sort = getenv("SAGE_NO_SAMPLE_SORT") != nullptr;
+    static const bool no_sort = sage::env_flag("SAGE_NO_SAMPLE_SORT");
     for (int k = 0; k < K; ++k)
     {
       if (status[2 * k] > 0)
@@ -1924,7 +1924,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
       (rc = w->stats_p.reserve(ne * 2 * sizeof(float))) || (rc = w->AtA_g.reserve(ne * Dg * Dg * sizeof(float))) ||
       (rc = w->Atb_g.reserve(ne * Dg * sizeof(float))) || (rc = w->stats_g.reserve(ne * 2 * sizeof(float))))
     return rc;
-  if (!getenv("SAGE_NO_WIDE_EDGES") &&
+  if (!sage::env_flag("SAGE_NO_WIDE_EDGES") &&
       ((rc = w->wide_p.reserve(ne * (Dp * Dp + Dp) * sizeof(double))) ||
        (rc = w->wide_g.reserve(ne * (Dg * Dg + Dg) * sizeof(double)))))
     return rc;
@@ -1952,7 +1952,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
   }
   w->host_packed.assign(sage_window_packed_count(w), 0.0);
   w->delta.assign((size_t)K * w->B, 0.0);
-  if (!getenv("SAGE_HOST_SOLVE"))
+  if (!sage::env_flag("SAGE_HOST_SOLVE"))
   {
     rc = solver_create(&w->solver, K, w->B, w->VS, w->links, w->stream);
     if (rc != SAGE_OK && rc != SAGE_E_UNSUPPORTED)
@@ -2055,7 +2055,7 @@ static int window_linearize_set(SageWindow *w, int set)
   {
     // depth maps of every keyframe at the current variables: both factor types read their sample depths from them
     // (an accepted candidate's maps from the error pass are still valid: only the gradients are missing then)
-    static const bool no_reuse = getenv("SAGE_NO_DEPTH_REUSE") != nullptr;
+    static const bool no_reuse = sage::env_flag("SAGE_NO_DEPTH_REUSE");
     const bool have_depth = w->dpt_set == set && !no_reuse;
     SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[set].as<DepthItem>(), w->n_depth, H, W, !have_depth,
                                 !(have_depth && w->dgrad_valid)));
@@ -2121,7 +2121,7 @@ extern "C" int sage_window_error(SageWindow *w, int which)
   ErrorTotalsSide ph{}, ge{};
   // both factor types: ONE kernel -- the photometric error kernel also evaluates the geometric edge at the same warp
   // (PhotoEdge::dpt1_geo), which saves the geometric launch (39 us + a gap) of the error pass
-  static const bool no_fusion = getenv("SAGE_NO_ERROR_FUSION") != nullptr;
+  static const bool no_fusion = sage::env_flag("SAGE_NO_ERROR_FUSION");
   const bool fused = has && c.use_photo && c.use_geo && !no_fusion;
   if (has && c.use_photo)
   {
@@ -2288,7 +2288,7 @@ extern "C" int sage_window_solve(SageWindow *w, double damp, double *step_norm)
     return SAGE_OK;
   }
   const size_t np = sage_window_packed_count(w);
-  static const bool dbg = getenv("SAGE_DEBUG_TIMING") != nullptr;
+  static const bool dbg = sage::env_flag("SAGE_DEBUG_TIMING");
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   auto t_a = tnow();
   SAGE_HIP(hipStreamSynchronize(w->stream));
@@ -2624,8 +2624,8 @@ extern "C" int sage_window_factor(const SageWindow *w, int type, int e, int psd_
 // ------------------------------------------------------------------------------------------------
 static bool pipe_wanted(const SageWindow *w)
 {
-  return w->world == 1 && w->cfg.use_photo && getenv("SAGE_PIPELINE") && !getenv("SAGE_DEVICE_SOLVE") &&
-         !getenv("SAGE_HOST_SOLVE");
+  return w->world == 1 && w->cfg.use_photo && sage::env_flag("SAGE_PIPELINE") && !sage::env_flag("SAGE_DEVICE_SOLVE") &&
+         !sage::env_flag("SAGE_HOST_SOLVE");
 }
 
 // the order the photometric work list walks the local links in: both ends inwards
@@ -2803,7 +2803,7 @@ static int pipe_linearize(SageWindow *w)
   w->pipe_epoch += 1;
   if (w->pipe_epoch == 0)
     w->pipe_epoch = 1;
-  static const bool no_reuse = getenv("SAGE_NO_DEPTH_REUSE") != nullptr;
+  static const bool no_reuse = sage::env_flag("SAGE_NO_DEPTH_REUSE");
   const bool have_depth = w->dpt_set == 0 && !no_reuse;
   SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[0].as<DepthItem>(), w->n_depth, H, W, !have_depth,
                               !(have_depth && w->dgrad_valid)));
@@ -2930,7 +2930,7 @@ static int pipe_ensure(SageWindow *w, int chunk)
       break;
     const auto t1 = std::chrono::steady_clock::now();
     rc = pipe_launch_chunk(w, next) ? 1 : 0;
-    if (getenv("SAGE_DEBUG_TIMING"))
+    if (sage::env_flag("SAGE_DEBUG_TIMING"))
       fprintf(stderr, "[sage pipeline] chunk %d launched at %.3f ms (waited %.3f for its links)\n", next,
               1e3 * std::chrono::duration<double>(t1 - w->pipe_t0).count(),
               1e3 * std::chrono::duration<double>(t1 - t0).count());
@@ -2943,7 +2943,7 @@ static int pipe_ensure(SageWindow *w, int chunk)
   // factorisation gets there
   while (!rc && next < nch && next <= chunk + 1 && pipe_chunk_ready(w, next))
   {
-    if (getenv("SAGE_DEBUG_TIMING"))
+    if (sage::env_flag("SAGE_DEBUG_TIMING"))
       fprintf(stderr, "[sage pipeline] chunk %d launched ahead at %.3f ms\n", next,
               1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w->pipe_t0).count());
     rc = pipe_launch_chunk(w, next) ? 1 : 0;
@@ -2973,7 +2973,7 @@ static void pipe_idle(void *user)
   int next = w->pipe_next.load(std::memory_order_relaxed);
   if (ok && next < nch && pipe_chunk_ready(w, next))
   {
-    if (getenv("SAGE_DEBUG_TIMING"))
+    if (sage::env_flag("SAGE_DEBUG_TIMING"))
       fprintf(stderr, "[sage pipeline] chunk %d launched eagerly at %.3f ms\n", next,
               1e3 * std::chrono::duration<double>(std::chrono::steady_clock::now() - w->pipe_t0).count());
     if (pipe_launch_chunk(w, next) == 0)
@@ -3002,7 +3002,7 @@ static int pipe_solve(SageWindow *w, double damp)
   if ((rc = solver_pipe_begin(w->solver, damp, c.code_prior_weight, c.scale_prior_weight, c.pose_prior_weight,
                               w->scale_init[0], &w->pose_init[0])))
     return rc;
-  static const bool dbgt = getenv("SAGE_DEBUG_TIMING") != nullptr;
+  static const bool dbgt = sage::env_flag("SAGE_DEBUG_TIMING");
   w->pipe_t_wait = w->pipe_t_launch = 0;
   const auto tp0 = std::chrono::steady_clock::now();
   rc = solver_pipe_factor(w->solver, w->stream, pipe_before_row, pipe_idle, w, w->vars[0].as<float>(),

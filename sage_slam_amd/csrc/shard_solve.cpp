@@ -167,7 +167,7 @@ static int finish_plan(SageShardPlan *p, const std::vector<int> &link_dom, const
   p->sep_doubles = (size_t)nb * p->B * p->B + p->sep_all.size() * (size_t)p->B + 8;
   // ---- block envelope of the local system for the fixed-block path
   p->Bp = (p->B + 7) / 8 * 8;
-  p->fast = (p->Bp == 40 || p->Bp == 24) && getenv("SAGE_SHARD_SCALAR") == nullptr;
+  p->fast = (p->Bp == 40 || p->Bp == 24) && !sage::env_flag("SAGE_SHARD_SCALAR");
   if (p->fast)
   {
     const int nI = (int)p->interior.size(), nS = (int)p->sep_local.size();
@@ -381,7 +381,7 @@ extern "C" int sage_shard_eliminate(SageShardPlan *p, const double *packed_local
     return SAGE_E_INVALID;
   const int B = p->B, BB = B * B, K = p->K;
   const LocalSystem S(*p, packed_local, damp, diag_add, g_add);
-  static const bool dbg = getenv("SAGE_DEBUG_TIMING") != nullptr;
+  static const bool dbg = sage::env_flag("SAGE_DEBUG_TIMING");
   auto tnow = [] { return std::chrono::steady_clock::now(); };
   const auto t0 = tnow();
   const int nI = (int)p->interior.size(), nS = (int)p->sep_local.size();

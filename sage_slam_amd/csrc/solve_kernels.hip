@@ -584,7 +584,7 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   const int Bp = solver_bp(B);
   if ((Bp != 40 && Bp != 24) || K < 1)
     return SAGE_E_UNSUPPORTED;
-  const bool device_factor = getenv("SAGE_DEVICE_SOLVE") != nullptr;
+  const bool device_factor = sage::env_flag("SAGE_DEVICE_SOLVE");
   if (device_factor)
   {
     // the device factorisation keeps x [K*Bp], L_jj and the partial sums of the back substitution in the panel's LDS
@@ -594,7 +594,7 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   }
   BlockPlan bp;
   {
-    const int rcp = plan_blocks(K, links, allow_split && !device_factor && !getenv("SAGE_SOLVE_NO_SPLIT"), bp);
+    const int rcp = plan_blocks(K, links, allow_split && !device_factor && !sage::env_flag("SAGE_SOLVE_NO_SPLIT"), bp);
     if (rcp != SAGE_OK)
       return rcp;
   }
@@ -705,7 +705,7 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
       hipMalloc(&S->d_tail, 2 * sizeof(double)) != hipSuccess)
     return fail((int)hipErrorOutOfMemory);
   S->d_y = reinterpret_cast<double *>(S->d_L) + (size_t)nblk * Bp * Bp;
-  if (getenv("SAGE_DEBUG_TIMING") && hipMalloc(&S->d_dbg, 8 * sizeof(unsigned long long)) != hipSuccess)
+  if (sage::env_flag("SAGE_DEBUG_TIMING") && hipMalloc(&S->d_dbg, 8 * sizeof(unsigned long long)) != hipSuccess)
     return fail((int)hipErrorOutOfMemory);
   S->device_factor = device_factor;
   S->h_row_first = row_first;
@@ -804,7 +804,7 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
     // hybrid: the dependency chain of the factorisation runs on host cores, everything around it stays on the device.
     // The scatter kernel streams the blocks into pinned host memory in the order the factorisation consumes them and
     // tickets each one, so the host works on row 0 while the rest is still crossing PCIe (no D2H copy, no stream sync).
-    static const bool dbgt = getenv("SAGE_DEBUG_TIMING") != nullptr;
+    static const bool dbgt = sage::env_flag("SAGE_DEBUG_TIMING");
     hipError_t eh;
     if (S->n1 > 0)
       block_chol_arm(); // the helper core wakes up while this thread waits for the device
@@ -906,7 +906,7 @@ int solver_pipe_factor(DeviceSolver *S, hipStream_t stream, int (*before_row)(vo
   env.n1 = S->n1; env.n2 = S->n2;
   env.ready = S->h_flags; env.epoch = S->epoch;
   env.before_row = before_row; env.idle = idle; env.user = user;
-  static const bool dbgt = getenv("SAGE_DEBUG_TIMING") != nullptr;
+  static const bool dbgt = sage::env_flag("SAGE_DEBUG_TIMING");
   double t_tickets = 0.0;
   if (dbgt)
     env.t_ticket_wait = &t_tickets; // (both threads add to it: indicative only)
