@@ -64,8 +64,16 @@ __device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i 
 
 // per-pixel hand-over from the sampling phase (lane = pixel) to the contraction phase (lane = (channel i, pixel k)):
 //   [0..7] rows of the cross tile: c(6) = S(0:6,6), sigma*d, u6      [8] sigma = S66     [9] loc*CS*4 (int bits)
-//   [12..27] A rows of the pose tile: G*Q rows (2 x 6), v (2), 0, 0   [28..43] its B columns: Q (2 x 6), q6*d (2), 0, 0
-constexpr int kPhotoStashLD = 44; // floats per pixel, 16-byte aligned rows
+//   [10..23] A rows of the pose tile: G*Q rows (2 x 6), v (2)         [24..37] its B columns: Q (2 x 6), q6*d (2)
+// Operand rows / columns 14, 15 of the pose tile read whatever follows (finite values): they only reach the output
+// rows / columns 14, 15, which nothing reads.
+constexpr int kPhotoStashLD = 40; // floats per pixel, 16-byte aligned rows
+// second-level accumulators of the noise-critical tiles (the two cross tiles and the pose tile: 3 x 4 floats per lane),
+// one region per wave (see "second level" in the kernel)
+#ifndef SAGE_PHOTO_L2_TILES
+#define SAGE_PHOTO_L2_TILES 3
+#endif
+constexpr int kPhotoL2Tiles = SAGE_PHOTO_L2_TILES;
 
 // One (level, channel-group) step of the sampler in the engine's channel-group layout: 4 taps x (f1, gx, gy) dwordx4
 // loads + the pre-sampled source features.
@@ -102,7 +110,9 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   constexpr int STASH = JAC ? kWaves * 64 * kPhotoStashLD : 1;
   constexpr int SUMBUF = JAC ? (NT + 1) * 256 : 1;
   __shared__ __attribute__((aligned(16))) float s_mem[STASH > SUMBUF ? STASH : SUMBUF];
-  __shared__ float s_red[kWaves * kPhotoScalars];
+  __shared__ float s_red[kWaves * 4]; // per wave: linearize {sigma d^2, error, inliers}, error pass {error, inliers, geo error, inliers}
+  // second level of the noise-critical tiles: [wave][tile][r][lane]
+  __shared__ float s_l2[JAC ? kWaves * kPhotoL2Tiles * 256 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bid = uni(xcd_work_index((int)blockIdx.x, prm.n_work, prm.xcd_chunk));
@@ -144,8 +154,8 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   const uint32_t plane = (uint32_t)pyr.P * 4u;
   const int nlev = pyr.levels;
 
-  for (int k = tid; k < kWaves * kPhotoScalars; k += kBlock)
-    s_red[k] = 0.f;
+  if (tid < kWaves * 4)
+    s_red[tid] = 0.f;
   f32x4 acc[NT + 1];
 #pragma unroll
   for (int t = 0; t < NT + 1; ++t)
@@ -416,15 +426,14 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     f32x4 *st = reinterpret_cast<f32x4 *>(st_w + lane * kPhotoStashLD);
     st[0] = f32x4{S6[0], S6[1], S6[2], S6[3]};
     st[1] = f32x4{S6[4], S6[5], S6[6] * d, u6};
-    st[2] = f32x4{S6[6], __int_as_float(my_loc * (CS * 4)), 0.f, 0.f};
-    st[3] = f32x4{GQ0[0], GQ0[1], GQ0[2], GQ0[3]};
-    st[4] = f32x4{GQ0[4], GQ0[5], GQ1[0], GQ1[1]};
-    st[5] = f32x4{GQ1[2], GQ1[3], GQ1[4], GQ1[5]};
-    st[6] = f32x4{v0, v1, 0.f, 0.f};
-    st[7] = f32x4{Q[0][0], Q[0][1], Q[0][2], Q[0][3]};
-    st[8] = f32x4{Q[0][4], Q[0][5], Q[1][0], Q[1][1]};
-    st[9] = f32x4{Q[1][2], Q[1][3], Q[1][4], Q[1][5]};
-    st[10] = f32x4{Q[0][6] * d, Q[1][6] * d, 0.f, 0.f};
+    st[2] = f32x4{S6[6], __int_as_float(my_loc * (CS * 4)), GQ0[0], GQ0[1]};
+    st[3] = f32x4{GQ0[2], GQ0[3], GQ0[4], GQ0[5]};
+    st[4] = f32x4{GQ1[0], GQ1[1], GQ1[2], GQ1[3]};
+    st[5] = f32x4{GQ1[4], GQ1[5], v0, v1};
+    st[6] = f32x4{Q[0][0], Q[0][1], Q[0][2], Q[0][3]};
+    st[7] = f32x4{Q[0][4], Q[0][5], Q[1][0], Q[1][1]};
+    st[8] = f32x4{Q[1][2], Q[1][3], Q[1][4], Q[1][5]};
+    st[9] = f32x4{Q[0][6] * d, Q[1][6] * d, 0.f, 0.f};
   }
   __builtin_amdgcn_wave_barrier(); // same-wave LDS hand-over (in-order LDS pipe): no workgroup barrier needed
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -448,8 +457,8 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
 #define SAGE_PHOTO_READ_POSE(g)                                                         \
   {                                                                                     \
     const float *p_ = st_w + ((g) * 4 + k) * kPhotoStashLD;                             \
-    ya[g] = p_[12 + i];                                                                 \
-    yb[g] = p_[28 + i];                                                                 \
+    ya[g] = p_[10 + i];                                                                 \
+    yb[g] = p_[24 + i];                                                                 \
   }
 #define SAGE_PHOTO_ISSUE(g)                                                             \
   {                                                                                     \
@@ -500,6 +509,33 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     }
   }
   __builtin_amdgcn_wave_barrier(); // the stash is rewritten by the next sub-tile
+  // ---- second level: the LM step's distance from the exact step is set by the fp32 accumulation chains of the two
+  //      cross tiles (rows c, sigma d, u6: the code gradient and the pose-code blocks) and of the pose tile; the code-code
+  //      tiles do not matter (measured tile by tile, DESIGN s4).  After every sub-tile each lane moves its 12 values of
+  //      those tiles into a wave-private LDS slot (fp32 add of 64-fmaf partial sums; no barrier, no record) and restarts
+  //      their chains at zero; the last sub-tile of the run adds the slot back before the record is written. ----
+  if (nsub > 1)
+  {
+    float *l2 = s_l2 + wave * (kPhotoL2Tiles * 256) + lane;
+    const bool last_of_run = sub + 1 == nsub || ((sub + 1) % flush) == 0;
+    const bool first_of_run = (sub % flush) == 0;
+    constexpr int T0 = NT + 1 - kPhotoL2Tiles; // CS = 32: tiles 3, 4 (cross) and 5 (pose); CS = 16: every tile
+#pragma unroll
+    for (int t = 0; t < kPhotoL2Tiles; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+      {
+        float *q = l2 + (t * 4 + r) * 64;
+        const float prev = first_of_run ? 0.f : *q;
+        if (last_of_run)
+          acc[T0 + t][r] += prev;
+        else
+        {
+          *q = prev + acc[T0 + t][r];
+          acc[T0 + t][r] = 0.f;
+        }
+      }
+  }
   // ---- flush: one partial record per `flush` sub-tiles.  The fp32 accumulation chains (64 fmaf per sub-tile and
   //      accumulator) are what the LM step's distance from the exact step grows with (DESIGN s4); the workgroup keeps
   //      walking its run of sub-tiles (pose / descriptor prologue amortised, vertically adjacent bands stay in its L1/L2)
@@ -522,9 +558,9 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     const float se = wave_sum(err_acc), sn = wave_sum(vm_acc), sd = wave_sum(sdd_acc);
     if (lane == 63)
     {
-      s_red[wave * kPhotoScalars + 27] = sd;
-      s_red[wave * kPhotoScalars + 35] = se;
-      s_red[wave * kPhotoScalars + 36] = sn;
+      s_red[wave * 4 + 0] = sd;
+      s_red[wave * 4 + 1] = se;
+      s_red[wave * 4 + 2] = sn;
     }
   }
   __syncthreads();
@@ -557,9 +593,12 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
     else if (tid == 34)
       a = yy(12, 12) + yy(13, 13);
     else if (tid == 27 || tid == 35 || tid == 36)
+    {
+      const int slot = tid == 27 ? 0 : tid - 34;
 #pragma unroll
       for (int w = 0; w < kWaves; ++w)
-        a += s_red[w * kPhotoScalars + tid];
+        a += s_red[w * 4 + slot];
+    }
     if (prm.sig_cnt) // signalling launches write the record through to memory (agent-scope stores): the consumer is
       __hip_atomic_store(out + tid, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // a kernel on another stream
     else

@@ -1883,7 +1883,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
     // chain length (K = 64 window, scripts/tpb_noise_probe.py: 8 -> 2.1e-4, 4 -> 1.2e-4, 2 -> 7.6e-5, 1 -> 4.9e-5 rel-L2;
     // the fp32 oracle itself sits at 5.5e-5).  Records every 2 sub-tiles keep the step inside the 1e-4 parity bar.
     int tpb = total >= 8192 ? 8 : (total >= 4096 ? 2 : 1);
-    int flush = 2;
+    int flush = 0; // 0 = one record per workgroup (the noise-critical tiles have their own second level in the kernel)
     if (const char *e = getenv("SAGE_PHOTO_FLUSH"))
       flush = std::max(1, atoi(e));
     if (const char *e = getenv("SAGE_PHOTO_TPB"))
