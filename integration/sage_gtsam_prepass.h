@@ -2,7 +2,9 @@
 // (core/gtsam/photometric_factor.cpp:72-219, geometric_factor.cpp:41-233) from ONE batched window evaluation per
 // gtsam::Values instead of one kernel sequence + NearestPsd per factor.
 //
-// NOT COMPILED IN THIS IMAGE: gtsam needs Boost, which the build container lacks.  Everything below the
+// NOT LINKED AGAINST gtsam IN THIS IMAGE: gtsam needs Boost, which the build container lacks; the header is
+// put through a compiler with the real Eigen / Sophus and syntax-check stand-ins for gtsam / boost
+// (integration/compile_check, tests/test_adapter_compiles.py).  Everything below the
 // gtsam types -- value comparison, batched linearize / error pass, device-to-host copy of the per-edge results,
 // NearestPsd (as written or Higham), the cut into the reference's G11..Gnn / g1..gn order -- is engine code behind the
 // C ABI (sage_window_prepass / sage_window_factor / sage_window_factor_error, include/sage_ba.h) and is tested on the GPU

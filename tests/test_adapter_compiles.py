@@ -41,3 +41,23 @@ def test_adapter_compiles_against_reference_headers_and_libtorch():
     for l in syms.splitlines():
         if " U sage_" in l:
             assert l.split()[-1] in capi.SYMBOLS, l
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF) and os.path.exists(HIPCC)), reason="needs the reference tree and hipcc")
+def test_gtsam_prepass_header_is_valid_cxx():
+    """integration/sage_gtsam_prepass.h (f2: the gtsam-side type conversion around sage_window_prepass / _factor) goes
+    through a compiler with the REAL Eigen and Sophus of the reference's thirdparty tree; gtsam and Boost are
+    syntax-check stand-ins (integration/compile_check/gtsam, absent from the image).  What the header computes is
+    engine code behind the C ABI and is tested on the GPU (tests/test_gpu_factor_cache.py)."""
+    cmd = [HIPCC, "-x", "c++", "-std=c++17", "-fsyntax-only", "-Wall",
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "integration", "compile_check"),
+           "-I" + REF + "/thirdparty/eigen", "-I" + REF + "/thirdparty/Sophus",
+           os.path.join(ROOT, "integration", "compile_check", "prepass_check.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    # the C-ABI functions it calls exist
+    from sage_slam_amd import capi
+    src = open(os.path.join(ROOT, "integration", "sage_gtsam_prepass.h")).read()
+    import re
+    for name in set(re.findall(r"\b(sage_[a-z_]+)\(", src)):
+        assert name in capi.SYMBOLS, name
