@@ -224,7 +224,9 @@ typedef struct SageLmConfig
                               * kernels (error and normal equations from one pass, the system at the current estimate kept
                               * aside): an accepted iteration costs one linearize + one solve and no separate error pass, a
                               * rejected one costs a linearize instead of an error pass.  Same accept / reject rule and the
-                              * same iterates as the default sequence (the two kernels' errors agree to fp32 rounding). */
+                              * same iterates as the default sequence (the two kernels' errors agree to fp32 rounding).
+                              * sage_window_get_edge then returns the per-edge results of the LAST evaluation (the
+                              * candidate's after a rejected one); the packed system is always the current estimate's. */
 } SageLmConfig;
 void sage_lm_config_default(SageLmConfig *cfg);
 
@@ -377,7 +379,8 @@ int sage_window_get_edge(const SageWindow *w, int type, int e, float *AtA, float
  *       sage_factor_hessian_blocks cuts them (NearestPsd per psd_mode), *f = the factor's error_ (the constant term the
  *       reference passes to gtsam::HessianFactor).  SAGE_E_STATE when the cache holds no linearisation.
  *   sage_window_factor_error(win, type, e, &err)     PhotometricFactor::error / GeometricFactor::error from the cache.
- * Host pointers throughout; type 0 = photometric, 1 = geometric. */
+ * Host pointers throughout; type 0 = photometric, 1 = geometric.  One window is not re-entrant: callers on several
+ * host threads serialise prepass + factor reads per window (integration/sage_gtsam_prepass.h holds a mutex). */
 int sage_window_prepass(SageWindow *w, const float *pose12, const float *codes, const float *scales, int jacobians,
                         int *recomputed);
 int sage_window_factor(const SageWindow *w, int type, int e, int psd_mode, double *G_out, double *g_out, double *f_out,
