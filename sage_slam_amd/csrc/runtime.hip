@@ -1880,7 +1880,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
     // run length of a workgroup (sub-tiles it walks: prologue amortisation, vertical L1/L2 reuse between its bands) and,
     // separately, the number of sub-tiles it accumulates in fp32 before a partial record goes out to the double sums
     // (MFMA chains of 64 fmaf per sub-tile and accumulator): the LM step's distance from the exact step grows with the
-    // chain length (K = 64 window, scripts/tpb_noise_probe.py: 8 -> 2.1e-4, 4 -> 1.2e-4, 2 -> 7.6e-5, 1 -> 4.9e-5 rel-L2;
+    // chain length (K = 64 window, tests/tools/tpb_noise_probe.py: 8 -> 2.1e-4, 4 -> 1.2e-4, 2 -> 7.6e-5, 1 -> 4.9e-5 rel-L2;
     // the fp32 oracle itself sits at 5.5e-5).  Records every 2 sub-tiles keep the step inside the 1e-4 parity bar.
     int tpb = total >= 8192 ? 8 : (total >= 4096 ? 2 : 1);
     int flush = 0; // 0 = one record per workgroup (the noise-critical tiles have their own second level in the kernel)

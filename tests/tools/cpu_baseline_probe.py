@@ -1,6 +1,6 @@
 """dev tool: how does the oracle (CPU port of the reference path) scale with OpenMP threads on this host?"""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as orc
 from sage_slam_amd import synth
 orc.build()

@@ -2,7 +2,7 @@
 next to the fp32 oracle's own distance.  Dev tool; prints one line per seed."""
 import sys
 import numpy as np
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from sage_slam_amd import synth, capi
 from oracle import oracle as orc
 from tests.helpers import oracle_photo, oracle_geo, damped_delta, rel

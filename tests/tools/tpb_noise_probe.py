@@ -2,10 +2,10 @@
 """LM-delta noise of the K-keyframe window against the exact (fp64-oracle) step as a function of the fp32 accumulation
 run length of the two linearize kernels (SAGE_PHOTO_TPB / SAGE_GEO_TPB = sub-tiles a workgroup sums before it writes a
 partial record; the partials are summed in double).  (SAGE_PHOTO_TPB = sub-tiles a workgroup walks, SAGE_PHOTO_FLUSH = sub-tiles per partial record).
-usage: python scripts/tpb_noise_probe.py [K]"""
+usage: python tests/tools/tpb_noise_probe.py [K]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import oracle as orc
 from sage_slam_amd import capi, synth
 from tests.helpers import damped_delta, oracle_geo, oracle_photo, rel
@@ -28,10 +28,9 @@ for prec in res:
     H, g = add_priors(*capi.unpack_dense(capi.assemble_packed(K, w.links, CS, res[prec]), K, w.links, CS)[:2], w, CS)
     D[prec] = damped_delta(H, g, 1e-3)
 print(f"fp32 oracle vs exact: {rel(D['f32'], D['f64']):.2e}")
-CASES = [(8, 8, 0x3f), (8, 2, 0x3f), (8, 2, 0x07), (8, 2, 0x18), (8, 2, 0x20), (8, 2, 0x1f), (8, 2, 0x27), (8, 1, 0x07), (8, 1, 0x3f)]
-for pt, fl, mask in CASES:   # mask: tiles the intermediate records take (0..2 code-code, 3..4 cross, 5 pose tile)
+CASES = [(8, 8), (8, 4), (8, 2), (8, 1), (4, 4), (16, 16)]
+for pt, fl in CASES:   # (run length, sub-tiles per partial record); the LDS second level of the cross / pose tiles is always on
     os.environ["SAGE_PHOTO_TPB"] = str(pt); os.environ["SAGE_PHOTO_FLUSH"] = str(fl); gt = 16
-    os.environ["SAGE_PHOTO_FLUSH_MASK"] = hex(mask)
     win = capi.Window(w)
     win.set_profiling(True)
     for _ in range(5):
@@ -39,6 +38,6 @@ for pt, fl, mask in CASES:   # mask: tiles the intermediate records take (0..2 c
     win.solve(1e-3)
     dh = win.delta()
     kt = [win.kernel_time(i) for i in range(2)]
-    print(f"photo run {pt:2d} sub-tiles, record every {fl:2d}, tiles {mask:#04x}: hip-exact {rel(dh, D['f64']):.2e}  hip-fp32oracle {rel(dh, D['f32']):.2e}   "
+    print(f"photo run {pt:2d} sub-tiles, record every {fl:2d}: hip-exact {rel(dh, D['f64']):.2e}  hip-fp32oracle {rel(dh, D['f32']):.2e}   "
           f"photo lin {kt[0][0] / max(1, kt[0][1]):.3f} ms  geo lin {kt[1][0] / max(1, kt[1][1]):.3f} ms", flush=True)
     win.close()
