@@ -14,6 +14,7 @@
 //      (v_mfma_f32_16x16x4_f32, K = 4 pixels) contractions fed from the LDS basis tile.
 //
 // Algorithmic bytes per source pixel: 4*[4*FS*rho + CS + 6].
+#include "host_math.h" // env_flag
 #include "sage_device.h"
 #include "sage_internal.h"
 
@@ -46,6 +47,10 @@ struct PhotoParams
   // flush == tiles_per_block is the plain "one record per work item"
   const int32_t *rec_first;
   int flush;
+  // error pass (MODE 1): the destination keyframe's feature texels of the levels >= lds_l0 (the tail [lds_base, P) of the
+  // concatenated pyramid, lds_ntex texels x FS/4 channel groups x 16 B) are staged in LDS once per workgroup and their
+  // taps read with ds_read_b128 instead of going through the texture path; lds_l0 >= levels: off
+  int lds_l0, lds_base, lds_ntex;
 };
 
 __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
@@ -58,6 +63,9 @@ __device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i 
   return i * 6 - (i * (i - 1)) / 2 + (j - i);
 }
 
+#ifndef SAGE_PHOTO_ERR_WAVES
+#define SAGE_PHOTO_ERR_WAVES 3 // error pass: lower bound only, the kernel needs far fewer registers
+#endif
 #ifndef SAGE_PHOTO_WAVES
 #define SAGE_PHOTO_WAVES 3 // workgroups per CU the linearize kernel is register-budgeted for (x4 waves)
 #endif
@@ -100,7 +108,7 @@ struct TapBatch
 //      (lane = (channel pair i, pixel k): 16 lanes x dwordx2 = one 128-byte basis row; CS = 32: operand block 0 = even
 //      channels, block 1 = odd channels)
 template <int CS, int FS, bool JAC, int MODE>
-__global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kernel(const PhotoParams prm)
+__global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : SAGE_PHOTO_ERR_WAVES) void photo_kernel(const PhotoParams prm)
 {
   constexpr bool PACKED = MODE >= 1;
   constexpr int NB = CS / 16;
@@ -165,7 +173,20 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
   const bool fuse_geo = !JAC && prm.geo_loss_param > 0.f && E.dpt1_geo != nullptr;
   const float geo_loss = E.geo_loss > 0.f ? E.geo_loss : prm.geo_loss_param; // per-link parameter (mapper.cpp:369)
   float *st_w = s_mem + wave * 64 * kPhotoStashLD; // this wave's stash
-  __syncthreads();                                 // s_red zeroed
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  f32x4 *s_lvl = reinterpret_cast<f32x4 *>(s_dyn);
+  const bool stage_lds = !JAC && PACKED && prm.lds_l0 < nlev;
+  if (stage_lds)
+  {
+    // every sub-tile of this workgroup samples the same destination keyframe: its coarse levels go to LDS once
+    const int ntex = prm.lds_ntex;
+    for (int idx = tid; idx < NG * ntex; idx += kBlock)
+    {
+      const int g = idx / ntex, t = idx - g * ntex;
+      s_lvl[idx] = buf_load4(r_f1, (uint32_t)(prm.lds_base + t) * 16u, (uint32_t)g * plane * 4u);
+    }
+  }
+  __syncthreads(); // s_red zeroed, staged levels visible
 
   const int nsub = min(prm.tiles_per_block, (N + kTile - 1) / kTile - wi.tile);
   const int flush = JAC ? max(1, prm.flush) : 1;
@@ -243,14 +264,24 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : 3) void photo_kern
         const uint32_t soff = (uint32_t)g * plane * 4u;
         TapBatch<JAC> B;
         B.f0 = f0s[((size_t)l * NG + g) * N];
+        if (!JAC && stage_lds && l >= prm.lds_l0) // (one loop body with this branch: splitting the level loop in two
+        {                                         //  specialised passes perturbed the linearize kernel's allocation: +3 %)
+          const f32x4 *lv = s_lvl + (g * prm.lds_ntex + ((int)lo - prm.lds_base));
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+          for (int k = 0; k < 4; ++k)
+            B.t1[k] = lv[td.off[k]];
+        }
+        else
         {
-          B.t1[k] = buf_load4(r_f1, dof[k], soff);
-          if (JAC)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
           {
-            B.tx[k] = buf_load4(r_g1, dof[k], soff);
-            B.ty[k] = buf_load4(r_g1y, dof[k], soff);
+            B.t1[k] = buf_load4(r_f1, dof[k], soff);
+            if (JAC)
+            {
+              B.tx[k] = buf_load4(r_g1, dof[k], soff);
+              B.ty[k] = buf_load4(r_g1y, dof[k], soff);
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0); // without it hipcc serialises load->wait->use through one register quad
@@ -868,6 +899,9 @@ static PhotoParams make_params(const PhotoEdge *single, const PhotoEdge *table, 
   p.order = lc.order;
   p.rec_first = lc.flush > 0 ? lc.edge_first : nullptr;
   p.flush = lc.flush > 0 ? lc.flush : lc.tiles_per_block;
+  p.lds_l0 = pyr.levels; // off
+  p.lds_base = 0;
+  p.lds_ntex = 0;
   for (int l = 0; l < pyr.levels; ++l)
   {
     p.rx[l] = pyr.cam[l].fx / pyr.cam[0].fx; // same fp32 quotient the kernels used to form per pixel
@@ -927,8 +961,27 @@ static hipError_t photo_err_impl(hipStream_t s, const PhotoEdge *single, const P
   PhotoParams p = make_params(single, table, lc, pyr, wh, eps, &wsum);
   if (lc.ev_start)
     (void)hipEventRecord(lc.ev_start, s);
+  size_t lds_bytes = 0;
+  if (lc.packed && lc.tiles_per_block >= 4)
+  {
+    // coarse levels of the destination keyframe into LDS (taps via ds_read_b128: the error pass is bound by the CU's
+    // texture path, the LDS pipe is idle): the longest tail of the pyramid that fits 25 KiB -- six workgroups per CU
+    // still fit (the kernel runs 6 waves/SIMD), and a workgroup of >= 4 sub-tiles amortises the staging loads
+    constexpr size_t kBudget = 25 * 1024;
+    int l0 = pyr.levels;
+    while (l0 > 0 && (size_t)(pyr.P - pyr.level_offsets[l0 - 1]) * (FS / 4) * 16 <= kBudget)
+      --l0;
+    static const bool off = env_flag("SAGE_NO_LDS_LEVELS");
+    if (l0 < pyr.levels && !off)
+    {
+      p.lds_l0 = l0;
+      p.lds_base = pyr.level_offsets[l0];
+      p.lds_ntex = pyr.P - pyr.level_offsets[l0];
+      lds_bytes = (size_t)p.lds_ntex * (FS / 4) * 16;
+    }
+  }
   if (lc.packed)
-    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 1>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
+    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 1>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), lds_bytes, s, p);
   else
     hipLaunchKernelGGL((photo_kernel<CS, FS, false, 0>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
   if (lc.ev_stop)
