@@ -12,8 +12,9 @@ from tests.helpers import damped_delta, oracle_geo, oracle_photo, rel
 from tests.test_gpu_configs import add_priors
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+SEED = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 orc.build()
-w = synth.make_window(K=K, H=128, W=160, FS=16, CS=32, L=4, seed=0)
+w = synth.make_window(K=K, H=128, W=160, FS=16, CS=32, L=4, seed=SEED)
 CS = 32
 t0 = time.time()
 res = {"f32": {}, "f64": {}}
@@ -28,7 +29,7 @@ for prec in res:
     H, g = add_priors(*capi.unpack_dense(capi.assemble_packed(K, w.links, CS, res[prec]), K, w.links, CS)[:2], w, CS)
     D[prec] = damped_delta(H, g, 1e-3)
 print(f"fp32 oracle vs exact: {rel(D['f32'], D['f64']):.2e}")
-CASES = [(8, 8), (8, 4), (8, 2), (8, 1), (4, 4), (16, 16)]
+CASES = [(8, 8), (8, 4), (8, 2), (8, 1)] if SEED else [(8, 8), (8, 4), (8, 2), (8, 1), (4, 4), (16, 16)]
 for pt, fl in CASES:   # (run length, sub-tiles per partial record); the LDS second level of the cross / pose tiles is always on
     os.environ["SAGE_PHOTO_TPB"] = str(pt); os.environ["SAGE_PHOTO_FLUSH"] = str(fl); gt = 16
     win = capi.Window(w)
