@@ -248,6 +248,38 @@ def main():
         synth_kw = dict(n_samples=3072, loop_radius=0.12)
         loops = [] if os.environ.get("SAGE_BENCH_NO_LOOPS") == "1" else [(0, 511), (2, 509), (1, 510), (0, 256), (100, 130)]
 
+    # ---- multi-GPU entry point.  Two ways in: (a) the driver's `python -m torch.distributed.run --nproc-per-node N
+    # bench.py --gpus N` (WORLD_SIZE set: this process is one rank); (b) plain `python bench.py --gpus N`: this process
+    # becomes the launcher and re-executes itself under torch.distributed.run with N ranks, one GPU per rank.  A box
+    # with fewer than N GPUs is refused (rc 2) instead of silently measuring one rank.
+    one_dev = os.environ.get("SAGE_BENCH_ONE_DEVICE") == "1"       # dev knob: all ranks on cuda:0, gloo collective
+    dry_run = os.environ.get("SAGE_BENCH_DRY_RUN") == "1"          # dev knob: launcher / rendezvous check without a GPU
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']} in the environment\n")
+        raise SystemExit(2)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if not (one_dev or dry_run):
+            import torch
+            have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+            if have < args.gpus:
+                sys.stderr.write(f"bench.py: --gpus {args.gpus} requested but this box has {have} visible HIP device(s); "
+                                 "refusing to run fewer ranks than asked for (SAGE_BENCH_ONE_DEVICE=1 runs all ranks "
+                                 "on cuda:0 over gloo as a functional check)\n")
+                raise SystemExit(2)
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        raise SystemExit(subprocess.call(cmd, env=env))
+
     # the driver reads ONE JSON line from stdout: libraries that print banners to fd 1 (RCCL prints its version block at
     # communicator teardown) are sent to stderr; the JSON line goes out through the saved descriptor
     sys.stdout.flush()
@@ -258,11 +290,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if dry_run:
+        # launcher check (CPU test): N ranks rendezvous over gloo, agree on the world size, rank 0 prints the line
+        import torch.distributed as dist
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        pids = [None] * world
+        dist.all_gather_object(pids, (rank, os.getpid()))
+        if rank == 0:
+            os.write(json_fd, (json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": len(set(pids)),
+                                           "pids": [p for _, p in sorted(pids)]}) + "\n").encode())
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU path")
-    # dev knob: SAGE_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 with the gloo backend -- a functional check of the
-    # sharded path on a 1-GPU box (the driver's multi-GPU runs use one GPU per rank and RCCL)
-    one_dev = os.environ.get("SAGE_BENCH_ONE_DEVICE") == "1"
+    # SAGE_BENCH_ONE_DEVICE=1 runs every rank on cuda:0 with the gloo backend -- a functional check of the sharded path
+    # on a 1-GPU box (the driver's multi-GPU runs use one GPU per rank and RCCL)
+    if not one_dev and torch.cuda.device_count() < world:
+        sys.stderr.write(f"bench.py: {world} ranks but {torch.cuda.device_count()} visible HIP device(s)\n")
+        raise SystemExit(2)
     dev_index = 0 if one_dev else local_rank
     torch.cuda.set_device(dev_index)
     dist = None
@@ -395,6 +440,15 @@ def main():
         elapsed = float(t.item())
     ktime = [win.kernel_time(which) for which in range(4)]
     win.set_profiling(False)
+    per_rank_ms = None
+    if dist is not None:
+        # average launch duration of the three hot kernels on every rank (HIP events on the window's stream)
+        mine = torch.tensor([ktime[i][0] / max(1, ktime[i][1]) for i in range(3)] + [1e3 * (time.perf_counter() - t0)],
+                            dtype=torch.float64, device="cpu" if one_dev else "cuda")
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [{"rank": r, "photo_linearize": float(v[0]), "geo_linearize": float(v[1]),
+                        "error_pass": float(v[2])} for r, v in enumerate(allr)]
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -420,6 +474,7 @@ def main():
                        "residuals_per_step": residuals_per_step,
                        "parallelism": f"edge-shard x{world}" if world > 1 else "single GPU",
                        "collective": collective,
+                       **({"per_rank_kernel_ms": per_rank_ms} if per_rank_ms else {}),
                        "lm": ("1 linearize + 1 solve (device scatter/retract, host block Cholesky) + 1 error pass per step"
                               if args.lm_variant == "classic" else
                               "linearize-at-candidate: per evaluation 1 solve + 1 linearize at the candidate (error and "

@@ -149,7 +149,9 @@ int sage_geometric_error_calculate(
 
 /* ---- input producers ---- */
 /* UpdateDepth + ComputeSpatialGrad (core/mapping/mapping_utils.h:215-252; caller side of the geometric
- * factor, geometric_factor.cpp:317-347): dpt[H,W] = scale*(bias+basis*code), grad[2,H,W] = scale*centraldiff. */
+ * factor, geometric_factor.cpp:317-347): dpt[H,W] = scale*(bias+basis*code), grad[2,H,W] = scale*centraldiff.
+ * The producers are ASYNCHRONOUS on the workspace's stream (unlike the operator calls, which end in a stream
+ * synchronise): every device input -- code_dev included -- must stay valid until the stream has passed the call. */
 int sage_depth_and_grad(SageWorkspace *ws, float *dpt_dev, float *dpt_grad_dev,
                         const float *bias_dev, const float *basis_dev, const float *code_dev,
                         float scale, int H, int W, int CS);

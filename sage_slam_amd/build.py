@@ -57,5 +57,33 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+GLUE_SRC = os.path.join(ROOT, "integration", "compile_check", "prepass_run.cpp")
+GLUE_BIN = os.path.join(ROOT, "integration", "compile_check", "_bin", "prepass_run")
+REF_THIRDPARTY = "/root/reference/system/thirdparty"
+
+
+def build_glue_check(verbose: bool = False):
+    """Test binary that EXECUTES integration/sage_gtsam_prepass.h (f2 glue) against the engine library: real Eigen and
+    Sophus (header-only, from the reference's thirdparty tree -> build container only), recording stand-ins for
+    gtsam / boost.  The binary travels to the GPU box with the tree; tests/test_gpu_gtsam_glue.py runs it there.
+    Returns the path, or None when the reference tree is absent."""
+    if not os.path.isdir(REF_THIRDPARTY):
+        return GLUE_BIN if os.path.exists(GLUE_BIN) else None
+    deps = [GLUE_SRC, os.path.join(ROOT, "integration", "sage_gtsam_prepass.h"), os.path.join(ROOT, "include", "sage_ba.h"),
+            os.path.join(ROOT, "integration", "compile_check", "gtsam", "linear", "HessianFactor.h"),
+            os.path.join(ROOT, "integration", "compile_check", "gtsam", "nonlinear", "Values.h"), LIB]
+    if _mtime(GLUE_BIN) >= max(_mtime(d) for d in deps):
+        return GLUE_BIN
+    os.makedirs(os.path.dirname(GLUE_BIN), exist_ok=True)
+    subprocess.check_call([HOSTCXX, "-std=c++17", "-O1", "-w", "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.join(ROOT, "integration", "compile_check"), "-I" + REF_THIRDPARTY + "/eigen",
+                           "-I" + REF_THIRDPARTY + "/Sophus", "-I/opt/rocm/include", GLUE_SRC, "-o", GLUE_BIN,
+                           "-L" + HERE, "-lsage_ba", "-L/opt/rocm/lib", "-lamdhip64",
+                           "-Wl,-rpath,$ORIGIN/../../../sage_slam_amd", "-Wl,-rpath,/opt/rocm/lib"])
+    if verbose:
+        print("built", GLUE_BIN)
+    return GLUE_BIN
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))

@@ -461,6 +461,10 @@ def depth_and_grad(ws: Workspace, bias, basis, code, scale, H, W, CS):
     code_d = _dev(code, np.float32)
     _chk(lib().sage_depth_and_grad(ws.h, dptr(dpt), dptr(grad), dptr(bias), dptr(basis), dptr(code_d),
                                    C.c_float(scale), H, W, CS), "sage_depth_and_grad")
+    # the producer is ASYNCHRONOUS on the workspace's stream: its inputs must outlive the launch.  `code_d` rides on the
+    # result (torch would otherwise hand its block to the next allocation of any thread while the kernel is queued --
+    # found by tests/test_gpu_threads.py)
+    dpt._sage_keepalive = code_d
     return dpt, grad
 
 

@@ -246,7 +246,7 @@ extern "C" int sage_nearest_psd(const double *M, int n, double *out)
       A3[(size_t)i * n + j] = A3[(size_t)j * n + i] = s;
     }
   // bump by (-min_eig*k + spacing) until LDLT-positive (mapping_utils.h:119-126)
-  int k = 1;
+  double k = 1; // (a double: 60 doublings of an int would overflow)
   const double spacing = 1e-15;
   for (int it = 0; it < 60 && !sage::is_psd(A3, n); ++it)
   {
@@ -437,7 +437,7 @@ extern "C" int sage_nearest_psd_reference(const double *M, int n, double *out)
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j)
       A3[(size_t)i * n + j] = (S[(size_t)i * n + j] + S[(size_t)j * n + i]) / 2;
-  int k = 1;
+  double k = 1; // (a double: 60 doublings of an int would overflow)
   const double spacing = 1e-15;
   for (int it = 0; it < 60 && !sage::eigen_ldlt_is_positive(A3, n); ++it)
   {
@@ -526,86 +526,133 @@ extern "C" int sage_damped_solve_qr_f32(const float *A, const float *b, int n, f
 {
   if (!A || !b || !x || n < 1 || n > 64)
     return SAGE_E_INVALID;
-  // M = A + damp*diag(A); column-pivoted Householder QR, all in fp32
-  std::vector<float> M((size_t)n * n), rhs(b, b + n);
+  // (AtA + damp*diag(AtA)).colPivHouseholderQr().solve(Atb) in fp32 (camera_tracker.cpp:1182-1183), restated after Eigen
+  // 3.3.9 step by step so that the RANK DECISION is Eigen's: ColPivHouseholderQR::computeInPlace (ColPivHouseholderQR.h:
+  // 480-570) pivots on DOWNDATED column norms (LAPACK xGEQPF rule, recomputed when the downdate loses accuracy), counts
+  // m_nonzero_pivots = the first k whose largest remaining squared norm is < (eps * max initial norm)^2 / rows * (rows-k),
+  // makeHouseholderInPlace's (tau, beta) convention (Householder.h:65-93), and _solve_impl (:589-610): only the first
+  // nonzero_pivots reflectors touch the right-hand side, the leading triangle is solved, the other components are zero.
+  // Pinned by tests/golden/colpiv_qr_eigen339.json (produced with the vendored Eigen).  Column-major like Eigen.
+  const float eps = std::numeric_limits<float>::epsilon();
+  std::vector<float> M((size_t)n * n), c(b, b + n), hco(n, 0.f), upd(n), dir(n), tmp(n);
+  auto at = [&](int i, int j) -> float & { return M[(size_t)j * n + i]; };
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < n; ++j)
-      M[(size_t)i * n + j] = A[(size_t)i * n + j] + (i == j ? damp * A[(size_t)i * n + i] : 0.f);
+      at(i, j) = A[(size_t)i * n + j] + (i == j ? damp * A[(size_t)i * n + i] : 0.f);
+  auto col_norm = [&](int j, int from) {
+    float sq = 0.f;
+    for (int i = from; i < n; ++i)
+      sq += at(i, j) * at(i, j);
+    return std::sqrt(sq);
+  };
+  float maxcol = 0.f;
+  for (int j = 0; j < n; ++j)
+  {
+    dir[j] = upd[j] = col_norm(j, 0);
+    maxcol = std::max(maxcol, upd[j]);
+  }
+  const float thr_helper = (maxcol * eps) * (maxcol * eps) / (float)n;
+  const float downdate_thr = std::sqrt(eps);
+  std::vector<int> transp(n);
+  int rank = n;
+  for (int k = 0; k < n; ++k)
+  {
+    int best = k;
+    for (int j = k + 1; j < n; ++j) // maxCoeff: the first maximal entry
+      if (upd[j] > upd[best])
+        best = j;
+    const float biggest_sq = upd[best] * upd[best];
+    if (rank == n && biggest_sq < thr_helper * (float)(n - k))
+      rank = k;
+    transp[k] = best;
+    if (best != k)
+    {
+      for (int i = 0; i < n; ++i)
+        std::swap(at(i, k), at(i, best));
+      std::swap(upd[k], upd[best]);
+      std::swap(dir[k], dir[best]);
+    }
+    // makeHouseholderInPlace on column k, rows k..n-1
+    float tail_sq = 0.f;
+    for (int i = k + 1; i < n; ++i)
+      tail_sq += at(i, k) * at(i, k);
+    const float c0 = at(k, k);
+    float tau, beta;
+    if (tail_sq <= std::numeric_limits<float>::min())
+    {
+      tau = 0.f;
+      beta = c0;
+      for (int i = k + 1; i < n; ++i)
+        at(i, k) = 0.f;
+    }
+    else
+    {
+      beta = std::sqrt(c0 * c0 + tail_sq);
+      if (c0 >= 0.f)
+        beta = -beta;
+      for (int i = k + 1; i < n; ++i)
+        at(i, k) /= (c0 - beta);
+      tau = (beta - c0) / beta;
+    }
+    hco[k] = tau;
+    at(k, k) = beta;
+    // applyHouseholderOnTheLeft to the trailing columns
+    if (n - k == 1)
+    { /* no trailing block */ }
+    else if (tau != 0.f)
+      for (int j = k + 1; j < n; ++j)
+      {
+        float t = 0.f;
+        for (int i = k + 1; i < n; ++i)
+          t += at(i, k) * at(i, j);
+        t += at(k, j);
+        at(k, j) -= tau * t;
+        for (int i = k + 1; i < n; ++i)
+          at(i, j) -= tau * at(i, k) * t;
+      }
+    for (int j = k + 1; j < n; ++j)
+      if (upd[j] != 0.f)
+      {
+        float t = std::fabs(at(k, j)) / upd[j];
+        t = (1.f + t) * (1.f - t);
+        t = t < 0.f ? 0.f : t;
+        const float q = upd[j] / dir[j];
+        const float t2 = t * (q * q);
+        if (t2 <= downdate_thr)
+          dir[j] = upd[j] = col_norm(j, k + 1);
+        else
+          upd[j] *= std::sqrt(t);
+      }
+  }
   std::vector<int> perm(n);
   for (int i = 0; i < n; ++i)
     perm[i] = i;
   for (int k = 0; k < n; ++k)
+    std::swap(perm[k], perm[transp[k]]);
+  for (int i = 0; i < n; ++i)
+    x[i] = 0.f;
+  if (rank == 0)
+    return SAGE_OK;
+  for (int k = 0; k < rank; ++k) // c = H_{rank-1} ... H_0 c
   {
-    int best = k;
-    float bn = -1.f;
-    for (int j = k; j < n; ++j)
-    {
-      float s = 0.f;
-      for (int i = k; i < n; ++i)
-        s += M[(size_t)i * n + j] * M[(size_t)i * n + j];
-      if (s > bn)
-      {
-        bn = s;
-        best = j;
-      }
-    }
-    if (best != k)
-    {
-      for (int i = 0; i < n; ++i)
-        std::swap(M[(size_t)i * n + k], M[(size_t)i * n + best]);
-      std::swap(perm[k], perm[best]);
-    }
-    float norm = std::sqrt(bn);
-    if (norm == 0.f)
+    if (hco[k] == 0.f)
       continue;
-    const float akk = M[(size_t)k * n + k];
-    const float alpha = akk > 0 ? -norm : norm;
-    std::vector<float> v(n, 0.f);
-    v[k] = akk - alpha;
+    float t = c[k];
     for (int i = k + 1; i < n; ++i)
-      v[i] = M[(size_t)i * n + k];
-    float vv = 0.f;
-    for (int i = k; i < n; ++i)
-      vv += v[i] * v[i];
-    if (vv == 0.f)
-      continue;
-    for (int j = k; j < n; ++j)
-    {
-      float s = 0.f;
-      for (int i = k; i < n; ++i)
-        s += v[i] * M[(size_t)i * n + j];
-      s = 2.f * s / vv;
-      for (int i = k; i < n; ++i)
-        M[(size_t)i * n + j] -= s * v[i];
-    }
-    float s = 0.f;
-    for (int i = k; i < n; ++i)
-      s += v[i] * rhs[i];
-    s = 2.f * s / vv;
-    for (int i = k; i < n; ++i)
-      rhs[i] -= s * v[i];
+      t += at(i, k) * c[i];
+    c[k] -= hco[k] * t;
+    for (int i = k + 1; i < n; ++i)
+      c[i] -= hco[k] * at(i, k) * t;
   }
-  // rank as Eigen's ColPivHouseholderQR::solve() determines it (the reference's solver, camera_tracker.cpp:1182-1183):
-  // pivots with |R_ii| <= eps * n * max|R_jj| do not count, only the leading rank x rank triangle is solved and the
-  // remaining components are zero -- a near-singular damped system gives a truncated step, not a division by a tiny pivot
-  float maxpiv = 0.f;
-  for (int i = 0; i < n; ++i)
-    maxpiv = std::max(maxpiv, std::fabs(M[(size_t)i * n + i]));
-  const float thr = maxpiv * (std::numeric_limits<float>::epsilon() * (float)n);
-  int rank = 0;
-  for (int i = 0; i < n; ++i)
-    rank += std::fabs(M[(size_t)i * n + i]) > thr ? 1 : 0;
-  std::vector<float> y(n, 0.f);
   for (int i = rank - 1; i >= 0; --i)
   {
-    float s = rhs[i];
+    float t = c[i];
     for (int j = i + 1; j < rank; ++j)
-      s -= M[(size_t)i * n + j] * y[j];
-    const float d = M[(size_t)i * n + i];
-    y[i] = (d != 0.f) ? s / d : 0.f;
+      t -= at(i, j) * tmp[j];
+    tmp[i] = t / at(i, i);
   }
-  for (int i = 0; i < n; ++i)
-    x[perm[i]] = y[i];
+  for (int i = 0; i < rank; ++i)
+    x[perm[i]] = tmp[i];
   return SAGE_OK;
 }
 

@@ -15,7 +15,23 @@
 #include <vector>
 
 #include <dlfcn.h>
-#include <rccl/rccl.h> // types only: the library is bound at run time (sage_rccl_*), CPU-only hosts never load it
+// RCCL: types only -- the library is bound at run time with dlopen (sage_rccl_*), hosts without it never load it, and a
+// build host without the RCCL headers still compiles (the handful of types the binding needs are declared here then)
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+extern "C"
+{
+  typedef struct ncclComm *ncclComm_t;
+  typedef struct
+  {
+    char internal[128];
+  } ncclUniqueId;
+  typedef enum { ncclSuccess = 0 } ncclResult_t;
+  typedef enum { ncclSum = 0 } ncclRedOp_t;
+  typedef enum { ncclDouble = 8 } ncclDataType_t; // nccl.h: ncclFloat64 = ncclDouble = 8
+}
+#endif
 
 #include "host_math.h"
 #include "sage_ba.h"
@@ -1201,6 +1217,7 @@ struct SageWindow
   // linearize-at-candidate LM (SageLmConfig::linearize_at_candidate): which variables the packed system belongs to
   uint64_t vars_epoch = 1, lin_epoch = 0; // lin_epoch == vars_epoch: `packed` is the linearisation at the current variables
   bool spec_err_valid = false;
+  bool packed_reduced = false; // sharded windows: `packed` has been summed over the ranks since it was last assembled
   double spec_error = 0.0;                // total error at that linearisation point (priors included)
   DevBuf packed_save;                     // the current system while the candidate's is being formed in `packed`
   // f2: per-Values factor cache (sage_window_prepass): host copies of every local edge's results and the values
@@ -2100,6 +2117,7 @@ static int window_linearize_set(SageWindow *w, int set)
   w->have_lin = true;
   w->lin_epoch = set == 0 ? w->vars_epoch : 0; // (a candidate's system becomes current only through lm_step's accept)
   w->spec_err_valid = false;
+  w->packed_reduced = false;
   return SAGE_OK;
 }
 
@@ -3108,12 +3126,17 @@ static int schur_solve(SageWindow *w, double damp, double *lin_error)
   std::vector<double> dadd, gadd;
   window_priors(w, dadd, gadd);
   int rc = sage_shard_eliminate(w->shard, w->host_packed.data(), damp, dadd.data(), gadd.data(), w->h_sep.data());
-  if (rc == SAGE_E_NOT_PSD)
-    std::fill(w->h_sep.begin(), w->h_sep.end(), NAN); // every rank will see it after the sum
-  else if (rc)
+  if (rc && rc != SAGE_E_NOT_PSD)
     return rc;
-  else
-    w->h_sep[ns - 4] = prior_error_owned(w, 0);
+  if (rc == SAGE_E_NOT_PSD)
+  {
+    // a failed local elimination is flagged in the spare tail slot [ns-3] (a positive count after the sum: every rank
+    // sees it); the separator blocks of this rank are void, the error totals at the linearisation point (tail[0..4],
+    // written by sage_shard_eliminate before it factorises) stay finite so that st->error is valid on every rank
+    std::fill(w->h_sep.begin(), w->h_sep.end() - 8, 0.0);
+    w->h_sep[ns - 3] = 1.0;
+  }
+  w->h_sep[ns - 4] = prior_error_owned(w, 0);
   SAGE_HIP(hipMemcpyAsync(w->sepbuf.p, w->h_sep.data(), ns * sizeof(double), hipMemcpyHostToDevice, w->stream));
   if (w->allreduce(w->sepbuf.as<double>(), ns, w->allreduce_user))
     return SAGE_E_STATE;
@@ -3121,7 +3144,7 @@ static int schur_solve(SageWindow *w, double damp, double *lin_error)
   SAGE_HIP(hipStreamSynchronize(w->stream));
   if (lin_error)
     *lin_error = w->h_sep[ns - 8] + w->h_sep[ns - 7] + w->h_sep[ns - 4];
-  if (std::isnan(w->h_sep[ns - 8]) || std::isnan(w->h_sep[0]))
+  if (w->h_sep[ns - 3] > 0.0 || std::isnan(w->h_sep[0]))
     return SAGE_E_NOT_PSD;
   w->delta.assign((size_t)K * B, 0.0);
   rc = sage_shard_solve(w->shard, w->h_sep.data(), w->delta.data());
@@ -3215,9 +3238,14 @@ static int lm_step_at_candidate(SageWindow *w, SageLmState *st, const SageLmConf
   auto clampd = [&](double d) { return std::min(std::max((double)cfg->min_damp, d), (double)cfg->max_damp); };
   const size_t np = sage_window_packed_count(w);
   auto reduce_packed = [&]() -> int {
-    return (sharded && w->allreduce(w->packed.as<double>(), np, w->allreduce_user)) ? SAGE_E_STATE : SAGE_OK;
+    if (sharded && w->allreduce(w->packed.as<double>(), np, w->allreduce_user))
+      return SAGE_E_STATE;
+    w->packed_reduced = true;
+    return SAGE_OK;
   };
-  if (!(w->have_lin && w->lin_epoch == w->vars_epoch))
+  // the system at the current estimate is reused only if it is the GLOBAL one: sage_window_linearize / _prepass leave a
+  // rank-local `packed` behind on a sharded window (every rank sees the same flags: same call sequence on all ranks)
+  if (!(w->have_lin && w->lin_epoch == w->vars_epoch && (!sharded || w->packed_reduced)))
   {
     if ((rc = window_linearize_set(w, 0)) || (rc = reduce_packed()))
       return rc;
@@ -3318,7 +3346,9 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
   auto clampd = [&](double d) { return std::min(std::max((double)cfg->min_damp, d), (double)cfg->max_damp); };
   const bool pipelined = w->pipe_enabled && !sharded && w->n_edges > 0;
   const bool schur = sharded && w->shard != nullptr;
-  if (cfg->linearize_at_candidate && !pipelined && !schur && w->n_edges > 0)
+  // (rank-independent decision: the window's link count, not this rank's share of it -- a rank without links must
+  //  issue the same collectives as the others)
+  if (cfg->linearize_at_candidate && !pipelined && !schur && !w->links.empty())
     return lm_step_at_candidate(w, st, cfg, sharded);
   if ((rc = pipelined ? pipe_linearize(w) : sage_window_linearize(w)))
     return rc;

@@ -1,10 +1,22 @@
 """Native RCCL collective of the window engine (sage_rccl_* / sage_window_use_rccl): one rank on one GPU -- the
 communicator is created in C++ (ncclGetUniqueId / ncclCommInitRank), the window's two all-reduces per LM iteration run
 as ncclAllReduce(double, sum) on the window's stream, and the iteration walks exactly the trajectory of the plain
-single-rank window.  (Multi-rank RCCL needs one GPU per rank: the driver's multi-GPU bench exercises it; the sharded
-arithmetic itself is covered on CPU by tests/test_sharded_reduce_gloo.py and on one GPU by test_gpu_sharded_lm.py.)"""
+single-rank window.  Multi-rank RCCL needs one GPU per rank (RCCL refuses two ranks on one device):
+test_rccl_multi_rank_lm_matches_single_rank runs 2 ranks natively (plain all-reduce of the packed system and the
+domain-decomposed SAGE_SHARD_SCHUR=1 path) wherever >= 2 GPUs are visible and is skipped on 1-GPU boxes; there
+`bench.py --gpus 2` must refuse (rc 2) and the SAGE_BENCH_ONE_DEVICE=1 gloo variant exercises the launcher.  The
+sharded arithmetic itself is covered on CPU by tests/test_sharded_reduce_gloo.py and on one GPU by
+test_gpu_sharded_lm.py."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 from sage_slam_amd import synth
 
@@ -50,3 +62,105 @@ def test_rccl_single_rank_lm_matches_plain_window():
     win.close()
     capi.rccl_comm_destroy(comm)
     assert float(x.sum()) == 499500.0
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# N > 1 ranks on the native RCCL path (one GPU per rank)
+# ---------------------------------------------------------------------------------------------------------------
+def _free_port():
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); p = sk.getsockname()[1]; sk.close(); return p
+
+
+def _make_multi():
+    return synth.make_window(K=14, H=32, W=40, FS=16, CS=16, L=2, n_samples=500, seed=8)
+
+
+def _trace(win, capi, steps):
+    cfg = capi.lm_config_default(); cfg.max_inner_evals = 1
+    st = capi.SageLmState()
+    tr = []
+    for _ in range(steps):
+        win.lm_step(st, cfg)
+        tr.append((st.error, st.candidate_error, int(st.accepted), st.damp))
+    return np.array(tr)
+
+
+def _all_vars(win, K):
+    return np.array([np.concatenate([p, c, [sc]]) for p, c, sc in (win.get_keyframe(k) for k in range(K))])
+
+
+def _rccl_worker(rank, world, port, out_dir, schur):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    os.environ["SAGE_SHARD_SCHUR"] = "1" if schur else "0"
+    torch.cuda.set_device(rank)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # ferries the 128-byte id only
+    from sage_slam_amd import capi
+    uid = [capi.rccl_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(uid, 0)
+    comm = capi.rccl_comm_create(uid[0], rank, world)
+    w = _make_multi()
+    win = capi.Window(w, rank=rank, world=world)
+    win.use_rccl(comm)
+    np.save(os.path.join(out_dir, f"t_{int(schur)}_{rank}.npy"), _trace(win, capi, 4))
+    win.sync_variables()
+    np.save(os.path.join(out_dir, f"v_{int(schur)}_{rank}.npy"), _all_vars(win, len(w.keyframes)))
+    win.close()
+    capi.rccl_comm_destroy(comm)
+    dist.destroy_process_group()
+
+
+def _n_devices():
+    import torch
+    return torch.cuda.device_count() if torch.cuda.is_available() else 0
+
+
+@pytest.mark.skipif(_n_devices() < 2, reason="native multi-rank RCCL needs one GPU per rank")
+@pytest.mark.parametrize("schur", [False, True])
+def test_rccl_multi_rank_lm_matches_single_rank(tmp_path, schur):
+    import torch.multiprocessing as mp
+    from sage_slam_amd import capi
+    world = min(_n_devices(), 4)
+    mp.spawn(_rccl_worker, args=(world, _free_port(), str(tmp_path), schur), nprocs=world, join=True)
+    tr = [np.load(tmp_path / f"t_{int(schur)}_{r}.npy") for r in range(world)]
+    for t in tr[1:]:
+        assert np.array_equal(t, tr[0])
+    w = _make_multi()
+    ref = capi.Window(w)
+    single = _trace(ref, capi, 4)
+    assert np.array_equal(single[:, 2], tr[0][:, 2]) and tr[0][0, 2] == 1
+    np.testing.assert_allclose(tr[0][:, :2], single[:, :2], rtol=1e-6)
+    v_ref = _all_vars(ref, len(w.keyframes))
+    for r in range(world):
+        v = np.load(tmp_path / f"v_{int(schur)}_{r}.npy")
+        assert np.abs(v - v_ref).max() < 2e-5 * max(1.0, np.abs(v_ref).max())
+
+
+def _bench(extra_env, *args, timeout=600):
+    env = dict(os.environ); env.update(extra_env)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+@pytest.mark.skipif(_n_devices() >= 2, reason="box has the GPUs: the refusal cannot be observed")
+def test_bench_refuses_more_ranks_than_devices():
+    r = _bench({}, "--gpus", "2", "--steps", "1", "--warmup", "0")
+    assert r.returncode == 2 and "visible HIP device" in r.stderr and r.stdout.strip() == ""
+
+
+def test_bench_launches_its_own_ranks_one_device_gloo():
+    """`python bench.py --gpus 2` without a launcher re-executes itself under torch.distributed.run: two ranks, ONE JSON
+    line with n_gpus 2, per-rank kernel times, the sharded collective named (gloo hook with the one-device knob)."""
+    r = _bench({"SAGE_BENCH_ONE_DEVICE": "1"}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--keyframes", "8",
+               "--height", "64", "--width", "80", "--no-cpu-baseline")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["parallelism"] == "edge-shard x2"
+    assert "all_reduce" in out["config"]["collective"]
+    assert [d["rank"] for d in out["config"]["per_rank_kernel_ms"]] == [0, 1]
+    assert all(d["photo_linearize"] > 0 for d in out["config"]["per_rank_kernel_ms"])

@@ -7,7 +7,9 @@ from hypothesis import HealthCheck, given, settings, strategies as st
 from sage_slam_amd import capi
 from tests.helpers import rel
 
-SET = settings(max_examples=20, deadline=None, suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
+# derandomize: the CPU suite runs the same cases on every box; no example database in the tree
+SET = settings(max_examples=30, deadline=None, derandomize=True, database=None,
+               suppress_health_check=[HealthCheck.too_slow, HealthCheck.data_too_large])
 
 
 def random_window_system(rng, K, CS, links):
@@ -77,7 +79,8 @@ def test_nearest_psd_properties(n, seed, neg):
     P = capi.nearest_psd(A)
     assert np.allclose(P, P.T, atol=1e-12)
     assert np.linalg.eigvalsh(P).min() > -1e-9 * max(1.0, np.abs(A).max())
-    assert rel(capi.nearest_psd(P), P) < 1e-9
+    scale = max(1.0, np.abs(A).max())                           # absolute bars: P may be numerically zero (A negative definite)
+    assert np.linalg.norm(capi.nearest_psd(P) - P) <= 1e-9 * scale * n
     w, V = np.linalg.eigh(A)
     clipped = (V * np.maximum(w, 0.0)) @ V.T
     assert np.linalg.norm(P - A) <= np.linalg.norm(clipped - A) * (1 + 1e-6) + 1e-9
