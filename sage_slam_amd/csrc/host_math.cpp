@@ -1616,6 +1616,8 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
       for (int c = 0; c < BP; ++c)
         y[(size_t)i * BP + c] = yi[c];
       LAP(4);
+      if (E.progress && i < E.n1 + E.n2)
+        E.progress[i >= E.n1 ? 1 : 0].store(i + 1, std::memory_order_release);
     }
     if (prof)
       fprintf(stderr, "[chol profile] rows %d..%d kcycles: wait %.0f gemm+syrk %.0f apply-inverse %.0f factor+inverse %.0f fwd-subst %.0f other %.0f\n",
@@ -1630,25 +1632,35 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
       z[t] = y[(size_t)i * BP + t];
     // (explicit vectors: strict fp semantics keep the compiler from vectorising a dot product on its own, and the
     // scalar loops made this sweep a tenth of the solve)
-    for (int m = i + 1; m < K; ++m)
+    // z[t] -= sum over the rows m below that store a block (m, i) of  sum_r Tm[t][r] x_m[r]: 8 values of t at a time keep
+    // one accumulator vector each across ALL those blocks (one horizontal sum per t and row instead of one per block --
+    // the arrow rows of a loop-closure plan put half a dozen blocks into every column)
+    const int nm = E.col_ptr ? E.col_ptr[i + 1] - E.col_ptr[i] : K - i - 1;
+    for (int t0 = 0; t0 < BP; t0 += 8)
     {
-      if (!has(m, i))
-        continue;
-      const double *Tm = blk(m, i), *xm = y + (size_t)m * BP;
-      v8d xv[NV];
-      for (int v = 0; v < NV; ++v)
-        SAGE_LOADU(xv[v], xm + 8 * v);
-      for (int t = 0; t < BP; ++t)
+      v8d acc[8];
+      for (int u = 0; u < 8; ++u)
+        acc[u] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
+      for (int q = 0; q < nm; ++q)
       {
-        v8d acc = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int m = E.col_ptr ? E.col_rows[E.col_ptr[i] + q] : i + 1 + q;
+        if (!E.col_ptr && !has(m, i))
+          continue;
+        const double *Tm = blk(m, i) + t0 * BP, *xm = y + (size_t)m * BP;
         for (int v = 0; v < NV; ++v)
         {
-          v8d a;
-          SAGE_LOADU(a, Tm + t * BP + 8 * v);
-          acc += a * xv[v];
+          v8d xv;
+          SAGE_LOADU(xv, xm + 8 * v);
+          for (int u = 0; u < 8; ++u)
+          {
+            v8d a;
+            SAGE_LOADU(a, Tm + u * BP + 8 * v);
+            acc[u] += a * xv;
+          }
         }
-        z[t] -= ((acc[0] + acc[4]) + (acc[1] + acc[5])) + ((acc[2] + acc[6]) + (acc[3] + acc[7]));
       }
+      for (int u = 0; u < 8; ++u)
+        z[t0 + u] -= ((acc[u][0] + acc[u][4]) + (acc[u][1] + acc[u][5])) + ((acc[u][2] + acc[u][6]) + (acc[u][3] + acc[u][7]));
     }
     const double *Xi = X + (size_t)i * BB;
     v8d zv[NV];
@@ -1735,6 +1747,333 @@ __attribute__((target_clones("avx512f", "avx2", "default"))) static void block_s
                                                                                         double *X, double *y, int nI)
 {
   block_schur_rows<3>(E, T, X, y, nI);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Separator rows on several cores (loop-closure plans, plan_blocks: cover keyframes).  A separator row i has a range in
+// the first half (A = [a_first, a_first + a_cnt)), a range in the second half ([row_first, sep0)) and the separator
+// columns [sep0, i).  Everything a row does inside ONE half only needs that half's factor and the row's own blocks:
+//   task A (row i, half h):  L_ij for the columns j of that range (ascending, following the half's progress counter),
+//                            the partial sums  -sum_j L_ij L_ij^T  (diagonal block) and  -sum_j L_ij y_j  (rhs)
+//   task B (rows i > i2, half h):  -sum_k L_i2,k L_ik^T over the common columns of the two rows in that half
+// all into private buffers; the separator block itself (a handful of rows) is then finished by the caller, who adds the
+// partial sums in a fixed order (deterministic: the result does not depend on which thread ran which task).
+// ---------------------------------------------------------------------------------------------------------------
+struct SepTaskA
+{
+  int row, half, j0, j1; // columns [j0, j1)
+};
+struct SepTaskB
+{
+  int i, i2, half, k0, k1; // common columns [k0, k1), i2 < i
+};
+struct SepJob
+{
+  const BlockEnvelope *E = nullptr;
+  double *T = nullptr, *X = nullptr, *y = nullptr;
+  int sep0 = 0;
+  std::vector<SepTaskA> ta;
+  std::vector<SepTaskB> tb;
+  std::vector<double> Sd, wd, Pp; // [ta][BB], [ta][Bp], [tb][BB]
+  std::atomic<int> nextA{0}, doneA{0}, nextB{0}, doneB{0};
+  std::atomic<int> abort{0};
+  std::atomic<int> progress[2];
+};
+
+static void sep_job_build(SepJob &J)
+{
+  const BlockEnvelope &E = *J.E;
+  const int sep0 = E.n1 + E.n2, K = E.K, BB = E.Bp * E.Bp;
+  J.sep0 = sep0;
+  auto rng = [&](int i, int h, int &a, int &b) { // separator row i, half h -> [a, b)
+    if (h == 0)
+    {
+      a = E.a_cnt ? E.a_first[i] : 0;
+      b = a + (E.a_cnt ? E.a_cnt[i] : 0);
+    }
+    else
+    {
+      a = std::min((int)E.row_first[i], sep0);
+      b = sep0;
+    }
+  };
+  for (int i = sep0; i < K; ++i)
+    for (int h = 0; h < 2; ++h)
+    {
+      int a, b;
+      rng(i, h, a, b);
+      if (b > a)
+        J.ta.push_back({i, h, a, b});
+    }
+  // longest first: the long arrow rows start early, the short middle-separator rows fill the gaps
+  std::stable_sort(J.ta.begin(), J.ta.end(), [](const SepTaskA &x, const SepTaskA &y) { return x.j1 - x.j0 > y.j1 - y.j0; });
+  for (int i = sep0; i < K; ++i)
+    for (int i2 = sep0; i2 < i; ++i2)
+      for (int h = 0; h < 2; ++h)
+      {
+        int a, b, a2, b2;
+        rng(i, h, a, b);
+        rng(i2, h, a2, b2);
+        const int k0 = std::max(a, a2), k1 = std::min(b, b2);
+        if (k1 > k0)
+          J.tb.push_back({i, i2, h, k0, k1});
+      }
+  std::stable_sort(J.tb.begin(), J.tb.end(), [](const SepTaskB &x, const SepTaskB &y) { return x.k1 - x.k0 > y.k1 - y.k0; });
+  J.Sd.assign(J.ta.size() * (size_t)BB, 0.0);
+  J.wd.assign(J.ta.size() * (size_t)E.Bp, 0.0);
+  J.Pp.assign(J.tb.size() * (size_t)BB, 0.0);
+  J.progress[0].store(0, std::memory_order_relaxed);
+  J.progress[1].store(E.n1, std::memory_order_relaxed);
+}
+
+template <int NV>
+static inline __attribute__((always_inline)) void sep_run_a(SepJob &J, int t)
+{
+  constexpr int BP = NV * 8, BB = BP * BP;
+  const BlockEnvelope &E = *J.E;
+  double *T = J.T, *X = J.X, *y = J.y;
+  const SepTaskA &a = J.ta[t];
+  const int i = a.row;
+  auto afirst = [&](int r) { return E.a_cnt ? E.a_first[r] : 0; };
+  auto acnt = [&](int r) { return E.a_cnt ? E.a_cnt[r] : 0; };
+  auto has = [&](int r, int c) { return (c >= E.row_first[r] && c <= r) || (c >= afirst(r) && c < afirst(r) + acnt(r)); };
+  auto blk = [&](int r, int c) {
+    return T + (size_t)(c < E.row_first[r] ? E.a_off[r] + c - E.a_first[r] : E.row_off[r] + c - E.row_first[r]) * BB;
+  };
+  double *Sd = J.Sd.data() + (size_t)t * BB, *wd = J.wd.data() + (size_t)t * BP;
+  RowPrefetch pf{nullptr, nullptr};
+  for (int j = a.j0; j < a.j1; ++j)
+  {
+    // the half's row j (its blocks, X_j and y_j) must be final
+    unsigned spins = 0;
+    while (J.progress[a.half].load(std::memory_order_acquire) <= j)
+    {
+      __builtin_ia32_pause();
+      if ((++spins & 0xff) == 0 && J.abort.load(std::memory_order_acquire))
+        return;
+    }
+    if (E.ready) // this block of row i has arrived from the device
+    {
+      const volatile unsigned *f = E.ready + (blk(i, j) - T) / BB;
+      const double t0 = mono_seconds();
+      spins = 0;
+      while (*f != E.epoch)
+      {
+        __builtin_ia32_pause();
+        if ((++spins & 0xfff) == 0 && (J.abort.load(std::memory_order_acquire) || mono_seconds() - t0 > 2.0))
+        {
+          J.abort.store(2, std::memory_order_release);
+          return;
+        }
+      }
+      std::atomic_thread_fence(std::memory_order_acquire);
+    }
+    double *CT = blk(i, j);
+    if (j + 1 < a.j1)
+    {
+      pf.p = reinterpret_cast<const char *>(blk(i, j + 1));
+      pf.end = pf.p + BB * sizeof(double);
+    }
+    for (int k = std::max(a.j0, (int)E.row_first[j]); k < j; ++k) // (row j is a half row: its columns are [row_first[j], j])
+      if (has(j, k))
+        tn_sub<NV>(CT, blk(j, k), blk(i, k), false, pf);
+    apply_inverse<NV>(CT, X + (size_t)j * BB);
+    tn_sub<NV>(Sd, CT, CT, true, pf);
+    const double *yk = y + (size_t)j * BP;
+    for (int tt = 0; tt < BP; ++tt)
+    {
+      const double f = yk[tt];
+      for (int r = 0; r < BP; ++r)
+        wd[r] -= f * CT[tt * BP + r];
+    }
+  }
+}
+
+template <int NV>
+static inline __attribute__((always_inline)) void sep_run_b(SepJob &J, int t)
+{
+  constexpr int BP = NV * 8, BB = BP * BP;
+  const BlockEnvelope &E = *J.E;
+  double *T = J.T;
+  const SepTaskB &b = J.tb[t];
+  auto blk = [&](int r, int c) {
+    return T + (size_t)(c < E.row_first[r] ? E.a_off[r] + c - E.a_first[r] : E.row_off[r] + c - E.row_first[r]) * BB;
+  };
+  double *P = J.Pp.data() + (size_t)t * BB;
+  RowPrefetch pf{nullptr, nullptr};
+  for (int k = b.k0; k < b.k1; ++k)
+    tn_sub<NV>(P, blk(b.i2, k), blk(b.i, k), false, pf);
+}
+
+// the separator block: rows [sep0, K) with the partial sums of the tasks folded in; then their back substitution
+template <int NV>
+static inline __attribute__((always_inline)) int sep_finish(SepJob &J)
+{
+  constexpr int BP = NV * 8, BB = BP * BP;
+  const BlockEnvelope &E = *J.E;
+  double *T = J.T, *X = J.X, *y = J.y;
+  const int sep0 = J.sep0, K = E.K;
+  auto blk = [&](int r, int c) {
+    return T + (size_t)(c < E.row_first[r] ? E.a_off[r] + c - E.a_first[r] : E.row_off[r] + c - E.row_first[r]) * BB;
+  };
+  RowPrefetch pf{nullptr, nullptr};
+  for (int i = sep0; i < K; ++i)
+  {
+    if (E.ready && !wait_row_tickets(E, i))
+      return -2;
+    const int c0 = std::max((int)E.row_first[i], sep0);
+    for (int j = c0; j < i; ++j)
+    {
+      double *CT = blk(i, j);
+      for (size_t t = 0; t < J.tb.size(); ++t) // fixed order: deterministic
+        if (J.tb[t].i == i && J.tb[t].i2 == j)
+        {
+          const double *P = J.Pp.data() + t * BB;
+          for (int o = 0; o < BB; ++o)
+            CT[o] += P[o];
+        }
+      for (int k = std::max(c0, std::max((int)E.row_first[j], sep0)); k < j; ++k)
+        tn_sub<NV>(CT, blk(j, k), blk(i, k), false, pf);
+      apply_inverse<NV>(CT, X + (size_t)j * BB);
+    }
+    double *S = blk(i, i);
+    double w[BP];
+    for (int r = 0; r < BP; ++r)
+      w[r] = y[(size_t)i * BP + r];
+    for (size_t t = 0; t < J.ta.size(); ++t)
+      if (J.ta[t].row == i)
+      {
+        const double *Sd = J.Sd.data() + t * BB, *wd = J.wd.data() + t * BP;
+        for (int o = 0; o < BB; ++o)
+          S[o] += Sd[o];
+        for (int r = 0; r < BP; ++r)
+          w[r] += wd[r];
+      }
+    for (int k = c0; k < i; ++k)
+    {
+      tn_sub<NV>(S, blk(i, k), blk(i, k), true, pf);
+      const double *Tk = blk(i, k), *yk = y + (size_t)k * BP;
+      for (int t = 0; t < BP; ++t)
+      {
+        const double f = yk[t];
+        for (int r = 0; r < BP; ++r)
+          w[r] -= f * Tk[t * BP + r];
+      }
+    }
+    if (!factor_diag<NV>(S, X + (size_t)i * BB))
+      return 1 + i;
+    double yi[BP];
+    for (int c = 0; c < BP; ++c)
+      yi[c] = 0.0;
+    const double *Xi = X + (size_t)i * BB;
+    for (int t = 0; t < BP; ++t)
+    {
+      const double f = w[t];
+      for (int c = 0; c < BP; ++c)
+        yi[c] += f * Xi[t * BP + c];
+    }
+    for (int c = 0; c < BP; ++c)
+      y[(size_t)i * BP + c] = yi[c];
+  }
+  return 0;
+}
+
+__attribute__((target_clones("avx512f", "avx2", "default"))) static void sep_run_a_40(SepJob &J, int t) { sep_run_a<5>(J, t); }
+__attribute__((target_clones("avx512f", "avx2", "default"))) static void sep_run_a_24(SepJob &J, int t) { sep_run_a<3>(J, t); }
+__attribute__((target_clones("avx512f", "avx2", "default"))) static void sep_run_b_40(SepJob &J, int t) { sep_run_b<5>(J, t); }
+__attribute__((target_clones("avx512f", "avx2", "default"))) static void sep_run_b_24(SepJob &J, int t) { sep_run_b<3>(J, t); }
+__attribute__((target_clones("avx512f", "avx2", "default"))) static int sep_finish_40(SepJob &J) { return sep_finish<5>(J); }
+__attribute__((target_clones("avx512f", "avx2", "default"))) static int sep_finish_24(SepJob &J) { return sep_finish<3>(J); }
+
+// take tasks until none is left (called by the pool's workers, the helper after its half, and the caller)
+static void sep_work(SepJob &J)
+{
+  const bool b40 = J.E->Bp == 40;
+  const int nA = (int)J.ta.size(), nB = (int)J.tb.size();
+  for (;;)
+  {
+    const int t = J.nextA.fetch_add(1, std::memory_order_acq_rel);
+    if (t >= nA)
+      break;
+    if (!J.abort.load(std::memory_order_acquire))
+      b40 ? sep_run_a_40(J, t) : sep_run_a_24(J, t);
+    J.doneA.fetch_add(1, std::memory_order_acq_rel);
+  }
+  while (J.doneA.load(std::memory_order_acquire) < nA) // phase B reads the rows phase A completes
+    __builtin_ia32_pause();
+  for (;;)
+  {
+    const int t = J.nextB.fetch_add(1, std::memory_order_acq_rel);
+    if (t >= nB)
+      break;
+    if (!J.abort.load(std::memory_order_acquire))
+      b40 ? sep_run_b_40(J, t) : sep_run_b_24(J, t);
+    J.doneB.fetch_add(1, std::memory_order_acq_rel);
+  }
+}
+
+// Worker pool for the arrow rows: persistent threads that sleep on a condition variable, are woken by
+// block_chol_arm(true) and spin for a job for a few milliseconds (like the helper of the second half).
+struct SepPool
+{
+  std::mutex mu;
+  std::condition_variable cv;
+  std::atomic<bool> armed{false};
+  std::atomic<unsigned> posted{0};
+  std::atomic<bool> open{false};
+  std::atomic<int> active{0};
+  std::atomic<bool> busy{false};
+  SepJob *job = nullptr;
+  std::vector<pthread_t> tids;
+  int near_cpu = -1;
+  void loop()
+  {
+    unsigned seen = posted.load(std::memory_order_acquire);
+    for (;;)
+    {
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return armed.load(std::memory_order_acquire); });
+      }
+      const double t0 = mono_seconds();
+      unsigned spins = 0;
+      while (armed.load(std::memory_order_acquire))
+      {
+        const unsigned p = posted.load(std::memory_order_acquire);
+        if (p != seen)
+        {
+          seen = p;
+          active.fetch_add(1, std::memory_order_acq_rel);
+          if (open.load(std::memory_order_acquire))
+            sep_work(*job);
+          active.fetch_sub(1, std::memory_order_acq_rel);
+        }
+        __builtin_ia32_pause();
+        if ((++spins & 1023) == 0 && mono_seconds() - t0 > 20e-3) // nobody came: back to sleep
+          armed.store(false, std::memory_order_release);
+      }
+    }
+  }
+};
+static SepPool *sep_pool()
+{
+  // deliberately leaked, like the helper
+  static SepPool *p = [] {
+    const unsigned hw = std::thread::hardware_concurrency();
+    int n = getenv("SAGE_SOLVE_POOL") ? atoi(getenv("SAGE_SOLVE_POOL")) : 6;
+    n = std::min(n, (int)hw - 2);
+    if (n < 1 || sage::env_flag("SAGE_SOLVE_NO_HELPER"))
+      return (SepPool *)nullptr;
+    SepPool *q = new SepPool;
+    for (int i = 0; i < n; ++i)
+    {
+      std::thread th([q] { q->loop(); });
+      q->tids.push_back(th.native_handle());
+      th.detach();
+    }
+    return q;
+  }();
+  return p;
 }
 
 static int block_chol_range(const BlockEnvelope &E, double *T, double *X, double *y, int phase, int lo, int hi)
@@ -1879,17 +2218,85 @@ static void place_helper_near(CholHelper *h, int cpu)
     (void)pthread_setaffinity_np(h->tid, sizeof(want), &want);
 }
 
-void block_chol_arm()
+static void place_pool_near(SepPool *q, int cpu)
+{
+  if (cpu < 0 || cpu == q->near_cpu || sage::env_flag("SAGE_SOLVE_NO_AFFINITY"))
+    return;
+  q->near_cpu = cpu;
+  char path[128];
+  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+  std::vector<int> l3 = read_cpu_list(path);
+  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+  const std::vector<int> sib = read_cpu_list(path);
+  // the pool may be larger than what is left of the caller's CCX: its NUMA node is the fallback set
+  cpu_set_t allowed, want;
+  if (l3.empty() || sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
+    return;
+  auto fill = [&](const std::vector<int> &cpus) {
+    CPU_ZERO(&want);
+    int n = 0;
+    for (int c : cpus)
+      if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed) && std::find(sib.begin(), sib.end(), c) == sib.end() && c != cpu)
+      {
+        CPU_SET(c, &want);
+        ++n;
+      }
+    return n;
+  };
+  int n = fill(l3);
+  if (n < (int)q->tids.size() + 1)
+  {
+    for (int node = 0; node < 64; ++node)
+    {
+      snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+      const std::vector<int> nl = read_cpu_list(path);
+      if (std::find(nl.begin(), nl.end(), cpu) != nl.end())
+      {
+        n = fill(nl);
+        break;
+      }
+    }
+  }
+  if (n > 0)
+    for (pthread_t t : q->tids)
+      (void)pthread_setaffinity_np(t, sizeof(want), &want);
+}
+
+void block_chol_arm(bool with_pool)
 {
   CholHelper *h = chol_helper();
-  if (!h || h->armed.load(std::memory_order_acquire))
-    return;
-  place_helper_near(h, sched_getcpu());
+  if (h && !h->armed.load(std::memory_order_acquire))
   {
-    std::lock_guard<std::mutex> lk(h->mu);
-    h->armed.store(true, std::memory_order_release);
+    place_helper_near(h, sched_getcpu());
+    {
+      std::lock_guard<std::mutex> lk(h->mu);
+      h->armed.store(true, std::memory_order_release);
+    }
+    h->cv.notify_one();
   }
-  h->cv.notify_one();
+  if (!with_pool)
+    return;
+  SepPool *q = sep_pool();
+  if (q && !q->armed.load(std::memory_order_acquire))
+  {
+    place_pool_near(q, sched_getcpu());
+    {
+      std::lock_guard<std::mutex> lk(q->mu);
+      q->armed.store(true, std::memory_order_release);
+    }
+    q->cv.notify_all();
+  }
+}
+
+bool block_plan_has_arrow_rows(const BlockEnvelope &E)
+{
+  if (E.n1 <= 0 || E.n2 <= 0 || !E.a_cnt)
+    return false;
+  const int sep0 = E.n1 + E.n2;
+  long long reach = 0;
+  for (int i = sep0; i < E.K; ++i)
+    reach += E.a_cnt[i] + (sep0 - std::min((int)E.row_first[i], sep0));
+  return reach > 64; // (a plain split window: <= 2 x 3 blocks per separator row)
 }
 
 int plan_blocks(int K, const std::vector<std::pair<int, int>> &links, bool allow_split, BlockPlan &out)
@@ -1915,34 +2322,78 @@ int plan_blocks(int K, const std::vector<std::pair<int, int>> &links, bool allow
     // the helper's half runs a little slower than the caller's (it wakes from sleep for every solve): give it
     // `bias` rows less
     static const int bias = getenv("SAGE_SPLIT_BIAS") ? atoi(getenv("SAGE_SPLIT_BIAS")) : 1;
-    int best_m = -1, best_w = 0, best_cost = 2 * K;
-    for (int m = K / 4; m <= (3 * K) / 4; ++m)
+    // Loop closures: a link that spans more than a separator's width crosses every candidate split.  Such links are
+    // covered by a small set C of keyframes (greedy: the keyframe on most still-uncovered long links first) that joins
+    // the separator: order = [first half | second half descending | middle separator | C].  The rows of C are "arrow"
+    // rows -- their ranges run the whole length of both halves -- but the two halves stay two independent banded
+    // factorisations, and the arrow rows are independent of each other until the (small) separator block: the host
+    // factorisation spreads them over a few cores (block_chol_solve_tr).  At most 8 cover keyframes; otherwise, and
+    // for windows without a split point, the identity order stays.
+    static const bool no_cover = sage::env_flag("SAGE_SOLVE_NO_COVER");
+    std::vector<char> inC(K, 0);
+    std::vector<int> cover;
+    int best_m = -1, best_w = 0;
+    for (;;)
     {
-      int wdt = 0;
-      for (auto &l : links)
-        if (l.first < m && l.second >= m)
-          wdt = std::max(wdt, l.second - m + 1);
-      if (wdt < 1 || wdt > 8 || m + wdt > K - 2)
-        continue;
-      const int cost = std::max(m, K - m - wdt + bias) + 2 * wdt;
-      if (cost < best_cost)
+      int best_cost = 2 * K;
+      best_m = -1;
+      for (int m = K / 4; m <= (3 * K) / 4; ++m)
       {
-        best_cost = cost;
-        best_m = m;
-        best_w = wdt;
+        int wdt = 0;
+        for (auto &l : links)
+          if (!inC[l.first] && !inC[l.second] && l.first < m && l.second >= m)
+            wdt = std::max(wdt, l.second - m + 1);
+        if (wdt < 1 || wdt > 8 || m + wdt > K - 2)
+          continue;
+        const int cost = std::max(m, K - m - wdt + bias) + 2 * wdt;
+        if (cost < best_cost)
+        {
+          best_cost = cost;
+          best_m = m;
+          best_w = wdt;
+        }
       }
+      if (best_m > 0 || no_cover || cover.size() >= 8)
+        break;
+      // no split point: cover one more long link (span > 8: it cannot sit inside a separator)
+      std::vector<int> deg(K, 0);
+      int any = 0;
+      for (auto &l : links)
+        if (!inC[l.first] && !inC[l.second] && l.second - l.first > 8)
+        {
+          ++deg[l.first];
+          ++deg[l.second];
+          ++any;
+        }
+      if (!any)
+        break;
+      const int pick = (int)(std::max_element(deg.begin(), deg.end()) - deg.begin()); // (first maximum: lowest keyframe)
+      inC[pick] = 1;
+      cover.push_back(pick);
     }
     if (best_m > 0)
     {
-      n1 = best_m;
-      n2 = K - best_m - best_w;
       int q = 0;
       for (int k = 0; k < best_m; ++k)
-        perm[q++] = k;
+        if (!inC[k])
+          perm[q++] = k;
+      n1 = q;
       for (int k = K - 1; k >= best_m + best_w; --k)
-        perm[q++] = k;
+        if (!inC[k])
+          perm[q++] = k;
+      n2 = q - n1;
       for (int k = best_m; k < best_m + best_w; ++k)
+        if (!inC[k])
+          perm[q++] = k;
+      std::sort(cover.begin(), cover.end());
+      for (int k : cover)
         perm[q++] = k;
+      if (n1 < 1 || n2 < 1) // (degenerate: everything on one side) -> identity order
+      {
+        for (int k = 0; k < K; ++k)
+          perm[k] = k;
+        n1 = n2 = 0;
+      }
     }
   }
   for (int q = 0; q < K; ++q)
@@ -2003,6 +2454,24 @@ int plan_blocks(int K, const std::vector<std::pair<int, int>> &links, bool allow
       blk_col[bidx(k, j)] = j;
     }
   }
+  // column lists (rows below the diagonal that store a block of the column, ascending)
+  out.col_ptr.assign(K + 1, 0);
+  for (int b = 0; b < nblk; ++b)
+    if (blk_row[b] != blk_col[b])
+      ++out.col_ptr[blk_col[b] + 1];
+  for (int j = 0; j < K; ++j)
+    out.col_ptr[j + 1] += out.col_ptr[j];
+  out.col_rows.assign(std::max(1, (int)out.col_ptr[K]), 0);
+  {
+    std::vector<int32_t> fill(out.col_ptr.begin(), out.col_ptr.end() - 1);
+    for (int k = 0; k < K; ++k) // rows ascending -> every column's list comes out ascending
+    {
+      for (int j = a_first[k]; j < a_first[k] + a_cnt[k]; ++j)
+        out.col_rows[fill[j]++] = k;
+      for (int j = row_first[k]; j < k; ++j)
+        out.col_rows[fill[j]++] = k;
+    }
+  }
   for (size_t l = 0; l < links.size(); ++l)
   {
     const int a = links[l].first, b = links[l].second;
@@ -2037,17 +2506,42 @@ int block_chol_partial_back(const BlockEnvelope &E, double *T, double *X, double
   return block_chol_range(E, T, X, y, 1, 0, nI); // x_i for the interior rows, y[nI..K) holding the separators' x
 }
 
-int block_chol_solve_tr(const BlockEnvelope &E, double *T, double *X, double *y)
+int block_chol_solve_tr(const BlockEnvelope &E0, double *T, double *X, double *y)
 {
-  if (E.Bp != 40 && E.Bp != 24)
+  if (E0.Bp != 40 && E0.Bp != 24)
     return -1;
-  const int K = E.K;
-  if (E.n1 <= 0 || E.n2 <= 0)
+  const int K = E0.K;
+  if (E0.n1 <= 0 || E0.n2 <= 0)
   {
-    const int rc = block_chol_range(E, T, X, y, 0, 0, K);
-    return rc ? rc : block_chol_range(E, T, X, y, 1, 0, K);
+    const int rc = block_chol_range(E0, T, X, y, 0, 0, K);
+    return rc ? rc : block_chol_range(E0, T, X, y, 1, 0, K);
   }
-  const int sep0 = E.n1 + E.n2;
+  const int sep0 = E0.n1 + E0.n2;
+  // loop-closure plans: the long separator rows are cut into tasks for the worker pool (SepJob); the halves publish
+  // their progress so that the tasks run right behind them
+  BlockEnvelope E = E0;
+  const bool arrow = block_plan_has_arrow_rows(E0);
+  SepJob job;
+  SepPool *pool = nullptr;
+  bool pool_mine = false;
+  if (arrow)
+  {
+    job.E = &E; job.T = T; job.X = X; job.y = y;
+    sep_job_build(job);
+    E.progress = job.progress;
+    pool = sep_pool();
+    if (pool && pool->armed.load(std::memory_order_acquire))
+    {
+      bool expect = false;
+      if (pool->busy.compare_exchange_strong(expect, true, std::memory_order_acq_rel))
+      {
+        pool_mine = true;
+        pool->job = &job;
+        pool->open.store(true, std::memory_order_release);
+        pool->posted.fetch_add(1, std::memory_order_release);
+      }
+    }
+  }
   CholHelper *h = chol_helper();
   bool shared = false;
   if (h && h->armed.load(std::memory_order_acquire))
@@ -2084,12 +2578,32 @@ int block_chol_solve_tr(const BlockEnvelope &E, double *T, double *X, double *y)
       CholHelper::cpu_relax();
   }
   else
-    rc2 = block_chol_range(E, T, X, y, 0, E.n1, sep0);
+    rc2 = rc == 0 ? block_chol_range(E, T, X, y, 0, E.n1, sep0) : 0;
   if (dbg)
     tp[2] = mono_seconds();
   if (rc == 0)
     rc = rc2;
-  if (rc == 0)
+  if (arrow)
+  {
+    if (rc != 0)
+      job.abort.store(1, std::memory_order_release);
+    sep_work(job); // the caller takes tasks too (all of them when no pool thread is around)
+    while (job.doneB.load(std::memory_order_acquire) < (int)job.tb.size())
+      CholHelper::cpu_relax();
+    if (pool_mine)
+    {
+      pool->open.store(false, std::memory_order_release);
+      while (pool->active.load(std::memory_order_acquire) != 0)
+        CholHelper::cpu_relax();
+      pool->armed.store(false, std::memory_order_release);
+      pool->busy.store(false, std::memory_order_release);
+    }
+    if (rc == 0 && job.abort.load(std::memory_order_acquire))
+      rc = -2;
+    if (rc == 0)
+      rc = E.Bp == 40 ? sep_finish_40(job) : sep_finish_24(job);
+  }
+  else if (rc == 0)
     rc = block_chol_range(E, T, X, y, 0, sep0, K);
   if (rc == 0)
     block_chol_range(E, T, X, y, 1, sep0, K);
@@ -2111,9 +2625,10 @@ int block_chol_solve_tr(const BlockEnvelope &E, double *T, double *X, double *y)
   if (dbg)
   {
     tp[5] = mono_seconds();
-    fprintf(stderr, "[sage block chol] us: first half %.0f (+wait for the %s %.0f) separator %.0f back-subst %.0f (+wait %.0f)\n",
+    fprintf(stderr, "[sage block chol] us: first half %.0f (+wait for the %s %.0f) separator %.0f%s back-subst %.0f (+wait %.0f)\n",
             1e6 * (tp[1] - tp[0]), helper_has_it ? "helper" : "second half, same thread", 1e6 * (tp[2] - tp[1]),
-            1e6 * (tp[3] - tp[2]), 1e6 * (tp[4] - tp[3]), 1e6 * (tp[5] - tp[4]));
+            1e6 * (tp[3] - tp[2]), arrow ? (pool_mine ? " (arrow rows, worker pool)" : " (arrow rows, no pool)") : "",
+            1e6 * (tp[4] - tp[3]), 1e6 * (tp[5] - tp[4]));
   }
   if (shared)
   {
@@ -2170,8 +2685,6 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
       else if (rcp != SAGE_OK)
         return rcp;
     }
-    if (bp.n1 > 0)
-      sage::block_chol_arm();
     const int nblk = bp.nblk;
     auto bidx = [&](int i, int j) {
       return j < bp.row_first[i] ? bp.a_off[i] + j - bp.a_first[i] : bp.row_off[i] + j - bp.row_first[i];
@@ -2215,6 +2728,9 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
     env.K = K; env.Bp = Bp; env.row_first = bp.row_first.data(); env.row_off = bp.row_off.data();
     env.a_first = bp.a_first.data(); env.a_cnt = bp.a_cnt.data(); env.a_off = bp.a_off.data();
     env.n1 = bp.n1; env.n2 = bp.n2;
+    env.col_ptr = bp.col_ptr.data(); env.col_rows = bp.col_rows.data();
+    if (bp.n1 > 0)
+      sage::block_chol_arm(sage::block_plan_has_arrow_rows(env));
     const int rcf = sage::block_chol_solve_tr(env, T.data(), X.data(), y.data());
     if (dbg2)
       fprintf(stderr, "[sage block_solve] fixed-block Cholesky + substitution %.3f ms\n",

@@ -4,6 +4,7 @@
 #include <stdlib.h>
 
 #include <utility>
+#include <atomic>
 #include <vector>
 
 namespace sage
@@ -58,6 +59,12 @@ struct BlockEnvelope
   void (*idle)(void *user) = nullptr; // optional: polled while a thread waits for tickets (e.g. to launch more work)
   void *user = nullptr;
   double *t_ticket_wait = nullptr; // optional: accumulates the seconds spent waiting for tickets (diagnostics)
+  // optional (set by block_chol_solve_tr): progress[h] = 1 + the last factorised row of half h (0: rows [0, n1),
+  // 1: rows [n1, n1 + n2)), published after the row's forward substitution -- the arrow-row tasks follow it
+  std::atomic<int> *progress = nullptr;
+  // optional: for every column j the rows i > j that store a block (i, j), ascending (col_rows[col_ptr[j] .. col_ptr[j+1]));
+  // the back substitution then visits exactly those instead of scanning all rows below j
+  const int32_t *col_ptr = nullptr, *col_rows = nullptr;
 };
 // In place: T becomes L^T blockwise, X (K*Bp*Bp) receives the inverses of the diagonal factors, y (K*Bp) the
 // right-hand side on entry and the solution on return.  Returns 0, or 1 + the block column of the first non-positive
@@ -71,7 +78,11 @@ int block_chol_partial(const BlockEnvelope &env, double *T, double *X, double *y
 int block_chol_partial_back(const BlockEnvelope &env, double *T, double *X, double *y, int nI);
 // Wake the helper thread ahead of a block_chol_solve_tr call with n1 > 0 (it then spins for the job for a few
 // milliseconds at most); call it when the system is about to be produced, e.g. before waiting on the D2H copy.
-void block_chol_arm();
+// with_pool: also wake the worker pool that shares the long separator ("arrow") rows of a loop-closure plan.
+void block_chol_arm(bool with_pool = false);
+// true when the separator rows of the plan reach far into the halves (cover keyframes of loop closures): the
+// factorisation then wants the worker pool
+bool block_plan_has_arrow_rows(const BlockEnvelope &env);
 
 // Elimination order and block storage plan of a window's normal equations (K keyframe blocks, links (a,b), a < b).
 // perm[position] = keyframe, pos[keyframe] = position.  Block b of the storage is (blk_row[b], blk_col[b]) in
@@ -80,6 +91,7 @@ void block_chol_arm();
 struct BlockPlan
 {
   std::vector<int32_t> perm, pos, row_first, row_off, a_first, a_cnt, a_off, blk_row, blk_col, blk_src;
+  std::vector<int32_t> col_ptr, col_rows; // BlockEnvelope::col_ptr / col_rows
   int nblk = 0, n1 = 0, n2 = 0;
 };
 int plan_blocks(int K, const std::vector<std::pair<int, int>> &links, bool allow_split, BlockPlan &out);

@@ -51,6 +51,9 @@ struct PhotoParams
   // concatenated pyramid, lds_ntex texels x FS/4 channel groups x 16 B) are staged in LDS once per workgroup and their
   // taps read with ds_read_b128 instead of going through the texture path; lds_l0 >= levels: off
   int lds_l0, lds_base, lds_ntex;
+  // split linearize (STAGE 1 -> 2): per-pixel hand-over record {G00, G01, G11, v0, v1, err*vm, vm, -} of the sampling
+  // phase, [n_work][tiles_per_block][256] x 8 floats (a workgroup owns the slab of its work item)
+  float *pixrec;
 };
 
 __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
@@ -68,6 +71,12 @@ __device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i 
 #endif
 #ifndef SAGE_PHOTO_WAVES
 #define SAGE_PHOTO_WAVES 3 // workgroups per CU the linearize kernel is register-budgeted for (x4 waves)
+#endif
+#ifndef SAGE_PHOTO_B_WAVES
+#define SAGE_PHOTO_B_WAVES 5 // split linearize, sampling stage: waves per SIMD it is register-budgeted for
+#endif
+#ifndef SAGE_PHOTO_CD_WAVES
+#define SAGE_PHOTO_CD_WAVES 3
 #endif
 
 // per-pixel hand-over from the sampling phase (lane = pixel) to the contraction phase (lane = (channel i, pixel k)):
@@ -107,20 +116,25 @@ struct TapBatch
 //   D  code blocks: f32 MFMA 16x16x4 with the basis rows loaded from global memory directly in operand layout
 //      (lane = (channel pair i, pixel k): 16 lanes x dwordx2 = one 128-byte basis row; CS = 32: operand block 0 = even
 //      channels, block 1 = odd channels)
-template <int CS, int FS, bool JAC, int MODE>
-__global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : SAGE_PHOTO_ERR_WAVES) void photo_kernel(const PhotoParams prm)
+// STAGE 0: the fused kernel.  STAGE 1 / 2: the linearize split in two launches -- 1 = phases A + B only (warp and the
+// tap gathers; no LDS, no reductions, high occupancy: bound by the CU's texture path), writes the per-pixel record
+// PhotoParams::pixrec; 2 = phases (A) + C + D from that record (bound by VALU / MFMA issue and LDS).  Same arithmetic in
+// the same order as the fused kernel: bit-identical partial records.
+template <int CS, int FS, bool JAC, int MODE, int STAGE = 0>
+__global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? SAGE_PHOTO_B_WAVES : STAGE == 2 ? SAGE_PHOTO_CD_WAVES : SAGE_PHOTO_WAVES) void photo_kernel(const PhotoParams prm)
 {
   constexpr bool PACKED = MODE >= 1;
   constexpr int NB = CS / 16;
   constexpr int NG = FS / 4;
   constexpr int NT = photo_tiles(CS);
   constexpr int YY = NT; // the pose tile: accumulated like the code tiles, folded into the scalar slots at the end
-  constexpr int STASH = JAC ? kWaves * 64 * kPhotoStashLD : 1;
-  constexpr int SUMBUF = JAC ? (NT + 1) * 256 : 1;
+  constexpr bool CONTRACT = JAC && STAGE != 1; // this launch runs phases C / D
+  constexpr int STASH = CONTRACT ? kWaves * 64 * kPhotoStashLD : 1;
+  constexpr int SUMBUF = CONTRACT ? (NT + 1) * 256 : 1;
   __shared__ __attribute__((aligned(16))) float s_mem[STASH > SUMBUF ? STASH : SUMBUF];
   __shared__ float s_red[kWaves * 4]; // per wave: linearize {sigma d^2, error, inliers}, error pass {error, inliers, geo error, inliers}
   // second level of the noise-critical tiles: [wave][tile][r][lane]
-  __shared__ float s_l2[JAC ? kWaves * kPhotoL2Tiles * 256 : 1];
+  __shared__ float s_l2[CONTRACT ? kWaves * kPhotoL2Tiles * 256 : 1];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int bid = uni(xcd_work_index((int)blockIdx.x, prm.n_work, prm.xcd_chunk));
@@ -224,8 +238,9 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : SAGE_PHOTO_ERR_WAV
   // the whole linearisation (every residual of the pixel inherits it), so no reciprocal shortcut here.
   const float p = (X[0] / X[2]) * fx0 + cx0; // :142-144 (level-0 pixel coordinates)
   const float q = (X[1] / X[2]) * fy0 + cy0;
-  const float m = mask_lookup(E.mask1, p, q, W0, H0);
-  const float vm = (pos && in_range) ? m : 0.0f; // sampled_valid_mask_1 (:237)
+  const float m = STAGE == 2 ? 0.f : mask_lookup(E.mask1, p, q, W0, H0);
+  float vm = (pos && in_range) ? m : 0.0f; // sampled_valid_mask_1 (:237)
+  float *const rec_px = (STAGE != 0) ? prm.pixrec + ((size_t)((size_t)bid * prm.tiles_per_block + sub) * kTile + tid) * 8 : nullptr;
   if (fuse_geo)
   {
     // geometric_factor_kernels.cpp:127-218 at the same warp: D1 bilinear at the level-0 coordinates (no half-pixel
@@ -241,7 +256,13 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : SAGE_PHOTO_ERR_WAV
   }
 
   float G00 = 0.f, G01 = 0.f, G11 = 0.f, v0 = 0.f, v1 = 0.f, err = 0.f;
-  if (PACKED)
+  if (STAGE == 2)
+  {
+    const f32x4 ra = reinterpret_cast<const f32x4 *>(rec_px)[0], rb = reinterpret_cast<const f32x4 *>(rec_px)[1];
+    G00 = ra[0]; G01 = ra[1]; G11 = ra[2]; v0 = ra[3];
+    v1 = rb[0]; err = rb[1]; vm = rb[2];
+  }
+  else if (PACKED)
   {
     // ---- sampler over (level, channel group): the 13 dwordx4 loads of a step are issued together, then reduced ----
     const f32x4 *f0s = reinterpret_cast<const f32x4 *>(E.f0s) + (in_range ? n : 0);
@@ -403,7 +424,14 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : SAGE_PHOTO_ERR_WAV
       }
     }
   }
-  err *= vm; // within_mask * pow(diff,2)  (:228)
+  if (STAGE != 2)
+    err *= vm; // within_mask * pow(diff,2)  (:228)
+  if (STAGE == 1)
+  {
+    reinterpret_cast<f32x4 *>(rec_px)[0] = f32x4{G00, G01, G11, v0};
+    reinterpret_cast<f32x4 *>(rec_px)[1] = f32x4{v1, err, vm, 0.f};
+    continue;
+  }
   err_acc += err;
   vm_acc += vm;
   if (!JAC)
@@ -654,6 +682,8 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_PHOTO_WAVES : SAGE_PHOTO_ERR_WAV
   }
   } // sub-tile loop
 
+  if (STAGE == 1)
+    return;
   if (!JAC)
   {
     const float se = wave_sum(err_acc), sn = wave_sum(vm_acc), sg = wave_sum(gerr_acc);
@@ -899,6 +929,7 @@ static PhotoParams make_params(const PhotoEdge *single, const PhotoEdge *table, 
   p.order = lc.order;
   p.rec_first = lc.flush > 0 ? lc.edge_first : nullptr;
   p.flush = lc.flush > 0 ? lc.flush : lc.tiles_per_block;
+  p.pixrec = lc.pixrec;
   p.lds_l0 = pyr.levels; // off
   p.lds_base = 0;
   p.lds_ntex = 0;
@@ -924,7 +955,13 @@ static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const P
   {
     if (lc.ev_start)
       (void)hipEventRecord(lc.ev_start, s);
-    if (lc.packed)
+    if (lc.packed && lc.pixrec)
+    {
+      // split linearize: sampling stage, then contraction stage (same work decomposition, hand-over in lc.pixrec)
+      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1, 1>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
+      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1, 2>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
+    }
+    else if (lc.packed)
       hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
     else
       hipLaunchKernelGGL((photo_kernel<CS, FS, true, 0>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);

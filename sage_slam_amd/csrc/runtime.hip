@@ -1203,6 +1203,7 @@ struct SageWindow
   DevBuf rec_first_p, rec_count_p;      // photometric linearize: partial RECORDS per edge (flush_p sub-tiles each)
   int flush_p = 0, n_rec_p = 0;
   DevBuf part_p, part_g;
+  DevBuf pixrec_p;                      // split photometric linearize (SAGE_PHOTO_SPLIT): per-pixel hand-over records
   DevBuf AtA_p, Atb_p, stats_p, AtA_g, Atb_g, stats_g;
   DevBuf adj_start, adj, link_edges, packed, errbuf;
   int n_work_p = 0, n_work_g = 0, tpb_p = 1, tpb_g = 1;
@@ -1334,7 +1335,7 @@ extern "C" void sage_window_destroy(SageWindow *w)
 {
   if (!w)
     return;
-  DevBuf *bufs[] = {&w->packed_save, &w->rec_first_p, &w->rec_count_p, &w->order_p, &w->order_g, &w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
+  DevBuf *bufs[] = {&w->pixrec_p, &w->packed_save, &w->rec_first_p, &w->rec_count_p, &w->order_p, &w->order_g, &w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
                     &w->pk, &w->f0s, &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
                     &w->work_g, &w->first_g, &w->tiles_g, &w->part_p, &w->part_g, &w->AtA_p, &w->Atb_p,
                     &w->stats_p, &w->AtA_g, &w->Atb_g, &w->stats_g, &w->adj_start, &w->adj, &w->link_edges,
@@ -1935,6 +1936,12 @@ extern "C" int sage_window_finalize(SageWindow *w)
   SAGE_HIP(hipStreamSynchronize(w->stream));
   const size_t Dp = 13 + CS, Dg = 14 + 2 * CS;
   const size_t ne = std::max(1, w->n_edges);
+  {
+    static const bool split = sage::env_flag("SAGE_PHOTO_SPLIT");
+    if (split && w->n_work_p > 0 &&
+        (rc = w->pixrec_p.reserve((size_t)w->n_work_p * w->tpb_p * kTile * 8 * sizeof(float))))
+      return rc;
+  }
   if ((rc = w->part_p.reserve(std::max<size_t>(1, std::max(w->n_work_p, w->n_rec_p)) * photo_partial_floats(CS) * sizeof(float))) ||
       (rc = w->part_g.reserve(std::max<size_t>(1, w->n_work_g) * geo_partial_floats(CS) * sizeof(float))) ||
       (rc = w->AtA_p.reserve(ne * Dp * Dp * sizeof(float))) || (rc = w->Atb_p.reserve(ne * Dp * sizeof(float))) ||
@@ -2022,6 +2029,8 @@ static LaunchCommon window_lc(SageWindow *w, bool photo, bool photo_linearize = 
     lc.edge_tiles = w->rec_count_p.as<int32_t>();
     lc.flush = w->flush_p;
   }
+  if (photo_linearize && w->pixrec_p.p && !w->pipe_enabled)
+    lc.pixrec = w->pixrec_p.as<float>();
   // opt-in, measured NEGATIVE on the K = 64 headline window (r02): giving every XCD a contiguous eighth of the work list
   // makes the eight L2s work on eight different edge sets at once -- L2 hit rate 59 % -> 25 %, HBM fetch 2.3 -> 5.5 GB per
   // launch, photometric linearize 0.88 -> 1.03 ms.  With the dispatcher's round-robin all XCDs walk the same edges

@@ -142,6 +142,9 @@ struct LaunchCommon
   // photometric linearize: > 0 -> one partial record per `flush` sub-tiles (edge_first / edge_tiles then count RECORDS:
   // record = edge_first[edge] + tile / flush); 0 -> one record per work item
   int32_t flush = 0;
+  // photometric linearize, optional: split into a sampling and a contraction launch that hand over a per-pixel record
+  // [n_work][tiles_per_block][256][8] floats through this buffer (photo_kernels.hip, STAGE 1 / 2)
+  float *pixrec = nullptr;
 };
 
 // per-edge results, reference layouts

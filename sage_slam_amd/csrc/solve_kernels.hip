@@ -556,7 +556,7 @@ struct DeviceSolver
   bool device_factor = false;               // SAGE_DEVICE_SOLVE=1
   void *h_T = nullptr, *h_y = nullptr;       // pinned, one allocation like d_L/d_y (hybrid path)
   std::vector<double> h_X;                   // inverses of the diagonal factors
-  std::vector<int32_t> h_row_first, h_row_off, h_a_first, h_a_cnt, h_a_off;
+  std::vector<int32_t> h_row_first, h_row_off, h_a_first, h_a_cnt, h_a_off, h_col_ptr, h_col_rows;
   int n1 = 0, n2 = 0; // two independent leading row ranges [0,n1) and [n1,n1+n2) of the elimination order (0: none)
   // hybrid path: the scatter kernel writes blocks + rhs straight into h_T / h_y in consumption order and posts a
   // ticket (the epoch of this solve) per block in h_flags
@@ -713,6 +713,8 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   S->h_a_first = a_first;
   S->h_a_cnt = a_cnt;
   S->h_a_off = a_off;
+  S->h_col_ptr = bp.col_ptr;
+  S->h_col_rows = bp.col_rows;
   if (!S->device_factor)
   {
     if (hipHostMalloc(&S->h_T, ty_doubles * sizeof(double) + (size_t)nblk * sizeof(unsigned), hipHostMallocDefault) !=
@@ -807,7 +809,16 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
     static const bool dbgt = sage::env_flag("SAGE_DEBUG_TIMING");
     hipError_t eh;
     if (S->n1 > 0)
-      block_chol_arm(); // the helper core wakes up while this thread waits for the device
+    {
+      // the helper core (and, for loop-closure plans with long separator rows, the worker pool) wakes up while this
+      // thread waits for the device
+      BlockEnvelope pe;
+      pe.K = S->K; pe.Bp = S->Bp;
+      pe.row_first = S->h_row_first.data(); pe.row_off = S->h_row_off.data();
+      pe.a_first = S->h_a_first.data(); pe.a_cnt = S->h_a_cnt.data(); pe.a_off = S->h_a_off.data();
+      pe.n1 = S->n1; pe.n2 = S->n2;
+      block_chol_arm(block_plan_has_arrow_rows(pe));
+    }
     S->epoch += 1;
     if (S->epoch == 0) // wrapped: 0 is the "never written" value
       S->epoch = 1;
@@ -821,6 +832,7 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
     env.K = S->K; env.Bp = S->Bp;
     env.row_first = S->h_row_first.data(); env.row_off = S->h_row_off.data();
     env.a_first = S->h_a_first.data(); env.a_cnt = S->h_a_cnt.data(); env.a_off = S->h_a_off.data();
+    env.col_ptr = S->h_col_ptr.data(); env.col_rows = S->h_col_rows.data();
     env.n1 = S->n1; env.n2 = S->n2;
     env.ready = S->h_flags; env.epoch = S->epoch;
     const int bad = block_chol_solve_tr(env, reinterpret_cast<double *>(S->h_T), S->h_X.data(),
@@ -904,6 +916,7 @@ int solver_pipe_factor(DeviceSolver *S, hipStream_t stream, int (*before_row)(vo
   env.row_first = S->h_row_first.data(); env.row_off = S->h_row_off.data();
   env.a_first = S->h_a_first.data(); env.a_cnt = S->h_a_cnt.data(); env.a_off = S->h_a_off.data();
   env.n1 = S->n1; env.n2 = S->n2;
+  env.col_ptr = S->h_col_ptr.data(); env.col_rows = S->h_col_rows.data();
   env.ready = S->h_flags; env.epoch = S->epoch;
   env.before_row = before_row; env.idle = idle; env.user = user;
   static const bool dbgt = sage::env_flag("SAGE_DEBUG_TIMING");

@@ -405,3 +405,38 @@ def test_bench_multi_gpu_entry_point_spawns_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="4"),
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 2 and "WORLD_SIZE" in r.stderr
+
+
+def test_block_solve_ring_closure_cover_plan_matches_dense():
+    """Loop-closure windows (BASELINE config 5 shape: a chain whose ends see each other + a mid-chain closure + a local
+    long link): plan_blocks covers the long links with a few keyframes that join the separator (order = [first half |
+    second half descending | middle separator | cover]), the halves stay two independent banded factorisations and the
+    long separator rows are cut into per-half tasks (worker pool when armed, the caller otherwise).  Result == dense
+    numpy solve of the same damped system."""
+    rng = np.random.default_rng(11)
+    for K, CS in ((96, 32), (128, 16)):
+        B = 7 + CS
+        links = [(j, i) for i in range(K) for j in range(max(0, i - 3), i)]
+        links += [(0, K - 1), (2, K - 3), (1, K - 2), (0, K // 2), (K // 5, K // 5 + 30)]
+        n = K * B
+        diag = np.zeros((K, B, B)); lnk = np.zeros((len(links), B, B))
+        for l, (a, b) in enumerate(links):
+            J = rng.normal(size=(2 * B, 2 * B + 3)); M = J @ J.T
+            diag[a] += M[:B, :B]; diag[b] += M[B:, B:]; lnk[l] = M[:B, B:]
+        for k in range(K):
+            diag[k] += 0.5 * np.eye(B)
+        g = rng.normal(size=n)
+        packed = np.concatenate([diag.reshape(-1), lnk.reshape(-1), g, np.zeros(4)])
+        H = np.zeros((n, n))
+        for k in range(K):
+            H[k * B:(k + 1) * B, k * B:(k + 1) * B] = 0.5 * (diag[k] + diag[k].T)
+        for l, (a, b) in enumerate(links):
+            H[a * B:(a + 1) * B, b * B:(b + 1) * B] += lnk[l]; H[b * B:(b + 1) * B, a * B:(a + 1) * B] += lnk[l].T
+        ref = np.linalg.solve(H + 1e-3 * np.diag(np.diag(H)), g)
+        for _ in range(3):                                   # (repeat: the pool is asleep on the first call, awake later)
+            d = capi.block_solve(packed, K, links, B, 1e-3)
+            assert rel(d, ref) < 1e-11
+        # a non-positive definite system is reported, not hung on (the tasks watch the abort flag)
+        bad = packed.copy(); bad[(K // 3) * B * B] = -1e6
+        with pytest.raises(capi.SageError):
+            capi.block_solve(bad, K, links, B, 0.0)
