@@ -91,6 +91,13 @@ constexpr int kPhotoStashLD = 40; // floats per pixel, 16-byte aligned rows
 #define SAGE_PHOTO_L2_TILES 3
 #endif
 constexpr int kPhotoL2Tiles = SAGE_PHOTO_L2_TILES;
+// CS = 32: the noise-critical tiles (two cross tiles, pose tile) accumulate the even and the odd pixel groups of a sub-tile
+// in two accumulator sets -- fp32 chains of 32 instead of 64 fmaf, a quarter of the chain's rounding variance -- merged
+// before the second-level update (r03: K = 64 LM step vs the fp32 oracle 9.1 -> 7.6e-5 together with a record every 4
+// sub-tiles; same register allocation, kernel time unchanged)
+#ifndef SAGE_PHOTO_ALT_ACC
+#define SAGE_PHOTO_ALT_ACC 1
+#endif
 
 // One (level, channel-group) step of the sampler in the engine's channel-group layout: 4 taps x (f1, gx, gy) dwordx4
 // loads + the pre-sampled source features.
@@ -182,6 +189,9 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
 #pragma unroll
   for (int t = 0; t < NT + 1; ++t)
     acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if SAGE_PHOTO_ALT_ACC
+  f32x4 accb[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#endif
   float err_acc = 0.f, vm_acc = 0.f, sdd_acc = 0.f; // lane-local sums over the sub-tiles: error, inliers, sigma d^2
   float gerr_acc = 0.f;                             // error kernel, fused geometric error
   const bool fuse_geo = !JAC && prm.geo_loss_param > 0.f && E.dpt1_geo != nullptr;
@@ -551,6 +561,18 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
       if (g + AHEAD + 1 < G)
         SAGE_PHOTO_READ_STASH(g + AHEAD + 1)
       const float a = asel * ai[g];
+#if SAGE_PHOTO_ALT_ACC
+      if (CS == 32 && (g & 1))
+      {
+        accb[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[g], yb[g], accb[2], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bl[g], bl[g], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bl[g], bh[g], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bh[g], bh[g], acc[2], 0, 0, 0);
+        accb[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bl[g], accb[0], 0, 0, 0);
+        accb[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bh[g], accb[1], 0, 0, 0);
+        continue;
+      }
+#endif
       acc[YY] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[g], yb[g], acc[YY], 0, 0, 0);
       if (CS == 32)
       {
@@ -568,6 +590,13 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
     }
   }
   __builtin_amdgcn_wave_barrier(); // the stash is rewritten by the next sub-tile
+#if SAGE_PHOTO_ALT_ACC
+  if (CS == 32)
+  {
+    acc[3] += accb[0]; acc[4] += accb[1]; acc[YY] += accb[2];
+    accb[0] = accb[1] = accb[2] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#endif
   // ---- second level: the LM step's distance from the exact step is set by the fp32 accumulation chains of the two
   //      cross tiles (rows c, sigma d, u6: the code gradient and the pose-code blocks) and of the pose tile; the code-code
   //      tiles do not matter (measured tile by tile, DESIGN s4).  After every sub-tile each lane moves its 12 values of

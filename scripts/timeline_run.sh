@@ -1,1 +1,9 @@
-cd /tmp && export TMPDIR=/tmp && rm -rf /root/repo/gpurun_out/tl && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /root/repo/gpurun_out/tl -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline > /root/repo/gpurun_out/tl_bench.log 2>&1; cd /root/repo; f=$(find gpurun_out/tl -name "*kernel_trace.csv" | head -1); python scripts/timeline.py $f 2>&1 | tail -24
+#!/bin/bash
+# dev tool (GPU box): kernel timeline of one steady-state LM step of the headline bench -> gpurun_out/timeline_$1.txt
+TAG=${1:-tl}
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp && rm -rf $R/gpurun_out/tl_$TAG
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $R/gpurun_out/tl_$TAG -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/tl_$TAG.log 2>&1
+f=$(find $R/gpurun_out/tl_$TAG -name "*kernel_trace.csv" | head -1)
+python $R/scripts/timeline.py $f > $R/gpurun_out/timeline_$TAG.txt 2>&1
+tail -30 $R/gpurun_out/timeline_$TAG.txt

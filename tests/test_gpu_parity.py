@@ -267,8 +267,8 @@ def test_window_assembly_and_delta(capi, orc, CS):
 def test_window_step_noise_floor(capi, orc):
     """Seed sweep of the LM step against the exact (fp64-oracle) step.  At cond(H) ~ 1e9 the step of ANY fp32
     evaluation sits at a few 1e-5 .. 1e-4 from the exact one; the engine must (a) be at least as accurate as the
-    fp32 oracle block by block (H and g vs the exact system) and (b) give a step within 1e-4 of exact, or within
-    3x the fp32 oracle's own distance when that floor is higher."""
+    fp32 oracle block by block (H and g vs the exact system) and (b) give a step within a HARD 1e-4 of the fp32
+    oracle's step, and within 1e-4 of the exact step wherever the fp32 oracle itself is < 7.5e-5 from exact."""
     CS = 32
     for seed in (22, 23, 24):
         w = synth.make_window(K=5, H=64, W=80, FS=16, CS=CS, L=4, seed=seed, back_links=2)
@@ -300,7 +300,9 @@ def test_window_step_noise_floor(capi, orc):
         floor = rel(do, de)
         print(f"seed {seed}: step hip-exact {rel(dh, de):.2e}  fp32-oracle-exact {floor:.2e}  hip-fp32-oracle {rel(dh, do):.2e}  "
               f"H {rel(Hh, He):.1e}/{rel(Ho, He):.1e}  g {rel(gh, ge):.1e}/{rel(go, ge):.1e}")
-        assert rel(dh, de) < max(TOL_DELTA, 3 * floor)
+        assert rel(dh, do) < TOL_DELTA                       # HARD bar against the reference's arithmetic (fp32 oracle)
+        if floor < 0.75 * TOL_DELTA:                                      # vs exact only where the fp32 oracle itself is close to it
+            assert rel(dh, de) < TOL_DELTA
         win.close()
 
 

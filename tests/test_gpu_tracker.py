@@ -168,7 +168,11 @@ def test_track_frame_matches_oracle_wired_lm(capi, scene, dof, use_photo, use_kp
     assert eh == pytest.approx(eo, rel=1e-3)
     assert rel(ph, po) < 1e-4
     if dof == 7:
-        assert sh == pytest.approx(so, rel=1e-4)
+        # photometric term alone: the scale trades against the translation exactly, the damped 7x7 system is numerically
+        # singular along that gauge and Eigen's colPivHouseholderQr().solve() KEEPS the tiny pivot (nonzeroPivots(), pinned
+        # by tests/golden/colpiv_qr_eigen339.json; the rank()-style cut of round 2 dropped it) -- the step along the gauge
+        # is then fp32 noise amplified by 1 / pivot in the reference as well; with a keypoint term the scale is observable
+        assert sh == pytest.approx(so, rel=1e-4 if use_kp else 2e-3)
         # the scale is a live variable of the cost (it used to drift without moving the depths): started 4 %
         # low, the LM pulls it back towards the true scale
         # (only the match-geometry term sees the scale; the photometric term trades s against t exactly)
