@@ -419,21 +419,38 @@ __global__ void mark_locations_kernel(const SortItem *__restrict__ items, int HW
     mark[(size_t)k * HW + l] = i;
 }
 
-__global__ __launch_bounds__(1024) void order_locations_kernel(const SortItem *__restrict__ items, int HW,
-                                                               const int *__restrict__ mark, int *__restrict__ status)
+// walk order of the plane: raster (TW = 0) or image tiles of TW x TH pixels, tiles in raster order, pixels inside a tile
+// in raster order (a wave's 64 consecutive samples then cover e.g. 16 x 4 pixels instead of a 64-pixel row segment: its
+// four tap loads share texel rows -- (x, y+1) of one pixel row is (x, y) of the next -- fewer distinct lines per step)
+__device__ __forceinline__ int walk_to_pixel(int c, int W, int H, int TW, int TH)
+{
+  if (TW <= 0)
+    return c < W * H ? c : -1;
+  const int per = TW * TH, tpr = (W + TW - 1) / TW;
+  const int t = c / per, in = c - t * per;
+  const int y = (t / tpr) * TH + in / TW, x = (t % tpr) * TW + in % TW;
+  return (x < W && y < H) ? y * W + x : -1;
+}
+
+__global__ __launch_bounds__(1024) void order_locations_kernel(const SortItem *__restrict__ items, int HW, int W, int TW,
+                                                               int TH, const int *__restrict__ mark,
+                                                               int *__restrict__ status)
 {
   __shared__ int s_wave[16];
   __shared__ int s_base;
   const int k = blockIdx.x;
   const SortItem it = items[k];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int H = HW / W;
+  const int n_walk = TW > 0 ? ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * TW * TH : HW;
   if (tid == 0)
     s_base = 0;
   __syncthreads();
-  for (int c0 = 0; c0 < HW; c0 += 1024)
+  for (int c0 = 0; c0 < n_walk; c0 += 1024)
   {
-    const int i = c0 + tid;
-    const int src = i < HW ? mark[(size_t)k * HW + i] : -1;
+    const int c = c0 + tid;
+    const int i = c < n_walk ? walk_to_pixel(c, W, H, TW, TH) : -1;
+    const int src = i >= 0 ? mark[(size_t)k * HW + i] : -1;
     const bool v = src >= 0;
     const unsigned long long b = __ballot(v);
     const int before = __popcll(b & ((1ull << lane) - 1ull));
@@ -466,8 +483,13 @@ __global__ __launch_bounds__(1024) void order_locations_kernel(const SortItem *_
 }
 
 hipError_t launch_sort_locations(hipStream_t s, const SortItem *items_dev, int K, int max_n, int HW, int *mark_dev,
-                                 int *status_dev)
+                                 int *status_dev, int W, int tile_w, int tile_h)
 {
+  if (W <= 0 || HW % W != 0 || tile_w <= 0 || tile_h <= 0)
+  {
+    W = HW; // raster walk
+    tile_w = tile_h = 0;
+  }
   hipError_t e;
   if ((e = hipMemsetAsync(mark_dev, 0xff, (size_t)K * HW * sizeof(int), s)) != hipSuccess ||
       (e = hipMemsetAsync(status_dev, 0, (size_t)2 * K * sizeof(int), s)) != hipSuccess)
@@ -475,7 +497,7 @@ hipError_t launch_sort_locations(hipStream_t s, const SortItem *items_dev, int K
   if (max_n > 0)
     hipLaunchKernelGGL(mark_locations_kernel, dim3((max_n + 255) / 256, K), dim3(256), 0, s, items_dev, HW, mark_dev,
                        status_dev);
-  hipLaunchKernelGGL(order_locations_kernel, dim3(K), dim3(1024), 0, s, items_dev, HW, mark_dev, status_dev);
+  hipLaunchKernelGGL(order_locations_kernel, dim3(K), dim3(1024), 0, s, items_dev, HW, W, tile_w, tile_h, mark_dev, status_dev);
   return hipGetLastError();
 }
 

@@ -1754,8 +1754,19 @@ extern "C" int sage_window_finalize(SageWindow *w)
     if (!rc)
       rc = d_status.reserve((size_t)2 * K * sizeof(int));
     hipError_t he = hipSuccess;
-    if (!rc)
-      he = launch_sort_locations(w->stream, d_items.as<SortItem>(), K, max_n, HW, d_mark.as<int>(), d_status.as<int>());
+    {
+      // walk order of the samples: raster, or image tiles (SAGE_SAMPLE_TILE=WxH, e.g. 16x4)
+      static const std::pair<int, int> tile = [] {
+        int tw = 0, th = 0;
+        if (const char *e = getenv("SAGE_SAMPLE_TILE"))
+          if (sscanf(e, "%dx%d", &tw, &th) != 2 || tw < 1 || th < 1)
+            tw = th = 0;
+        return std::make_pair(tw, th);
+      }();
+      if (!rc)
+        he = launch_sort_locations(w->stream, d_items.as<SortItem>(), K, max_n, HW, d_mark.as<int>(), d_status.as<int>(),
+                                   (int)c.pyr.cam[0].w, tile.first, tile.second);
+    }
     if (!rc && he == hipSuccess)
       he = hipMemcpyAsync(status.data(), d_status.p, status.size() * sizeof(int), hipMemcpyDeviceToHost, w->stream);
     if (!rc && he == hipSuccess)
