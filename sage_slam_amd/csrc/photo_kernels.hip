@@ -295,6 +295,26 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
         const uint32_t soff = (uint32_t)g * plane * 4u;
         TapBatch<JAC> B;
         B.f0 = f0s[((size_t)l * NG + g) * N];
+#if defined(SAGE_EXP_LDS_FROM)
+        // TIMING-ONLY experiment (wrong values): the taps of the levels >= SAGE_EXP_LDS_FROM are read from LDS (whatever
+        // the stash / staged region holds) instead of through the texture path: upper bound of what staging them could buy
+        if (l >= SAGE_EXP_LDS_FROM)
+        {
+          const f32x4 *lv = reinterpret_cast<const f32x4 *>(JAC ? s_mem : s_dyn);
+          const int msk = JAC ? (STASH / 4 - 1) / 2 : 1023;
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+          {
+            B.t1[k] = lv[(td.off[k] + g * 64) & msk];
+            if (JAC)
+            {
+              B.tx[k] = lv[(td.off[k] + g * 64 + 17) & msk];
+              B.ty[k] = lv[(td.off[k] + g * 64 + 33) & msk];
+            }
+          }
+        }
+        else
+#endif
         if (!JAC && stage_lds && l >= prm.lds_l0) // (one loop body with this branch: splitting the level loop in two
         {                                         //  specialised passes perturbed the linearize kernel's allocation: +3 %)
           const f32x4 *lv = s_lvl + (g * prm.lds_ntex + ((int)lo - prm.lds_base));
