@@ -980,3 +980,41 @@ def cycle_match(ws, desc0, desc1, kp_loc0, H, W, cyc_thresh):
     _chk(lib().sage_cycle_match(ws.h, _dptr(desc0), _dptr(desc1), _dptr(kp_loc0), K, Cc, H, W, C.c_float(cyc_thresh),
                                 _dptr(m1), _dptr(c0), _dptr(fl), C.byref(n)), "sage_cycle_match")
     return m1[:K], c0[:K], fl[:K], n.value
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# keyframe ingest: the outputs of the (TorchScript) feature / depth networks -> the tensor bundle of a keyframe, on the
+# device end to end (what Mapper::BuildKeyframe does with libtorch ops, core/mapping/mapper.cpp:1318-1426, 1242-1252)
+# ----------------------------------------------------------------------------------------------------------------------
+class IngestedKeyframe:
+    """device tensors of one keyframe in the reference layouts (a10) + the host-side variables; duck-types a
+    ``synth.Keyframe`` for :class:`Window` / :class:`DeviceKeyframe` (no host copy is made of the big tensors)."""
+
+    def __init__(self, feat_pyr, grad_pyr, bias, basis, loc1d, homo, R, t, code, scale, avg_squared_dpt_bias):
+        self.feat_pyr, self.grad_pyr, self.bias, self.basis = feat_pyr, grad_pyr, bias, basis
+        self.loc1d, self.homo = loc1d, homo
+        self.R, self.t, self.code, self.scale = R, t, code, scale
+        self.avg_squared_dpt_bias = avg_squared_dpt_bias
+
+
+def keyframe_from_net_outputs(ws: "Workspace", feat_map, dpt_bias, dpt_jac_code, mask, pyr: SagePyramid, seed: int,
+                              num_samples: int, R=None, t=None):
+    """feat_map [1,FS,H,W] or [FS,H,W] (feature net), dpt_bias [1,1,H,W] or [H,W], dpt_jac_code [H*W,CS] (depth net),
+    mask [H,W] float 0/1 -- CUDA tensors that stay where they are.  Masked Gaussian pyramid + central-difference
+    gradients (mapper.cpp:1384-1426), valid-pixel enumeration (mapping_utils.h:254-287), seeded std::shuffle subsample
+    with seed = timestamp (mapper.cpp:1326-1340), zero initial code, unit scale (mapper.cpp:1242, :1318)."""
+    import torch
+    feat = feat_map.reshape(feat_map.shape[-3], feat_map.shape[-2], feat_map.shape[-1]).contiguous().float()
+    FS, H, W = feat.shape
+    bias = dpt_bias.reshape(-1).contiguous().float()
+    basis = dpt_jac_code.reshape(H * W, -1).contiguous().float()
+    CS = int(basis.shape[1])
+    assert bias.numel() == H * W and mask.shape == (H, W)
+    feat_pyr, grad_pyr = gaussian_pyramid_with_grad(ws, feat, mask, pyr, FS)
+    vloc, vhomo = valid_locations(ws, mask, pyr.cam[0])
+    loc, homo = sample_locations(ws, vloc, vhomo, seed, num_samples)
+    # avg_squared_dpt_bias (mapper.cpp:1248-1250): the per-link Cauchy parameter of the geometric factor derives from it
+    avg = float((torch.sum(torch.square(bias * mask.reshape(-1))) / torch.sum(mask)).item())
+    R = np.eye(3, dtype=np.float32) if R is None else np.asarray(R, np.float32)
+    t = np.zeros(3, np.float32) if t is None else np.asarray(t, np.float32)
+    return IngestedKeyframe(feat_pyr, grad_pyr, bias, basis, loc, homo, R, t, np.zeros(CS, np.float32), 1.0, avg)
