@@ -871,6 +871,17 @@ bool solver_split_info(const DeviceSolver *S, int *n1, int *n2, const int32_t **
 {
   if (S->device_factor || S->n1 <= 0)
     return false;
+  {
+    // loop-closure plans (cover keyframes in the separator: long "arrow" rows) are not pipelined: the row-by-row hand-over
+    // of the pipeline assumes a separator of a few short rows
+    BlockEnvelope pe;
+    pe.K = S->K; pe.Bp = S->Bp;
+    pe.row_first = S->h_row_first.data(); pe.row_off = S->h_row_off.data();
+    pe.a_first = S->h_a_first.data(); pe.a_cnt = S->h_a_cnt.data(); pe.a_off = S->h_a_off.data();
+    pe.n1 = S->n1; pe.n2 = S->n2;
+    if (block_plan_has_arrow_rows(pe))
+      return false;
+  }
   *n1 = S->n1; *n2 = S->n2;
   *pos = S->h_pos.data(); *perm = S->h_perm.data();
   *pair_off = S->h_pair_off.data(); *n_pair_off = (int)S->h_pair_off.size();
