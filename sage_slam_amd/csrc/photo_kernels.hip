@@ -84,7 +84,11 @@ __device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i 
 //   [10..23] A rows of the pose tile: G*Q rows (2 x 6), v (2)         [24..37] its B columns: Q (2 x 6), q6*d (2)
 // Operand rows / columns 14, 15 of the pose tile read whatever follows (finite values): they only reach the output
 // rows / columns 14, 15, which nothing reads.
+#ifdef SAGE_EXP_STASH_LD // TIMING-ONLY experiment (wrong values): a smaller stash row so that four workgroups fit a CU
+constexpr int kPhotoStashLD = SAGE_EXP_STASH_LD;
+#else
 constexpr int kPhotoStashLD = 40; // floats per pixel, 16-byte aligned rows
+#endif
 // second-level accumulators of the noise-critical tiles (the two cross tiles and the pose tile: 3 x 4 floats per lane),
 // one region per wave (see "second level" in the kernel)
 #ifndef SAGE_PHOTO_L2_TILES
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
   constexpr int NT = photo_tiles(CS);
   constexpr int YY = NT; // the pose tile: accumulated like the code tiles, folded into the scalar slots at the end
   constexpr bool CONTRACT = JAC && STAGE != 1; // this launch runs phases C / D
-  constexpr int STASH = CONTRACT ? kWaves * 64 * kPhotoStashLD : 1;
+  constexpr int STASH = CONTRACT ? kWaves * 64 * kPhotoStashLD + (kPhotoStashLD < 40 ? 64 : 0) : 1;
   constexpr int SUMBUF = CONTRACT ? (NT + 1) * 256 : 1;
   __shared__ __attribute__((aligned(16))) float s_mem[STASH > SUMBUF ? STASH : SUMBUF];
   __shared__ float s_red[kWaves * 4]; // per wave: linearize {sigma d^2, error, inliers}, error pass {error, inliers, geo error, inliers}
@@ -656,7 +660,9 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
   // (every wave dumps into ITS OWN stash region -- it is done with it, the other waves' phase D is not disturbed: no
   //  barrier before the dump)
   constexpr int SLICE = 64 * kPhotoStashLD; // distance between the waves' regions
+#ifndef SAGE_EXP_STASH_LD
   static_assert(!JAC || (NT + 1) * 256 <= SLICE, "a wave's tiles must fit its own stash region");
+#endif
 #pragma unroll
   for (int t = 0; t < NT + 1; ++t)
 #pragma unroll
