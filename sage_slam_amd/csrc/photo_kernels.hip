@@ -72,8 +72,16 @@ __device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i 
 #ifndef SAGE_PHOTO_WAVES
 #define SAGE_PHOTO_WAVES 3 // workgroups per CU the linearize kernel is register-budgeted for (x4 waves)
 #endif
+// error pass: channel groups of a level unrolled together (their tap loads are then in flight together).  Fully unrolled,
+// the FS = 32 kernel (8 groups) needs 168 VGPR + 61 spilled registers; 4 -> 150 / 0
+#ifndef SAGE_PHOTO_ERR_GUNROLL
+#define SAGE_PHOTO_ERR_GUNROLL 4
+#endif
+#ifndef SAGE_PHOTO_LIN_GUNROLL
+#define SAGE_PHOTO_LIN_GUNROLL 8
+#endif
 #ifndef SAGE_PHOTO_B_WAVES
-#define SAGE_PHOTO_B_WAVES 5 // split linearize, sampling stage: waves per SIMD it is register-budgeted for
+#define SAGE_PHOTO_B_WAVES 4 // split linearize, sampling stage: waves per SIMD it is register-budgeted for (128 VGPR, no spills)
 #endif
 #ifndef SAGE_PHOTO_CD_WAVES
 #define SAGE_PHOTO_CD_WAVES 3
@@ -137,6 +145,9 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
   constexpr bool PACKED = MODE >= 1;
   constexpr int NB = CS / 16;
   constexpr int NG = FS / 4;
+  // channel groups of a level unrolled together (linearize: all; error pass: at most SAGE_PHOTO_ERR_GUNROLL)
+  constexpr int GUNROLL_MAX = JAC ? SAGE_PHOTO_LIN_GUNROLL : SAGE_PHOTO_ERR_GUNROLL;
+  constexpr int GUNROLL = NG > GUNROLL_MAX ? GUNROLL_MAX : NG;
   constexpr int NT = photo_tiles(CS);
   constexpr int YY = NT; // the pose tile: accumulated like the code tiles, folded into the scalar slots at the end
   constexpr bool CONTRACT = JAC && STAGE != 1; // this launch runs phases C / D
@@ -294,6 +305,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
       // register pairs of the interpolated quads; the level's fx_l / fy_l scaling (h = (fx_l gx, fy_l gy)) is applied once
       // to the five sums instead of to every channel
       f32x2 q00 = {0.f, 0.f}, q01 = q00, q11 = q00, qa0 = q00, qa1 = q00, qee = q00;
+#pragma unroll GUNROLL
       for (int g = 0; g < NG; ++g)
       {
         const uint32_t soff = (uint32_t)g * plane * 4u;
