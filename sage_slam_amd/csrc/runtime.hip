@@ -1911,7 +1911,9 @@ extern "C" int sage_window_finalize(SageWindow *w)
     // (MFMA chains of 64 fmaf per sub-tile and accumulator): the LM step's distance from the exact step grows with the
     // chain length (K = 64 window, tests/tools/tpb_noise_probe.py: 8 -> 2.1e-4, 4 -> 1.2e-4, 2 -> 7.6e-5, 1 -> 4.9e-5 rel-L2;
     // the fp32 oracle itself sits at 5.5e-5).  Records every 2 sub-tiles keep the step inside the 1e-4 parity bar.
-    int tpb = total >= 8192 ? 8 : (total >= 4096 ? 2 : 1);
+    // (r03, one rank's shard of the K = 64 window at world 8 / 4 = 2.9 k / 5.8 k sub-tiles: runs of 4 / 8 are 19 % / 8 % faster
+    //  than the 1 / 2 the first heuristic picked; >= ~3 workgroups per CU stay in flight)
+    int tpb = total >= 4096 ? 8 : (total >= 1536 ? 4 : (total >= 768 ? 2 : 1));
     if (const char *e = getenv("SAGE_PHOTO_TPB"))
       tpb = std::max(1, atoi(e));
     // a partial record every 4 sub-tiles of a run of 8 (0 = one per workgroup): with the second level of the
