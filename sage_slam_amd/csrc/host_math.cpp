@@ -7,6 +7,7 @@
 //   sage_damped_solve_qr_f32 core/system/camera_tracker.cpp:1182-1183 (colPivHouseholderQr in fp32)
 //   sage_track_lm            core/system/camera_tracker.cpp:1156-1279 (+ LMConvergence :527-573)
 #include <algorithm>
+#include <map>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -2191,31 +2192,88 @@ static std::vector<int> read_cpu_list(const char *path)
   return out;
 }
 
-// Keep the helper on a core that shares the caller's L3 (same CCX, not its SMT sibling): the two halves then work out
-// of one cache and one NUMA node -- on a two-socket host a helper on the far socket takes ~35 % longer for its half.
+// Thread placement of the solve: the caller, the helper of the second half and the worker pool each get their own
+// PHYSICAL core of the caller's CCX (cores that share its L3): the halves and the arrow-row tasks then work out of one
+// cache and one NUMA node (a helper on the far socket takes ~35 % longer for its half), and no two of them share a core
+// through SMT (r03: a pool thread on the helper's sibling made the helper's half 35-45 % slower on config 5).
+// cores[0] -> helper, cores[1 + t] -> pool thread t; threads the CCX has no core left for fall back to the rest of the
+// caller's NUMA node as a set.
+static std::vector<int> sibling_free_cores(const std::vector<int> &cpus, int caller_cpu, const cpu_set_t &allowed)
+{
+  std::vector<int> cores, seen_core;
+  char path[128];
+  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", caller_cpu);
+  const std::vector<int> caller_sib = read_cpu_list(path);
+  const int caller_core = caller_sib.empty() ? caller_cpu : *std::min_element(caller_sib.begin(), caller_sib.end());
+  for (int c : cpus)
+  {
+    if (c >= CPU_SETSIZE || !CPU_ISSET(c, &allowed))
+      continue;
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", c);
+    const std::vector<int> sib = read_cpu_list(path);
+    const int core = sib.empty() ? c : *std::min_element(sib.begin(), sib.end());
+    if (core == caller_core || std::find(seen_core.begin(), seen_core.end(), core) != seen_core.end())
+      continue;
+    seen_core.push_back(core);
+    cores.push_back(c); // the first allowed hardware thread of that core
+  }
+  return cores;
+}
+
+static std::vector<int> node_cpus_of(int cpu)
+{
+  char path[128];
+  for (int node = 0; node < 64; ++node)
+  {
+    snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
+    const std::vector<int> nl = read_cpu_list(path);
+    if (std::find(nl.begin(), nl.end(), cpu) != nl.end())
+      return nl;
+  }
+  return {};
+}
+
+// (sysfs is read once per caller CPU: the arm call sits at the start of every solve)
+static const std::vector<int> &ccx_cores_of(int cpu, bool with_node)
+{
+  static std::mutex mu;
+  static std::map<std::pair<int, bool>, std::vector<int>> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find({cpu, with_node});
+  if (it != cache.end())
+    return it->second;
+  std::vector<int> cores;
+  char path[128];
+  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+  const std::vector<int> l3 = read_cpu_list(path);
+  cpu_set_t allowed;
+  if (!l3.empty() && sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+  {
+    cores = sibling_free_cores(l3, cpu, allowed);
+    if (with_node)
+      for (int c : sibling_free_cores(node_cpus_of(cpu), cpu, allowed))
+        if (std::find(cores.begin(), cores.end(), c) == cores.end())
+          cores.push_back(c);
+  }
+  return cache.emplace(std::make_pair(cpu, with_node), std::move(cores)).first->second;
+}
+
+static void pin_one(pthread_t t, int cpu)
+{
+  cpu_set_t want;
+  CPU_ZERO(&want);
+  CPU_SET(cpu, &want);
+  (void)pthread_setaffinity_np(t, sizeof(want), &want);
+}
+
 static void place_helper_near(CholHelper *h, int cpu)
 {
   if (cpu < 0 || cpu == h->near_cpu || sage::env_flag("SAGE_SOLVE_NO_AFFINITY"))
     return;
   h->near_cpu = cpu;
-  char path[128];
-  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
-  const std::vector<int> l3 = read_cpu_list(path);
-  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
-  const std::vector<int> sib = read_cpu_list(path);
-  cpu_set_t allowed, want;
-  if (l3.empty() || sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
-    return;
-  CPU_ZERO(&want);
-  int n = 0;
-  for (int c : l3)
-    if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed) && std::find(sib.begin(), sib.end(), c) == sib.end() && c != cpu)
-    {
-      CPU_SET(c, &want);
-      ++n;
-    }
-  if (n > 0)
-    (void)pthread_setaffinity_np(h->tid, sizeof(want), &want);
+  const std::vector<int> &cores = ccx_cores_of(cpu, false);
+  if (!cores.empty())
+    pin_one(h->tid, cores[0]);
 }
 
 static void place_pool_near(SepPool *q, int cpu)
@@ -2223,43 +2281,10 @@ static void place_pool_near(SepPool *q, int cpu)
   if (cpu < 0 || cpu == q->near_cpu || sage::env_flag("SAGE_SOLVE_NO_AFFINITY"))
     return;
   q->near_cpu = cpu;
-  char path[128];
-  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
-  std::vector<int> l3 = read_cpu_list(path);
-  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
-  const std::vector<int> sib = read_cpu_list(path);
-  // the pool may be larger than what is left of the caller's CCX: its NUMA node is the fallback set
-  cpu_set_t allowed, want;
-  if (l3.empty() || sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
-    return;
-  auto fill = [&](const std::vector<int> &cpus) {
-    CPU_ZERO(&want);
-    int n = 0;
-    for (int c : cpus)
-      if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed) && std::find(sib.begin(), sib.end(), c) == sib.end() && c != cpu)
-      {
-        CPU_SET(c, &want);
-        ++n;
-      }
-    return n;
-  };
-  int n = fill(l3);
-  if (n < (int)q->tids.size() + 1)
-  {
-    for (int node = 0; node < 64; ++node)
-    {
-      snprintf(path, sizeof(path), "/sys/devices/system/node/node%d/cpulist", node);
-      const std::vector<int> nl = read_cpu_list(path);
-      if (std::find(nl.begin(), nl.end(), cpu) != nl.end())
-      {
-        n = fill(nl);
-        break;
-      }
-    }
-  }
-  if (n > 0)
-    for (pthread_t t : q->tids)
-      (void)pthread_setaffinity_np(t, sizeof(want), &want);
+  // cores[0] is the helper's; more workers than cores left in the CCX continue on the other cores of the NUMA node
+  const std::vector<int> &cores = ccx_cores_of(cpu, true);
+  for (size_t t = 0; t < q->tids.size() && t + 1 < cores.size(); ++t)
+    pin_one(q->tids[t], cores[t + 1]);
 }
 
 void block_chol_arm(bool with_pool)
