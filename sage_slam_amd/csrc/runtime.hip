@@ -141,7 +141,16 @@ struct SageWorkspace
   int cached_N = -1;
   int n_work = 0;
   int tiles_per_block = 1;
+  // tracker wiring (sage_track_frame): one evaluation = several operator launches that leave their statistics on the
+  // device (defer_fetch: no D2H + stream synchronise per operator; stats_ptr: where this operator's {error, inliers} go),
+  // then ONE copy of everything into pinned memory and one synchronise.  Buffers persist across frames.
+  bool defer_fetch = false;
+  float *stats_ptr = nullptr;
+  DevBuf trk, trk_dpts, trk_kp_dpts; // trk: [pose 12 | photo AtA 49 Atb 7 | keypoint AtA 49 Atb 7 | stats 2 + 2 | pad]
+  float *trk_host = nullptr;         // pinned: [pose 12 | pad 4 | results 116]
 };
+
+static inline float *ws_stats(SageWorkspace *ws) { return ws->stats_ptr ? ws->stats_ptr : ws->stats.as<float>(); }
 
 extern "C" int sage_workspace_create(void *hip_stream, SageWorkspace **out)
 {
@@ -174,8 +183,13 @@ extern "C" void sage_workspace_destroy(SageWorkspace *ws)
   ws->stats.release();
   ws->misc.release();
   ws->dpt0.release();
+  ws->trk.release();
+  ws->trk_dpts.release();
+  ws->trk_kp_dpts.release();
   if (ws->host_stats)
     (void)hipHostFree(ws->host_stats);
+  if (ws->trk_host)
+    (void)hipHostFree(ws->trk_host);
   delete ws;
 }
 
@@ -360,11 +374,13 @@ static int track_common(SageWorkspace *ws, bool jac, int dof, float *AtA, float 
   e.R = R; e.t = t; e.weights = weights_dev; e.scale0 = scale0; e.N = N;
   if (jac)
   {
-    EdgeOut out{AtA, Atb, ws->stats.as<float>()};
+    EdgeOut out{AtA, Atb, ws_stats(ws)};
     SAGE_HIP(launch_track_linearize(ws->stream, dof, FS, e, lc, *pyr, eps, out));
   }
   else
-    SAGE_HIP(launch_track_error(ws->stream, FS, e, lc, *pyr, eps, ws->stats.as<float>()));
+    SAGE_HIP(launch_track_error(ws->stream, FS, e, lc, *pyr, eps, ws_stats(ws)));
+  if (ws->defer_fetch)
+    return SAGE_OK;
   return ws_fetch_stats(ws, error_host, num_inliers_host);
 }
 
@@ -475,7 +491,9 @@ static int reproj_common(SageWorkspace *ws, bool tracker, bool jac, float *AtA, 
     return rc;
   SAGE_HIP(launch_reproj(ws->stream, CS, tracker, jac, R10, t10, R0, t0, R1, t1, bias0, basis0, code0, loc, dpts0, homo,
                          matched, scale0, *cam, eps, loss_param, weight, N, ws->misc.as<float>(), AtA, Atb,
-                         ws->stats.as<float>()));
+                         ws_stats(ws)));
+  if (ws->defer_fetch)
+    return SAGE_OK;
   return ws_fetch_stats(ws, error_host, num_inliers_host);
 }
 
@@ -550,7 +568,9 @@ static int mg_common(SageWorkspace *ws, int mode, int loss, bool jac, float *AtA
     return rc;
   SAGE_HIP(launch_match_geom(ws->stream, mode, loss, CS, jac, R10, t10, R0, t0, R1, t1, bias0, bias1, basis0, basis1,
                              code0, code1, dpts0, dpts1, homo0, homo1, loc0, loc1, scale0, scale1, loss_param, weight, N,
-                             ws->misc.as<float>(), AtA, Atb, ws->stats.as<float>()));
+                             ws->misc.as<float>(), AtA, Atb, ws_stats(ws)));
+  if (ws->defer_fetch)
+    return SAGE_OK;
   return ws_fetch_stats(ws, error_host, nullptr);
 }
 
@@ -744,68 +764,102 @@ struct TrackCtx
 {
   const SageTrackProblem *prob;
   int dof;
-  DevBuf pose, out;      // pose: 12 floats; out: 2 x (AtA(49)+Atb(7)) -- photometric and keypoint term
-  DevBuf dpts, kp_dpts;  // dof 7: scale * unscaled depths of the evaluation in flight
 };
+
+// layout of SageWorkspace::trk (floats) and of the pinned mirror trk_host
+constexpr int kTrkPose = 0, kTrkOut = 12, kTrkStats = 12 + 112, kTrkFloats = 12 + 112 + 4 + 4;
+constexpr int kTrkHostOut = 16; // results start here in trk_host ([0, 12) is the pose on its way to the device)
 
 // depths the kernels of one evaluation read: dof 6 -> the caller's metric depths; dof 7 -> scale * unscaled
 // (camera_tracker.cpp:264, :273 candidate error; :431, :453 Jacobian)
 int track_depths(TrackCtx *c, float scale, const float **photo, const float **kp)
 {
   const SageTrackProblem *p = c->prob;
+  SageWorkspace *ws = p->ws;
   *photo = p->dpts0_dev;
   *kp = p->kp_dpts0_dev;
   if (c->dof != 7)
     return 0;
-  hipStream_t s = p->ws->stream;
+  hipStream_t s = ws->stream;
   if (p->use_photo)
   {
-    SAGE_HIP(launch_scale_array(s, c->dpts.as<float>(), p->dpts0_dev, scale, p->N));
-    *photo = c->dpts.as<float>();
+    SAGE_HIP(launch_scale_array(s, ws->trk_dpts.as<float>(), p->dpts0_dev, scale, p->N));
+    *photo = ws->trk_dpts.as<float>();
   }
   if (p->use_keypoints)
   {
-    SAGE_HIP(launch_scale_array(s, c->kp_dpts.as<float>(), p->kp_dpts0_dev, scale, p->NK));
-    *kp = c->kp_dpts.as<float>();
+    SAGE_HIP(launch_scale_array(s, ws->trk_kp_dpts.as<float>(), p->kp_dpts0_dev, scale, p->NK));
+    *kp = ws->trk_kp_dpts.as<float>();
   }
   return 0;
 }
 
-// CameraTracker::ComputeJacobianAndError (camera_tracker.cpp:282-328 dof 6, :330-374 dof 7)
+// the pose of the evaluation -> device (from pinned memory: a true asynchronous copy)
+static int track_upload_pose(SageWorkspace *ws, const float *pose12)
+{
+  std::memcpy(ws->trk_host, pose12, 12 * sizeof(float));
+  SAGE_HIP(hipMemcpyAsync(ws->trk.as<float>() + kTrkPose, ws->trk_host, 12 * sizeof(float), hipMemcpyHostToDevice,
+                          ws->stream));
+  return 0;
+}
+
+struct DeferGuard // operators called inside leave their statistics on the device (no per-operator synchronise)
+{
+  SageWorkspace *ws;
+  explicit DeferGuard(SageWorkspace *w) : ws(w) { ws->defer_fetch = true; }
+  ~DeferGuard()
+  {
+    ws->defer_fetch = false;
+    ws->stats_ptr = nullptr;
+  }
+};
+
+// CameraTracker::ComputeJacobianAndError (camera_tracker.cpp:282-328 dof 6, :330-374 dof 7): every term's kernels are
+// enqueued, then ONE device-to-host copy of both terms' AtA / Atb / statistics and one stream synchronise (the reference
+// pays a .item() synchronise per term and three more in each term's host reduction)
 int track_lin_cb(void *vctx, const float *pose12, float scale, float *AtA, float *Atb, float *error)
 {
   TrackCtx *c = static_cast<TrackCtx *>(vctx);
   const SageTrackProblem *p = c->prob;
-  hipStream_t s = p->ws->stream;
+  SageWorkspace *ws = p->ws;
+  hipStream_t s = ws->stream;
   const int dof = c->dof;
-  SAGE_HIP(hipMemcpyAsync(c->pose.p, pose12, 12 * sizeof(float), hipMemcpyHostToDevice, s));
-  const float *R = c->pose.as<float>(), *t = R + 9;
-  const float *dp, *kdp;
-  int rc = track_depths(c, scale, &dp, &kdp);
+  int rc = track_upload_pose(ws, pose12);
   if (rc)
     return rc;
-  float *dA = c->out.as<float>(), *db = dA + 49, *dA2 = dA + 56, *db2 = dA2 + 49;
-  float e_photo = 0.f, e_kp = 0.f;
-  if (p->use_photo &&
-      (rc = sage_tracker_photo_jac_error_calculate(p->ws, dof, dA, db, &e_photo, nullptr, R, t, p->mask1_dev, dp,
-                                                   p->homo_dev, p->feat0s_dev, p->feat1_dev, p->grad1_dev, &p->pyr,
-                                                   scale, p->eps, p->weights_dev, p->N, p->FS)))
+  const float *R = ws->trk.as<float>() + kTrkPose, *t = R + 9;
+  const float *dp, *kdp;
+  if ((rc = track_depths(c, scale, &dp, &kdp)))
     return rc;
-  if (p->use_keypoints)
+  float *dA = ws->trk.as<float>() + kTrkOut, *db = dA + 49, *dA2 = dA + 56, *db2 = dA2 + 49;
+  float *st = ws->trk.as<float>() + kTrkStats;
   {
-    if (dof == 6)
-      rc = sage_tracker_reproj_jac_error_calculate(p->ws, dA2, db2, &e_kp, nullptr, R, t, kdp, p->kp_homo0_dev,
-                                                   p->kp_matched_2d_dev, &p->pyr.cam[0], p->eps, p->kp_loss_param,
-                                                   p->kp_weight, p->NK);
-    else
-      rc = sage_tracker_match_geom_jac_error_calculate(p->ws, dA2, db2, &e_kp, R, t, kdp, p->kp_matched_dpts1_dev,
-                                                       p->kp_homo0_dev, p->kp_matched_homo1_dev, scale,
-                                                       p->kp_loss_param, p->kp_weight, 1, p->NK);
-    if (rc)
+    DeferGuard guard(ws);
+    ws->stats_ptr = st;
+    if (p->use_photo &&
+        (rc = sage_tracker_photo_jac_error_calculate(ws, dof, dA, db, nullptr, nullptr, R, t, p->mask1_dev, dp, p->homo_dev,
+                                                     p->feat0s_dev, p->feat1_dev, p->grad1_dev, &p->pyr, scale, p->eps,
+                                                     p->weights_dev, p->N, p->FS)))
       return rc;
+    ws->stats_ptr = st + 2;
+    if (p->use_keypoints)
+    {
+      if (dof == 6)
+        rc = sage_tracker_reproj_jac_error_calculate(ws, dA2, db2, nullptr, nullptr, R, t, kdp, p->kp_homo0_dev,
+                                                     p->kp_matched_2d_dev, &p->pyr.cam[0], p->eps, p->kp_loss_param,
+                                                     p->kp_weight, p->NK);
+      else
+        rc = sage_tracker_match_geom_jac_error_calculate(ws, dA2, db2, nullptr, R, t, kdp, p->kp_matched_dpts1_dev,
+                                                         p->kp_homo0_dev, p->kp_matched_homo1_dev, scale,
+                                                         p->kp_loss_param, p->kp_weight, 1, p->NK);
+      if (rc)
+        return rc;
+    }
   }
-  float host[112];
-  SAGE_HIP(hipMemcpy(host, dA, 112 * sizeof(float), hipMemcpyDeviceToHost));
+  float *host = ws->trk_host + kTrkHostOut;
+  SAGE_HIP(hipMemcpyAsync(host, dA, (112 + 4) * sizeof(float), hipMemcpyDeviceToHost, s));
+  SAGE_HIP(hipStreamSynchronize(s));
+  const float e_photo = p->use_photo ? host[112] : 0.f, e_kp = p->use_keypoints ? host[114] : 0.f;
   // AtA = zeros; AtA += photo_AtA; AtA += keypoint_AtA  (fp32 tensor adds, :296-318 / :344-364)
   for (int i = 0; i < dof * dof; ++i)
     AtA[i] = (p->use_photo ? 0.f + host[i] : 0.f) + (p->use_keypoints ? host[56 + i] : 0.f);
@@ -820,30 +874,39 @@ int track_err_cb(void *vctx, const float *pose12, float scale, float *error)
 {
   TrackCtx *c = static_cast<TrackCtx *>(vctx);
   const SageTrackProblem *p = c->prob;
-  SAGE_HIP(hipMemcpyAsync(c->pose.p, pose12, 12 * sizeof(float), hipMemcpyHostToDevice, p->ws->stream));
-  const float *R = c->pose.as<float>(), *t = R + 9;
-  const float *dp, *kdp;
-  int rc = track_depths(c, scale, &dp, &kdp);
+  SageWorkspace *ws = p->ws;
+  int rc = track_upload_pose(ws, pose12);
   if (rc)
     return rc;
-  float e_photo = 0.f, e_kp = 0.f;
-  if (p->use_photo &&
-      (rc = sage_tracker_photo_error_calculate(p->ws, &e_photo, nullptr, R, t, p->mask1_dev, dp, p->homo_dev,
-                                               p->feat0s_dev, p->feat1_dev, &p->pyr, p->eps, p->weights_dev, p->N,
-                                               p->FS)))
+  const float *R = ws->trk.as<float>() + kTrkPose, *t = R + 9;
+  const float *dp, *kdp;
+  if ((rc = track_depths(c, scale, &dp, &kdp)))
     return rc;
-  if (p->use_keypoints)
+  float *st = ws->trk.as<float>() + kTrkStats;
   {
-    if (c->dof == 6)
-      rc = sage_tracker_reproj_error_calculate(p->ws, &e_kp, nullptr, R, t, kdp, p->kp_homo0_dev, p->kp_matched_2d_dev,
-                                               &p->pyr.cam[0], p->eps, p->kp_loss_param, p->kp_weight, p->NK);
-    else
-      rc = sage_tracker_match_geom_error_calculate(p->ws, &e_kp, R, t, kdp, p->kp_matched_dpts1_dev, p->kp_homo0_dev,
-                                                   p->kp_matched_homo1_dev, p->kp_loss_param, p->kp_weight, p->NK);
-    if (rc)
+    DeferGuard guard(ws);
+    ws->stats_ptr = st;
+    if (p->use_photo &&
+        (rc = sage_tracker_photo_error_calculate(ws, nullptr, nullptr, R, t, p->mask1_dev, dp, p->homo_dev, p->feat0s_dev,
+                                                 p->feat1_dev, &p->pyr, p->eps, p->weights_dev, p->N, p->FS)))
       return rc;
+    ws->stats_ptr = st + 2;
+    if (p->use_keypoints)
+    {
+      if (c->dof == 6)
+        rc = sage_tracker_reproj_error_calculate(ws, nullptr, nullptr, R, t, kdp, p->kp_homo0_dev, p->kp_matched_2d_dev,
+                                                 &p->pyr.cam[0], p->eps, p->kp_loss_param, p->kp_weight, p->NK);
+      else
+        rc = sage_tracker_match_geom_error_calculate(ws, nullptr, R, t, kdp, p->kp_matched_dpts1_dev, p->kp_homo0_dev,
+                                                     p->kp_matched_homo1_dev, p->kp_loss_param, p->kp_weight, p->NK);
+      if (rc)
+        return rc;
+    }
   }
-  *error = e_photo + e_kp;
+  float *host = ws->trk_host + kTrkHostOut;
+  SAGE_HIP(hipMemcpyAsync(host + 112, st, 4 * sizeof(float), hipMemcpyDeviceToHost, ws->stream));
+  SAGE_HIP(hipStreamSynchronize(ws->stream));
+  *error = (p->use_photo ? host[112] : 0.f) + (p->use_keypoints ? host[114] : 0.f);
   return 0;
 }
 } // namespace
@@ -866,19 +929,20 @@ extern "C" int sage_track_frame(const SageLmConfig *cfg, int dof, const SageTrac
   TrackCtx ctx;
   ctx.prob = prob;
   ctx.dof = dof;
+  SageWorkspace *ws = prob->ws;
   int rc;
-  if ((rc = ctx.pose.reserve(12 * sizeof(float))) || (rc = ctx.out.reserve(112 * sizeof(float))))
+  // evaluation buffers of the workspace: allocated once, reused by every frame tracked through it
+  if ((rc = ws->trk.reserve(kTrkFloats * sizeof(float))))
     return rc;
-  if (dof == 7 && ((prob->use_photo && (rc = ctx.dpts.reserve((size_t)prob->N * sizeof(float)))) ||
-                   (prob->use_keypoints && (rc = ctx.kp_dpts.reserve((size_t)prob->NK * sizeof(float))))))
+  if (!ws->trk_host)
+    SAGE_HIP(hipHostMalloc((void **)&ws->trk_host, (kTrkHostOut + 112 + 4 + 12) * sizeof(float), hipHostMallocDefault));
+  if (dof == 7 && ((prob->use_photo && (rc = ws->trk_dpts.reserve((size_t)prob->N * sizeof(float)))) ||
+                   (prob->use_keypoints && (rc = ws->trk_kp_dpts.reserve((size_t)prob->NK * sizeof(float))))))
     return rc;
   rc = sage_track_lm(cfg, dof, track_lin_cb, track_err_cb, &ctx, pose12, scale, final_error, iters, trace, trace_cap,
                      trace_len);
-  (void)hipStreamSynchronize(prob->ws->stream);
-  ctx.pose.release();
-  ctx.out.release();
-  ctx.dpts.release();
-  ctx.kp_dpts.release();
+  ws->defer_fetch = false;
+  ws->stats_ptr = nullptr;
   return rc;
 }
 
