@@ -388,6 +388,16 @@ int sage_window_prepass(SageWindow *w, const float *pose12, const float *codes, 
 int sage_window_factor(const SageWindow *w, int type, int e, int psd_mode, double *G_out, double *g_out, double *f_out,
                        int *dims_out, int *nkeys_out);
 int sage_window_factor_error(const SageWindow *w, int type, int e, double *err_out);
+/* Optional, after a prepass with jacobians: NearestPsd (psd_mode as above) of EVERY cached factor on n_threads host threads
+ * (0 = all, at most 32).  The projection -- an SVD / eigen-decomposition of a (13+CS)^2 and a (14+2CS)^2 matrix per link
+ * direction -- is the host cost of the gtsam path (photometric_factor.cpp:142-149); ISAM2 pays it factor by factor, this
+ * pays it once per Values in parallel, and sage_window_factor with the same psd_mode then only cuts blocks.  The next
+ * prepass that recomputes invalidates it. */
+int sage_window_prepare_factors(SageWindow *w, int psd_mode, int n_threads);
+/* the two halves of sage_factor_hessian_blocks: projection of one factor's AtA (double D x D out), block cutting */
+int sage_factor_psd(int type, int CS, const float *AtA, int psd_mode, double *C_out);
+int sage_factor_cut_blocks(int type, int CS, const double *C, const float *Atb, double *G_out, double *g_out,
+                           int32_t *dims_out, int32_t *nkeys_out);
 
 /* kernel timing with HIP events on the engine's own stream (bench.py's roofline): when enabled every launch of
  * the four hot kernels is bracketed by an event pair.  which: 0 photometric linearize, 1 geometric linearize,

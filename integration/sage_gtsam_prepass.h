@@ -73,6 +73,10 @@ public:
       fprintf(stderr, "sage_window_prepass: %s\n", sage_error_string(rc)); // the reference's gpuErrchk convention
       exit(rc);
     }
+    // the per-factor NearestPsd (the host cost of linearize(): an SVD of a 45 x 45 / 78 x 78 matrix each) for the whole
+    // window at once on the host's cores; Linearize() below then only cuts blocks
+    if (recomputed && jacobians && eager_psd_threads_ >= 0)
+      sage_window_prepare_factors(win_, psd_mode_, eager_psd_threads_);
     return recomputed != 0;
   }
 
@@ -131,6 +135,11 @@ private:
   int CS_, psd_mode_;
   std::vector<float> pose_, code_, scale_;
   std::mutex mutex_;
+
+public:
+  // >= 0: project every factor right after a batched linearisation on this many host threads (0 = all); -1: lazily, factor
+  // by factor inside Linearize() (what ISAM2's partial relinearisation wants when it touches a few factors only)
+  int eager_psd_threads_ = 0;
 };
 
 // In core/gtsam/photometric_factor.cpp the two bodies become (geometric_factor.cpp alike with type 1):

@@ -98,7 +98,7 @@ SYMBOLS = [
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_sort_locations", "sage_bind_thread_to_device",
+    "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_prepare_factors", "sage_factor_psd", "sage_factor_cut_blocks", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_sort_locations", "sage_bind_thread_to_device",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
@@ -641,6 +641,10 @@ class Window:
                 blocks[(i, j)] = G[o:o + dims[i] * dims[j]].reshape(dims[i], dims[j]); o += dims[i] * dims[j]
         offs = np.concatenate([[0], np.cumsum(dims)])
         return blocks, [g[offs[i]:offs[i + 1]] for i in range(nk.value)], f.value, dims
+
+    def prepare_factors(self, psd_mode: int = 1, n_threads: int = 0):
+        """f2: NearestPsd of every cached factor on host threads; factor(.., psd_mode) then only cuts blocks."""
+        _chk(lib().sage_window_prepare_factors(self.h, psd_mode, n_threads), "sage_window_prepare_factors")
 
     def factor_error(self, type_, e) -> float:
         v = C.c_double()

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #include <dlfcn.h>
@@ -1292,6 +1293,10 @@ struct SageWindow
     bool lin = false, err = false;
     std::vector<float> pose, code, scale;         // the key: [K][12], [K][CS], [K]
     std::vector<float> Ap, bp, sp, Ag, bg, sg;    // per local directed edge: AtA, Atb, (error, n_inliers)
+    // sage_window_prepare_factors: the projected (NearestPsd) double matrices of every local edge, computed on several
+    // host threads right after a prepass; psd_mode < 0: not prepared for the cached linearisation
+    std::vector<double> Cp, Cg;
+    int psd_mode = -1;
   } fc;
   // optional kernel timing (HIP events on `stream`)
   bool profiling = false;
@@ -2616,6 +2621,7 @@ extern "C" int sage_window_prepass(SageWindow *w, const float *pose12, const flo
   {
     (void)sync_candidate(w);
     fc.lin = fc.err = false;
+    fc.psd_mode = -1;
     fc.pose.assign(pose12, pose12 + np);
     fc.code.assign(codes, codes + nc);
     fc.scale.assign(scales, scales + K);
@@ -2705,8 +2711,64 @@ extern "C" int sage_window_factor(const SageWindow *w, int type, int e, int psd_
     return SAGE_E_INVALID;
   if (f_out)
     *f_out = (double)st[(size_t)le * 2];
+  const std::vector<double> &Cc = type == 0 ? fc.Cp : fc.Cg;
+  if (fc.psd_mode == psd_mode && ((size_t)le + 1) * D * D <= Cc.size()) // prepared on the host threads already
+    return sage_factor_cut_blocks(type, CS, Cc.data() + (size_t)le * D * D, b.data() + (size_t)le * D, G_out, g_out,
+                                  dims_out, nkeys_out);
   return sage_factor_hessian_blocks(type, CS, A.data() + (size_t)le * D * D, b.data() + (size_t)le * D, psd_mode, G_out,
                                     g_out, dims_out, nkeys_out);
+}
+
+// NearestPsd of EVERY cached factor on `n_threads` host threads (0 = as many as the host has, at most 32): the per-factor
+// projection is the host cost of the gtsam path (an SVD / eigen-decomposition of a 45 x 45 and a 78 x 78 matrix per link
+// direction, photometric_factor.cpp:142-149) -- ISAM2 pays it factor by factor, here it is paid once per Values in
+// parallel and sage_window_factor only cuts blocks afterwards.
+extern "C" int sage_window_prepare_factors(SageWindow *w, int psd_mode, int n_threads)
+{
+  if (!w || !w->finalized || psd_mode < 0 || psd_mode > 2)
+    return SAGE_E_INVALID;
+  SageWindow::FactorCache &fc = w->fc;
+  if (!fc.lin)
+    return SAGE_E_STATE;
+  if (fc.psd_mode == psd_mode)
+    return SAGE_OK;
+  const int CS = w->cfg.CS;
+  const size_t Dp = 13 + CS, Dg = 14 + 2 * CS;
+  const size_t nep = fc.Ap.size() / (Dp * Dp), neg = fc.Ag.size() / (Dg * Dg);
+  fc.Cp.assign(nep * Dp * Dp, 0.0);
+  fc.Cg.assign(neg * Dg * Dg, 0.0);
+  const size_t total = nep + neg;
+  if (n_threads <= 0)
+    n_threads = (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));
+  n_threads = (int)std::min<size_t>((size_t)n_threads, std::max<size_t>(1, total));
+  std::atomic<size_t> next{0};
+  std::atomic<int> bad{0};
+  auto work = [&]() {
+    for (;;)
+    {
+      // geometric factors first: they are the long jobs (78 x 78)
+      const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= total)
+        return;
+      int rc;
+      if (i < neg)
+        rc = sage_factor_psd(1, CS, fc.Ag.data() + i * Dg * Dg, psd_mode, fc.Cg.data() + i * Dg * Dg);
+      else
+        rc = sage_factor_psd(0, CS, fc.Ap.data() + (i - neg) * Dp * Dp, psd_mode, fc.Cp.data() + (i - neg) * Dp * Dp);
+      if (rc)
+        bad.store(rc, std::memory_order_relaxed);
+    }
+  };
+  std::vector<std::thread> th;
+  for (int t = 1; t < n_threads; ++t)
+    th.emplace_back(work);
+  work();
+  for (auto &t : th)
+    t.join();
+  if (bad.load())
+    return bad.load();
+  fc.psd_mode = psd_mode;
+  return SAGE_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -138,3 +138,45 @@ def test_per_link_geometric_loss_parameter(capi, orc):
     tot = win.error_tensor().cpu().numpy()      # [err_photo err_geo n_photo n_geo]
     assert tot[1] == pytest.approx(tot_lin, rel=1e-5)
     win.close()
+
+
+def test_prepare_factors_on_host_threads_matches_lazy(capi):
+    """sage_window_prepare_factors: NearestPsd of every cached factor on host threads right after the prepass; the blocks
+    sage_window_factor then hands out are bit-identical to the ones it computes factor by factor, for every psd_mode; a
+    prepass at new Values invalidates the prepared set."""
+    import time
+    CS = 32
+    w = synth.make_window(K=6, H=64, W=80, FS=16, CS=CS, L=4, seed=9)
+    win = capi.Window(w)
+    poses, codes, scales = window_values(w)
+    assert win.prepass(poses, codes, scales, jacobians=True)
+    ne = 2 * len(w.links)
+    for psd in (1, 2, 0):
+        t0 = time.perf_counter()
+        lazy = {(t, e): win.factor(t, e, psd_mode=psd) for t in (0, 1) for e in range(ne)}
+        t_lazy = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        win.prepare_factors(psd, 0)
+        t_prep = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        for (t, e), (blocks, gs, f, dims) in lazy.items():
+            b2, g2, f2, d2 = win.factor(t, e, psd_mode=psd)
+            assert d2 == dims and f2 == f
+            assert all(np.array_equal(b2[k], blocks[k]) for k in blocks)
+            assert all(np.array_equal(x, y) for x, y in zip(g2, gs))
+        t_cut = time.perf_counter() - t0
+        print(f"psd_mode {psd}: {2 * ne} factors lazily {1e3 * t_lazy:.1f} ms; prepared on host threads {1e3 * t_prep:.1f} ms "
+              f"+ block cutting {1e3 * t_cut:.1f} ms")
+        # a different mode is served lazily again (and still right)
+        other = 1 if psd != 1 else 2
+        bo, _, _, _ = win.factor(0, 0, psd_mode=other)
+        assert all(np.array_equal(bo[k], v) for k, v in
+                   capi.factor_hessian_blocks(0, CS, win.get_edge(0, 0)["AtA"], win.get_edge(0, 0)["Atb"], psd_mode=other)[0].items())
+    # new Values: the prepared set is dropped with the cache
+    poses2 = poses.copy(); poses2[1, 9:] += np.float32(0.003)
+    assert win.prepass(poses2, codes, scales, jacobians=True)
+    b_new, _, _, _ = win.factor(0, 0, psd_mode=1)
+    he = win.get_edge(0, 0)
+    ref = capi.factor_hessian_blocks(0, CS, he["AtA"], he["Atb"], psd_mode=1)[0]
+    assert all(np.array_equal(b_new[k], ref[k]) for k in ref)
+    win.close()
