@@ -389,7 +389,7 @@ int sage_window_factor(const SageWindow *w, int type, int e, int psd_mode, doubl
                        int *dims_out, int *nkeys_out);
 int sage_window_factor_error(const SageWindow *w, int type, int e, double *err_out);
 /* Optional, after a prepass with jacobians: NearestPsd (psd_mode as above) of EVERY cached factor on n_threads host threads
- * (0 = all, at most 32).  The projection -- an SVD / eigen-decomposition of a (13+CS)^2 and a (14+2CS)^2 matrix per link
+ * (0 = a quarter of the host's hardware threads, at most 64).  The projection -- an SVD / eigen-decomposition of a (13+CS)^2 and a (14+2CS)^2 matrix per link
  * direction -- is the host cost of the gtsam path (photometric_factor.cpp:142-149); ISAM2 pays it factor by factor, this
  * pays it once per Values in parallel, and sage_window_factor with the same psd_mode then only cuts blocks.  The next
  * prepass that recomputes invalidates it. */

@@ -2719,7 +2719,7 @@ extern "C" int sage_window_factor(const SageWindow *w, int type, int e, int psd_
                                     g_out, dims_out, nkeys_out);
 }
 
-// NearestPsd of EVERY cached factor on `n_threads` host threads (0 = as many as the host has, at most 32): the per-factor
+// NearestPsd of EVERY cached factor on `n_threads` host threads (0 = a quarter of the host's hardware threads, at most 64): the per-factor
 // projection is the host cost of the gtsam path (an SVD / eigen-decomposition of a 45 x 45 and a 78 x 78 matrix per link
 // direction, photometric_factor.cpp:142-149) -- ISAM2 pays it factor by factor, here it is paid once per Values in
 // parallel and sage_window_factor only cuts blocks afterwards.
@@ -2739,7 +2739,7 @@ extern "C" int sage_window_prepare_factors(SageWindow *w, int psd_mode, int n_th
   fc.Cg.assign(neg * Dg * Dg, 0.0);
   const size_t total = nep + neg;
   if (n_threads <= 0)
-    n_threads = (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));
+    n_threads = (int)std::min<unsigned>(64u, std::max(1u, std::thread::hardware_concurrency() / 4)); // a quarter of the host, <= 64
   n_threads = (int)std::min<size_t>((size_t)n_threads, std::max<size_t>(1, total));
   std::atomic<size_t> next{0};
   std::atomic<int> bad{0};
