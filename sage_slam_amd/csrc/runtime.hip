@@ -1470,28 +1470,27 @@ extern "C" int sage_window_set_link_geo_loss(SageWindow *w, int link, float loss
   return SAGE_OK;
 }
 
-extern "C" int sage_bind_thread_to_device(int device)
+static bool device_local_cpulist(int device, char *buf, size_t n)
 {
   char bdf[64] = {0};
   if (hipDeviceGetPCIBusId(bdf, (int)sizeof(bdf), device) != hipSuccess)
-    return SAGE_E_INVALID;
+    return false;
   for (char *p = bdf; *p; ++p)
     *p = (char)tolower((unsigned char)*p);
   char path[160];
   snprintf(path, sizeof(path), "/sys/bus/pci/devices/%s/local_cpulist", bdf);
   FILE *f = fopen(path, "r");
   if (!f)
-    return 0;
-  char buf[4096] = {0};
-  const bool got = fgets(buf, sizeof(buf), f) != nullptr;
+    return false;
+  buf[0] = 0;
+  const bool got = fgets(buf, (int)n, f) != nullptr;
   fclose(f);
-  if (!got)
-    return 0;
-  cpu_set_t allowed, want;
-  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
-    return 0;
-  CPU_ZERO(&want);
-  int n = 0;
+  return got;
+}
+
+static std::vector<int> parse_cpulist(const char *buf)
+{
+  std::vector<int> out;
   for (const char *p = buf; *p;)
   {
     char *end;
@@ -1506,17 +1505,85 @@ extern "C" int sage_bind_thread_to_device(int device)
       p = end;
     }
     for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
-      if (CPU_ISSET(c, &allowed))
-      {
-        CPU_SET(c, &want);
-        ++n;
-      }
+      out.push_back((int)c);
     if (*p == ',')
       ++p;
   }
-  if (n == 0 || sched_setaffinity(0, sizeof(want), &want) != 0)
+  return out;
+}
+
+// One process per GPU: keep the driving thread on the CPUs the GPU hangs off (its NUMA node: the window solve reads
+// freshly DMA'd pinned memory), and -- when several GPUs share that node -- on its own L3 domain (CCX) of the node: the
+// solve pins its helper / worker threads to the other cores of the caller's CCX (host_math.cpp), so two ranks whose
+// driving threads shared a CCX would share those cores.  Returns the number of CPUs the thread is bound to (0: unchanged).
+extern "C" int sage_bind_thread_to_device(int device)
+{
+  char buf[4096] = {0};
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+    return SAGE_E_INVALID;
+  if (!device_local_cpulist(device, buf, sizeof(buf)))
     return 0;
-  return n;
+  cpu_set_t allowed, want;
+  if (sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
+    return 0;
+  std::vector<int> cpus;
+  for (int c : parse_cpulist(buf))
+    if (CPU_ISSET(c, &allowed))
+      cpus.push_back(c);
+  if (cpus.empty())
+    return 0;
+  // devices on the same node, this one's position among them
+  int on_node = 0, my_pos = 0;
+  for (int d = 0; d < ndev; ++d)
+  {
+    char other[4096] = {0};
+    if (d == device || (device_local_cpulist(d, other, sizeof(other)) && strcmp(other, buf) == 0))
+    {
+      if (d < device)
+        ++my_pos;
+      ++on_node;
+    }
+  }
+  if (on_node > 1)
+  {
+    // L3 domains of the node, in the order of their first CPU
+    std::vector<std::vector<int>> groups;
+    std::vector<char> seen(CPU_SETSIZE, 0);
+    for (int c : cpus)
+    {
+      if (seen[c])
+        continue;
+      char path[160], lb[4096] = {0};
+      snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", c);
+      FILE *f = fopen(path, "r");
+      std::vector<int> g;
+      if (f)
+      {
+        if (fgets(lb, sizeof(lb), f))
+          for (int x : parse_cpulist(lb))
+            if (x < CPU_SETSIZE && CPU_ISSET(x, &allowed) && std::find(cpus.begin(), cpus.end(), x) != cpus.end())
+              g.push_back(x);
+        fclose(f);
+      }
+      if (g.empty())
+        g.push_back(c);
+      for (int x : g)
+        seen[x] = 1;
+      groups.push_back(g);
+    }
+    if (groups.size() > 1)
+    {
+      const size_t stride = std::max<size_t>(1, groups.size() / (size_t)on_node);
+      cpus = groups[((size_t)my_pos * stride) % groups.size()];
+    }
+  }
+  CPU_ZERO(&want);
+  for (int c : cpus)
+    CPU_SET(c, &want);
+  if (sched_setaffinity(0, sizeof(want), &want) != 0)
+    return 0;
+  return (int)cpus.size();
 }
 
 extern "C" int sage_window_set_allreduce(SageWindow *w, SageAllReduceFn fn, void *user)
