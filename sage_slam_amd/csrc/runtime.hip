@@ -2061,8 +2061,9 @@ extern "C" int sage_window_finalize(SageWindow *w)
       {
         std::nth_element(tiles.begin(), tiles.begin() + tiles.size() / 2, tiles.end());
         const int T = std::max(1, tiles[tiles.size() / 2]); // the typical edge
-        const int nwg = (T + tpb - 1) / tpb;
-        tpb = (T + nwg - 1) / nwg;
+        const int nwg = (T + tpb - 1) / tpb, rem = T % tpb;
+        if (rem != 0 && 4 * rem < 3 * tpb) // (a nearly full last run is left alone: T = 63 stays at runs of 8 -- 7 x 9 and
+          tpb = (T + nwg - 1) / nwg;       //  9 x 7 measured 5-7 % slower on the headline window)
       }
     }
     if (const char *e = getenv("SAGE_PHOTO_TPB"))
