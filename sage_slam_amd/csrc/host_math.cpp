@@ -2015,8 +2015,9 @@ static void sep_job_build(SepJob &J)
         rng(i, h, a, b);
         rng(i2, h, a2, b2);
         const int k0 = std::max(a, a2), k1 = std::min(b, b2);
-        if (k1 > k0)
-          J.tb.push_back({i, i2, h, k0, k1});
+        // (pieces of <= 64 columns: the pair products of two long arrow rows spread over the whole pool)
+        for (int c0 = k0; c0 < k1; c0 += 64)
+          J.tb.push_back({i, i2, h, c0, std::min(k1, c0 + 64)});
       }
   std::stable_sort(J.tb.begin(), J.tb.end(), [](const SepTaskB &x, const SepTaskB &y) { return x.k1 - x.k0 > y.k1 - y.k0; });
   J.Sd.assign(J.ta.size() * (size_t)BB, 0.0);
