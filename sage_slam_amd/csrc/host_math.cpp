@@ -1844,6 +1844,8 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
       for (int q = 0; q < nm; ++q)
       {
         const int m = E.col_ptr ? E.col_rows[E.col_ptr[i] + q] : i + 1 + q;
+        if (m >= E.bs_skip_from)
+          break; // (ascending lists: the separator rows come last)
         if (!E.col_ptr && !has(m, i))
           continue;
         const double *Tm = blk(m, i) + t0 * BP, *xm = y + (size_t)m * BP;
@@ -1978,6 +1980,10 @@ struct SepJob
   std::atomic<int> nextA{0}, doneA{0}, nextB{0}, doneB{0};
   std::atomic<int> abort{0};
   std::atomic<int> progress[2];
+  // phase C (back substitution): y_i -= sum over the separator rows m of L_mi^T x_m for the rows i of the halves, in
+  // chunks of rows -- after the separator rows' x are known (goC: 0 wait, 1 go, 2 skip)
+  std::vector<std::pair<int, int>> tc;
+  std::atomic<int> goC{0}, nextC{0}, doneC{0};
 };
 
 static void sep_job_build(SepJob &J)
@@ -2025,6 +2031,54 @@ static void sep_job_build(SepJob &J)
   J.Pp.assign(J.tb.size() * (size_t)BB, 0.0);
   J.progress[0].store(0, std::memory_order_relaxed);
   J.progress[1].store(E.n1, std::memory_order_relaxed);
+  if (E.col_ptr)
+    for (int r0 = 0; r0 < sep0; r0 += 32)
+      J.tc.push_back({r0, std::min(sep0, r0 + 32)});
+}
+
+template <int NV>
+static inline __attribute__((always_inline)) void sep_run_c(SepJob &J, int t)
+{
+  constexpr int BP = NV * 8, BB = BP * BP;
+  const BlockEnvelope &E = *J.E;
+  double *T = J.T, *y = J.y;
+  auto blk = [&](int r, int c) {
+    return T + (size_t)(c < E.row_first[r] ? E.a_off[r] + c - E.a_first[r] : E.row_off[r] + c - E.row_first[r]) * BB;
+  };
+  for (int i = J.tc[t].first; i < J.tc[t].second; ++i)
+  {
+    const int n0 = E.col_ptr[i], n1 = E.col_ptr[i + 1];
+    int q0 = n0;
+    while (q0 < n1 && E.col_rows[q0] < J.sep0)
+      ++q0;
+    if (q0 == n1)
+      continue;
+    for (int t0 = 0; t0 < BP; t0 += 8)
+    {
+      v8d acc[8];
+      for (int u = 0; u < 8; ++u)
+        acc[u] = v8d{0, 0, 0, 0, 0, 0, 0, 0};
+      for (int q = q0; q < n1; ++q)
+      {
+        const int m = E.col_rows[q];
+        const double *Tm = blk(m, i) + t0 * BP, *xm = y + (size_t)m * BP;
+        for (int v = 0; v < NV; ++v)
+        {
+          v8d xv;
+          SAGE_LOADU(xv, xm + 8 * v);
+          for (int u = 0; u < 8; ++u)
+          {
+            v8d a;
+            SAGE_LOADU(a, Tm + u * BP + 8 * v);
+            acc[u] += a * xv;
+          }
+        }
+      }
+      for (int u = 0; u < 8; ++u)
+        y[(size_t)i * BP + t0 + u] -=
+            ((acc[u][0] + acc[u][4]) + (acc[u][1] + acc[u][5])) + ((acc[u][2] + acc[u][6]) + (acc[u][3] + acc[u][7]));
+    }
+  }
 }
 
 template <int NV>
@@ -2183,6 +2237,8 @@ __attribute__((target_clones("avx512f", "avx2", "default"))) static void sep_run
 __attribute__((target_clones("avx512f", "avx2", "default"))) static void sep_run_a_24(SepJob &J, int t) { sep_run_a<3>(J, t); }
 __attribute__((target_clones("avx512f", "avx2", "default"))) static void sep_run_b_40(SepJob &J, int t) { sep_run_b<5>(J, t); }
 __attribute__((target_clones("avx512f", "avx2", "default"))) static void sep_run_b_24(SepJob &J, int t) { sep_run_b<3>(J, t); }
+__attribute__((target_clones("avx512f", "avx2", "default"))) static void sep_run_c_40(SepJob &J, int t) { sep_run_c<5>(J, t); }
+__attribute__((target_clones("avx512f", "avx2", "default"))) static void sep_run_c_24(SepJob &J, int t) { sep_run_c<3>(J, t); }
 __attribute__((target_clones("avx512f", "avx2", "default"))) static int sep_finish_40(SepJob &J) { return sep_finish<5>(J); }
 __attribute__((target_clones("avx512f", "avx2", "default"))) static int sep_finish_24(SepJob &J) { return sep_finish<3>(J); }
 
@@ -2210,6 +2266,30 @@ static void sep_work(SepJob &J)
     if (!J.abort.load(std::memory_order_acquire))
       b40 ? sep_run_b_40(J, t) : sep_run_b_24(J, t);
     J.doneB.fetch_add(1, std::memory_order_acq_rel);
+  }
+}
+
+// phase C: entered by the pool's workers right after sep_work (they wait for the caller's go), by the caller when the
+// separator rows are back-substituted
+static void sep_work_c(SepJob &J, bool wait_for_go)
+{
+  if (wait_for_go)
+  {
+    int g;
+    while ((g = J.goC.load(std::memory_order_acquire)) == 0)
+      __builtin_ia32_pause();
+    if (g != 1)
+      return;
+  }
+  const bool b40 = J.E->Bp == 40;
+  const int nC = (int)J.tc.size();
+  for (;;)
+  {
+    const int t = J.nextC.fetch_add(1, std::memory_order_acq_rel);
+    if (t >= nC)
+      break;
+    b40 ? sep_run_c_40(J, t) : sep_run_c_24(J, t);
+    J.doneC.fetch_add(1, std::memory_order_acq_rel);
   }
 }
 
@@ -2246,7 +2326,10 @@ struct SepPool
           seen = p;
           active.fetch_add(1, std::memory_order_acq_rel);
           if (open.load(std::memory_order_acquire))
+          {
             sep_work(*job);
+            sep_work_c(*job, true);
+          }
           active.fetch_sub(1, std::memory_order_acq_rel);
         }
         __builtin_ia32_pause();
@@ -2815,14 +2898,6 @@ int block_chol_solve_tr(const BlockEnvelope &E0, double *T, double *X, double *y
     sep_work(job); // the caller takes tasks too (all of them when no pool thread is around)
     while (job.doneB.load(std::memory_order_acquire) < (int)job.tb.size())
       CholHelper::cpu_relax();
-    if (pool_mine)
-    {
-      pool->open.store(false, std::memory_order_release);
-      while (pool->active.load(std::memory_order_acquire) != 0)
-        CholHelper::cpu_relax();
-      pool->armed.store(false, std::memory_order_release);
-      pool->busy.store(false, std::memory_order_release);
-    }
     if (rc == 0 && job.abort.load(std::memory_order_acquire))
       rc = -2;
     if (rc == 0)
@@ -2832,6 +2907,28 @@ int block_chol_solve_tr(const BlockEnvelope &E0, double *T, double *X, double *y
     rc = block_chol_range(E, T, X, y, 0, sep0, K);
   if (rc == 0)
     block_chol_range(E, T, X, y, 1, sep0, K);
+  if (arrow)
+  {
+    // the separator rows' share of every half row's back substitution, in row chunks on the pool (the arrow rows put three
+    // more blocks into every column: streaming them once, in parallel, instead of inside the two sequential sweeps)
+    const bool par_c = rc == 0 && !job.tc.empty();
+    job.goC.store(par_c ? 1 : 2, std::memory_order_release);
+    if (par_c)
+    {
+      sep_work_c(job, false);
+      while (job.doneC.load(std::memory_order_acquire) < (int)job.tc.size())
+        CholHelper::cpu_relax();
+      E.bs_skip_from = sep0;
+    }
+    if (pool_mine)
+    {
+      pool->open.store(false, std::memory_order_release);
+      while (pool->active.load(std::memory_order_acquire) != 0)
+        CholHelper::cpu_relax();
+      pool->armed.store(false, std::memory_order_release);
+      pool->busy.store(false, std::memory_order_release);
+    }
+  }
   if (dbg)
     tp[3] = mono_seconds();
   if (helper_has_it)

@@ -65,6 +65,9 @@ struct BlockEnvelope
   // optional: for every column j the rows i > j that store a block (i, j), ascending (col_rows[col_ptr[j] .. col_ptr[j+1]));
   // the back substitution then visits exactly those instead of scanning all rows below j
   const int32_t *col_ptr = nullptr, *col_rows = nullptr;
+  // back substitution: rows m >= bs_skip_from are left out of  sum_m L_mi^T x_m  (their part has been subtracted from y
+  // beforehand, in parallel: the arrow rows of a loop-closure plan)
+  int bs_skip_from = 0x7fffffff;
 };
 // In place: T becomes L^T blockwise, X (K*Bp*Bp) receives the inverses of the diagonal factors, y (K*Bp) the
 // right-hand side on entry and the solution on return.  Returns 0, or 1 + the block column of the first non-positive
