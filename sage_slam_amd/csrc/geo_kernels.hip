@@ -151,6 +151,10 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
   for (int h = 0; h < nsub; ++h)
   {
     {
+    // wave priority: the geometry phase (loads + per-pixel arithmetic) ahead of the other waves' contraction phases
+    // (r03: 0.550 -> 0.534 ms)
+    if (JAC)
+      __builtin_amdgcn_s_setprio(3);
     const int tile = wi.tile + h;
     const int n = tile * kTile + wq * 64 + lane;
     bool in_range = n < N;
@@ -253,6 +257,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
     } // geometry phase
     if (JAC)
     {
+    __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_wave_barrier(); // same-wave LDS hand-over (in-order LDS pipe): no workgroup barrier needed
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     // ---- contraction over this wave's 64 pixels (staged by this wave in the previous half-step), K = 4 pixels per MFMA ----
