@@ -33,11 +33,11 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 # HBM bytes per launch of the dominant kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-# passes, same workload: scripts/pmc_run.sh -> profiles/r03_v1_pmc_summary.txt).  FETCH_SIZE is doubled as
+# passes, same workload: scripts/pmc_run.sh -> profiles/r03_v3_pmc_summary.txt).  FETCH_SIZE is doubled as
 # MI355X_MICROARCH.md prescribes for 16 B/lane reads on gfx950 (all tap loads are dwordx4).  bench.py cannot collect
 # PMC counters itself; this is the committed measurement for the K=64 headline window (null for any other workload).
-PMC_TRAFFIC_BYTES_K64 = {"fetch_size_kb": 1.15389e6, "write_size_kb": 82583.0,
-                         "hbm_bytes_per_launch": (2 * 1.15389e6 + 82583.0) * 1024.0}
+PMC_TRAFFIC_BYTES_K64 = {"fetch_size_kb": 1.06839e6, "write_size_kb": 82245.9,
+                         "hbm_bytes_per_launch": (2 * 1.06839e6 + 82245.9) * 1024.0}
 
 
 def cpu_baseline(win, budget_s: float = 20.0):
@@ -485,7 +485,7 @@ def main():
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                          "traffic": (PMC_TRAFFIC_BYTES_K64["hbm_bytes_per_launch"]
                                      if (world == 1 and args.keyframes == 64 and args.height == 128 and args.fs == 16) else None),
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, profiles/r03_v1_pmc_summary.txt",
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, profiles/r03_v3_pmc_summary.txt",
                          "bytes_per_launch": px_launch * bytes_photo_px, "avg_launch_ms": ms_photo,
                          "geo_kernel": {"achieved": ach_geo, "frac": ach_geo / HBM_PEAK_GBS, "avg_launch_ms": ms_geo,
                                         "bytes_per_launch": px_launch * bytes_geo_px},
