@@ -426,12 +426,27 @@ def main():
         win.kernel_time(which)
     barrier()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        if i % RESTART == 0:
+    if dist is None or not py_steps:
+        # the engine's own loop: sage_window_lm_run drives the RESTART iterations between two restarts from C++ (no
+        # Python between the iterations being timed; a sharded window still enters Python for a gloo hook, never for RCCL)
+        i = 0
+        while i < args.steps:
             win.reset()
             damp = float(cfg.init_damp)
             state.iters = 0
-        hist.append(lm_step())
+            state.damp = damp
+            n = min(RESTART, args.steps - i)
+            for e0, e1, acc, d in win.lm_run(state, cfg, n):
+                hist.append((float(e0), float(e1), bool(acc)))
+            damp = state.damp
+            i += n
+    else:
+        for i in range(args.steps):
+            if i % RESTART == 0:
+                win.reset()
+                damp = float(cfg.init_damp)
+                state.iters = 0
+            hist.append(lm_step())
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:

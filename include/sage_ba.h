@@ -571,6 +571,9 @@ typedef struct SageLmState
   int accepted, iters;
 } SageLmState;
 int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmConfig *cfg);
+/* n iterations of sage_window_lm_step in one call; trace (optional): n x {error, candidate_error, accepted, damp after the
+ * step}; *done (optional) = iterations completed (an error code ends the run early). */
+int sage_window_lm_run(SageWindow *w, SageLmState *st, const SageLmConfig *cfg, int n, double *trace, int *done);
 /* Sharded windows with the domain-decomposed solve (sage_shard_*: chosen at sage_window_finalize for world > 1 when
  * SAGE_SHARD_SCHUR=1, or by default from K >= 256 keyframes): sage_window_lm_step all-reduces the separator system
  * instead of the packed normal equations, and a rank only updates the keyframes its own links touch.  Call this (a

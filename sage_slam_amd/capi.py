@@ -98,7 +98,7 @@ SYMBOLS = [
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_prepare_factors", "sage_factor_psd", "sage_factor_cut_blocks", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_sort_locations", "sage_bind_thread_to_device",
+    "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_prepare_factors", "sage_factor_psd", "sage_factor_cut_blocks", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_lm_step", "sage_window_lm_run", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_sort_locations", "sage_bind_thread_to_device",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
@@ -592,6 +592,14 @@ class Window:
     def lm_step(self, state: SageLmState, cfg: SageLmConfig):
         _chk(lib().sage_window_lm_step(self.h, C.byref(state), C.byref(cfg)), "sage_window_lm_step")
         return state
+
+    def lm_run(self, state: SageLmState, cfg: SageLmConfig, n: int):
+        """n LM iterations without returning to Python in between -> [n, 4] trace {error, candidate, accepted, damp}."""
+        tr = np.zeros((n, 4), np.float64)
+        done = C.c_int()
+        _chk(lib().sage_window_lm_run(self.h, C.byref(state), C.byref(cfg), n, tr.ctypes.data_as(C.POINTER(C.c_double)),
+                                      C.byref(done)), "sage_window_lm_run")
+        return tr[:done.value]
 
     def delta(self):
         d = np.zeros(self.K * self.B, np.float64)

@@ -3700,3 +3700,28 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
   st->iters += 1;
   return SAGE_OK;
 }
+
+// n LM iterations in one call (the loop a C++ caller writes around sage_window_lm_step; bench.py uses it so that no Python
+// runs between the iterations it times).  trace (optional): n x {error, candidate_error, accepted, damp after the step}.
+// Stops early on an error code; *done (optional) = iterations completed.
+extern "C" int sage_window_lm_run(SageWindow *w, SageLmState *st, const SageLmConfig *cfg, int n, double *trace, int *done)
+{
+  if (!w || !st || !cfg || n < 0)
+    return SAGE_E_INVALID;
+  int i = 0, rc = SAGE_OK;
+  for (; i < n; ++i)
+  {
+    if ((rc = sage_window_lm_step(w, st, cfg)))
+      break;
+    if (trace)
+    {
+      trace[4 * i + 0] = st->error;
+      trace[4 * i + 1] = st->candidate_error;
+      trace[4 * i + 2] = (double)st->accepted;
+      trace[4 * i + 3] = st->damp;
+    }
+  }
+  if (done)
+    *done = i;
+  return rc;
+}
