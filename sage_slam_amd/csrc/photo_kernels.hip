@@ -14,6 +14,8 @@
 //      (v_mfma_f32_16x16x4_f32, K = 4 pixels) contractions fed from the LDS basis tile.
 //
 // Algorithmic bytes per source pixel: 4*[4*FS*rho + CS + 6].
+#include <type_traits>
+
 #include "host_math.h" // env_flag
 #include "sage_device.h"
 #include "sage_internal.h"
@@ -51,9 +53,6 @@ struct PhotoParams
   // concatenated pyramid, lds_ntex texels x FS/4 channel groups x 16 B) are staged in LDS once per workgroup and their
   // taps read with ds_read_b128 instead of going through the texture path; lds_l0 >= levels: off
   int lds_l0, lds_base, lds_ntex;
-  // split linearize (STAGE 1 -> 2): per-pixel hand-over record {G00, G01, G11, v0, v1, err*vm, vm, -} of the sampling
-  // phase, [n_work][tiles_per_block][256] x 8 floats (a workgroup owns the slab of its work item)
-  float *pixrec;
 };
 
 __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
@@ -83,23 +82,100 @@ __device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i 
 #ifndef SAGE_PHOTO_LIN_GUNROLL
 #define SAGE_PHOTO_LIN_GUNROLL 8
 #endif
-#ifndef SAGE_PHOTO_B_WAVES
-#define SAGE_PHOTO_B_WAVES 4 // split linearize, sampling stage: waves per SIMD it is register-budgeted for (128 VGPR, no spills)
-#endif
-#ifndef SAGE_PHOTO_CD_WAVES
-#define SAGE_PHOTO_CD_WAVES 3
-#endif
 
 // per-pixel hand-over from the sampling phase (lane = pixel) to the contraction phase (lane = (channel i, pixel k)):
 //   [0..7] rows of the cross tile: c(6) = S(0:6,6), sigma*d, u6      [8] sigma = S66     [9] loc*CS*4 (int bits)
 //   [10..23] A rows of the pose tile: G*Q rows (2 x 6), v (2)         [24..37] its B columns: Q (2 x 6), q6*d (2)
 // Operand rows / columns 14, 15 of the pose tile read whatever follows (finite values): they only reach the output
 // rows / columns 14, 15, which nothing reads.
-#ifdef SAGE_EXP_STASH_LD // TIMING-ONLY experiment (wrong values): a smaller stash row so that four workgroups fit a CU
-constexpr int kPhotoStashLD = SAGE_EXP_STASH_LD;
-#else
 constexpr int kPhotoStashLD = 40; // floats per pixel, 16-byte aligned rows
+
+// ---- LDS-staged sampler of the linearize kernel (engine layout) ------------------------------------------------------
+// A wave's 64 source pixels (an 8 x 8 image tile when the samples are in the engine's tile order) warp to a compact
+// footprint in the destination keyframe: per channel group the wave copies the texels of that footprint's bounding box
+// -- level 0 into one region, the coarser levels together into a second one, for feat1, d/dx and d/dy -- into its own
+// stash memory (idle during the sampling phase) with LDS-direct buffer loads (lane = texel, no VGPR round trip), and
+// every bilinear tap is a ds_read_b128 instead of a gather through the CU's texture path: ~9 wave-loads per channel
+// group through the texture path instead of 48.  The regions of group g + 1 are filled while group g is reduced
+// (level 0 right after its taps were read, the coarse levels at the end of the group).  Footprints that do not fit
+// (strong zoom / rotation between the keyframes, samples that are not in tile order) take the texture path.
+constexpr int kStageLevels = 4;  // the staged sampler is built for 4-level pyramids (straight-line code, static counters)
+// (capacities = whole rounds of 64 lanes: the number of loads per fill is fixed -- 6 and 3 -- and the wait counts exact)
+constexpr int kStageCap0 = 128;  // texels per array, level 0: two rounds      (11 x 11 footprints fit)
+constexpr int kStageCapC = 64;   // texels per array, levels >= 1 together: one round (6 x 6 + 4 x 4 + 3 x 3 = 61)
+static_assert(3 * (kStageCap0 + kStageCapC) * 16 <= 64 * kPhotoStashLD * 4, "the staging regions alias the wave's stash");
+
+// 16-byte LDS read at a byte address of the workgroup's LDS allocation (ds_read_b128 v, vaddr offset:imm)
+__device__ __forceinline__ f32x4 lds_read16(uint32_t addr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef const f32x4 __attribute__((address_space(3))) *LdsF4;
+  return *(LdsF4)(addr);
+#else
+  (void)addr;
+  return f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
+}
+
+// one LDS-direct 16-byte-per-lane load: LDS[lds_byte + 16 * lane] = buffer[voff + soff]  (lds_byte, soff wave-uniform).
+// Invisible to the compiler's wait-count bookkeeping: every consumer sits behind an explicit vm_wait below.
+// s_nop 4: the hazard recogniser does not look inside inline asm -- an SGPR operand written by a VALU instruction right
+// before the statement (v_readlane of a spilled SGPR, v_readfirstlane) needs 5 wait states before a VMEM instruction
+// reads it (the first build faulted on exactly that), and m0 needs one before the LDS-direct load.
+template <uint32_t LDS_OFF>
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, uint32_t lds_base, uint32_t voff, uint32_t soff)
+{
+  // (m0 = base + compile-time offset formed by the instruction itself: nine live SGPRs of precomputed addresses less)
+  asm volatile("s_add_u32 m0, %0, %4\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+               :
+               : "s"(lds_base), "v"(voff), "s"(r), "s"(soff), "n"(LDS_OFF)
+               : "memory", "scc");
+}
+// 16-byte global load (wave-uniform base, per-lane byte offset) the compiler does not track either: the value must pass
+// through vm_wait_keep before its first use (scripts/check_asm_loads.py verifies that nothing touches the registers earlier)
+__device__ __forceinline__ f32x4 gload16(const float *sbase, uint32_t voff)
+{
+  f32x4 v;
+  asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_keep(f32x4 &v)
+{
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N) : "memory");
+}
+__device__ __forceinline__ void lgkm_wait0() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// optimisation barrier on six running sums: what feeds them is computed before this point, what reads them after it
+__device__ __forceinline__ void pin6(f32x2 &a, f32x2 &b, f32x2 &c, f32x2 &d, f32x2 &e, f32x2 &f)
+{
+  asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
+}
+
+// level-l pixel coordinate of a level-0 coordinate (:101-103, :142-144): ONE rounding sequence for the lanes and for the
+// bounding box (floor() of it is then monotone in p, so the box of [min p, max p] contains every lane's taps)
+__device__ __forceinline__ float level_coord(float p, float ratio) { return __builtin_fmaf(p + 0.5f, ratio, -0.5f); }
+
+template <int CTRL, int ROW_MASK, bool IS_MIN>
+__device__ __forceinline__ float dpp_fminmax(float v, float identity)
+{
+  const int x = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+  const float xf = __builtin_bit_cast(float, x);
+  return IS_MIN ? fminf(v, xf) : fmaxf(v, xf);
+}
+// wave64 float min / max, returned wave-uniform (same DPP ladder as wave_sum; lanes a masked step does not write keep `identity`)
+template <bool IS_MIN>
+__device__ __forceinline__ float wave_fminmax(float v)
+{
+  const float id = IS_MIN ? __builtin_inff() : -__builtin_inff();
+  v = dpp_fminmax<0xB1, 0xF, IS_MIN>(v, id);
+  v = dpp_fminmax<0x4E, 0xF, IS_MIN>(v, id);
+  v = dpp_fminmax<0x141, 0xF, IS_MIN>(v, id);
+  v = dpp_fminmax<0x140, 0xF, IS_MIN>(v, id);
+  v = dpp_fminmax<0x142, 0xA, IS_MIN>(v, id);
+  v = dpp_fminmax<0x143, 0xC, IS_MIN>(v, id);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
 // second-level accumulators of the noise-critical tiles (the two cross tiles and the pose tile: 3 x 4 floats per lane),
 // one region per wave (see "second level" in the kernel)
 #ifndef SAGE_PHOTO_L2_TILES
@@ -138,12 +214,8 @@ struct TapBatch
 //   D  code blocks: f32 MFMA 16x16x4 with the basis rows loaded from global memory directly in operand layout
 //      (lane = (channel pair i, pixel k): 16 lanes x dwordx2 = one 128-byte basis row; CS = 32: operand block 0 = even
 //      channels, block 1 = odd channels)
-// STAGE 0: the fused kernel.  STAGE 1 / 2: the linearize split in two launches -- 1 = phases A + B only (warp and the
-// tap gathers; no LDS, no reductions, high occupancy: bound by the CU's texture path), writes the per-pixel record
-// PhotoParams::pixrec; 2 = phases (A) + C + D from that record (bound by VALU / MFMA issue and LDS).  Same arithmetic in
-// the same order as the fused kernel: bit-identical partial records.
-template <int CS, int FS, bool JAC, int MODE, int STAGE = 0>
-__global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? SAGE_PHOTO_B_WAVES : STAGE == 2 ? SAGE_PHOTO_CD_WAVES : SAGE_PHOTO_WAVES) void photo_kernel(const PhotoParams prm)
+template <int CS, int FS, bool JAC, int MODE>
+__global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WAVES) void photo_kernel(const PhotoParams prm)
 {
   constexpr bool PACKED = MODE >= 1;
   constexpr int NB = CS / 16;
@@ -153,15 +225,14 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
   constexpr int GUNROLL = NG > GUNROLL_MAX ? GUNROLL_MAX : NG;
   constexpr int NT = photo_tiles(CS);
   constexpr int YY = NT; // the pose tile: accumulated like the code tiles, folded into the scalar slots at the end
-  constexpr bool CONTRACT = JAC && STAGE != 1; // this launch runs phases C / D
-  constexpr int STASH = CONTRACT ? kWaves * 64 * kPhotoStashLD + (kPhotoStashLD < 40 ? 64 : 0) : 1;
-  constexpr int SUMBUF = CONTRACT ? (NT + 1) * 256 : 1;
+  constexpr int STASH = JAC ? kWaves * 64 * kPhotoStashLD : 1;
+  constexpr int SUMBUF = JAC ? (NT + 1) * 256 : 1;
   __shared__ __attribute__((aligned(16))) float s_mem[STASH > SUMBUF ? STASH : SUMBUF];
   __shared__ float s_red[kWaves * 4]; // per wave: linearize {sigma d^2, error, inliers}, error pass {error, inliers, geo error, inliers}
   // second level of the noise-critical tiles: [wave][tile][r][lane]
-  __shared__ float s_l2[CONTRACT ? kWaves * kPhotoL2Tiles * 256 : 1];
+  __shared__ float s_l2[JAC ? kWaves * kPhotoL2Tiles * 256 : 1];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid_wg = threadIdx.x, tid = tid_wg, lane = tid & 63, wave = tid_wg >> 6;
   int bid = uni(xcd_work_index((int)blockIdx.x, prm.n_work, prm.xcd_chunk));
   if (bid < 0)
     return;
@@ -172,7 +243,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
   wi.tile = uni(wi.tile);
   PhotoEdge E = prm.table ? prm.table[wi.edge] : prm.single;
   E.feat0 = uni(E.feat0); E.feat1 = uni(E.feat1); E.grad1 = uni(E.grad1); E.dpt0 = uni(E.dpt0);
-  E.feat1_pk = uni(E.feat1_pk); E.gx1_pk = uni(E.gx1_pk); E.gy1_pk = uni(E.gy1_pk);
+  E.feat1_pk = uni(E.feat1_pk);
   E.basis0 = uni(E.basis0); E.mask1 = uni(E.mask1); E.homo = uni(E.homo); E.loc = uni(E.loc);
   E.R0 = uni(E.R0); E.t0 = uni(E.t0); E.R1 = uni(E.R1); E.t1 = uni(E.t1); E.R10 = uni(E.R10); E.t10 = uni(E.t10);
   E.N = uni(E.N); E.loc_is_i64 = uni(E.loc_is_i64); E.f0s = uni(E.f0s);
@@ -180,23 +251,31 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
   const int N = E.N;
 
   // ---- poses (wave-uniform) ----
-  const Pose p0 = JAC ? load_pose2(E.R0, E.t0) : Pose{};
-  const Pose p1 = JAC ? load_pose2(E.R1, E.t1) : Pose{};
   Pose p10;
   if (E.R10)
     p10 = load_pose2(E.R10, E.t10);
   else
+  {
     p10 = relative_pose(load_pose2(E.R0, E.t0), load_pose2(E.R1, E.t1));
+    // computed on the vector unit (no scalar float arithmetic on this part), wave-uniform: moved to SGPRs -- as 12 long-lived
+    // VGPRs it was spilled to scratch and reloaded (with a full vmcnt drain) in every sub-tile
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      p10.R[i] = uni(p10.R[i]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      p10.t[i] = uni(p10.t[i]);
+  }
 
   const SagePyramid &pyr = prm.pyr;
   const float fx0 = pyr.cam[0].fx, fy0 = pyr.cam[0].fy, cx0 = pyr.cam[0].cx, cy0 = pyr.cam[0].cy;
   const int W0 = prm.width, H0 = prm.height;
   const uint32_t pyr_bytes = (uint32_t)FS * (uint32_t)pyr.P * 4u;
   const __amdgpu_buffer_rsrc_t r_f0 = make_rsrc(E.feat0, pyr_bytes);
-  const __amdgpu_buffer_rsrc_t r_f1 = make_rsrc(PACKED ? E.feat1_pk : E.feat1, pyr_bytes);
-  const __amdgpu_buffer_rsrc_t r_g1 =
-      make_rsrc(PACKED ? (JAC ? E.gx1_pk : E.feat1_pk) : (JAC ? E.grad1 : E.feat1), (JAC && !PACKED) ? 2u * pyr_bytes : pyr_bytes);
-  const __amdgpu_buffer_rsrc_t r_g1y = make_rsrc((PACKED && JAC) ? E.gy1_pk : E.feat1, pyr_bytes);
+  // engine layout: feat1 | fx_l d/dx | fy_l d/dy of the destination keyframe are consecutive [3][FS/4][P][4] arrays under
+  // one descriptor (array a at + a * pyr_bytes, through the scalar offset)
+  const __amdgpu_buffer_rsrc_t r_f1 = make_rsrc(PACKED ? E.feat1_pk : E.feat1, (PACKED && JAC) ? 3u * pyr_bytes : pyr_bytes);
+  const __amdgpu_buffer_rsrc_t r_g1 = make_rsrc((JAC && !PACKED) ? E.grad1 : E.feat1, (JAC && !PACKED) ? 2u * pyr_bytes : pyr_bytes);
   const __amdgpu_buffer_rsrc_t r_b0 = make_rsrc(E.basis0, (uint32_t)W0 * (uint32_t)H0 * (uint32_t)(CS * 4));
   const uint32_t plane = (uint32_t)pyr.P * 4u;
   const int nlev = pyr.levels;
@@ -207,14 +286,10 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
 #pragma unroll
   for (int t = 0; t < NT + 1; ++t)
     acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#if SAGE_PHOTO_ALT_ACC
-  f32x4 accb[3] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
-#endif
   float err_acc = 0.f, vm_acc = 0.f, sdd_acc = 0.f; // lane-local sums over the sub-tiles: error, inliers, sigma d^2
   float gerr_acc = 0.f;                             // error kernel, fused geometric error
   const bool fuse_geo = !JAC && prm.geo_loss_param > 0.f && E.dpt1_geo != nullptr;
   const float geo_loss = E.geo_loss > 0.f ? E.geo_loss : prm.geo_loss_param; // per-link parameter (mapper.cpp:369)
-  float *st_w = s_mem + wave * 64 * kPhotoStashLD; // this wave's stash
   extern __shared__ __attribute__((aligned(16))) float s_dyn[];
   f32x4 *s_lvl = reinterpret_cast<f32x4 *>(s_dyn);
   const bool stage_lds = !JAC && PACKED && prm.lds_l0 < nlev;
@@ -235,6 +310,22 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
   const int rec_base = (JAC && prm.rec_first) ? uni(prm.rec_first[wi.edge]) + wi.tile / flush : bid;
   for (int sub = 0; sub < nsub; ++sub)
   {
+  // (the thread index is re-derived per sub-tile behind an opaque barrier: everything computed from it -- operand lane
+  //  offsets, stash addresses, record indices -- would otherwise be hoisted out of this loop as invariants and spilled)
+  int tid = tid_wg;
+  if (JAC)
+    asm volatile("" : "+v"(tid));
+  const int lane = tid & 63, wave = tid >> 6;
+  float *const st_w = s_mem + wave * 64 * kPhotoStashLD; // this wave's stash
+  if (JAC)
+  {
+    // the second-level tiles are zero at this point (moved to their LDS slot after every sub-tile, or flushed): said
+    // explicitly, they are dead between the sub-tiles' contraction phases instead of 12 registers held (spilled) across
+    // the sampling phase
+#pragma unroll
+    for (int t = NT + 1 - kPhotoL2Tiles; t < NT + 1; ++t)
+      acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
   const int tile = wi.tile + sub;
   const int n = tile * kTile + tid;
   bool in_range = n < N;
@@ -261,14 +352,12 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
     X[i] = d * rh[i] + p10.t[i];
   }
   const bool pos = X[2] > prm.eps; // photometric_factor_kernels.cpp:96
-  const float inv_z = 1.0f / X[2];
   // true divisions, like the reference: the coordinate chain's fp32 rounding is the dominant noise term of
   // the whole linearisation (every residual of the pixel inherits it), so no reciprocal shortcut here.
   const float p = (X[0] / X[2]) * fx0 + cx0; // :142-144 (level-0 pixel coordinates)
   const float q = (X[1] / X[2]) * fy0 + cy0;
-  const float m = STAGE == 2 ? 0.f : mask_lookup(E.mask1, p, q, W0, H0);
+  const float m = mask_lookup(E.mask1, p, q, W0, H0);
   float vm = (pos && in_range) ? m : 0.0f; // sampled_valid_mask_1 (:237)
-  float *const rec_px = (STAGE != 0) ? prm.pixrec + ((size_t)((size_t)bid * prm.tiles_per_block + sub) * kTile + tid) * 8 : nullptr;
   if (fuse_geo)
   {
     // geometric_factor_kernels.cpp:127-218 at the same warp: D1 bilinear at the level-0 coordinates (no half-pixel
@@ -284,121 +373,369 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
   }
 
   float G00 = 0.f, G01 = 0.f, G11 = 0.f, v0 = 0.f, v1 = 0.f, err = 0.f;
-  if (STAGE == 2)
-  {
-    const f32x4 ra = reinterpret_cast<const f32x4 *>(rec_px)[0], rb = reinterpret_cast<const f32x4 *>(rec_px)[1];
-    G00 = ra[0]; G01 = ra[1]; G11 = ra[2]; v0 = ra[3];
-    v1 = rb[0]; err = rb[1]; vm = rb[2];
-  }
-  else if (PACKED)
-  {
-    // ---- sampler over (level, channel group): the 13 dwordx4 loads of a step are issued together, then reduced ----
-    const f32x4 *f0s = reinterpret_cast<const f32x4 *>(E.f0s) + (in_range ? n : 0);
-    // wave priority: a wave in its sampling phase (feeding the texture path) goes ahead of the waves of its SIMD that are
-    // in their VALU / MFMA phases -- the texture path is the longer of the kernel's two floors (r03: 0.906 -> 0.879 ms)
-    if (JAC)
-      __builtin_amdgcn_s_setprio(SAGE_PHOTO_PRIO_SAMPLING);
-    for (int l = 0; l < nlev; ++l)
+  // one (level, channel group) step: bilinear interpolation of the 4 taps of feat1 (and d/dx, d/dy), difference to the
+  // pre-sampled source quad, the six sums of the level (:200-236) as channel PAIRS -- every update is one v_pk_fma_f32
+  // on naturally aligned register pairs of the interpolated quads
+  auto reduce_step = [&](const TapBatch<JAC> &B, const float (&tw)[4], f32x2 &q00, f32x2 &q01, f32x2 &q11, f32x2 &qa0,
+                         f32x2 &qa1, f32x2 &qee) {
+    f32x4 f1 = {0.f, 0.f, 0.f, 0.f}, gx = f1, gy = f1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
     {
-      const float fxl = pyr.cam[l].fx, fyl = pyr.cam[l].fy;
-      Taps td;
-      make_taps(td, (p + 0.5f) * prm.rx[l] - 0.5f, (q + 0.5f) * prm.ry[l] - 0.5f, prm.lw[l], prm.lh[l]);
-      const uint32_t lo = (uint32_t)pyr.level_offsets[l];
-      uint32_t dof[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        dof[k] = (lo + (uint32_t)td.off[k]) * 16u;
-      // level accumulators (:200-236) as channel PAIRS: every update below is one v_pk_fma_f32 on naturally aligned
-      // register pairs of the interpolated quads; the level's fx_l / fy_l scaling (h = (fx_l gx, fy_l gy)) is applied once
-      // to the five sums instead of to every channel
-      f32x2 q00 = {0.f, 0.f}, q01 = q00, q11 = q00, qa0 = q00, qa1 = q00, qee = q00;
-#pragma unroll GUNROLL
-      for (int g = 0; g < NG; ++g)
-      {
-        const uint32_t soff = (uint32_t)g * plane * 4u;
-        TapBatch<JAC> B;
-        B.f0 = f0s[((size_t)l * NG + g) * N];
-#if defined(SAGE_EXP_LDS_FROM)
-        // TIMING-ONLY experiment (wrong values): the taps of the levels >= SAGE_EXP_LDS_FROM are read from LDS (whatever
-        // the stash / staged region holds) instead of through the texture path: upper bound of what staging them could buy
-        if (l >= SAGE_EXP_LDS_FROM)
-        {
-          const f32x4 *lv = reinterpret_cast<const f32x4 *>(JAC ? s_mem : s_dyn);
-          const int msk = JAC ? (STASH / 4 - 1) / 2 : 1023;
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-          {
-            B.t1[k] = lv[(td.off[k] + g * 64) & msk];
-            if (JAC)
-            {
-              B.tx[k] = lv[(td.off[k] + g * 64 + 17) & msk];
-              B.ty[k] = lv[(td.off[k] + g * 64 + 33) & msk];
-            }
-          }
-        }
-        else
-#endif
-        if (!JAC && stage_lds && l >= prm.lds_l0) // (one loop body with this branch: splitting the level loop in two
-        {                                         //  specialised passes perturbed the linearize kernel's allocation: +3 %)
-          const f32x4 *lv = s_lvl + (g * prm.lds_ntex + ((int)lo - prm.lds_base));
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-            B.t1[k] = lv[td.off[k]];
-        }
-        else
-        {
-#pragma unroll
-          for (int k = 0; k < 4; ++k)
-          {
-            B.t1[k] = buf_load4(r_f1, dof[k], soff);
-            if (JAC)
-            {
-              B.tx[k] = buf_load4(r_g1, dof[k], soff);
-              B.ty[k] = buf_load4(r_g1y, dof[k], soff);
-            }
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0); // without it hipcc serialises load->wait->use through one register quad
-        f32x4 f1 = {0.f, 0.f, 0.f, 0.f}, gx = f1, gy = f1;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-        {
-          f1 += td.w[k] * B.t1[k];
-          if (JAC)
-          {
-            gx += td.w[k] * B.tx[k];
-            gy += td.w[k] * B.ty[k];
-          }
-        }
-        const f32x4 d4 = B.f0 - f1;
-        const f32x2 dl = {d4[0], d4[1]}, dh = {d4[2], d4[3]};
-        qee += dl * dl;
-        qee += dh * dh;
-        if (JAC)
-        {
-          const f32x2 xl = {gx[0], gx[1]}, xh = {gx[2], gx[3]}, yl = {gy[0], gy[1]}, yh = {gy[2], gy[3]};
-          q00 += xl * xl;
-          q00 += xh * xh;
-          q01 += xl * yl;
-          q01 += xh * yh;
-          q11 += yl * yl;
-          q11 += yh * yh;
-          qa0 += xl * dl;
-          qa0 += xh * dh;
-          qa1 += yl * dl;
-          qa1 += yh * dh;
-        }
-      }
-      const float wl = prm.w[l];
-      err += wl * (qee[0] + qee[1]);
+      f1 += tw[k] * B.t1[k];
       if (JAC)
       {
+        gx += tw[k] * B.tx[k];
+        gy += tw[k] * B.ty[k];
+      }
+    }
+    const f32x4 d4 = B.f0 - f1;
+    const f32x2 dl = {d4[0], d4[1]}, dh = {d4[2], d4[3]};
+    qee += dl * dl;
+    qee += dh * dh;
+    if (JAC)
+    {
+      const f32x2 xl = {gx[0], gx[1]}, xh = {gx[2], gx[3]}, yl = {gy[0], gy[1]}, yh = {gy[2], gy[3]};
+      q00 += xl * xl;
+      q00 += xh * xh;
+      q01 += xl * yl;
+      q01 += xh * yh;
+      q11 += yl * yl;
+      q11 += yh * yh;
+      qa0 += xl * dl;
+      qa0 += xh * dh;
+      qa1 += yl * dl;
+      qa1 += yh * dh;
+    }
+  };
+  // the level's weight and its fx_l / fy_l scaling (h = (fx_l gx, fy_l gy)) applied once to the six sums of a step
+  auto fold_step = [&](int l, const f32x2 &q00, const f32x2 &q01, const f32x2 &q11, const f32x2 &qa0, const f32x2 &qa1,
+                       const f32x2 &qee) {
+    const float wl = prm.w[l];
+    err += wl * (qee[0] + qee[1]);
+    if (JAC)
+    {
+      if (PACKED)
+      {
+        // engine layout: the gradient pyramids hold h = (fx_l d/dx, fy_l d/dy) already (scaled once per keyframe)
+        G00 += wl * (q00[0] + q00[1]);
+        G01 += wl * (q01[0] + q01[1]);
+        G11 += wl * (q11[0] + q11[1]);
+        v0 += wl * (qa0[0] + qa0[1]);
+        v1 += wl * (qa1[0] + qa1[1]);
+      }
+      else
+      {
+        const float fxl = pyr.cam[l].fx, fyl = pyr.cam[l].fy;
         const float wx = wl * fxl, wy = wl * fyl;
         G00 += (wx * fxl) * (q00[0] + q00[1]);
         G01 += (wx * fyl) * (q01[0] + q01[1]);
         G11 += (wy * fyl) * (q11[0] + q11[1]);
         v0 += wx * (qa0[0] + qa0[1]);
         v1 += wy * (qa1[0] + qa1[1]);
+      }
+    }
+  };
+  bool slice_live = true; // linearize, engine layout: false when no pixel of this wave's slice is an inlier
+  if (PACKED)
+  {
+    // wave priority: a wave in its sampling phase goes ahead of the waves of its SIMD that are in their VALU / MFMA
+    // phases (r03: 0.906 -> 0.879 ms)
+    if (JAC)
+      __builtin_amdgcn_s_setprio(SAGE_PHOTO_PRIO_SAMPLING);
+    bool staged = false;
+    float pmn = 0.f, pmx = 0.f, qmn = 0.f, qmx = 0.f;
+    if (JAC)
+    {
+      // bounding box of the inliers' level-0 destination coordinates (an inlier passed the mask lookup: it lies inside
+      // the image).  A slice without inliers contributes exact zeros to every sum: it is skipped.
+      const bool lv = vm != 0.f;
+      const float inf = __builtin_inff();
+      pmn = wave_fminmax<true>(lv ? p : inf);
+      pmx = wave_fminmax<false>(lv ? p : -inf);
+      qmn = wave_fminmax<true>(lv ? q : inf);
+      qmx = wave_fminmax<false>(lv ? q : -inf);
+      slice_live = pmn <= pmx;
+    }
+    // per level: box origin, width, first slot inside its staging region (wave-uniform)
+    int bx0[kStageLevels] = {}, by0[kStageLevels] = {}, bwd[kStageLevels] = {}, bhd[kStageLevels] = {}, sb[kStageLevels] = {};
+    int cnt0 = 0, cntC = 0;
+    if (JAC && slice_live && nlev == kStageLevels)
+    {
+#pragma unroll
+      for (int l = 0; l < kStageLevels; ++l)
+      {
+        // (floor coordinate of the first tap .. second tap, NOT clamped to the image: columns -1 / W_l and rows -1 / H_l
+        //  are part of the box when an inlier's taps reach them -- those taps carry weight 0 and are filled with a
+        //  repeated border texel -- so that every inlier's four taps sit at a0, a0 + 16, a0 + row, a0 + row + 16)
+        const int Wl = prm.lw[l], Hl = prm.lh[l];
+        const int x0 = min(max((int)floorf(level_coord(pmn, prm.rx[l])), -1), Wl - 1);
+        const int x1 = max(min((int)floorf(level_coord(pmx, prm.rx[l])) + 1, Wl), x0 + 1);
+        const int y0 = min(max((int)floorf(level_coord(qmn, prm.ry[l])), -1), Hl - 1);
+        const int y1 = max(min((int)floorf(level_coord(qmx, prm.ry[l])) + 1, Hl), y0 + 1);
+        bx0[l] = uni(x0);
+        by0[l] = uni(y0);
+        bwd[l] = uni(x1 - x0 + 1);
+        bhd[l] = uni(y1 - y0 + 1);
+        const int c = bwd[l] * bhd[l];
+        if (l == 0)
+        {
+          sb[l] = 0;
+          cnt0 = c;
+        }
+        else
+        {
+          sb[l] = cntC;
+          cntC += c;
+        }
+      }
+      staged = cnt0 <= kStageCap0 && cntC <= kStageCapC; // (6 x 6 + 4 x 4 + 3 x 3 = 61 coarse texels, one more row / column at an image border)
+    }
+    if (JAC && !slice_live)
+    {
+      // nothing to sample
+    }
+    else if (JAC && staged)
+    {
+     if constexpr (JAC)
+     {
+      // ================= LDS-staged sampler =================
+      const uint32_t lds0 = uni((int)(uint32_t)(uintptr_t)st_w); // region of level 0: [3][kStageCap0] float4
+      const uint32_t ldsC = lds0 + 3u * kStageCap0 * 16u;        // region of the levels >= 1: [3][kStageCapC] float4
+      // lane -> texel of the two regions (two rounds of 64 slots each), as byte offsets inside a channel group's plane
+      uint32_t vo0[2], voC;
+      {
+        const float ib0 = __builtin_amdgcn_rcpf((float)bwd[0]);
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+        {
+          const int t = min(lane + 64 * r, cnt0 - 1);
+          const int by = (int)(((float)t + 0.5f) * ib0);
+          const int bx = t - by * bwd[0];
+          const int yy = min(max(by0[0] + by, 0), prm.lh[0] - 1), xx = min(max(bx0[0] + bx, 0), prm.lw[0] - 1);
+          vo0[r] = (uint32_t)(pyr.level_offsets[0] + yy * prm.lw[0] + xx) * 16u;
+        }
+        {
+          const int t = min(lane, cntC - 1);
+          int s_ = sb[1], w_ = bwd[1], x_ = bx0[1], y_ = by0[1], lo_ = pyr.level_offsets[1], lw_ = prm.lw[1], lh_ = prm.lh[1];
+#pragma unroll
+          for (int l = 2; l < kStageLevels; ++l)
+          {
+            const bool up = t >= sb[l];
+            s_ = up ? sb[l] : s_;
+            w_ = up ? bwd[l] : w_;
+            x_ = up ? bx0[l] : x_;
+            y_ = up ? by0[l] : y_;
+            lo_ = up ? pyr.level_offsets[l] : lo_;
+            lw_ = up ? prm.lw[l] : lw_;
+            lh_ = up ? prm.lh[l] : lh_;
+          }
+          const int tl = t - s_;
+          const int by = (int)(((float)tl + 0.5f) * __builtin_amdgcn_rcpf((float)w_));
+          const int bx = tl - by * w_;
+          const int yy = min(max(y_ + by, 0), lh_ - 1), xx = min(max(x_ + bx, 0), lw_ - 1);
+          voC = (uint32_t)(lo_ + yy * lw_ + xx) * 16u;
+        }
+      }
+      // fill a region with channel group g: always 6 loads (3 arrays x 2 rounds; slots past the box repeat its last
+      // texel) for level 0 and 3 for the coarse levels -- the wait counts below are exact
+      auto stage0 = [&](uint32_t soff) {
+        dma16<0u>(r_f1, lds0, vo0[0], soff);
+        dma16<kStageCap0 * 16u>(r_f1, lds0, vo0[0], soff + pyr_bytes);
+        dma16<2u * kStageCap0 * 16u>(r_f1, lds0, vo0[0], soff + 2u * pyr_bytes);
+        dma16<1024u>(r_f1, lds0, vo0[1], soff);
+        dma16<kStageCap0 * 16u + 1024u>(r_f1, lds0, vo0[1], soff + pyr_bytes);
+        dma16<2u * kStageCap0 * 16u + 1024u>(r_f1, lds0, vo0[1], soff + 2u * pyr_bytes);
+      };
+      auto stageC = [&](uint32_t soff) {
+        dma16<3u * kStageCap0 * 16u>(r_f1, lds0, voC, soff);
+        dma16<3u * kStageCap0 * 16u + kStageCapC * 16u>(r_f1, lds0, voC, soff + pyr_bytes);
+        dma16<3u * kStageCap0 * 16u + 2u * kStageCapC * 16u>(r_f1, lds0, voC, soff + 2u * pyr_bytes);
+      };
+      // pre-sampled source quads [L][NG][N][4]: base of (level, group) wave-uniform, lane offset n * 16
+      const uint32_t f0_vo = (uint32_t)(in_range ? n : 0) * 16u;
+      auto f0_base = [&](int l, int g) { return E.f0s + ((size_t)(l * NG + g) * (size_t)N) * 4; };
+      lgkm_wait0(); // the stash reads of the previous sub-tile's contraction are done before the region is rewritten
+      // the source quads of a channel group live in a ring of four registers quads: quad l is reloaded with the next
+      // group's level l right after its use, a full group (~4 level steps) before it is needed
+      f32x4 f0q[kStageLevels];
+#pragma unroll
+      for (int l = 0; l < kStageLevels; ++l)
+        f0q[l] = gload16(f0_base(l, 0), f0_vo);
+      stage0(0u);
+      stageC(0u);
+      // per level and lane: the 4 tap weights and the LDS byte address a0 of the first tap (xf, yf); the others are
+      // (xc, yf) = a0 + 16, (xf, yc) = a0 + row, (xc, yc) = a0 + row + 16 with row = 16 * box width (wave-uniform).  Inliers
+      // are box-interior by construction; the clamp only matters for the other lanes (wild coordinates, weight x 0).  A
+      // tap outside the image has weight 0 and reads a finite repeated border texel.
+      float tw[kStageLevels][4];
+      uint32_t tap[kStageLevels];
+#pragma unroll
+      for (int l = 0; l < kStageLevels; ++l)
+      {
+        Taps td;
+        make_taps(td, level_coord(p, prm.rx[l]), level_coord(q, prm.ry[l]), prm.lw[l], prm.lh[l]);
+        const int cx0 = min(max(td.xf - bx0[l], 0), bwd[l] - 2), cy0 = min(max(td.yf - by0[l], 0), bhd[l] - 2);
+        tap[l] = (l == 0 ? lds0 : ldsC) + (uint32_t)(sb[l] + cy0 * bwd[l] + cx0) * 16u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          tw[l][k] = td.w[k];
+      }
+      // running sums of the slice as channel PAIRS (one v_pk_fma_f32 per sum and step; the halves meet once, below)
+      f32x2 P00 = {0.f, 0.f}, P01 = P00, P11 = P00, Pv0 = P00, Pv1 = P00, Pee = P00;
+      auto level_step = [&](auto lc, const f32x4 &f0v) {
+        constexpr int l = decltype(lc)::value;
+        constexpr uint32_t AS = (l == 0 ? kStageCap0 : kStageCapC) * 16u; // byte stride between the three arrays
+        const uint32_t a0 = tap[l], a2 = a0 + (uint32_t)bwd[l] * 16u;
+        // two batches (feat1 + d/dx, then d/dy): 8 + 4 reads in flight instead of 12
+        f32x4 t1[4], tx[4], ty[4];
+        t1[0] = lds_read16(a0);           tx[0] = lds_read16(a0 + AS);
+        t1[1] = lds_read16(a2 + 16u);     tx[1] = lds_read16(a2 + 16u + AS);
+        t1[2] = lds_read16(a2);           tx[2] = lds_read16(a2 + AS);
+        t1[3] = lds_read16(a0 + 16u);     tx[3] = lds_read16(a0 + 16u + AS);
+        f32x4 f1 = {0.f, 0.f, 0.f, 0.f}, gx = f1, gy = f1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+        {
+          f1 += tw[l][k] * t1[k];
+          gx += tw[l][k] * tx[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        ty[0] = lds_read16(a0 + 2u * AS);
+        ty[1] = lds_read16(a2 + 16u + 2u * AS);
+        ty[2] = lds_read16(a2 + 2u * AS);
+        ty[3] = lds_read16(a0 + 16u + 2u * AS);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          gy += tw[l][k] * ty[k];
+        const f32x4 d4 = f0v - f1;
+        const f32x2 dl = {d4[0], d4[1]}, dh = {d4[2], d4[3]};
+        const f32x2 xl = {gx[0], gx[1]}, xh = {gx[2], gx[3]}, yl = {gy[0], gy[1]}, yh = {gy[2], gy[3]};
+        f32x2 q00 = xl * xl, q01 = xl * yl, q11 = yl * yl, qa0 = xl * dl, qa1 = yl * dl, qee = dl * dl;
+        q00 += xh * xh;
+        q01 += xh * yh;
+        q11 += yh * yh;
+        qa0 += xh * dh;
+        qa1 += yh * dh;
+        qee += dh * dh;
+        // the level's weight, once per step and sum (the focal scalings h = (fx_l d/dx, fy_l d/dy) are in the pyramids)
+        const float wl = prm.w[l];
+        P00 += wl * q00;
+        P01 += wl * q01;
+        P11 += wl * q11;
+        Pv0 += wl * qa0;
+        Pv1 += wl * qa1;
+        Pee += wl * qee;
+      };
+      // Straight-line over the channel groups (static wait counts, and no control-flow merge while a register is still in
+      // flight: the compiler may place a register copy at a merge, ahead of the wait -- scripts/check_asm_loads.py walks
+      // the generated code for exactly that).  Issue order of the loads the waits count:
+      //   f0(0,0..3) L0(0) LC(0) | per group g: [level 0] f0(g+1,0) L0(g+1) [level 1] f0(g+1,1) [level 2] f0(g+1,2)
+      //   [level 3] f0(g+1,3) LC(g+1)
+      // level 0 of group g needs f0(g,0) and L0(g): younger are f0(g,1..3) and the 3 loads of LC(g) (g = 0: only LC(0));
+      // level 1 needs LC(g) (f0(g,1) is older): younger are f0(g+1,0) and the 6 loads of L0(g+1) (nothing in the last
+      // group); levels 2, 3 are covered by the wait of level 1 (vmcnt(15) = no wait, ties the register to it).  pin6 keeps every step where it is written: without a use
+      // at that point the reduction sinks towards the end and the taps of several levels stay live.
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+      {
+        const bool more = g + 1 < NG; // (compile-time after unrolling)
+        const uint32_t soffn = (uint32_t)(g + 1) * plane * 4u;
+        if (g == 0)
+          vm_wait_keep<3>(f0q[0]);
+        else
+          vm_wait_keep<6>(f0q[0]);
+        level_step(std::integral_constant<int, 0>{}, f0q[0]);
+        pin6(P00, P01, P11, Pv0, Pv1, Pee);
+        if (more)
+        {
+          f0q[0] = gload16(f0_base(0, g + 1), f0_vo);
+          lgkm_wait0(); // level-0 taps have been read: the region takes the next group
+          stage0(soffn);
+          vm_wait_keep<7>(f0q[1]);
+        }
+        else
+          vm_wait_keep<0>(f0q[1]);
+        level_step(std::integral_constant<int, 1>{}, f0q[1]);
+        pin6(P00, P01, P11, Pv0, Pv1, Pee);
+        if (more)
+        {
+          f0q[1] = gload16(f0_base(1, g + 1), f0_vo);
+          vm_wait_keep<15>(f0q[2]);
+        }
+        else
+          vm_wait_keep<0>(f0q[2]);
+        level_step(std::integral_constant<int, 2>{}, f0q[2]);
+        pin6(P00, P01, P11, Pv0, Pv1, Pee);
+        if (more)
+        {
+          f0q[2] = gload16(f0_base(2, g + 1), f0_vo);
+          vm_wait_keep<15>(f0q[3]);
+        }
+        else
+          vm_wait_keep<0>(f0q[3]);
+        level_step(std::integral_constant<int, 3>{}, f0q[3]);
+        pin6(P00, P01, P11, Pv0, Pv1, Pee);
+        if (more)
+        {
+          f0q[3] = gload16(f0_base(3, g + 1), f0_vo);
+          lgkm_wait0();
+          stageC(soffn);
+        }
+      }
+      G00 = P00[0] + P00[1];
+      G01 = P01[0] + P01[1];
+      G11 = P11[0] + P11[1];
+      v0 = Pv0[0] + Pv0[1];
+      v1 = Pv1[0] + Pv1[1];
+      err = Pee[0] + Pee[1];
+     }
+    }
+    else
+    {
+      // ================= texture-path sampler: (level, channel group) steps, the 13 dwordx4 loads of a step issued
+      // together, then reduced =================
+      const f32x4 *f0s = reinterpret_cast<const f32x4 *>(E.f0s) + (in_range ? n : 0);
+      for (int l = 0; l < nlev; ++l)
+      {
+        Taps td;
+        make_taps(td, level_coord(p, prm.rx[l]), level_coord(q, prm.ry[l]), prm.lw[l], prm.lh[l]);
+        const uint32_t lo = (uint32_t)pyr.level_offsets[l];
+        uint32_t dof[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          dof[k] = (lo + (uint32_t)td.off[k]) * 16u;
+        f32x2 q00 = {0.f, 0.f}, q01 = q00, q11 = q00, qa0 = q00, qa1 = q00, qee = q00;
+#pragma unroll GUNROLL
+        for (int g = 0; g < NG; ++g)
+        {
+          const uint32_t soff = (uint32_t)g * plane * 4u;
+          TapBatch<JAC> B;
+          B.f0 = f0s[((size_t)l * NG + g) * N];
+          if (!JAC && stage_lds && l >= prm.lds_l0) // (one loop body with this branch: two specialised passes were slower)
+          {
+            const f32x4 *lv = s_lvl + (g * prm.lds_ntex + ((int)lo - prm.lds_base));
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              B.t1[k] = lv[td.off[k]];
+          }
+          else
+          {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+            {
+              B.t1[k] = buf_load4(r_f1, dof[k], soff);
+              if (JAC)
+              {
+                B.tx[k] = buf_load4(r_f1, dof[k], soff + pyr_bytes);
+                B.ty[k] = buf_load4(r_f1, dof[k], soff + 2u * pyr_bytes);
+              }
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0); // without it hipcc serialises load->wait->use through one register quad
+          reduce_step(B, td.w, q00, q01, q11, qa0, qa1, qee);
+        }
+        fold_step(l, q00, q01, q11, qa0, qa1, qee);
       }
     }
   }
@@ -477,14 +814,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
       }
     }
   }
-  if (STAGE != 2)
-    err *= vm; // within_mask * pow(diff,2)  (:228)
-  if (STAGE == 1)
-  {
-    reinterpret_cast<f32x4 *>(rec_px)[0] = f32x4{G00, G01, G11, v0};
-    reinterpret_cast<f32x4 *>(rec_px)[1] = f32x4{v1, err, vm, 0.f};
-    continue;
-  }
+  err *= vm; // within_mask * pow(diff,2)  (:228)
   err_acc += err;
   vm_acc += vm;
   if (!JAC)
@@ -492,6 +822,8 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
 
   // ---- per-pixel 7x7 reduced system ----
   __builtin_amdgcn_s_setprio(0);
+  if (slice_live)
+  {
   const bool live = vm != 0.0f;
   const float vm2 = vm * vm; // gradient and residual both carry m (:200, :234)
   G00 *= vm2;
@@ -501,6 +833,27 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
   v1 *= vm2;
   float Q[2][7];
   {
+    // world-from-keyframe poses (wave-uniform scalar loads), re-read per sub-tile behind an opaque pointer: held across the
+    // sampling phase their 24 SGPRs were spilled to VGPR lanes and every use paid a v_readlane
+    const float *R0p = E.R0, *R1p = E.R1;
+    asm volatile("" : "+s"(R0p), "+s"(R1p));
+    const Pose p0 = load_pose2(R0p, E.t0), p1 = load_pose2(R1p, E.t1);
+    // (engine layout: the homogeneous coordinates are read again and the warp of phase A recomputed -- same operations,
+    //  same values -- instead of ten registers staying live across the sampling phase)
+    if (PACKED)
+    {
+      const float *hp = E.homo + 3 * (in_range ? n : 0);
+      hm[0] = in_range ? hp[0] : 0.f;
+      hm[1] = in_range ? hp[1] : 0.f;
+      hm[2] = in_range ? hp[2] : 1.f;
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+      {
+        rh[i] = p10.R[i * 3 + 0] * hm[0] + p10.R[i * 3 + 1] * hm[1] + p10.R[i * 3 + 2] * hm[2];
+        X[i] = d * rh[i] + p10.t[i];
+      }
+    }
+    const float inv_z = 1.0f / X[2];
     float Xw[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
@@ -554,9 +907,20 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
   // ---- MFMA contractions over this wave's 64 pixels, 4 pixels (K) per instruction; basis rows streamed from
   //      global memory in operand layout, AHEAD groups in flight ----
   {
+#if SAGE_PHOTO_ALT_ACC
+    // extra accumulator sets of the three noise-critical tiles (live in this phase only): pixel group g goes to set g mod
+    // (SAGE_PHOTO_ALT_ACC + 1), set 0 = acc
+    f32x4 accb[SAGE_PHOTO_ALT_ACC][3];
+#pragma unroll
+    for (int u = 0; u < SAGE_PHOTO_ALT_ACC; ++u)
+      accb[u][0] = accb[u][1] = accb[u][2] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
     const int i = lane & 15, k = lane >> 4;
     const uint32_t lane_off = (uint32_t)i * (NB == 2 ? 8u : 4u);
-    constexpr int G = 16, AHEAD = 3;
+#ifndef SAGE_PHOTO_AHEAD
+#define SAGE_PHOTO_AHEAD 6
+#endif
+    constexpr int G = 16, AHEAD = SAGE_PHOTO_AHEAD;
     float bl[G], bh[G], ai[G], sg[G], ya[G], yb[G];
     int locp[G];
 #define SAGE_PHOTO_READ_STASH(g)                                                        \
@@ -606,14 +970,16 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
         SAGE_PHOTO_READ_STASH(g + AHEAD + 1)
       const float a = asel * ai[g];
 #if SAGE_PHOTO_ALT_ACC
-      if (CS == 32 && (g & 1))
+      if (CS == 32 && (g % (SAGE_PHOTO_ALT_ACC + 1)) != 0)
       {
-        accb[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[g], yb[g], accb[2], 0, 0, 0);
+        constexpr int NS = SAGE_PHOTO_ALT_ACC + 1;
+        const int u = g % NS - 1;
+        accb[u][2] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[g], yb[g], accb[u][2], 0, 0, 0);
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bl[g], bl[g], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bl[g], bh[g], acc[1], 0, 0, 0);
         acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bh[g], bh[g], acc[2], 0, 0, 0);
-        accb[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bl[g], accb[0], 0, 0, 0);
-        accb[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bh[g], accb[1], 0, 0, 0);
+        accb[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bl[g], accb[u][0], 0, 0, 0);
+        accb[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bh[g], accb[u][1], 0, 0, 0);
         continue;
       }
 #endif
@@ -632,15 +998,26 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bl[g], acc[1], 0, 0, 0);
       }
     }
+#if SAGE_PHOTO_ALT_ACC
+    if (CS == 32)
+    {
+      // pairwise merge of the sets
+#if SAGE_PHOTO_ALT_ACC == 3
+      acc[3] = (acc[3] + accb[0][0]) + (accb[1][0] + accb[2][0]);
+      acc[4] = (acc[4] + accb[0][1]) + (accb[1][1] + accb[2][1]);
+      acc[YY] = (acc[YY] + accb[0][2]) + (accb[1][2] + accb[2][2]);
+#else
+#pragma unroll
+      for (int u = 0; u < SAGE_PHOTO_ALT_ACC; ++u)
+      {
+        acc[3] += accb[u][0]; acc[4] += accb[u][1]; acc[YY] += accb[u][2];
+      }
+#endif
+    }
+#endif
   }
   __builtin_amdgcn_wave_barrier(); // the stash is rewritten by the next sub-tile
-#if SAGE_PHOTO_ALT_ACC
-  if (CS == 32)
-  {
-    acc[3] += accb[0]; acc[4] += accb[1]; acc[YY] += accb[2];
-    accb[0] = accb[1] = accb[2] = f32x4{0.f, 0.f, 0.f, 0.f};
-  }
-#endif
+  } // slice_live
   // ---- second level: the LM step's distance from the exact step is set by the fp32 accumulation chains of the two
   //      cross tiles (rows c, sigma d, u6: the code gradient and the pose-code blocks) and of the pose tile; the code-code
   //      tiles do not matter (measured tile by tile, DESIGN s4).  After every sub-tile each lane moves its 12 values of
@@ -680,9 +1057,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
   // (every wave dumps into ITS OWN stash region -- it is done with it, the other waves' phase D is not disturbed: no
   //  barrier before the dump)
   constexpr int SLICE = 64 * kPhotoStashLD; // distance between the waves' regions
-#ifndef SAGE_EXP_STASH_LD
   static_assert(!JAC || (NT + 1) * 256 <= SLICE, "a wave's tiles must fit its own stash region");
-#endif
 #pragma unroll
   for (int t = 0; t < NT + 1; ++t)
 #pragma unroll
@@ -701,14 +1076,21 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
   auto tsum = [&](int idx) { // element idx of the summed tiles
     return ((s_mem[idx] + s_mem[SLICE + idx]) + s_mem[2 * SLICE + idx]) + s_mem[3 * SLICE + idx];
   };
+  auto tsumd = [&](int idx) { // the same in double (exact: four fp32 terms)
+    return (((double)s_mem[idx] + (double)s_mem[SLICE + idx]) + (double)s_mem[2 * SLICE + idx]) + (double)s_mem[3 * SLICE + idx];
+  };
   static_assert(kWaves == 4, "tsum adds four slices");
+  constexpr int NCC = photo_cc_tiles(CS);
   float *out = prm.partials + (size_t)(rec_base + sub / flush) * photo_partial_floats(CS);
+  double *outd = reinterpret_cast<double *>(out + photo_partial_double_offset(CS));
+  const bool wt = prm.sig_cnt != nullptr; // signalling launches write the record through to memory (agent-scope stores):
+                                          // the consumer is a kernel on another stream
   if (tid < kPhotoScalars)
   {
-    // scalar slots of the partial record (layout unchanged): [0..20] Q^T G Q (upper triangle), [21..26] Q^T G q6 d,
+    // scalar slots of the partial record (doubles): [0..20] Q^T G Q (upper triangle), [21..26] Q^T G q6 d,
     // [27] sigma d^2, [28..33] Q^T v, [34] q6^T v d, [35] error, [36] inliers.  Pose tile element (row r of A, col c of B):
-    auto yy = [&](int r, int c) { return tsum(YY * 256 + (r & 3) * 64 + ((r >> 2) * 16 + c)); };
-    float a = 0.f;
+    auto yy = [&](int r, int c) { return tsumd(YY * 256 + (r & 3) * 64 + ((r >> 2) * 16 + c)); };
+    double a = 0.0;
     if (tid < 21)
     {
       int i = 0, rem = tid;
@@ -731,19 +1113,30 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
       const int slot = tid == 27 ? 0 : tid - 34;
 #pragma unroll
       for (int w = 0; w < kWaves; ++w)
-        a += s_red[w * 4 + slot];
+        a += (double)s_red[w * 4 + slot];
     }
-    if (prm.sig_cnt) // signalling launches write the record through to memory (agent-scope stores): the consumer is
-      __hip_atomic_store(out + tid, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // a kernel on another stream
+    if (wt)
+      __hip_atomic_store(outd + tid, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     else
-      out[tid] = a;
+      outd[tid] = a;
   }
-  if (prm.sig_cnt)
-    for (int idx = tid; idx < NT * 256; idx += kBlock)
-      __hip_atomic_store(out + kPhotoScalars + idx, tsum(idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else
-    for (int idx = tid; idx < NT * 256; idx += kBlock)
-      out[kPhotoScalars + idx] = tsum(idx);
+  for (int idx = tid; idx < NT * 256; idx += kBlock)
+  {
+    if (idx < NCC * 256) // code-code tiles: fp32
+    {
+      if (wt)
+        __hip_atomic_store(out + kPhotoScalars + idx, tsum(idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        out[kPhotoScalars + idx] = tsum(idx);
+    }
+    else // cross tiles: double
+    {
+      if (wt)
+        __hip_atomic_store(outd + kPhotoScalars + (idx - NCC * 256), tsumd(idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        outd[kPhotoScalars + (idx - NCC * 256)] = tsumd(idx);
+    }
+  }
     if (!last_sub)
     {
       __syncthreads(); // the slices are about to become stash memory again
@@ -757,8 +1150,6 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : STAGE == 1 ? 
   }
   } // sub-tile loop
 
-  if (STAGE == 1)
-    return;
   if (!JAC)
   {
     const float se = wave_sum(err_acc), sn = wave_sum(vm_acc), sg = wave_sum(gerr_acc);
@@ -828,28 +1219,44 @@ __device__ __forceinline__ double tile_elem(const double *s, int base, int tile,
 template <int CS>
 __global__ __launch_bounds__(kFinalizeBlock) void photo_finalize_kernel(const PhotoFinalizeParams prm)
 {
-  constexpr int PP = photo_partial_floats(CS);
+  constexpr int PP = kPhotoScalars + photo_tiles(CS) * 256; // entries of a summed record
   constexpr int D = 13 + CS;
   __shared__ double s[PP]; // partial sums and every derived product stay in double until the single final rounding
   const int e = prm.edge_base + blockIdx.x, tid = threadIdx.x;
   const PhotoEdge &E = prm.table ? prm.table[e] : prm.single;
   const float s0 = E.scale0 ? *E.scale0 : E.scale0_val;
   const int first = prm.edge_first[e], nt = prm.edge_tiles[e];
+  // s[] keeps the historic index space: [0..39] scalars, then NT tiles of 256; the scalars and the cross tiles come from
+  // the double part of the records, the code-code tiles from the fp32 part
+  constexpr int NCCF = photo_cc_tiles(CS), DOFF = photo_partial_double_offset(CS), PF = photo_partial_floats(CS);
   for (int idx = tid; idx < PP; idx += (int)blockDim.x)
   {
-    double a = 0.0; // the per-workgroup partials are summed in double: free (a few dozen adds), and it keeps the
-                    // engine's accumulation noise below the reference's own fp32 floor
-    double a1 = 0.0, a2 = 0.0, a3 = 0.0; // four independent chains: the loads of a round are in flight together
-    const float *pp = prm.partials + (size_t)first * PP + idx;
+    const bool dbl = idx < kPhotoScalars || idx >= kPhotoScalars + NCCF * 256;
+    double a = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0; // four independent chains: the loads of a round are in flight together
     int t = 0;
-    for (; t + 4 <= nt; t += 4)
+    if (dbl)
     {
-      const float v0 = pp[(size_t)t * PP], v1 = pp[(size_t)(t + 1) * PP], v2 = pp[(size_t)(t + 2) * PP],
-                  v3 = pp[(size_t)(t + 3) * PP];
-      a += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+      const int di = idx < kPhotoScalars ? idx : idx - NCCF * 256;
+      const double *pp = reinterpret_cast<const double *>(prm.partials + (size_t)first * PF + DOFF) + di;
+      constexpr size_t STR = PF / 2; // record stride in doubles
+      for (; t + 4 <= nt; t += 4)
+      {
+        a += pp[(size_t)t * STR]; a1 += pp[(size_t)(t + 1) * STR]; a2 += pp[(size_t)(t + 2) * STR]; a3 += pp[(size_t)(t + 3) * STR];
+      }
+      for (; t < nt; ++t)
+        a += pp[(size_t)t * STR];
     }
-    for (; t < nt; ++t)
-      a += (double)pp[(size_t)t * PP];
+    else
+    {
+      const float *pp = prm.partials + (size_t)first * PF + idx;
+      for (; t + 4 <= nt; t += 4)
+      {
+        const float v0 = pp[(size_t)t * PF], v1 = pp[(size_t)(t + 1) * PF], v2 = pp[(size_t)(t + 2) * PF], v3 = pp[(size_t)(t + 3) * PF];
+        a += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
+      }
+      for (; t < nt; ++t)
+        a += (double)pp[(size_t)t * PF];
+    }
     s[idx] = (a + a1) + (a2 + a3);
   }
   __syncthreads();
@@ -1004,7 +1411,6 @@ static PhotoParams make_params(const PhotoEdge *single, const PhotoEdge *table, 
   p.order = lc.order;
   p.rec_first = lc.flush > 0 ? lc.edge_first : nullptr;
   p.flush = lc.flush > 0 ? lc.flush : lc.tiles_per_block;
-  p.pixrec = lc.pixrec;
   p.lds_l0 = pyr.levels; // off
   p.lds_base = 0;
   p.lds_ntex = 0;
@@ -1030,13 +1436,7 @@ static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const P
   {
     if (lc.ev_start)
       (void)hipEventRecord(lc.ev_start, s);
-    if (lc.packed && lc.pixrec)
-    {
-      // split linearize: sampling stage, then contraction stage (same work decomposition, hand-over in lc.pixrec)
-      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1, 1>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
-      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1, 2>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
-    }
-    else if (lc.packed)
+    if (lc.packed)
       hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
     else
       hipLaunchKernelGGL((photo_kernel<CS, FS, true, 0>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);

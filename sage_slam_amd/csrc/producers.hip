@@ -190,24 +190,38 @@ hipError_t launch_presample_source(hipStream_t s, float *f0s, const float *feat_
   return hipGetLastError();
 }
 
-// [C][P] channel-major -> [C/4][P][4] channel-group layout (engine-internal, once per keyframe)
-__global__ void repack_groups_kernel(float *__restrict__ dst, const float *__restrict__ src, int C, int P)
+// [C][P] channel-major -> [C/4][P][4] channel-group layout (engine-internal, once per keyframe).  axis 1 / 2: the texels of
+// pyramid level l are multiplied by fx_l / fy_l on the way -- the photometric linearize samples h = (fx_l d/dx, fy_l d/dy)
+// (photometric_factor_kernels.cpp:200-222 scales the sampled gradient by the level's focal lengths; here once per texel)
+__global__ void repack_groups_kernel(float *__restrict__ dst, const float *__restrict__ src, int C, int P, int axis,
+                                     SagePyramid pyr)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y;
   if (p >= P)
     return;
+  float sc = 1.0f;
+  if (axis != 0)
+  {
+    int l = 0;
+    for (int i = 1; i < pyr.levels; ++i)
+      l = p >= pyr.level_offsets[i] ? i : l;
+    sc = axis == 1 ? pyr.cam[l].fx : pyr.cam[l].fy;
+  }
   f32x4 v;
-  v[0] = src[(size_t)(4 * g + 0) * P + p];
-  v[1] = src[(size_t)(4 * g + 1) * P + p];
-  v[2] = src[(size_t)(4 * g + 2) * P + p];
-  v[3] = src[(size_t)(4 * g + 3) * P + p];
+  v[0] = sc * src[(size_t)(4 * g + 0) * P + p];
+  v[1] = sc * src[(size_t)(4 * g + 1) * P + p];
+  v[2] = sc * src[(size_t)(4 * g + 2) * P + p];
+  v[3] = sc * src[(size_t)(4 * g + 3) * P + p];
   *reinterpret_cast<f32x4 *>(dst + ((size_t)g * P + p) * 4) = v;
 }
 
-hipError_t launch_repack_groups(hipStream_t s, float *dst, const float *src, int C, int P)
+hipError_t launch_repack_groups(hipStream_t s, float *dst, const float *src, int C, int P, int axis, const SagePyramid *pyr)
 {
-  hipLaunchKernelGGL(repack_groups_kernel, dim3((P + 255) / 256, C / 4), dim3(256), 0, s, dst, src, C, P);
+  SagePyramid py{};
+  if (pyr)
+    py = *pyr;
+  hipLaunchKernelGGL(repack_groups_kernel, dim3((P + 255) / 256, C / 4), dim3(256), 0, s, dst, src, C, P, pyr ? axis : 0, py);
   return hipGetLastError();
 }
 

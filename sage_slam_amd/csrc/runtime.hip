@@ -1268,7 +1268,6 @@ struct SageWindow
   DevBuf rec_first_p, rec_count_p;      // photometric linearize: partial RECORDS per edge (flush_p sub-tiles each)
   int flush_p = 0, n_rec_p = 0;
   DevBuf part_p, part_g;
-  DevBuf pixrec_p;                      // split photometric linearize (SAGE_PHOTO_SPLIT): per-pixel hand-over records
   DevBuf AtA_p, Atb_p, stats_p, AtA_g, Atb_g, stats_g;
   DevBuf adj_start, adj, link_edges, packed, errbuf;
   int n_work_p = 0, n_work_g = 0, tpb_p = 1, tpb_g = 1;
@@ -1404,7 +1403,7 @@ extern "C" void sage_window_destroy(SageWindow *w)
 {
   if (!w)
     return;
-  DevBuf *bufs[] = {&w->pixrec_p, &w->packed_save, &w->rec_first_p, &w->rec_count_p, &w->order_p, &w->order_g, &w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
+  DevBuf *bufs[] = {&w->packed_save, &w->rec_first_p, &w->rec_count_p, &w->order_p, &w->order_g, &w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
                     &w->pk, &w->f0s, &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
                     &w->work_g, &w->first_g, &w->tiles_g, &w->part_p, &w->part_g, &w->AtA_p, &w->Atb_p,
                     &w->stats_p, &w->AtA_g, &w->Atb_g, &w->stats_g, &w->adj_start, &w->adj, &w->link_edges,
@@ -1856,8 +1855,8 @@ extern "C" int sage_window_finalize(SageWindow *w)
   {
     float *base = w->pk.as<float>() + (size_t)k * 3 * plane_f;
     SAGE_HIP(launch_repack_groups(w->stream, base, w->views[k].feat_pyr, FS, c.pyr.P));
-    SAGE_HIP(launch_repack_groups(w->stream, base + plane_f, w->views[k].grad_pyr, FS, c.pyr.P));
-    SAGE_HIP(launch_repack_groups(w->stream, base + 2 * plane_f, w->views[k].grad_pyr + plane_f, FS, c.pyr.P));
+    SAGE_HIP(launch_repack_groups(w->stream, base + plane_f, w->views[k].grad_pyr, FS, c.pyr.P, 1, &c.pyr));
+    SAGE_HIP(launch_repack_groups(w->stream, base + 2 * plane_f, w->views[k].grad_pyr + plane_f, FS, c.pyr.P, 2, &c.pyr));
   }
   // ---- sampled locations: validated (the kernels index depth maps / basis rows with them unchecked) and relaid in
   //      raster order (engine-owned copies; see producers.hip: the sums are order independent, the L1 is not)
@@ -1891,9 +1890,11 @@ extern "C" int sage_window_finalize(SageWindow *w)
       rc = d_status.reserve((size_t)2 * K * sizeof(int));
     hipError_t he = hipSuccess;
     {
-      // walk order of the samples: raster, or image tiles (SAGE_SAMPLE_TILE=WxH, e.g. 16x4)
+      // walk order of the samples: image tiles of 8 x 8 pixels -- a wave's 64 consecutive samples then warp to a compact
+      // footprint in every destination keyframe, which is what the LDS-staged sampler of the photometric linearize
+      // needs (photo_kernels.hip).  SAGE_SAMPLE_TILE=WxH picks another tile, 0x0 the raster walk.
       static const std::pair<int, int> tile = [] {
-        int tw = 0, th = 0;
+        int tw = 8, th = 8;
         if (const char *e = getenv("SAGE_SAMPLE_TILE"))
           if (sscanf(e, "%dx%d", &tw, &th) != 2 || tw < 1 || th < 1)
             tw = th = 0;
@@ -1961,8 +1962,6 @@ extern "C" int sage_window_finalize(SageWindow *w)
         pe.feat0 = v0.feat_pyr; pe.feat1 = v1.feat_pyr; pe.grad1 = v1.grad_pyr; pe.bias0 = v0.bias;
         pe.feat0_pk = w->pk.as<float>() + (size_t)k0 * 3 * plane_f;
         pe.feat1_pk = w->pk.as<float>() + (size_t)k1 * 3 * plane_f;
-        pe.gx1_pk = pe.feat1_pk + plane_f;
-        pe.gy1_pk = pe.feat1_pk + 2 * plane_f;
         pe.f0s = w->f0s.as<float>() + f0s_off[k0];
         pe.dpt0 = w->dpt.as<float>() + (size_t)k0 * HW;
         pe.dpt1_geo = (c.use_photo && c.use_geo) ? w->dpt.as<float>() + (size_t)k1 * HW : nullptr;
@@ -2104,12 +2103,6 @@ extern "C" int sage_window_finalize(SageWindow *w)
   SAGE_HIP(hipStreamSynchronize(w->stream));
   const size_t Dp = 13 + CS, Dg = 14 + 2 * CS;
   const size_t ne = std::max(1, w->n_edges);
-  {
-    static const bool split = sage::env_flag("SAGE_PHOTO_SPLIT");
-    if (split && w->n_work_p > 0 &&
-        (rc = w->pixrec_p.reserve((size_t)w->n_work_p * w->tpb_p * kTile * 8 * sizeof(float))))
-      return rc;
-  }
   if ((rc = w->part_p.reserve(std::max<size_t>(1, std::max(w->n_work_p, w->n_rec_p)) * photo_partial_floats(CS) * sizeof(float))) ||
       (rc = w->part_g.reserve(std::max<size_t>(1, w->n_work_g) * geo_partial_floats(CS) * sizeof(float))) ||
       (rc = w->AtA_p.reserve(ne * Dp * Dp * sizeof(float))) || (rc = w->Atb_p.reserve(ne * Dp * sizeof(float))) ||
@@ -2197,8 +2190,6 @@ static LaunchCommon window_lc(SageWindow *w, bool photo, bool photo_linearize = 
     lc.edge_tiles = w->rec_count_p.as<int32_t>();
     lc.flush = w->flush_p;
   }
-  if (photo_linearize && w->pixrec_p.p && !w->pipe_enabled)
-    lc.pixrec = w->pixrec_p.as<float>();
   // opt-in, measured NEGATIVE on the K = 64 headline window (r02): giving every XCD a contiguous eighth of the work list
   // makes the eight L2s work on eight different edge sets at once -- L2 hit rate 59 % -> 25 %, HBM fetch 2.3 -> 5.5 GB per
   // launch, photometric linearize 0.88 -> 1.03 ms.  With the dispatcher's round-robin all XCDs walk the same edges

@@ -126,8 +126,9 @@ struct Taps
 __device__ __forceinline__ void make_taps(Taps &t, float u, float v, int W, int H)
 {
   // keep the float->int conversion defined for wild coordinates; anything clamped is far outside.
-  const float fu = fminf(fmaxf(floorf(u), -8.0f), (float)W + 8.0f);
-  const float fv = fminf(fmaxf(floorf(v), -8.0f), (float)H + 8.0f);
+  // (a constant upper clamp: `(float)W + 8` per pyramid level is a loop-invariant the compiler hoists and spills)
+  const float fu = fminf(fmaxf(floorf(u), -8.0f), 32768.0f);
+  const float fv = fminf(fmaxf(floorf(v), -8.0f), 32768.0f);
   const int xf = (int)fu, yf = (int)fv;
   const int xc = xf + 1, yc = yf + 1;
   const float lx = (float)xc - u, ly = (float)yc - v;
@@ -151,8 +152,8 @@ __device__ __forceinline__ void make_taps(Taps &t, float u, float v, int W, int 
 // photometric_factor_kernels.cpp:159-166, geometric_factor_kernels.cpp:585-598
 __device__ __forceinline__ float mask_lookup(const float *__restrict__ mask, float p, float q, int W, int H)
 {
-  const float rp = fminf(fmaxf(roundf(p), -8.0f), (float)W + 8.0f);
-  const float rq = fminf(fmaxf(roundf(q), -8.0f), (float)H + 8.0f);
+  const float rp = fminf(fmaxf(roundf(p), -8.0f), 32768.0f); // (keeps the float -> int conversion defined)
+  const float rq = fminf(fmaxf(roundf(q), -8.0f), 32768.0f);
   const int xr = (int)rp, yr = (int)rq;
   const bool ok = (xr >= 0) & (xr < W) & (yr >= 0) & (yr < H);
   return ok ? mask[yr * W + xr] : 0.0f;
@@ -209,14 +210,21 @@ __device__ __forceinline__ Pose relative_pose(const Pose &p0, const Pose &p1)
 
 // world-frame left-perturbation Jacobian of X = T1^-1 T0 (d x~):  dX/dT0 = R1^T [ I | -[Xw]x ]
 // (photometric_factor_kernels.cpp:283-297); dX/dT1 = -dX/dT0 (:258-268).  Rows i of the 3x6.
+// Written out term by term: as a dense 3x3 * 3x6 product the zeros of [I | -[Xw]x] survive as `R * 0` products (not
+// foldable under IEEE rules), which the compiler hoists out of the sub-tile loop as loop invariants and then spills.
 __device__ __forceinline__ void dX_dT0(const Pose &p1, const float Xw[3], float out[3][6])
 {
-  const float E[3][6] = {{1, 0, 0, 0, Xw[2], -Xw[1]}, {0, 1, 0, -Xw[2], 0, Xw[0]}, {0, 0, 1, Xw[1], -Xw[0], 0}};
 #pragma unroll
   for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-      out[i][j] = p1.R[0 * 3 + i] * E[0][j] + p1.R[1 * 3 + i] * E[1][j] + p1.R[2 * 3 + i] * E[2][j];
+  {
+    const float r0 = p1.R[0 * 3 + i], r1 = p1.R[1 * 3 + i], r2 = p1.R[2 * 3 + i]; // row i of R1^T
+    out[i][0] = r0;
+    out[i][1] = r1;
+    out[i][2] = r2;
+    out[i][3] = r2 * Xw[1] - r1 * Xw[2];
+    out[i][4] = r0 * Xw[2] - r2 * Xw[0];
+    out[i][5] = r1 * Xw[0] - r0 * Xw[1];
+  }
 }
 
 // ---------------------------------------------------------------- basis tile -> LDS, sampled depth

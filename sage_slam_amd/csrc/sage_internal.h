@@ -25,7 +25,9 @@ struct PhotoEdge
   const float *grad1;   // [2,FS,P]
   // engine-internal channel-group layout [FS/4][P][4] (float4 per texel per group of 4 channels): one
   // buffer_load_dwordx4 per tap and group, fully coalesced across the wave.  nullptr -> use the reference layout.
-  const float *feat0_pk, *feat1_pk, *gx1_pk, *gy1_pk;
+  // feat1_pk heads three consecutive arrays of the destination keyframe: feat | fx_l d/dx | fy_l d/dy (the gradient
+  // pyramids pre-multiplied by their level's focal lengths)
+  const float *feat0_pk, *feat1_pk;
   // pose-independent pre-sampled source features of the source keyframe [L][FS/4][N][4] (what the reference's
   // tracker calls cat_sampled_features_0, camera_tracker.cpp:1104-1123), built once per keyframe
   const float *f0s;
@@ -101,7 +103,14 @@ struct WorkItem
 constexpr int kPhotoScalars = 40;
 constexpr int kGeoScalars = 48;
 __host__ __device__ constexpr int photo_tiles(int CS) { return CS == 32 ? 5 : 2; }
-__host__ __device__ constexpr int photo_partial_floats(int CS) { return kPhotoScalars + photo_tiles(CS) * 256; }
+// the first photo_cc_tiles(CS) tiles are the code-code blocks (fp32 in the record); the cross tiles X and the 40 scalar
+// slots (pose tile, error, inliers) follow the fp32 part as DOUBLES: summed over the workgroup's waves in double and never
+// rounded to fp32 again (r04: with the samples in 8 x 8 tile order a wave's / a sub-tile's sums are spatially coherent and
+// large against the edge total they cancel into -- their fp32 roundings were the step noise of the small windows)
+__host__ __device__ constexpr int photo_cc_tiles(int CS) { return CS == 32 ? 3 : 1; }
+__host__ __device__ constexpr int photo_partial_double_offset(int CS) { return kPhotoScalars + photo_tiles(CS) * 256; } // in floats, even
+__host__ __device__ constexpr int photo_partial_doubles(int CS) { return kPhotoScalars + (photo_tiles(CS) - photo_cc_tiles(CS)) * 256; }
+__host__ __device__ constexpr int photo_partial_floats(int CS) { return photo_partial_double_offset(CS) + 2 * photo_partial_doubles(CS); }
 __host__ __device__ constexpr int geo_n16(int CS) { return 2 * CS / 16; }
 __host__ __device__ constexpr int geo_tiles(int CS) { return geo_n16(CS) * (geo_n16(CS) + 1) / 2 + geo_n16(CS); }
 __host__ __device__ constexpr int geo_partial_floats(int CS) { return kGeoScalars + geo_tiles(CS) * 256; }
@@ -142,9 +151,6 @@ struct LaunchCommon
   // photometric linearize: > 0 -> one partial record per `flush` sub-tiles (edge_first / edge_tiles then count RECORDS:
   // record = edge_first[edge] + tile / flush); 0 -> one record per work item
   int32_t flush = 0;
-  // photometric linearize, optional: split into a sampling and a contraction launch that hand over a per-pixel record
-  // [n_work][tiles_per_block][256][8] floats through this buffer (photo_kernels.hip, STAGE 1 / 2)
-  float *pixrec = nullptr;
 };
 
 // per-edge results, reference layouts
@@ -186,7 +192,8 @@ struct DepthItem
 };
 hipError_t launch_presample_source(hipStream_t s, float *f0s, const float *feat_pk, const float *homo, int N, int FS,
                                    const SagePyramid &pyr);
-hipError_t launch_repack_groups(hipStream_t s, float *dst, const float *src, int C, int P);
+hipError_t launch_repack_groups(hipStream_t s, float *dst, const float *src, int C, int P, int axis = 0,
+                                const SagePyramid *pyr = nullptr);
 // raster-order relayout of sampled locations (producers.hip)
 struct SortItem
 {

@@ -1,6 +1,6 @@
-"""Opt-in switches of the photometric linearize that change HOW the work is laid out, not what is computed: the split into
-a sampling and a contraction launch (SAGE_PHOTO_SPLIT=1: per-pixel hand-over record in HBM), the 2-D walk order of the samples
-(SAGE_SAMPLE_TILE=WxH) and the partial-record cadence (SAGE_PHOTO_FLUSH).  The switches are read once per process, so every
+"""Switches of the photometric linearize that change HOW the work is laid out, not what is computed: the walk order of the
+samples (SAGE_SAMPLE_TILE=WxH; the default 8x8 tiles feed the LDS-staged sampler, the raster walk 0x0 and wide tiles send
+most waves through the texture-path sampler) and the partial-record cadence (SAGE_PHOTO_FLUSH).  The switches are read once per process, so every
 variant runs in its own subprocess on the same window; the packed normal equations must agree with the default build's to
 fp32 accumulation-order noise, inlier totals exactly."""
 import os
@@ -38,8 +38,8 @@ def _run(tmp_path, name, env):
 def test_layout_switches_do_not_change_the_result(tmp_path):
     rel = lambda a, b: float(np.linalg.norm(a - b) / np.linalg.norm(b))
     base = _run(tmp_path, "base", {})
-    for name, env in (("split", {"SAGE_PHOTO_SPLIT": "1"}), ("tile16x4", {"SAGE_SAMPLE_TILE": "16x4"}),
-                      ("tile8x8", {"SAGE_SAMPLE_TILE": "8x8"}), ("flush0", {"SAGE_PHOTO_FLUSH": "0"}),
+    for name, env in (("raster", {"SAGE_SAMPLE_TILE": "0x0"}), ("tile16x4", {"SAGE_SAMPLE_TILE": "16x4"}),
+                      ("tile4x16", {"SAGE_SAMPLE_TILE": "4x16"}), ("flush0", {"SAGE_PHOTO_FLUSH": "0"}),
                       ("flush2", {"SAGE_PHOTO_FLUSH": "2"})):
         v = _run(tmp_path, name, env)
         assert np.array_equal(v["packed"][-2:], base["packed"][-2:]), name          # inlier totals: exact
