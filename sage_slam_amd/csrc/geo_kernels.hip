@@ -34,8 +34,7 @@ struct GeoParams
   float eps, loss_param;
   int tiles_per_block;
   int width, height; // cam.w / cam.h as integers: scalar (SGPR) values for the buffer descriptors
-  int n_work, xcd_chunk; // xcd_chunk > 0: XCD-aware work order (xcd_work_index)
-  const int32_t *order;  // optional launch order (LaunchCommon::order)
+  int n_work;
 };
 
 __device__ __forceinline__ int gload_loc(const void *loc, int is64, int n)
@@ -109,11 +108,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wq = wave; // quarter of the 256-pixel sub-tile this wave owns
-  int bid = uni(xcd_work_index((int)blockIdx.x, prm.n_work, prm.xcd_chunk));
-  if (bid < 0)
-    return;
-  if (prm.order)
-    bid = uni(prm.order[bid]);
+  const int bid = (int)blockIdx.x;
   WorkItem wi = prm.work[bid];
   wi.edge = uni(wi.edge);
   wi.tile = uni(wi.tile);
@@ -267,11 +262,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
     {
       const int i = lane & 15, k = lane >> 4;
       const uint32_t lane_off = (uint32_t)i * (NB == 2 ? 8u : 4u);
-#ifdef SAGE_EXP_NO_CONTRACT
-      constexpr int G = 0, AHEAD = 0;
-#else
       constexpr int G = 16, AHEAD = SAGE_GEO_AHEAD;
-#endif
       f32x4 o4[G + 1], w4[G + 1];
       float yi[G + 1], kap[G + 1];
       int locp[G + 1];
@@ -291,16 +282,6 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
 // CS = 32: one dwordx2 per lane covers the whole 128-byte row / texel with 16 lanes (one L1 request per pixel and tap
 // instead of two); lane i then holds channels (2i, 2i+1), i.e. operand block 0 = even channels, block 1 = odd channels
 // (the finalize kernel indexes the tiles accordingly).  CS = 16: one dword, block 0 = the 16 channels.
-#ifdef SAGE_EXP_NO_LOADS
-#define SAGE_GEO_ISSUE_LOADS(g)                                                        \
-  {                                                                                    \
-    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                     \
-    {                                                                                  \
-      tb[g][b] = w4[g][b];                                                             \
-      _Pragma("unroll") for (int q = 0; q < 4; ++q) tq[g][q][b] = w4[g][q] + kap[g];   \
-    }                                                                                  \
-  }
-#else
 #define SAGE_GEO_ISSUE_LOADS(g)                                                                              \
   {                                                                                                          \
     if (NB == 2)                                                                                             \
@@ -322,7 +303,6 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
           tq[g][q][0] = buf_load(r_b1, (uint32_t)__float_as_int(o4[g][q]) + lane_off, 0);                    \
     }                                                                                                        \
   }
-#endif
 // operands of group g: t' = sqrt(omega) [kappa*b0 ; beta], both MFMA operands of the t t^T tiles
 #define SAGE_GEO_STAGE_OPERANDS(g)                                                                             \
   {                                                                                                            \
@@ -586,13 +566,11 @@ static hipError_t geo_lin_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   p.width = (int)cam.w;
   p.height = (int)cam.h;
   p.n_work = lc.n_work;
-  p.xcd_chunk = lc.xcd_order ? (lc.n_work + 7) / 8 : 0;
-  p.order = lc.order;
   if (lc.stage != 2)
   {
     if (lc.ev_start)
       (void)hipEventRecord(lc.ev_start, s);
-    hipLaunchKernelGGL((geo_kernel<CS, true>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kGeoLinBlock), 0, s, p);
+    hipLaunchKernelGGL((geo_kernel<CS, true>), dim3(lc.n_work), dim3(kGeoLinBlock), 0, s, p);
     if (lc.ev_stop)
       (void)hipEventRecord(lc.ev_stop, s);
   }
@@ -634,11 +612,9 @@ static hipError_t geo_err_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   p.width = (int)cam.w;
   p.height = (int)cam.h;
   p.n_work = lc.n_work;
-  p.xcd_chunk = lc.xcd_order ? (lc.n_work + 7) / 8 : 0;
-  p.order = lc.order;
   if (lc.ev_start)
     (void)hipEventRecord(lc.ev_start, s);
-  hipLaunchKernelGGL((geo_kernel<CS, false>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
+  hipLaunchKernelGGL((geo_kernel<CS, false>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   if (lc.ev_stop)
     (void)hipEventRecord(lc.ev_stop, s);
   if (lc.stage == 1) // the caller forms the per-edge statistics itself (window error pass)

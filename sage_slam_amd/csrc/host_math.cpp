@@ -1745,7 +1745,6 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
   };
   if (phase == 0)
   {
-    static const bool getenv_no_prefetch = sage::env_flag("SAGE_SOLVE_NO_PREFETCH");
     static const bool prof = sage::env_flag("SAGE_CHOL_PROFILE");
     unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_readcyclecounter();
 #define LAP(k) do { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); tp[k] += t_ - tl; tl = t_; } } while (0)
@@ -1760,7 +1759,7 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
       // the column ranges of row i, in ascending order
       const int r0[2] = {afirst(i), row_first[i]}, r1[2] = {afirst(i) + acnt(i), i};
       RowPrefetch pf{nullptr, nullptr};
-      if (i + 1 < hi && !getenv_no_prefetch)
+      if (i + 1 < hi)
       {
         // row i+1's blocks are contiguous in the storage: [A range | B range]
         const size_t b0 = (size_t)(acnt(i + 1) ? E.a_off[i + 1] : row_off[i + 1]);
@@ -2346,7 +2345,7 @@ static SepPool *sep_pool()
     const unsigned hw = std::thread::hardware_concurrency();
     int n = getenv("SAGE_SOLVE_POOL") ? atoi(getenv("SAGE_SOLVE_POOL")) : 6;
     n = std::min(n, (int)hw - 2);
-    if (n < 1 || sage::env_flag("SAGE_SOLVE_NO_HELPER"))
+    if (n < 1)
       return (SepPool *)nullptr;
     SepPool *q = new SepPool;
     for (int i = 0; i < n; ++i)
@@ -2429,7 +2428,7 @@ static CholHelper *chol_helper()
 {
   // deliberately leaked: the thread may still be parked on the condition variable when the process exits
   static CholHelper *h = [] {
-    if (sage::env_flag("SAGE_SOLVE_NO_HELPER") || std::thread::hardware_concurrency() < 2)
+    if (std::thread::hardware_concurrency() < 2)
       return (CholHelper *)nullptr;
     CholHelper *p = new CholHelper;
     p->th = std::thread([p] { p->loop(); });
@@ -2551,7 +2550,7 @@ static void pin_one(pthread_t t, int cpu)
 
 static void place_helper_near(CholHelper *h, int cpu)
 {
-  if (cpu < 0 || cpu == h->near_cpu || sage::env_flag("SAGE_SOLVE_NO_AFFINITY"))
+  if (cpu < 0 || cpu == h->near_cpu)
     return;
   h->near_cpu = cpu;
   const std::vector<int> &cores = ccx_cores_of(cpu, false);
@@ -2561,7 +2560,7 @@ static void place_helper_near(CholHelper *h, int cpu)
 
 static void place_pool_near(SepPool *q, int cpu)
 {
-  if (cpu < 0 || cpu == q->near_cpu || sage::env_flag("SAGE_SOLVE_NO_AFFINITY"))
+  if (cpu < 0 || cpu == q->near_cpu)
     return;
   q->near_cpu = cpu;
   // cores[0] is the helper's; more workers than cores left in the CCX continue on the other cores of the NUMA node
@@ -2629,7 +2628,7 @@ int plan_blocks(int K, const std::vector<std::pair<int, int>> &links, bool allow
   {
     // the helper's half runs a little slower than the caller's (it wakes from sleep for every solve): give it
     // `bias` rows less
-    static const int bias = getenv("SAGE_SPLIT_BIAS") ? atoi(getenv("SAGE_SPLIT_BIAS")) : 1;
+    constexpr int bias = 1;
     // Loop closures: a link that spans more than a separator's width crosses every candidate split.  Such links are
     // covered by a small set C of keyframes (greedy: the keyframe on most still-uncovered long links first) that joins
     // the separator: order = [first half | second half descending | middle separator | C].  The rows of C are "arrow"
@@ -2637,7 +2636,7 @@ int plan_blocks(int K, const std::vector<std::pair<int, int>> &links, bool allow
     // factorisations, and the arrow rows are independent of each other until the (small) separator block: the host
     // factorisation spreads them over a few cores (block_chol_solve_tr).  At most 8 cover keyframes; otherwise, and
     // for windows without a split point, the identity order stays.
-    static const bool no_cover = sage::env_flag("SAGE_SOLVE_NO_COVER");
+    constexpr bool no_cover = false;
     std::vector<char> inC(K, 0);
     std::vector<int> cover;
     int best_m = -1, best_w = 0;
@@ -2984,8 +2983,7 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
       return SAGE_E_INVALID;
     first_blk[b] = std::min(first_blk[b], a);
   }
-  static const bool force_envelope = sage::env_flag("SAGE_SOLVE_ENVELOPE");
-  if ((Bp == 40 || Bp == 24) && !force_envelope)
+  if (Bp == 40 || Bp == 24)
   {
     // fixed-size transposed-block path (the one the window engine runs on the device-scattered storage), with the
     // same elimination order and two-core split

@@ -16,7 +16,6 @@
 // Algorithmic bytes per source pixel: 4*[4*FS*rho + CS + 6].
 #include <type_traits>
 
-#include "host_math.h" // env_flag
 #include "sage_device.h"
 #include "sage_internal.h"
 
@@ -36,15 +35,8 @@ struct PhotoParams
   int width, height;   // level-0 size as integers (scalar values for the basis descriptor)
   float rx[SAGE_MAX_LEVELS], ry[SAGE_MAX_LEVELS]; // fx_l/fx_0, fy_l/fy_0 (host-computed: no per-level divisions on the device)
   int lw[SAGE_MAX_LEVELS], lh[SAGE_MAX_LEVELS];   // level sizes as integers
-  // progress signalling (LaunchCommon::sig_*), null when unused
-  const int32_t *sig_group;
-  int32_t *sig_cnt;
-  const int32_t *sig_total;
-  unsigned *sig_flag_host;
-  unsigned sig_epoch;
   float geo_loss_param; // error kernel: > 0 -> also the geometric error of the edge (LaunchCommon::fused_geo_loss_param)
-  int n_work, xcd_chunk; // xcd_chunk > 0: XCD-aware work order (xcd_work_index)
-  const int32_t *order;  // optional launch order (LaunchCommon::order)
+  int n_work;
   // linearize: a workgroup writes one partial record per `flush` sub-tiles (record index = rec_first[edge] + tile / flush);
   // flush == tiles_per_block is the plain "one record per work item"
   const int32_t *rec_first;
@@ -233,11 +225,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
   __shared__ float s_l2[JAC ? kWaves * kPhotoL2Tiles * 256 : 1];
 
   const int tid_wg = threadIdx.x, tid = tid_wg, lane = tid & 63, wave = tid_wg >> 6;
-  int bid = uni(xcd_work_index((int)blockIdx.x, prm.n_work, prm.xcd_chunk));
-  if (bid < 0)
-    return;
-  if (prm.order)
-    bid = uni(prm.order[bid]);
+  const int bid = (int)blockIdx.x;
   WorkItem wi = prm.work[bid];
   wi.edge = uni(wi.edge);
   wi.tile = uni(wi.tile);
@@ -1083,8 +1071,6 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
   constexpr int NCC = photo_cc_tiles(CS);
   float *out = prm.partials + (size_t)(rec_base + sub / flush) * photo_partial_floats(CS);
   double *outd = reinterpret_cast<double *>(out + photo_partial_double_offset(CS));
-  const bool wt = prm.sig_cnt != nullptr; // signalling launches write the record through to memory (agent-scope stores):
-                                          // the consumer is a kernel on another stream
   if (tid < kPhotoScalars)
   {
     // scalar slots of the partial record (doubles): [0..20] Q^T G Q (upper triangle), [21..26] Q^T G q6 d,
@@ -1115,27 +1101,14 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
       for (int w = 0; w < kWaves; ++w)
         a += (double)s_red[w * 4 + slot];
     }
-    if (wt)
-      __hip_atomic_store(outd + tid, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    else
-      outd[tid] = a;
+    outd[tid] = a;
   }
   for (int idx = tid; idx < NT * 256; idx += kBlock)
   {
     if (idx < NCC * 256) // code-code tiles: fp32
-    {
-      if (wt)
-        __hip_atomic_store(out + kPhotoScalars + idx, tsum(idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else
-        out[kPhotoScalars + idx] = tsum(idx);
-    }
+      out[kPhotoScalars + idx] = tsum(idx);
     else // cross tiles: double
-    {
-      if (wt)
-        __hip_atomic_store(outd + kPhotoScalars + (idx - NCC * 256), tsumd(idx), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else
-        outd[kPhotoScalars + (idx - NCC * 256)] = tsumd(idx);
-    }
+      outd[kPhotoScalars + (idx - NCC * 256)] = tsumd(idx);
   }
     if (!last_sub)
     {
@@ -1171,25 +1144,6 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
       prm.partials[(size_t)bid * rec + tid] = a;
     }
     return;
-  }
-
-  if (prm.sig_cnt)
-  {
-    // this workgroup's partial record is complete: agent-scope release, then count it; the
-    // last one of the group tells the host, which launches the group's post-processing on another stream
-    // the record went out as write-through stores: no L2 write-back (an agent-scope release fence per workgroup costs
-    // 0.15 ms over the launch), only their completion before the count
-    __builtin_amdgcn_s_waitcnt(0);
-    __syncthreads();
-    if (tid == 0)
-    {
-      const int g = prm.sig_group[bid];
-      if (atomicAdd(&prm.sig_cnt[g], 1) == prm.sig_total[g] - 1)
-      { // (every record of the group is in memory already; the host only reads this flag, kernels launched after it
-        // start with fresh caches)
-        *reinterpret_cast<volatile unsigned *>(prm.sig_flag_host + g) = prm.sig_epoch;
-      }
-    }
   }
 }
 
@@ -1403,12 +1357,8 @@ static PhotoParams make_params(const PhotoEdge *single, const PhotoEdge *table, 
   p.tiles_per_block = lc.tiles_per_block;
   p.width = (int)pyr.cam[0].w;
   p.height = (int)pyr.cam[0].h;
-  p.sig_group = lc.sig_group; p.sig_cnt = lc.sig_cnt; p.sig_total = lc.sig_total;
-  p.sig_flag_host = lc.sig_flag_host; p.sig_epoch = lc.sig_epoch;
   p.geo_loss_param = lc.fused_geo_loss_param;
   p.n_work = lc.n_work;
-  p.xcd_chunk = lc.xcd_order ? (lc.n_work + 7) / 8 : 0;
-  p.order = lc.order;
   p.rec_first = lc.flush > 0 ? lc.edge_first : nullptr;
   p.flush = lc.flush > 0 ? lc.flush : lc.tiles_per_block;
   p.lds_l0 = pyr.levels; // off
@@ -1437,9 +1387,9 @@ static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const P
     if (lc.ev_start)
       (void)hipEventRecord(lc.ev_start, s);
     if (lc.packed)
-      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
+      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
     else
-      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 0>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
+      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 0>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
     if (lc.ev_stop)
       (void)hipEventRecord(lc.ev_stop, s);
   }
@@ -1483,8 +1433,7 @@ static hipError_t photo_err_impl(hipStream_t s, const PhotoEdge *single, const P
     int l0 = pyr.levels;
     while (l0 > 0 && (size_t)(pyr.P - pyr.level_offsets[l0 - 1]) * (FS / 4) * 16 <= kBudget)
       --l0;
-    static const bool off = env_flag("SAGE_NO_LDS_LEVELS");
-    if (l0 < pyr.levels && !off)
+    if (l0 < pyr.levels)
     {
       p.lds_l0 = l0;
       p.lds_base = pyr.level_offsets[l0];
@@ -1493,9 +1442,9 @@ static hipError_t photo_err_impl(hipStream_t s, const PhotoEdge *single, const P
     }
   }
   if (lc.packed)
-    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 1>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), lds_bytes, s, p);
+    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 1>), dim3(lc.n_work), dim3(kBlock), lds_bytes, s, p);
   else
-    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 0>), dim3(p.xcd_chunk ? 8 * p.xcd_chunk : lc.n_work), dim3(kBlock), 0, s, p);
+    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 0>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   if (lc.ev_stop)
     (void)hipEventRecord(lc.ev_stop, s);
   if (lc.stage == 1) // the caller forms the per-edge statistics itself (window error pass)

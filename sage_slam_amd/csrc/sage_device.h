@@ -32,17 +32,6 @@ __device__ __forceinline__ T *uni(T *p)
   return reinterpret_cast<T *>(((unsigned long long)hi << 32) | lo);
 }
 
-// ---------------------------------------------------------------- XCD-aware work order
-// MI355X: 8 XCDs with private L2s, consecutive workgroup ids are dealt to them round-robin.  chunk = ceil(n / 8):
-// workgroup b of a grid of 8 * chunk takes work item (b % 8) * chunk + b / 8 (or none, when that is past the end).
-__device__ __forceinline__ int xcd_work_index(int b, int n_work, int chunk)
-{
-  if (chunk <= 0)
-    return b;
-  const int w = (b & 7) * chunk + (b >> 3);
-  return ((b >> 3) < chunk && w < n_work) ? w : -1;
-}
-
 // ---------------------------------------------------------------- buffer loads
 // Raw buffer descriptors (T8 in the CDNA guide): one SGPR quad per array, the per-lane
 // tap offset in a VGPR, the per-channel plane offset in an SGPR (soffset).  Out-of-image

@@ -134,20 +134,6 @@ struct LaunchCommon
   // photometric error launches: > 0 -> the kernel also evaluates the geometric error of every edge (PhotoEdge::dpt1_geo)
   // with this Cauchy parameter; its partial record is then 4 floats {err_photo, n, err_geo, n} instead of 2
   float fused_geo_loss_param = 0.f;
-  // progress signalling of the photometric linearize (pipelined window solve, runtime.hip): work item i belongs to
-  // group sig_group[i]; the last workgroup of a group to finish publishes sig_epoch in sig_flag_host[group] (pinned)
-  const int32_t *sig_group = nullptr;
-  int32_t *sig_cnt = nullptr;
-  const int32_t *sig_total = nullptr;
-  unsigned *sig_flag_host = nullptr;
-  unsigned sig_epoch = 0;
-  // XCD-aware work order (window launches): workgroup b runs work item (b % 8) * ceil(n_work / 8) + b / 8, so that the
-  // workgroups the dispatcher deals round-robin to one XCD walk a CONTIGUOUS eighth of the work list (consecutive
-  // sub-tile runs of the same edges, edges sharing a destination keyframe) and find each other's lines in that XCD's L2
-  bool xcd_order = false;
-  // launch order (window launches, optional): workgroup b runs work item order[b] (a permutation of 0..n_work-1); the
-  // partial record stays indexed by the WORK ITEM, so every edge's records remain contiguous for its finalize
-  const int32_t *order = nullptr;
   // photometric linearize: > 0 -> one partial record per `flush` sub-tiles (edge_first / edge_tiles then count RECORDS:
   // record = edge_first[edge] + tile / flush); 0 -> one record per work item
   int32_t flush = 0;
@@ -244,15 +230,6 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
 void solver_destroy(DeviceSolver *S);
 int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, const float *vars0, float *vars1, int CS,
                double damp, double code_w, double scale_w, double pose_w, float scale_init0, const float *pose_init0);
-// pipelined use of the hybrid two-halves solve: see solve_kernels.hip
-bool solver_split_info(const DeviceSolver *S, int *n1, int *n2, const int32_t **pos, const int32_t **perm,
-                       const int32_t **pair_off, int *n_pair_off);
-int solver_pipe_begin(DeviceSolver *S, double damp, double code_w, double scale_w, double pose_w, float scale_init0,
-                      const float *pose_init0);
-int solver_pipe_scatter(DeviceSolver *S, hipStream_t stream, const double *packed_dev, const float *vars0, int CS,
-                        int ord_first, int ord_count);
-int solver_pipe_factor(DeviceSolver *S, hipStream_t stream, int (*before_row)(void *, int), void (*idle)(void *),
-                       void *user, const float *vars0, float *vars1, int CS);
 // valid after the stream has been synchronised
 const float *solver_host_vars(const DeviceSolver *S);
 const double *solver_host_delta(const DeviceSolver *S);

@@ -167,7 +167,7 @@ static int finish_plan(SageShardPlan *p, const std::vector<int> &link_dom, const
   p->sep_doubles = (size_t)nb * p->B * p->B + p->sep_all.size() * (size_t)p->B + 8;
   // ---- block envelope of the local system for the fixed-block path
   p->Bp = (p->B + 7) / 8 * 8;
-  p->fast = (p->Bp == 40 || p->Bp == 24) && !sage::env_flag("SAGE_SHARD_SCALAR");
+  p->fast = (p->Bp == 40 || p->Bp == 24);
   if (p->fast)
   {
     const int nI = (int)p->interior.size(), nS = (int)p->sep_local.size();

@@ -39,8 +39,6 @@
 namespace sage
 {
 
-constexpr int kSolveThreads = 1024;
-
 struct SolvePlan
 {
   int K, B, Bp, nblk, nlinks;
@@ -184,265 +182,6 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)
   return __longlong_as_double(((unsigned long long)hi << 32) | lo);
 }
 
-template <int BP, int NC>
-__global__ __launch_bounds__(kSolveThreads) void solve_factor_kernel(const SolvePlan P, double *L, double *y,
-                                                                     int *status, unsigned long long *dbg)
-{
-  unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tprev = dbg ? wall_clock64() : 0;
-  auto tick = [&](int slot) {
-    if (dbg)
-    {
-      const unsigned long long t = wall_clock64();
-      tacc[slot] += t - tprev;
-      tprev = t;
-    }
-  };
-  constexpr int NT = kSolveThreads;
-  constexpr int LDX = BP + 1;                                    // odd row stride (in doubles): conflict-free rows
-  constexpr int MAXROWS = (NC + 1) * BP + 1;                     // diagonal block, NC sub-blocks, the rhs row
-  constexpr int PE = ((NC + 1) * BP * BP + BP + NT - 1) / NT;    // panel elements per lane
-  constexpr int NPART = NT / BP;
-  __shared__ double sX[(NC + 1) * BP * LDX]; // normalised panel: slot 0 = L_jj, slots 1.. = L_ij
-  __shared__ double sY[BP];                  // y_j = L_jj^-1 (g_j - ...)
-  __shared__ double scol[2 * MAXROWS];       // column broadcast buffers
-  __shared__ double spiv[BP];                // pivots -> 1/sqrt(pivot)
-  __shared__ int sblk[NC + 1];
-  const int tid = threadIdx.x;
-  const int K = P.K;
-
-  for (int j = 0; j < K; ++j)
-  {
-    const int r0 = P.col_ptr[j], nR = P.col_ptr[j + 1] - r0;
-    if (tid <= nR)
-    {
-      const int i = tid == 0 ? j : P.col_rows[r0 + tid - 1];
-      sblk[tid] = P.row_off[i] + j - P.row_first[i];
-    }
-    __syncthreads();
-    const int nel = (1 + nR) * BP * BP + BP;
-    const int nq = (nel + NT - 1) / NT;
-    // ---- panel -> registers.  element e = rowg*BP + c ; rowg < BP: diagonal block (lower triangle live),
-    //      rowg = (1+nR)*BP: the right-hand side row ----
-    double a[PE];
-    int code[PE]; // rowg << 8 | (c + 1) ; 0 = dead element
-#pragma unroll
-    for (int q = 0; q < PE; ++q)
-    {
-      a[q] = 0.0;
-      code[q] = 0;
-      if (q < nq)
-      {
-        const int e = tid + q * NT;
-        if (e < nel)
-        {
-          const int rowg = e / BP, c = e - rowg * BP;
-          const int slot = rowg / BP, r = rowg - slot * BP;
-          const bool rhs = slot > nR;
-          const bool live = rhs || slot > 0 || c <= r;
-          if (live)
-          {
-            a[q] = rhs ? y[(size_t)j * BP + c] : L[(size_t)sblk[slot] * BP * BP + r * BP + c];
-            code[q] = (rowg << 8) | (c + 1);
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < PE; ++q)
-      if (q < nq && (code[q] & 0xff) == 1)
-        scol[code[q] >> 8] = a[q];
-    __syncthreads();
-    tick(0);
-    // ---- right-looking elimination, un-normalised (LDL^T style): a_rc -= a_rk a_ck / a_kk ----
-    bool bad = false;
-    for (int k = 0; k < BP; ++k)
-    {
-      const double *cur = scol + (k & 1) * MAXROWS;
-      double *nxt = scol + ((k + 1) & 1) * MAXROWS;
-      const double akk = cur[k];
-      if (!(akk > 0.0))
-      {
-        bad = true; // uniform: every lane reads the same pivot
-        break;
-      }
-      if (tid == 0)
-        spiv[k] = akk;
-      const double inv = 1.0 / akk;
-#pragma unroll
-      for (int q = 0; q < PE; ++q)
-        if (q < nq)
-        {
-          const int c1 = code[q] & 0xff, rowg = code[q] >> 8;
-          if (c1 > k + 1) // c > k
-          {
-            a[q] -= (cur[rowg] * inv) * cur[c1 - 1];
-            if (c1 == k + 2)
-              nxt[rowg] = a[q];
-          }
-        }
-      __syncthreads();
-    }
-    if (bad)
-    {
-      if (tid == 0)
-        *status = 1 + j;
-      return;
-    }
-    tick(1);
-    if (tid < BP)
-      spiv[tid] = 1.0 / sqrt(spiv[tid]);
-    __syncthreads();
-    // ---- normalise: L_rc = a_rc / sqrt(d_c); keep the panel in LDS for the trailing updates, store it for the
-    //      back substitution ----
-#pragma unroll
-    for (int q = 0; q < PE; ++q)
-      if (q < nq && code[q] != 0)
-      {
-        const int c = (code[q] & 0xff) - 1, rowg = code[q] >> 8;
-        const int slot = rowg / BP, r = rowg - slot * BP;
-        const double l = a[q] * spiv[c];
-        if (slot > nR)
-        {
-          sY[c] = l;
-          y[(size_t)j * BP + c] = l;
-        }
-        else
-        {
-          sX[(slot * BP + r) * LDX + c] = l;
-          L[(size_t)sblk[slot] * BP * BP + r * BP + c] = l;
-        }
-      }
-    __syncthreads();
-    tick(2);
-    // ---- trailing updates: C_ii' -= L_ij L_i'j^T (4x4 register tiles), g_i -= L_ij y_j ----
-    for (int jb = P.job_ptr[j] + tid; jb < P.job_ptr[j + 1]; jb += NT)
-    {
-      const int2 job = P.jobs[jb];
-      const int s = job.x & 15, s2 = (job.x >> 4) & 15, tr = (job.x >> 8) & 15, tc = (job.x >> 12) & 15;
-      const int kind = job.x >> 16;
-      const double *A = sX + (s * BP + 4 * tr) * LDX;
-      if (kind == 0)
-      {
-        const double *Bm = sX + (s2 * BP + 4 * tc) * LDX;
-        double *C = L + (size_t)job.y * BP * BP + (4 * tr) * BP + 4 * tc;
-        double cv[4][4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int v = 0; v < 4; ++v)
-            cv[u][v] = C[u * BP + v];
-        double acc[4][4] = {};
-#pragma unroll 4
-        for (int k = 0; k < BP; ++k)
-        {
-          double av[4], bv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-          {
-            av[u] = A[u * LDX + k];
-            bv[u] = Bm[u * LDX + k];
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-#pragma unroll
-            for (int v = 0; v < 4; ++v)
-              acc[u][v] += av[u] * bv[v];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-#pragma unroll
-          for (int v = 0; v < 4; ++v)
-            C[u * BP + v] = cv[u][v] - acc[u][v];
-      }
-      else
-      {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int k = 0; k < BP; ++k)
-        {
-          const double yk = sY[k];
-#pragma unroll
-          for (int u = 0; u < 4; ++u)
-            acc[u] += A[u * LDX + k] * yk;
-        }
-        double *yi = y + (size_t)job.y * BP + 4 * tr;
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          yi[u] -= acc[u];
-      }
-    }
-    __threadfence_block();
-    __syncthreads();
-    tick(3);
-  }
-
-  // ---- back substitution: x_j = L_jj^-T (y_j - sum_{i in R_j} L_ij^T x_i), j descending ----
-  double *xs = sX;                 // [K*BP] solution so far
-  double *sD = sX + K * BP;        // [BP*LDX] L_jj
-  double *spart = sD + BP * LDX;   // [NPART*BP]
-  int *srow = sblk;                // rows of R_j (sblk is rebuilt per column anyway)
-  __shared__ int srows[NC + 1];
-  (void)srow;
-  for (int j = K - 1; j >= 0; --j)
-  {
-    const int r0 = P.col_ptr[j], nR = P.col_ptr[j + 1] - r0;
-    if (tid <= nR)
-    {
-      const int i = tid == 0 ? j : P.col_rows[r0 + tid - 1];
-      sblk[tid] = P.row_off[i] + j - P.row_first[i];
-      srows[tid] = i;
-    }
-    __syncthreads();
-    {
-      const int c = tid % BP, part = tid / BP;
-      if (part < NPART)
-      {
-        double acc = 0.0;
-        for (int m = part; m < nR * BP; m += NPART)
-        {
-          const int s = m / BP, r = m - s * BP;
-          acc += L[(size_t)sblk[1 + s] * BP * BP + r * BP + c] * xs[srows[1 + s] * BP + r];
-        }
-        spart[part * BP + c] = acc;
-      }
-      for (int idx = tid; idx < BP * BP; idx += NT)
-      {
-        const int r = idx / BP, cc = idx - r * BP;
-        sD[r * LDX + cc] = L[(size_t)sblk[0] * BP * BP + idx];
-      }
-    }
-    __syncthreads();
-    if (tid < 64) // one wave: lane c owns z_c
-    {
-      double z = 0.0, dinv = 0.0, x = 0.0;
-      if (tid < BP)
-      {
-        z = y[(size_t)j * BP + tid];
-        for (int p = 0; p < NPART; ++p)
-          z -= spart[p * BP + tid];
-        dinv = 1.0 / sD[tid * LDX + tid];
-      }
-#pragma unroll
-      for (int c = BP - 1; c >= 0; --c)
-      {
-        const double xc = readlane_f64(z * dinv, c);
-        if (tid == c)
-          x = xc;
-        if (tid < c)
-          z -= sD[c * LDX + tid] * xc;
-      }
-      if (tid < BP)
-        xs[j * BP + tid] = x;
-    }
-    __syncthreads();
-  }
-  for (int idx = tid; idx < K * BP; idx += NT)
-    y[idx] = xs[idx];
-  tick(4);
-  if (dbg && tid == 0)
-    for (int i = 0; i < 6; ++i)
-      dbg[i] = tacc[i];
-}
-
 // ------------------------------------------------------------------------------------------------
 // retract: candidate = current (+) delta   (gtsam_traits.h:45-70; tangent order [trans, rot], left update)
 // ------------------------------------------------------------------------------------------------
@@ -553,7 +292,6 @@ struct DeviceSolver
   size_t h_vars_off = 0, h_delta_off = 0, h_tail_off = 0, h_status_off = 0, h_bytes = 0;
   SolvePlan plan{};
   int VS = 0;
-  bool device_factor = false;               // SAGE_DEVICE_SOLVE=1
   void *h_T = nullptr, *h_y = nullptr;       // pinned, one allocation like d_L/d_y (hybrid path)
   std::vector<double> h_X;                   // inverses of the diagonal factors
   std::vector<int32_t> h_row_first, h_row_off, h_a_first, h_a_cnt, h_a_off, h_col_ptr, h_col_rows;
@@ -567,13 +305,7 @@ struct DeviceSolver
   std::vector<int32_t> h_pos, h_perm; // elimination order (host copies)
   std::vector<int32_t> h_pair_off;    // order-list offset of "pair row" t (row t of the first half + row t of the second);
                                       // entry T = start of the separator rows, entry T+1 = nblk
-  // pipelined solve (solver_pipe_*): parameters of the solve in progress
-  SolvePriors pipe_pri{};
-  double pipe_damp = 0.0;
 };
-
-constexpr int kSolveNC40 = 10; // sub-diagonal blocks of one block column kept in LDS (BP = 40)
-constexpr int kSolveNC24 = 10;
 
 static int solver_bp(int B) { return (B + 7) / 8 * 8; }
 
@@ -584,17 +316,9 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   const int Bp = solver_bp(B);
   if ((Bp != 40 && Bp != 24) || K < 1)
     return SAGE_E_UNSUPPORTED;
-  const bool device_factor = sage::env_flag("SAGE_DEVICE_SOLVE");
-  if (device_factor)
-  {
-    // the device factorisation keeps x [K*Bp], L_jj and the partial sums of the back substitution in the panel's LDS
-    const int NC = Bp == 40 ? kSolveNC40 : kSolveNC24;
-    if (K * Bp + Bp * (Bp + 1) + (kSolveThreads / Bp) * Bp > (NC + 1) * Bp * (Bp + 1))
-      return SAGE_E_UNSUPPORTED;
-  }
   BlockPlan bp;
   {
-    const int rcp = plan_blocks(K, links, allow_split && !device_factor && !sage::env_flag("SAGE_SOLVE_NO_SPLIT"), bp);
+    const int rcp = plan_blocks(K, links, allow_split && !sage::env_flag("SAGE_SOLVE_NO_SPLIT"), bp);
     if (rcp != SAGE_OK)
       return rcp;
   }
@@ -605,7 +329,6 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   std::vector<int32_t> col_ptr(K + 1, 0), col_rows, job_ptr(K + 1, 0);
   std::vector<int2> jobs;
   int max_rows = 0;
-  const int T = Bp / 4;
   for (int j = 0; j < K; ++j)
   {
     col_ptr[j] = (int)col_rows.size();
@@ -617,25 +340,9 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
     max_rows = std::max(max_rows, (int)rows.size());
     for (int i : rows)
       col_rows.push_back(i);
-    if (!device_factor)
-      continue; // the tile-job lists below are only used by the device factorisation
-    for (size_t s = 0; s < rows.size(); ++s)
-      for (size_t s2 = 0; s2 <= s; ++s2)
-      {
-        const int i = rows[s], i2 = rows[s2];
-        const int cblk = row_off[i] + i2 - row_first[i];
-        for (int tr = 0; tr < T; ++tr)
-          for (int tc = 0; tc < (s == s2 ? tr + 1 : T); ++tc)
-            jobs.push_back(make_int2((int)(s + 1) | ((int)(s2 + 1) << 4) | (tr << 8) | (tc << 12), cblk));
-      }
-    for (size_t s = 0; s < rows.size(); ++s)
-      for (int tr = 0; tr < T; ++tr)
-        jobs.push_back(make_int2((int)(s + 1) | (tr << 8) | (1 << 16), rows[s]));
   }
   col_ptr[K] = (int)col_rows.size();
   job_ptr[K] = (int)jobs.size();
-  if (device_factor && max_rows > (Bp == 40 ? kSolveNC40 : kSolveNC24))
-    return SAGE_E_UNSUPPORTED; // envelope wider than the LDS panel (the hybrid path has no such limit)
   if (col_rows.empty())
     col_rows.push_back(0);
   if (jobs.empty())
@@ -707,7 +414,6 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   S->d_y = reinterpret_cast<double *>(S->d_L) + (size_t)nblk * Bp * Bp;
   if (sage::env_flag("SAGE_DEBUG_TIMING") && hipMalloc(&S->d_dbg, 8 * sizeof(unsigned long long)) != hipSuccess)
     return fail((int)hipErrorOutOfMemory);
-  S->device_factor = device_factor;
   S->h_row_first = row_first;
   S->h_row_off = row_off;
   S->h_a_first = a_first;
@@ -715,7 +421,6 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   S->h_a_off = a_off;
   S->h_col_ptr = bp.col_ptr;
   S->h_col_rows = bp.col_rows;
-  if (!S->device_factor)
   {
     if (hipHostMalloc(&S->h_T, ty_doubles * sizeof(double) + (size_t)nblk * sizeof(unsigned), hipHostMallocDefault) !=
         hipSuccess)
@@ -723,8 +428,6 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
     S->h_y = reinterpret_cast<double *>(S->h_T) + (size_t)nblk * Bp * Bp;
     S->h_flags = reinterpret_cast<unsigned *>(reinterpret_cast<double *>(S->h_T) + ty_doubles);
     std::memset(S->h_flags, 0, (size_t)nblk * sizeof(unsigned));
-    if (const char *e = getenv("SAGE_SCATTER_WGS"))
-      S->scatter_wgs = std::max(1, atoi(e));
     S->h_X.assign((size_t)K * Bp * Bp, 0.0);
   }
   S->h_vars_off = 0;
@@ -775,33 +478,6 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
   pri.code_w = code_w; pri.scale_w = scale_w; pri.pose_w = pose_w; pri.scale_init0 = scale_init0;
   for (int i = 0; i < 12; ++i)
     pri.pose_init0[i] = pose_init0[i];
-  double *tail = reinterpret_cast<double *>(S->d_tail);
-  int *status = reinterpret_cast<int *>(tail + 1);
-  if (S->device_factor && hipMemsetAsync(S->d_tail, 0, 2 * sizeof(double), stream) != hipSuccess)
-    return (int)hipGetLastError();
-  double *dL = reinterpret_cast<double *>(S->d_L), *dy = reinterpret_cast<double *>(S->d_y);
-  if (S->device_factor)
-    hipLaunchKernelGGL(solve_scatter_kernel, dim3(S->nblk), dim3(256), 0, stream, S->plan, packed_dev, vars0, S->VS, CS,
-                       pri, damp, 0, dL, dy, (const int32_t *)nullptr, (unsigned *)nullptr, 0u, 0, S->nblk);
-  if (S->device_factor)
-  {
-    unsigned long long *dbg = reinterpret_cast<unsigned long long *>(S->d_dbg);
-    if (S->Bp == 40)
-      hipLaunchKernelGGL((solve_factor_kernel<40, kSolveNC40>), dim3(1), dim3(kSolveThreads), 0, stream, S->plan, dL, dy,
-                         status, dbg);
-    else
-      hipLaunchKernelGGL((solve_factor_kernel<24, kSolveNC24>), dim3(1), dim3(kSolveThreads), 0, stream, S->plan, dL, dy,
-                         status, dbg);
-    if (S->d_dbg)
-    {
-      unsigned long long h[6];
-      (void)hipStreamSynchronize(stream);
-      (void)hipMemcpy(h, S->d_dbg, sizeof(h), hipMemcpyDeviceToHost);
-      fprintf(stderr, "[sage device solve] us: load+publish %.1f eliminate %.1f normalise %.1f update %.1f backsub %.1f\n",
-              h[0] * 0.01, h[1] * 0.01, h[2] * 0.01, h[3] * 0.01, h[4] * 0.01);
-    }
-  }
-  else
   {
     // hybrid: the dependency chain of the factorisation runs on host cores, everything around it stays on the device.
     // The scatter kernel streams the blocks into pinned host memory in the order the factorisation consumes them and
@@ -850,104 +526,13 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
   char *h = reinterpret_cast<char *>(S->h_pinned);
   // (hybrid: the solution is read straight from the pinned buffer the host solved in)
   hipLaunchKernelGGL(solve_retract_kernel, dim3(1), dim3(1024), 0, stream,
-                     reinterpret_cast<const double *>(S->device_factor ? S->d_y : S->h_y), S->K,
+                     reinterpret_cast<const double *>(S->h_y), S->K,
                      S->B, S->Bp, CS, S->VS, S->plan.pos, vars0, vars1, reinterpret_cast<float *>(h + S->h_vars_off),
                      reinterpret_cast<double *>(h + S->h_delta_off), reinterpret_cast<double *>(h + S->h_tail_off));
   hipError_t e = hipGetLastError();
   if (e != hipSuccess)
     return (int)e;
-  if (S->device_factor && // the pivot status of the device factorisation (the hybrid path reports it synchronously)
-      (e = hipMemcpyAsync(h + S->h_tail_off + sizeof(double), status, sizeof(int), hipMemcpyDeviceToHost, stream)) !=
-          hipSuccess)
-    return (int)e;
   return SAGE_OK;
-}
-
-// ---- pipelined use of the hybrid path (runtime.hip, sage_window_lm_step): the caller scatters slices of the order
-// list as the linearisation produces their rows (solver_pipe_scatter, any stream) while solver_pipe_factor runs the
-// two-halves host factorisation, which calls `before_row` ahead of every block row (from both threads).
-bool solver_split_info(const DeviceSolver *S, int *n1, int *n2, const int32_t **pos, const int32_t **perm,
-                       const int32_t **pair_off, int *n_pair_off)
-{
-  if (S->device_factor || S->n1 <= 0)
-    return false;
-  {
-    // loop-closure plans (cover keyframes in the separator: long "arrow" rows) are not pipelined: the row-by-row hand-over
-    // of the pipeline assumes a separator of a few short rows
-    BlockEnvelope pe;
-    pe.K = S->K; pe.Bp = S->Bp;
-    pe.row_first = S->h_row_first.data(); pe.row_off = S->h_row_off.data();
-    pe.a_first = S->h_a_first.data(); pe.a_cnt = S->h_a_cnt.data(); pe.a_off = S->h_a_off.data();
-    pe.n1 = S->n1; pe.n2 = S->n2;
-    if (block_plan_has_arrow_rows(pe))
-      return false;
-  }
-  *n1 = S->n1; *n2 = S->n2;
-  *pos = S->h_pos.data(); *perm = S->h_perm.data();
-  *pair_off = S->h_pair_off.data(); *n_pair_off = (int)S->h_pair_off.size();
-  return true;
-}
-
-int solver_pipe_begin(DeviceSolver *S, double damp, double code_w, double scale_w, double pose_w, float scale_init0,
-                      const float *pose_init0)
-{
-  if (S->device_factor)
-    return SAGE_E_STATE;
-  S->pipe_pri = SolvePriors{};
-  S->pipe_pri.code_w = code_w; S->pipe_pri.scale_w = scale_w; S->pipe_pri.pose_w = pose_w;
-  S->pipe_pri.scale_init0 = scale_init0;
-  for (int i = 0; i < 12; ++i)
-    S->pipe_pri.pose_init0[i] = pose_init0[i];
-  S->pipe_damp = damp;
-  S->epoch += 1;
-  if (S->epoch == 0)
-    S->epoch = 1;
-  if (S->n1 > 0)
-    block_chol_arm();
-  return SAGE_OK;
-}
-
-int solver_pipe_scatter(DeviceSolver *S, hipStream_t stream, const double *packed_dev, const float *vars0, int CS,
-                        int ord_first, int ord_count)
-{
-  if (ord_count <= 0)
-    return SAGE_OK;
-  hipLaunchKernelGGL(solve_scatter_kernel, dim3(std::min(S->scatter_wgs, ord_count)), dim3(256), 0, stream, S->plan,
-                     packed_dev, vars0, S->VS, CS, S->pipe_pri, S->pipe_damp, 1, reinterpret_cast<double *>(S->h_T),
-                     reinterpret_cast<double *>(S->h_y), S->d_order, S->h_flags, S->epoch, ord_first, ord_count);
-  const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? SAGE_OK : (int)e;
-}
-
-int solver_pipe_factor(DeviceSolver *S, hipStream_t stream, int (*before_row)(void *, int), void (*idle)(void *),
-                       void *user, const float *vars0, float *vars1, int CS)
-{
-  BlockEnvelope env;
-  env.K = S->K; env.Bp = S->Bp;
-  env.row_first = S->h_row_first.data(); env.row_off = S->h_row_off.data();
-  env.a_first = S->h_a_first.data(); env.a_cnt = S->h_a_cnt.data(); env.a_off = S->h_a_off.data();
-  env.n1 = S->n1; env.n2 = S->n2;
-  env.col_ptr = S->h_col_ptr.data(); env.col_rows = S->h_col_rows.data();
-  env.ready = S->h_flags; env.epoch = S->epoch;
-  env.before_row = before_row; env.idle = idle; env.user = user;
-  static const bool dbgt = sage::env_flag("SAGE_DEBUG_TIMING");
-  double t_tickets = 0.0;
-  if (dbgt)
-    env.t_ticket_wait = &t_tickets; // (both threads add to it: indicative only)
-  const int bad = block_chol_solve_tr(env, reinterpret_cast<double *>(S->h_T), S->h_X.data(),
-                                      reinterpret_cast<double *>(S->h_y));
-  if (dbgt)
-    fprintf(stderr, "[sage pipelined solve] %.3f ms waiting for tickets\n", 1e3 * t_tickets);
-  if (bad == -2)
-    return SAGE_E_STATE;
-  if (bad)
-    return SAGE_E_NOT_PSD;
-  char *h = reinterpret_cast<char *>(S->h_pinned);
-  hipLaunchKernelGGL(solve_retract_kernel, dim3(1), dim3(1024), 0, stream, reinterpret_cast<const double *>(S->h_y), S->K,
-                     S->B, S->Bp, CS, S->VS, S->plan.pos, vars0, vars1, reinterpret_cast<float *>(h + S->h_vars_off),
-                     reinterpret_cast<double *>(h + S->h_delta_off), reinterpret_cast<double *>(h + S->h_tail_off));
-  const hipError_t e = hipGetLastError();
-  return e == hipSuccess ? SAGE_OK : (int)e;
 }
 
 const float *solver_host_vars(const DeviceSolver *S) { return reinterpret_cast<const float *>(reinterpret_cast<const char *>(S->h_pinned) + S->h_vars_off); }

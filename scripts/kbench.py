@@ -6,7 +6,8 @@ import torch
 from sage_slam_amd import capi, synth
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-w = synth.make_window(K=K, H=128, W=160, FS=16, CS=32, L=4, seed=0)
+H, W, FS, CS = (int(a) for a in sys.argv[3:7]) if len(sys.argv) > 6 else (128, 160, 16, 32)   # config 4: 16 3 256 320 32 32
+w = synth.make_window(K=K, H=H, W=W, FS=FS, CS=CS, L=4, seed=0)
 win = capi.Window(w)
 win.linearize(); win.error(1); torch.cuda.synchronize()
 win.set_profiling(True)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 PMC passes over the kernel micro-bench (separate passes per counter group; gpurun forbids mixing --pmc
 # with trace domains other than --kernel-trace).  Every pass has its own timeout: a TA_* pass once hung for the whole
-# gpurun limit.  Results: gpurun_out/pmc_<tag>/pass*/ + summary.txt
+# gpurun limit.  Results: gpurun_out/pmc_<tag>/pass*/ + summary.txt.  KBENCH_ARGS="16 3 256 320 32 32" profiles BASELINE config 4.
 TAG=${1:-r01}
 shift
 cd /tmp && export TMPDIR=/tmp
@@ -17,6 +17,6 @@ GROUPS_DEFAULT=("FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" \
 if [ $# -gt 0 ]; then GROUPS_DEFAULT=("$@"); fi
 for grp in "${GROUPS_DEFAULT[@]}"; do
   i=$((i+1))
-  timeout 90 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pass$i -o p -- python $R/scripts/kbench.py 64 3 > $OUT/pass$i.log 2>&1 || echo "pass $i ($grp) failed or timed out" >> $OUT/failed.txt
+  timeout 90 rocprofv3 --pmc $grp --kernel-trace --output-format csv -d $OUT/pass$i -o p -- python $R/scripts/kbench.py ${KBENCH_ARGS:-64 3} > $OUT/pass$i.log 2>&1 || echo "pass $i ($grp) failed or timed out" >> $OUT/failed.txt
 done
 python $R/scripts/pmc_summary.py $OUT > $OUT/summary.txt 2>&1

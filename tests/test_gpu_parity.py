@@ -394,37 +394,6 @@ def test_window_with_ragged_sample_counts(capi, orc):
     win.close()
 
 
-def test_pipelined_lm_step_matches_classic(capi, monkeypatch):
-    """SAGE_PIPELINE=1: the LM iteration that post-processes finished row chunks while the photometric kernel is still
-    running, and factors rows as they arrive, walks the same trajectory as the classic sequence (same per-edge
-    arithmetic; the factorisation order differs: one piece vs two halves)."""
-    w = synth.make_window(K=20, H=48, W=64, FS=16, CS=32, L=3, n_samples=1200, seed=12)
-
-    def run():
-        win = capi.Window(w)
-        cfg = capi.lm_config_default(); cfg.max_inner_evals = 1
-        st = capi.SageLmState()
-        tr = []
-        d = None
-        for _ in range(5):
-            win.lm_step(st, cfg)
-            tr.append((st.error, st.candidate_error, st.accepted, st.damp))
-            if d is None:
-                d = win.delta().copy()          # the first (large) step: later ones shrink into the solve's noise
-        p = win.packed_host().astype(np.float64)
-        win.close()
-        return np.array(tr), d, p
-
-    monkeypatch.delenv("SAGE_PIPELINE", raising=False)
-    t0, d0, p0 = run()
-    monkeypatch.setenv("SAGE_PIPELINE", "1")
-    monkeypatch.setenv("SAGE_PIPE_ROWS", "3")                                   # 7 chunks, the last one ragged
-    t1, d1, p1 = run()
-    assert np.array_equal(t0[:, 2], t1[:, 2])                                   # same accept / reject decisions
-    np.testing.assert_allclose(t1[:, :2], t0[:, :2], rtol=1e-6)
-    assert rel(p1, p0) < 1e-6 and rel(d1, d0) < 1e-5
-
-
 @pytest.mark.parametrize("dec,inner", [(10.0, 0), (1.0e5, 0), (1.0e5, 1)])
 def test_linearize_at_candidate_lm_matches_classic(capi, dec, inner):
     """SageLmConfig.linearize_at_candidate: the candidate is evaluated by the linearize kernels (error + system from one
