@@ -32,12 +32,39 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
-# HBM bytes per launch of the dominant kernel from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate
-# passes, same workload: scripts/pmc_run.sh -> profiles/r03_v3_pmc_summary.txt).  FETCH_SIZE is doubled as
-# MI355X_MICROARCH.md prescribes for 16 B/lane reads on gfx950 (all tap loads are dwordx4).  bench.py cannot collect
-# PMC counters itself; this is the committed measurement for the K=64 headline window (null for any other workload).
-PMC_TRAFFIC_BYTES_K64 = {"fetch_size_kb": 1.06839e6, "write_size_kb": 82245.9,
-                         "hbm_bytes_per_launch": (2 * 1.06839e6 + 82245.9) * 1024.0}
+# Counter constants of the K = 64 headline window (rocprofv3 --pmc, separate passes, scripts/pmc_run.sh ->
+# profiles/r04_v1_pmc_summary.txt; bench.py cannot collect PMC counters itself, null for any other workload).  They are
+# per-launch INSTRUCTION / BYTE counts of one build on one workload -- fixed by the code, not by the box -- and are combined
+# below with the launch durations measured live in this run.
+#   traffic: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane reads on gfx950, + WRITE_SIZE
+PMC_K64 = {
+    "source": "profiles/r04_v1_pmc_summary.txt",
+    "photo": {"fetch_size_kb": 735074.0, "write_size_kb": 43969.0, "insts_vmem_rd": 7.85302e6, "insts_valu": 1.84123e8,
+              "insts_mfma": 8.96938e6, "lds_idx_active": 1.37959e8, "lds_bank_conflict": 3.24344e7},
+    "geo": {"insts_vmem_rd": 9.10057e6, "insts_valu": 7.931e7, "insts_mfma": 2.24986e7, "lds_idx_active": 3.24502e7},
+}
+PMC_TRAFFIC_BYTES_K64 = {"hbm_bytes_per_launch": (2 * PMC_K64["photo"]["fetch_size_kb"] + PMC_K64["photo"]["write_size_kb"]) * 1024.0}
+N_CU, N_SIMD, CLK_HZ = 256, 1024, 2.4e9          # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
+L1_PEAK_GBS = N_CU * 64 * CLK_HZ / 1e9         # CU texture path: 64 B / clk / CU  (39.3 TB/s)
+MFMA_F32_PEAK_TFLOPS = 157.3                    # dense f32 matrix peak (= the f32 vector peak on this part)
+
+
+def issue_roofline(pmc, ms):
+    """Per-pipe utilisation of one launch from its instruction counts (committed PMC constants) and its duration measured
+    in this run.  l1: wave-loads x 1 KiB (16 B / lane, the dwordx4 taps / staging loads) against the CUs' texture-path
+    rate; lds: LDS-array busy cycles per CU; valu: one issue slot (4 cycles per SIMD) per wave instruction; mfma: FLOP of
+    the 16x16x4 f32 instructions against the dense f32 matrix peak.  The peak clock is assumed (the part runs ~2.0-2.1 GHz
+    under this load: fractions are lower bounds of the pipes' busy time)."""
+    if not pmc or ms <= 0:
+        return None
+    t = ms * 1e-3
+    out = {"l1": {"achieved": pmc["insts_vmem_rd"] * 1024.0 / t / 1e9, "peak": L1_PEAK_GBS, "unit": "GB/s"},
+           "valu": {"achieved": pmc["insts_valu"] * 4.0 / N_SIMD / t / 1e9, "peak": CLK_HZ / 1e9, "unit": "Gcycles/s per SIMD"},
+           "mfma": {"achieved": pmc["insts_mfma"] * 2048.0 / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s"},
+           "lds": {"achieved": pmc["lds_idx_active"] / N_CU / t / 1e9, "peak": CLK_HZ / 1e9, "unit": "Gcycles/s per CU"}}
+    for v in out.values():
+        v["frac"] = v["achieved"] / v["peak"]
+    return out
 
 
 def cpu_baseline(win, budget_s: float = 20.0):
@@ -417,7 +444,7 @@ def main():
         torch.cuda.synchronize()
 
     hist = []
-    RESTART = 5   # the LM converges in ~3 steps on this scene: restart from the initial estimate every RESTART steps so
+    RESTART = 3   # the LM converges in ~3 steps on this scene: restart from the initial estimate every RESTART steps so
                   # the timed steps are live descent steps (a restart is one small H2D of the variables, inside the timing)
     for i in range(args.warmup):
         hist.append(lm_step())
@@ -454,6 +481,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     ktime = [win.kernel_time(which) for which in range(4)]
+    phase, phase_n = win.phase_time()
     win.set_profiling(False)
     per_rank_ms = None
     if dist is not None:
@@ -474,11 +502,21 @@ def main():
         ms_geo = ktime[1][0] / max(1, ktime[1][1])
         ach = px_launch * bytes_photo_px / (ms_photo * 1e-3) / 1e9 if ms_photo > 0 else 0.0
         ach_geo = px_launch * bytes_geo_px / (ms_geo * 1e-3) / 1e9 if ms_geo > 0 else 0.0
+        headline = world == 1 and args.keyframes == 64 and args.height == 128 and args.fs == 16 and args.cs == 32
+        n_acc = int(sum(1 for h in hist[args.warmup:] if h[2]))
+        # phases of an iteration on rank 0's stream timeline (HIP events); "host_idle" = the rest of the step: accept /
+        # reject decision, the error totals' all-reduce, launch gaps
+        phase_ms = None
+        if phase_n > 0:
+            phase_ms = {k: v / phase_n for k, v in phase.items()}
+            phase_ms["host_idle"] = max(0.0, ms_per_step - sum(phase_ms.values()))
+            phase_ms["iterations_sampled"] = phase_n
         out = {
             "metric": f"M residuals/sec (+ LM iters/sec), {args.keyframes}-keyframe feature-metric BA @{args.height}x{args.width}",
             "value": residuals_per_step * args.steps / elapsed / 1e6,
             "unit": "Mresiduals/s",
             "lm_iters_per_sec": args.steps / elapsed,
+            "accepted_iters_per_sec": n_acc / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
@@ -494,21 +532,25 @@ def main():
                               if args.lm_variant == "classic" else
                               "linearize-at-candidate: per evaluation 1 solve + 1 linearize at the candidate (error and "
                               "system from one pass); no separate error pass; +1 linearize after every restart"),
-                       "accepted_steps": int(sum(1 for h in hist[args.warmup:] if h[2])),
+                       "accepted_steps": n_acc,
                        "error_first_last": [hist[0][0], hist[-1][1]]},
             "roofline": {"bound": "hbm", "kernel": "photo_kernel<CS,FS,true> (fused photometric linearize)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "traffic": (PMC_TRAFFIC_BYTES_K64["hbm_bytes_per_launch"]
-                                     if (world == 1 and args.keyframes == 64 and args.height == 128 and args.fs == 16) else None),
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, profiles/r03_v3_pmc_summary.txt",
+                         "bound_note": "the HBM figure is SURVEY s8(d)'s algorithmic-byte roofline; what binds the kernel is VALU + MFMA issue (see issue)",
+                         "traffic": PMC_TRAFFIC_BYTES_K64["hbm_bytes_per_launch"] if headline else None,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, " + PMC_K64["source"],
+                         "issue": issue_roofline(PMC_K64["photo"], ms_photo) if headline else None,
                          "bytes_per_launch": px_launch * bytes_photo_px, "avg_launch_ms": ms_photo,
                          "geo_kernel": {"achieved": ach_geo, "frac": ach_geo / HBM_PEAK_GBS, "avg_launch_ms": ms_geo,
-                                        "bytes_per_launch": px_launch * bytes_geo_px},
+                                        "bytes_per_launch": px_launch * bytes_geo_px,
+                                        "issue": issue_roofline(PMC_K64["geo"], ms_geo) if headline else None},
                          # (the window's error pass evaluates both factor types in the photometric error kernel: no
-                         #  separate geometric launch unless SAGE_NO_ERROR_FUSION=1)
+                         #  separate geometric launch)
                          "error_pass_ms": {"photo+geo" if ktime[3][1] == 0 else "photo": ktime[2][0] / max(1, ktime[2][1]),
                                            **({"geo": ktime[3][0] / ktime[3][1]} if ktime[3][1] else {})}},
         }
+        if phase_ms:
+            out["phase_ms"] = phase_ms
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(win_h)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -405,6 +405,11 @@ int sage_factor_cut_blocks(int type, int CS, const double *C, const float *Atb, 
  * launch count since the last reset, and resets them. */
 int sage_window_set_profiling(SageWindow *w, int on);
 int sage_window_get_kernel_time(SageWindow *w, int which, double *total_ms, int *launches);
+/* phases of the LM iterations run through sage_window_lm_step / _lm_run since the last call (profiling on), on the
+ * stream's own timeline (HIP events): ms4 = {linearize (depth maps .. assembled system), all-reduce of the system,
+ * solve (scatter + host factorisation + retract), error pass}, summed over `iterations`; whatever a step takes beyond
+ * their sum is host time with the device idle (accept / reject decision, second all-reduce, launch gaps). */
+int sage_window_get_phase_time(SageWindow *w, double *ms4, int *iterations);
 
 /* ---- f3 (first part): sparse reprojection factor with the fair loss ----------------------------------------------
  * Replaces cuda/reprojection_factor_kernels.h:8-46 (reference: reprojection_factor_kernels.cpp):

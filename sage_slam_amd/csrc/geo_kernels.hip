@@ -145,6 +145,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
   const int nsub = min(prm.tiles_per_block, (N + kTile - 1) / kTile - wi.tile);
   for (int h = 0; h < nsub; ++h)
   {
+    bool slice_live = true; // false: no pixel of this wave's 64 is an inlier -- its contraction would add exact zeros
     {
     // wave priority: the geometry phase (loads + per-pixel arithmetic) ahead of the other waves' contraction phases
     // (r03: 0.550 -> 0.534 ms)
@@ -190,7 +191,8 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
     const float err = (pos && in_range) ? logf(1.0f + mr * mr / loss_param) : 0.f; // :600
     err_acc += err;
     vm_acc += vm;
-    if (JAC)
+    slice_live = __ballot(vm != 0.f) != 0ull;
+    if (JAC && slice_live)
     {
     const bool live = vm != 0.f;
     float y[9];
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
     }
     } // JAC
     } // geometry phase
-    if (JAC)
+    if (JAC && slice_live)
     {
     __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_wave_barrier(); // same-wave LDS hand-over (in-order LDS pipe): no workgroup barrier needed

@@ -445,6 +445,8 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
       qmx = wave_fminmax<false>(lv ? q : -inf);
       slice_live = pmn <= pmx;
     }
+    else
+      slice_live = __ballot(vm != 0.f) != 0ull; // error pass: a slice without inliers adds exact zeros
     // per level: box origin, width, first slot inside its staging region (wave-uniform)
     int bx0[kStageLevels] = {}, by0[kStageLevels] = {}, bwd[kStageLevels] = {}, bhd[kStageLevels] = {}, sb[kStageLevels] = {};
     int cnt0 = 0, cntC = 0;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
       }
       staged = cnt0 <= kStageCap0 && cntC <= kStageCapC; // (6 x 6 + 4 x 4 + 3 x 3 = 61 coarse texels, one more row / column at an image border)
     }
-    if (JAC && !slice_live)
+    if (!slice_live)
     {
       // nothing to sample
     }

@@ -277,6 +277,17 @@ struct SageWindow
     int psd_mode = -1;
   } fc;
   // optional kernel timing (HIP events on `stream`)
+  // phase marks of an LM iteration on the stream's timeline (profiling only): 0 start of the linearize, 1 system
+  // assembled, 2 all-reduce of the system enqueued / done, 3 candidate written (scatter + host factorisation + retract),
+  // 4 error pass done
+  struct PhaseMarks
+  {
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  };
+  std::vector<PhaseMarks> phase_pending;
+  PhaseMarks phase_cur;
+  double phase_ms[4] = {0, 0, 0, 0}; // linearize, all-reduce, solve, error pass
+  int phase_n = 0;
   bool profiling = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[4];
   double prof_ms[4] = {0, 0, 0, 0};
@@ -298,3 +309,4 @@ static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t s)
 int window_upload_vars(SageWindow *w, int set);
 int window_linearize_set(SageWindow *w, int set);
 int window_sync_candidate(SageWindow *w);
+void window_phase_mark(SageWindow *w, int which); // profiling: record phase mark `which` on the window's stream

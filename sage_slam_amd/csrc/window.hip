@@ -226,6 +226,63 @@ static void prof_attach(SageWindow *w, int which, LaunchCommon &lc)
   w->pending[which].emplace_back(a, b);
 }
 
+void window_phase_mark(SageWindow *w, int which)
+{
+  if (!w->profiling)
+    return;
+  if (which == 0) // a new iteration: the previous one's marks are complete (or abandoned)
+  {
+    bool complete = true;
+    for (hipEvent_t e : w->phase_cur.ev)
+      complete = complete && e != nullptr;
+    if (complete)
+      w->phase_pending.push_back(w->phase_cur);
+    else
+      for (hipEvent_t e : w->phase_cur.ev)
+        if (e)
+          (void)hipEventDestroy(e);
+    w->phase_cur = SageWindow::PhaseMarks{};
+  }
+  hipEvent_t e;
+  if (w->phase_cur.ev[which] || hipEventCreate(&e) != hipSuccess)
+    return;
+  (void)hipEventRecord(e, w->stream);
+  w->phase_cur.ev[which] = e;
+}
+
+extern "C" int sage_window_get_phase_time(SageWindow *w, double *ms4, int *iterations)
+{
+  if (!w || !ms4)
+    return SAGE_E_INVALID;
+  SAGE_HIP(hipStreamSynchronize(w->stream));
+  window_phase_mark(w, 0); // flush the iteration in progress
+  for (auto &pm : w->phase_pending)
+  {
+    float d[4] = {0, 0, 0, 0};
+    bool ok = true;
+    for (int i = 0; i < 4; ++i)
+      ok = ok && hipEventElapsedTime(&d[i], pm.ev[i], pm.ev[i + 1]) == hipSuccess;
+    if (ok)
+    {
+      for (int i = 0; i < 4; ++i)
+        w->phase_ms[i] += d[i];
+      w->phase_n += 1;
+    }
+    for (hipEvent_t e : pm.ev)
+      (void)hipEventDestroy(e);
+  }
+  w->phase_pending.clear();
+  for (int i = 0; i < 4; ++i)
+  {
+    ms4[i] = w->phase_ms[i];
+    w->phase_ms[i] = 0;
+  }
+  if (iterations)
+    *iterations = w->phase_n;
+  w->phase_n = 0;
+  return SAGE_OK;
+}
+
 extern "C" int sage_window_set_profiling(SageWindow *w, int on)
 {
   if (!w)
@@ -322,6 +379,13 @@ extern "C" void sage_window_destroy(SageWindow *w)
   solver_destroy(w->solver);
   if (w->h_err)
     (void)hipHostFree(w->h_err);
+  for (auto &pm : w->phase_pending)
+    for (hipEvent_t e : pm.ev)
+      if (e)
+        (void)hipEventDestroy(e);
+  for (hipEvent_t e : w->phase_cur.ev)
+    if (e)
+      (void)hipEventDestroy(e);
   delete w;
 }
 
@@ -778,6 +842,7 @@ int window_linearize_set(SageWindow *w, int set)
   {
     // depth maps of every keyframe at the current variables: both factor types read their sample depths from them
     // (an accepted candidate's maps from the error pass are still valid: only the gradients are missing then)
+    window_phase_mark(w, 0);
     const bool have_depth = w->dpt_set == set;
     SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[set].as<DepthItem>(), w->n_depth, H, W, !have_depth,
                                 !(have_depth && w->dgrad_valid)));
@@ -808,6 +873,7 @@ int window_linearize_set(SageWindow *w, int set)
   ap.split = 4;
   hipLaunchKernelGGL(assemble_kernel, dim3((w->K + ap.nlinks + 1) * ap.split), dim3(512), 0, w->stream, ap);
   SAGE_HIP(hipGetLastError());
+  window_phase_mark(w, 1);
   w->have_lin = true;
   w->lin_epoch = set == 0 ? w->vars_epoch : 0; // (a candidate's system becomes current only through lm_step's accept)
   w->spec_err_valid = false;
@@ -864,6 +930,7 @@ extern "C" int sage_window_error(SageWindow *w, int which)
   hipLaunchKernelGGL(error_totals_kernel, dim3(1), dim3(1024), 0, w->stream, ph, ge, w->errbuf.as<double>(),
                      w->world == 1 && w->h_err ? w->h_err + 4 : nullptr);
   SAGE_HIP(hipGetLastError());
+  window_phase_mark(w, 4);
   return SAGE_OK;
 }
 
@@ -988,6 +1055,7 @@ extern "C" int sage_window_solve(SageWindow *w, double damp, double *step_norm)
                     &w->pose_init[0]);
     if (rc)
       return rc;
+    window_phase_mark(w, 3);
     w->cand_pending = true;
     w->last_solver = w->solver;
     if (step_norm)
@@ -1456,6 +1524,7 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
     return rc;
   if (sharded && !schur && w->allreduce(w->packed.as<double>(), sage_window_packed_count(w), w->allreduce_user))
     return SAGE_E_STATE;
+  window_phase_mark(w, 2);
   int evals = 0;
   st->accepted = 0;
   while (schur)
@@ -1465,6 +1534,7 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
     rc = schur_solve(w, st->damp, &lin_error);
     if (rc && rc != SAGE_E_NOT_PSD)
       return rc;
+    window_phase_mark(w, 3);
     if (evals == 0)
       st->error = lin_error;
     if (rc == SAGE_E_NOT_PSD)
