@@ -76,7 +76,13 @@ public:
     // the per-factor NearestPsd (the host cost of linearize(): an SVD of a 45 x 45 / 78 x 78 matrix each) for the whole
     // window at once on the host's cores; Linearize() below then only cuts blocks
     if (recomputed && jacobians && eager_psd_threads_ >= 0)
-      sage_window_prepare_factors(win_, psd_mode_, eager_psd_threads_);
+    {
+      // a failed projection is not fatal here: the cache is marked unprepared by the engine and Linearize() projects the
+      // factors it is asked for one by one (and reports their errors)
+      const int rcp = sage_window_prepare_factors(win_, psd_mode_, eager_psd_threads_);
+      if (rcp != SAGE_OK)
+        fprintf(stderr, "sage_window_prepare_factors: %s (falling back to per-factor projection)\n", sage_error_string(rcp));
+    }
     return recomputed != 0;
   }
 
@@ -137,7 +143,8 @@ private:
   std::mutex mutex_;
 
 public:
-  // >= 0: project every factor right after a batched linearisation on this many host threads (0 = all); -1: lazily, factor
+  // >= 0: project every factor right after a batched linearisation on this many host threads (0 = the engine's default: a
+  // quarter of the hardware threads, at most 64 -- include/sage_ba.h); -1: lazily, factor
   // by factor inside Linearize() (what ISAM2's partial relinearisation wants when it touches a few factors only)
   int eager_psd_threads_ = 0;
 };

@@ -465,6 +465,7 @@ def depth_and_grad(ws: Workspace, bias, basis, code, scale, H, W, CS):
     # result (torch would otherwise hand its block to the next allocation of any thread while the kernel is queued --
     # found by tests/test_gpu_threads.py)
     dpt._sage_keepalive = code_d
+    grad._sage_keepalive = code_d    # (a caller may keep only one of the two)
     return dpt, grad
 
 

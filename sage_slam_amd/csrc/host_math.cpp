@@ -424,7 +424,20 @@ extern "C" int sage_nearest_psd(const double *M, int n, double *out)
       mn = *std::min_element(w2.begin(), w2.end());
       have_min = true;
     }
-    const double bump = -mn * k + spacing;
+    // a bump below the rounding granularity of the diagonal would move the tracked minimum but not the matrix: never
+    // less than one ulp of the largest diagonal entry, and never negative (the tracked minimum turns positive after the
+    // first round; the matrix is re-measured then instead of being walked back)
+    double dmax = 0.0;
+    for (int i = 0; i < n; ++i)
+      dmax = std::max(dmax, std::fabs(A3[(size_t)i * n + i]));
+    const double ulp = dmax * 2.220446049250313e-16;
+    double bump = -mn * k + spacing;
+    if (bump < ulp)
+    {
+      if (mn > 0.0) // the estimate says PSD but the LDLT test disagrees: measure again on the matrix as it is now
+        have_min = false;
+      bump = ulp;
+    }
     for (int i = 0; i < n; ++i)
       A3[(size_t)i * n + i] += bump;
     mn += bump;
@@ -2303,7 +2316,7 @@ struct SepPool
   std::atomic<bool> open{false};
   std::atomic<int> active{0};
   std::atomic<bool> busy{false};
-  SepJob *job = nullptr;
+  std::atomic<SepJob *> job{nullptr};
   std::vector<pthread_t> tids;
   int near_cpu = -1;
   void loop()
@@ -2315,7 +2328,7 @@ struct SepPool
         std::unique_lock<std::mutex> lk(mu);
         cv.wait(lk, [&] { return armed.load(std::memory_order_acquire); });
       }
-      const double t0 = mono_seconds();
+      double t0 = mono_seconds();
       unsigned spins = 0;
       while (armed.load(std::memory_order_acquire))
       {
@@ -2323,16 +2336,24 @@ struct SepPool
         if (p != seen)
         {
           seen = p;
-          active.fetch_add(1, std::memory_order_acq_rel);
-          if (open.load(std::memory_order_acquire))
+          // hand-off: the owner does `open = false` THEN reads `active`; a worker does `active += 1` THEN reads `open`.
+          // A store followed by a load of another variable needs sequential consistency on both sides (with release /
+          // acquire the two may be reordered -- the owner reads active == 0 while a late worker still reads open == true
+          // and runs a job that lives on the owner's stack after the owner has returned)
+          active.fetch_add(1, std::memory_order_seq_cst);
+          if (open.load(std::memory_order_seq_cst))
           {
-            sep_work(*job);
-            sep_work_c(*job, true);
+            SepJob *j = job.load(std::memory_order_acquire);
+            sep_work(*j);
+            sep_work_c(*j, true);
           }
-          active.fetch_sub(1, std::memory_order_acq_rel);
+          active.fetch_sub(1, std::memory_order_seq_cst);
+          t0 = mono_seconds(); // the idle time-out counts from the last job, not from the wake-up
         }
         __builtin_ia32_pause();
-        if ((++spins & 1023) == 0 && mono_seconds() - t0 > 20e-3) // nobody came: back to sleep
+        // nobody came for 20 ms: back to sleep.  Only while no job is open (the owner clears `armed` itself when its solve
+        // is done): a worker that timed out in the middle of another caller's arm / post must not disarm the pool
+        if ((++spins & 1023) == 0 && mono_seconds() - t0 > 20e-3 && !open.load(std::memory_order_acquire))
           armed.store(false, std::memory_order_release);
       }
     }
@@ -2843,8 +2864,8 @@ int block_chol_solve_tr(const BlockEnvelope &E0, double *T, double *X, double *y
       if (pool->busy.compare_exchange_strong(expect, true, std::memory_order_acq_rel))
       {
         pool_mine = true;
-        pool->job = &job;
-        pool->open.store(true, std::memory_order_release);
+        pool->job.store(&job, std::memory_order_release);
+        pool->open.store(true, std::memory_order_seq_cst);
         pool->posted.fetch_add(1, std::memory_order_release);
       }
     }
@@ -2921,8 +2942,8 @@ int block_chol_solve_tr(const BlockEnvelope &E0, double *T, double *X, double *y
     }
     if (pool_mine)
     {
-      pool->open.store(false, std::memory_order_release);
-      while (pool->active.load(std::memory_order_acquire) != 0)
+      pool->open.store(false, std::memory_order_seq_cst);
+      while (pool->active.load(std::memory_order_seq_cst) != 0)
         CholHelper::cpu_relax();
       pool->armed.store(false, std::memory_order_release);
       pool->busy.store(false, std::memory_order_release);

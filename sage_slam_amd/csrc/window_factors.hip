@@ -182,6 +182,7 @@ extern "C" int sage_window_prepare_factors(SageWindow *w, int psd_mode, int n_th
   const int CS = w->cfg.CS;
   const size_t Dp = 13 + CS, Dg = 14 + 2 * CS;
   const size_t nep = fc.Ap.size() / (Dp * Dp), neg = fc.Ag.size() / (Dg * Dg);
+  fc.psd_mode = -1; // the projected matrices are being rewritten: whatever they held is gone until this call succeeds
   fc.Cp.assign(nep * Dp * Dp, 0.0);
   fc.Cg.assign(neg * Dg * Dg, 0.0);
   const size_t total = nep + neg;

@@ -27,3 +27,20 @@ def orc():
     from oracle import oracle
     oracle.build()
     return oracle
+
+
+# Lines the GPU tests want in the run's tail even when they pass (measured distances from the oracle): collected here and
+# printed in the terminal summary -- `pytest -q` shows nothing of a passing test otherwise.
+_SUMMARY_LINES = []
+
+
+def summary_line(text: str) -> None:
+    print(text)
+    _SUMMARY_LINES.append(text)
+
+
+def pytest_terminal_summary(terminalreporter):
+    if _SUMMARY_LINES:
+        terminalreporter.section("engine vs oracle (measured)")
+        for ln in _SUMMARY_LINES:
+            terminalreporter.write_line(ln)
