@@ -41,10 +41,6 @@ struct PhotoParams
   // flush == tiles_per_block is the plain "one record per work item"
   const int32_t *rec_first;
   int flush;
-  // error pass (MODE 1): the destination keyframe's feature texels of the levels >= lds_l0 (the tail [lds_base, P) of the
-  // concatenated pyramid, lds_ntex texels x FS/4 channel groups x 16 B) are staged in LDS once per workgroup and their
-  // taps read with ds_read_b128 instead of going through the texture path; lds_l0 >= levels: off
-  int lds_l0, lds_base, lds_ntex;
 };
 
 __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
@@ -96,6 +92,13 @@ constexpr int kStageLevels = 4;  // the staged sampler is built for 4-level pyra
 constexpr int kStageCap0 = 128;  // texels per array, level 0: two rounds      (11 x 11 footprints fit)
 constexpr int kStageCapC = 64;   // texels per array, levels >= 1 together: one round (6 x 6 + 4 x 4 + 3 x 3 = 61)
 static_assert(3 * (kStageCap0 + kStageCapC) * 16 <= 64 * kPhotoStashLD * 4, "the staging regions alias the wave's stash");
+// error pass: only feat1 is sampled -- one array, kErrStageGroups channel groups staged together (their regions side by
+// side: [group][level 0: kStageCap0 | coarse: kStageCapC] float4 = 3 KiB per group and wave)
+#ifndef SAGE_PHOTO_ERR_STAGE_GROUPS
+#define SAGE_PHOTO_ERR_STAGE_GROUPS 2
+#endif
+constexpr int kErrStageGroups = SAGE_PHOTO_ERR_STAGE_GROUPS;
+constexpr int kErrStageGroupBytes = (kStageCap0 + kStageCapC) * 16;
 
 // 16-byte LDS read at a byte address of the workgroup's LDS allocation (ds_read_b128 v, vaddr offset:imm)
 __device__ __forceinline__ f32x4 lds_read16(uint32_t addr)
@@ -223,6 +226,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
   __shared__ float s_red[kWaves * 4]; // per wave: linearize {sigma d^2, error, inliers}, error pass {error, inliers, geo error, inliers}
   // second level of the noise-critical tiles: [wave][tile][r][lane]
   __shared__ float s_l2[JAC ? kWaves * kPhotoL2Tiles * 256 : 1];
+  __shared__ __attribute__((aligned(16))) float s_estage[(!JAC && PACKED) ? kWaves * kErrStageGroups * kErrStageGroupBytes / 4 : 4];
 
   const int tid_wg = threadIdx.x, tid = tid_wg, lane = tid & 63, wave = tid_wg >> 6;
   const int bid = (int)blockIdx.x;
@@ -278,20 +282,10 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
   float gerr_acc = 0.f;                             // error kernel, fused geometric error
   const bool fuse_geo = !JAC && prm.geo_loss_param > 0.f && E.dpt1_geo != nullptr;
   const float geo_loss = E.geo_loss > 0.f ? E.geo_loss : prm.geo_loss_param; // per-link parameter (mapper.cpp:369)
-  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
-  f32x4 *s_lvl = reinterpret_cast<f32x4 *>(s_dyn);
-  const bool stage_lds = !JAC && PACKED && prm.lds_l0 < nlev;
-  if (stage_lds)
-  {
-    // every sub-tile of this workgroup samples the same destination keyframe: its coarse levels go to LDS once
-    const int ntex = prm.lds_ntex;
-    for (int idx = tid; idx < NG * ntex; idx += kBlock)
-    {
-      const int g = idx / ntex, t = idx - g * ntex;
-      s_lvl[idx] = buf_load4(r_f1, (uint32_t)(prm.lds_base + t) * 16u, (uint32_t)g * plane * 4u);
-    }
-  }
-  __syncthreads(); // s_red zeroed, staged levels visible
+  if (!JAC && PACKED && tid == 0)
+    s_estage[0] = 0.f; // (the staging memory is otherwise only reached through LDS-direct loads and integer addresses: an
+                       //  array nothing in the program writes or reads is not allocated)
+  __syncthreads(); // s_red zeroed
 
   const int nsub = min(prm.tiles_per_block, (N + kTile - 1) / kTile - wi.tile);
   const int flush = JAC ? max(1, prm.flush) : 1;
@@ -433,7 +427,6 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
       __builtin_amdgcn_s_setprio(SAGE_PHOTO_PRIO_SAMPLING);
     bool staged = false;
     float pmn = 0.f, pmx = 0.f, qmn = 0.f, qmx = 0.f;
-    if (JAC)
     {
       // bounding box of the inliers' level-0 destination coordinates (an inlier passed the mask lookup: it lies inside
       // the image).  A slice without inliers contributes exact zeros to every sum: it is skipped.
@@ -445,12 +438,10 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
       qmx = wave_fminmax<false>(lv ? q : -inf);
       slice_live = pmn <= pmx;
     }
-    else
-      slice_live = __ballot(vm != 0.f) != 0ull; // error pass: a slice without inliers adds exact zeros
     // per level: box origin, width, first slot inside its staging region (wave-uniform)
     int bx0[kStageLevels] = {}, by0[kStageLevels] = {}, bwd[kStageLevels] = {}, bhd[kStageLevels] = {}, sb[kStageLevels] = {};
     int cnt0 = 0, cntC = 0;
-    if (JAC && slice_live && nlev == kStageLevels)
+    if (slice_live && nlev == kStageLevels)
     {
 #pragma unroll
       for (int l = 0; l < kStageLevels; ++l)
@@ -485,13 +476,14 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
     {
       // nothing to sample
     }
-    else if (JAC && staged)
+    else if (staged)
     {
-     if constexpr (JAC)
-     {
       // ================= LDS-staged sampler =================
-      const uint32_t lds0 = uni((int)(uint32_t)(uintptr_t)st_w); // region of level 0: [3][kStageCap0] float4
-      const uint32_t ldsC = lds0 + 3u * kStageCap0 * 16u;        // region of the levels >= 1: [3][kStageCapC] float4
+      // linearize: the wave's stash holds [3 arrays][kStageCap0] float4 of level 0, then [3][kStageCapC] of the coarse levels;
+      // error pass: its own region, per staged group [kStageCap0 | kStageCapC] float4 of feat1
+      const uint32_t lds0 = JAC ? uni((int)(uint32_t)(uintptr_t)st_w)
+                                : uni((int)(uint32_t)(uintptr_t)(s_estage + wave * (kErrStageGroups * kErrStageGroupBytes / 4)));
+      const uint32_t ldsC = lds0 + (JAC ? 3u : 1u) * kStageCap0 * 16u;
       // lane -> texel of the two regions (two rounds of 64 slots each), as byte offsets inside a channel group's plane
       uint32_t vo0[2], voC;
       {
@@ -527,33 +519,9 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
           voC = (uint32_t)(lo_ + yy * lw_ + xx) * 16u;
         }
       }
-      // fill a region with channel group g: always 6 loads (3 arrays x 2 rounds; slots past the box repeat its last
-      // texel) for level 0 and 3 for the coarse levels -- the wait counts below are exact
-      auto stage0 = [&](uint32_t soff) {
-        dma16<0u>(r_f1, lds0, vo0[0], soff);
-        dma16<kStageCap0 * 16u>(r_f1, lds0, vo0[0], soff + pyr_bytes);
-        dma16<2u * kStageCap0 * 16u>(r_f1, lds0, vo0[0], soff + 2u * pyr_bytes);
-        dma16<1024u>(r_f1, lds0, vo0[1], soff);
-        dma16<kStageCap0 * 16u + 1024u>(r_f1, lds0, vo0[1], soff + pyr_bytes);
-        dma16<2u * kStageCap0 * 16u + 1024u>(r_f1, lds0, vo0[1], soff + 2u * pyr_bytes);
-      };
-      auto stageC = [&](uint32_t soff) {
-        dma16<3u * kStageCap0 * 16u>(r_f1, lds0, voC, soff);
-        dma16<3u * kStageCap0 * 16u + kStageCapC * 16u>(r_f1, lds0, voC, soff + pyr_bytes);
-        dma16<3u * kStageCap0 * 16u + 2u * kStageCapC * 16u>(r_f1, lds0, voC, soff + 2u * pyr_bytes);
-      };
       // pre-sampled source quads [L][NG][N][4]: base of (level, group) wave-uniform, lane offset n * 16
       const uint32_t f0_vo = (uint32_t)(in_range ? n : 0) * 16u;
       auto f0_base = [&](int l, int g) { return E.f0s + ((size_t)(l * NG + g) * (size_t)N) * 4; };
-      lgkm_wait0(); // the stash reads of the previous sub-tile's contraction are done before the region is rewritten
-      // the source quads of a channel group live in a ring of four registers quads: quad l is reloaded with the next
-      // group's level l right after its use, a full group (~4 level steps) before it is needed
-      f32x4 f0q[kStageLevels];
-#pragma unroll
-      for (int l = 0; l < kStageLevels; ++l)
-        f0q[l] = gload16(f0_base(l, 0), f0_vo);
-      stage0(0u);
-      stageC(0u);
       // per level and lane: the 4 tap weights and the LDS byte address a0 of the first tap (xf, yf); the others are
       // (xc, yf) = a0 + 16, (xf, yc) = a0 + row, (xc, yc) = a0 + row + 16 with row = 16 * box width (wave-uniform).  Inliers
       // are box-interior by construction; the clamp only matters for the other lanes (wild coordinates, weight x 0).  A
@@ -571,6 +539,32 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
         for (int k = 0; k < 4; ++k)
           tw[l][k] = td.w[k];
       }
+      if constexpr (JAC)
+      {
+      // fill a region with channel group g: always 6 loads (3 arrays x 2 rounds; slots past the box repeat its last
+      // texel) for level 0 and 3 for the coarse levels -- the wait counts below are exact
+      auto stage0 = [&](uint32_t soff) {
+        dma16<0u>(r_f1, lds0, vo0[0], soff);
+        dma16<kStageCap0 * 16u>(r_f1, lds0, vo0[0], soff + pyr_bytes);
+        dma16<2u * kStageCap0 * 16u>(r_f1, lds0, vo0[0], soff + 2u * pyr_bytes);
+        dma16<1024u>(r_f1, lds0, vo0[1], soff);
+        dma16<kStageCap0 * 16u + 1024u>(r_f1, lds0, vo0[1], soff + pyr_bytes);
+        dma16<2u * kStageCap0 * 16u + 1024u>(r_f1, lds0, vo0[1], soff + 2u * pyr_bytes);
+      };
+      auto stageC = [&](uint32_t soff) {
+        dma16<3u * kStageCap0 * 16u>(r_f1, lds0, voC, soff);
+        dma16<3u * kStageCap0 * 16u + kStageCapC * 16u>(r_f1, lds0, voC, soff + pyr_bytes);
+        dma16<3u * kStageCap0 * 16u + 2u * kStageCapC * 16u>(r_f1, lds0, voC, soff + 2u * pyr_bytes);
+      };
+      lgkm_wait0(); // the stash reads of the previous sub-tile's contraction are done before the region is rewritten
+      // the source quads of a channel group live in a ring of four registers quads: quad l is reloaded with the next
+      // group's level l right after its use, a full group (~4 level steps) before it is needed
+      f32x4 f0q[kStageLevels];
+#pragma unroll
+      for (int l = 0; l < kStageLevels; ++l)
+        f0q[l] = gload16(f0_base(l, 0), f0_vo);
+      stage0(0u);
+      stageC(0u);
       // running sums of the slice as channel PAIRS (one v_pk_fma_f32 per sum and step; the halves meet once, below)
       f32x2 P00 = {0.f, 0.f}, P01 = P00, P11 = P00, Pv0 = P00, Pv1 = P00, Pee = P00;
       auto level_step = [&](auto lc, const f32x4 &f0v) {
@@ -679,7 +673,62 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
       v0 = Pv0[0] + Pv0[1];
       v1 = Pv1[0] + Pv1[1];
       err = Pee[0] + Pee[1];
-     }
+      }
+      else
+      {
+      // ---- error pass: feat1 only.  kErrStageGroups channel groups are staged together (3 loads each: two rounds of level 0,
+      //      one of the coarse levels) and reduced level by level; no hand-over between batches beyond the single wait (this
+      //      kernel runs 4+ waves per SIMD, the other waves cover it)
+      f32x2 Pee = {0.f, 0.f};
+#pragma unroll
+      for (int g0 = 0; g0 < NG; g0 += kErrStageGroups)
+      {
+        lgkm_wait0(); // (the previous batch's taps / the previous sub-tile's have been read)
+#pragma unroll
+        for (int j = 0; j < kErrStageGroups; ++j)
+        {
+          const uint32_t soff = (uint32_t)(g0 + j) * plane * 4u;
+          const uint32_t base = lds0 + (uint32_t)j * kErrStageGroupBytes;
+          dma16<0u>(r_f1, base, vo0[0], soff);
+          dma16<1024u>(r_f1, base, vo0[1], soff);
+          dma16<kStageCap0 * 16u>(r_f1, base, voC, soff);
+        }
+        f32x4 f0v[kStageLevels][kErrStageGroups];
+#pragma unroll
+        for (int l = 0; l < kStageLevels; ++l)
+#pragma unroll
+          for (int j = 0; j < kErrStageGroups; ++j)
+            f0v[l][j] = gload16(f0_base(l, g0 + j), f0_vo);
+        // everything of this batch has landed (quads and regions)
+#pragma unroll
+        for (int l = 0; l < kStageLevels; ++l)
+#pragma unroll
+          for (int j = 0; j < kErrStageGroups; ++j)
+            vm_wait_keep<0>(f0v[l][j]);
+#pragma unroll
+        for (int l = 0; l < kStageLevels; ++l)
+        {
+          const uint32_t a0 = tap[l], a2 = a0 + (uint32_t)bwd[l] * 16u;
+          f32x2 qee = {0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < kErrStageGroups; ++j)
+          {
+            const uint32_t o = (uint32_t)j * kErrStageGroupBytes;
+            const f32x4 t0 = lds_read16(a0 + o), t1 = lds_read16(a2 + 16u + o), t2 = lds_read16(a2 + o), t3 = lds_read16(a0 + 16u + o);
+            f32x4 f1 = tw[l][0] * t0;
+            f1 += tw[l][1] * t1;
+            f1 += tw[l][2] * t2;
+            f1 += tw[l][3] * t3;
+            const f32x4 d4 = f0v[l][j] - f1;
+            const f32x2 dl = {d4[0], d4[1]}, dh = {d4[2], d4[3]};
+            qee += dl * dl;
+            qee += dh * dh;
+          }
+          Pee += prm.w[l] * qee;
+        }
+      }
+      err = Pee[0] + Pee[1];
+      }
     }
     else
     {
@@ -702,24 +751,14 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
           const uint32_t soff = (uint32_t)g * plane * 4u;
           TapBatch<JAC> B;
           B.f0 = f0s[((size_t)l * NG + g) * N];
-          if (!JAC && stage_lds && l >= prm.lds_l0) // (one loop body with this branch: two specialised passes were slower)
-          {
-            const f32x4 *lv = s_lvl + (g * prm.lds_ntex + ((int)lo - prm.lds_base));
 #pragma unroll
-            for (int k = 0; k < 4; ++k)
-              B.t1[k] = lv[td.off[k]];
-          }
-          else
+          for (int k = 0; k < 4; ++k)
           {
-#pragma unroll
-            for (int k = 0; k < 4; ++k)
+            B.t1[k] = buf_load4(r_f1, dof[k], soff);
+            if (JAC)
             {
-              B.t1[k] = buf_load4(r_f1, dof[k], soff);
-              if (JAC)
-              {
-                B.tx[k] = buf_load4(r_f1, dof[k], soff + pyr_bytes);
-                B.ty[k] = buf_load4(r_f1, dof[k], soff + 2u * pyr_bytes);
-              }
+              B.tx[k] = buf_load4(r_f1, dof[k], soff + pyr_bytes);
+              B.ty[k] = buf_load4(r_f1, dof[k], soff + 2u * pyr_bytes);
             }
           }
           __builtin_amdgcn_sched_barrier(0); // without it hipcc serialises load->wait->use through one register quad
@@ -1363,9 +1402,6 @@ static PhotoParams make_params(const PhotoEdge *single, const PhotoEdge *table, 
   p.n_work = lc.n_work;
   p.rec_first = lc.flush > 0 ? lc.edge_first : nullptr;
   p.flush = lc.flush > 0 ? lc.flush : lc.tiles_per_block;
-  p.lds_l0 = pyr.levels; // off
-  p.lds_base = 0;
-  p.lds_ntex = 0;
   for (int l = 0; l < pyr.levels; ++l)
   {
     p.rx[l] = pyr.cam[l].fx / pyr.cam[0].fx; // same fp32 quotient the kernels used to form per pixel
@@ -1425,26 +1461,8 @@ static hipError_t photo_err_impl(hipStream_t s, const PhotoEdge *single, const P
   PhotoParams p = make_params(single, table, lc, pyr, wh, eps, &wsum);
   if (lc.ev_start)
     (void)hipEventRecord(lc.ev_start, s);
-  size_t lds_bytes = 0;
-  if (lc.packed && lc.tiles_per_block >= 4)
-  {
-    // coarse levels of the destination keyframe into LDS (taps via ds_read_b128: the error pass is bound by the CU's
-    // texture path, the LDS pipe is idle): the longest tail of the pyramid that fits 25 KiB -- six workgroups per CU
-    // still fit (the kernel runs 6 waves/SIMD), and a workgroup of >= 4 sub-tiles amortises the staging loads
-    constexpr size_t kBudget = 25 * 1024;
-    int l0 = pyr.levels;
-    while (l0 > 0 && (size_t)(pyr.P - pyr.level_offsets[l0 - 1]) * (FS / 4) * 16 <= kBudget)
-      --l0;
-    if (l0 < pyr.levels)
-    {
-      p.lds_l0 = l0;
-      p.lds_base = pyr.level_offsets[l0];
-      p.lds_ntex = pyr.P - pyr.level_offsets[l0];
-      lds_bytes = (size_t)p.lds_ntex * (FS / 4) * 16;
-    }
-  }
   if (lc.packed)
-    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 1>), dim3(lc.n_work), dim3(kBlock), lds_bytes, s, p);
+    hipLaunchKernelGGL((photo_kernel<CS, FS, false, 1>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   else
     hipLaunchKernelGGL((photo_kernel<CS, FS, false, 0>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   if (lc.ev_stop)
