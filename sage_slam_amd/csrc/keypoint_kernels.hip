@@ -3,9 +3,11 @@
 //
 // Replaces cuda/reprojection_factor_kernels.cpp of the reference: kernels :27-213 / :215-286 (mapper factor,
 // D = 13+CS, [pose0 pose1 code0 scale0]) and :288-366 / :367-415 (tracker, D = 6), hosts :417-628.
-// N is a few hundred keypoints at most (launch-latency, not bandwidth): the weighted rows are written
-// once (2N x (D+1) floats, the residual is the last column) and contracted by D workgroups in double -- two launches
-// per call, nothing clever.  Same conventions as the dense factors: world-frame left-perturbation Jacobians,
+// N is a few hundred keypoints at most (launch-latency, not bandwidth).  Small systems (tracker D = 6 / 7,
+// loop closure D = 14): ONE launch -- a single workgroup keeps the weighted rows in LDS and contracts them itself in
+// double (r04: tracker frame with a reprojection term 0.28 -> 0.20 ms, with match geometry 0.38 -> 0.23 ms).  The mapper
+// factors (D = 13 + CS, 14 + 2 CS): rows written once (2N x (D+1) floats, the residual is the last column) and contracted
+// by D workgroups in double -- two launches per call.  Same conventions as the dense factors: world-frame left-perturbation Jacobians,
 // P_pose1 = -P_pose0, weight/num_inliers normalisation, 10*weight fallback without inliers.
 // Second half of the file: cuda/match_geometry_factor_kernels.cpp (13 kernels there, one templated kernel here).
 #include "sage_device.h"
@@ -32,12 +34,9 @@ struct ReprojParams
 
 // MODE 0: mapper factor (D = 13+CS), MODE 1: tracker (D = 6)
 template <int CS, int MODE, bool JAC>
-__global__ __launch_bounds__(256) void reproj_rows_kernel(const ReprojParams p)
+__device__ __forceinline__ void reproj_rows_body(const ReprojParams &p, int idx)
 {
   constexpr int D = MODE == 0 ? 13 + CS : 6;
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= p.N)
-    return;
   const float fx = p.cam.fx, fy = p.cam.fy, cx = p.cam.cx, cy = p.cam.cy;
   const float hm[3] = {p.homo[3 * idx + 0], p.homo[3 * idx + 1], p.homo[3 * idx + 2]};
   float d0;
@@ -120,6 +119,126 @@ __global__ __launch_bounds__(256) void reproj_rows_kernel(const ReprojParams p)
   }
   row0[D] = sw[0] * diff[0]; // :188-189
   row1[D] = sw[1] * diff[1];
+}
+
+template <int CS, int MODE, bool JAC>
+__global__ __launch_bounds__(256) void reproj_rows_kernel(const ReprojParams p)
+{
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < p.N)
+    reproj_rows_body<CS, MODE, JAC>(p, idx);
+}
+
+// ---- one launch for the small systems (r04; tracker D = 6 / 7, loop closure D = 14): ONE workgroup writes the weighted
+// rows of all keypoints into LDS and contracts them itself -- entry (a, j) of [AtA | Atb] by 256 / (D (D + 1)) threads over
+// interleaved rows in double, folded in a fixed order -- instead of rows to memory + a D-workgroup reduce launch.  A tracker
+// evaluation is launch-latency bound: one launch less per keypoint term and evaluation.
+//   dynamic LDS: rows [RPP * N][D + 1] | serr [N] | sval [N] floats, then the partial sums
+template <int D>
+__device__ __forceinline__ void small_system_reduce(const float *rows, const float *serr, const float *sval, int N, int rpp,
+                                                    float weight, float *AtA, float *Atb, float *stats, double *s_part)
+{
+  constexpr int NENT = D * (D + 1);            // (a, j): a < D, j <= D (j == D: the residual column -> Atb)
+  constexpr int NGRP = 256 / NENT;             // row groups (D = 6: 6, D = 7: 4, D = 14: 1)
+  static_assert(NGRP >= 1, "system too large for the one-workgroup contraction");
+  const int tid = threadIdx.x;
+  __shared__ double s_n[256], s_e[256];
+  double n_in = 0.0, se = 0.0;
+  for (int i = tid; i < N; i += 256)
+  {
+    n_in += (double)sval[i];
+    se += (double)serr[i];
+  }
+  s_n[tid] = n_in;
+  s_e[tid] = se;
+  const int ent = tid % NENT, grp = tid / NENT;
+  if (grp < NGRP)
+  {
+    const int a = ent / (D + 1), j = ent % (D + 1);
+    double acc = 0.0;
+    for (int k = grp; k < rpp * N; k += NGRP)
+      acc += (double)rows[(size_t)k * (D + 1) + a] * (double)rows[(size_t)k * (D + 1) + j];
+    s_part[grp * NENT + ent] = acc;
+  }
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1)
+  {
+    if (tid < off)
+    {
+      s_n[tid] += s_n[tid + off];
+      s_e[tid] += s_e[tid + off];
+    }
+    __syncthreads();
+  }
+  const double ninl = s_n[0];
+  const double sc = ninl > 0.0 ? (double)weight / ninl : 0.0;
+  if (tid < NENT)
+  {
+    double v = 0.0;
+    for (int g = 0; g < NGRP; ++g)
+      v += s_part[g * NENT + tid];
+    v *= sc;
+    const int a = tid / (D + 1), j = tid % (D + 1);
+    if (j < D)
+      AtA[(size_t)a * D + j] = (float)v;
+    else
+      Atb[a] = (float)v;
+  }
+  if (tid == 0)
+  {
+    stats[0] = ninl > 0.0 ? (float)(sc * s_e[0]) : weight * 10.0f;
+    stats[1] = (float)ninl;
+  }
+}
+
+template <int CS, int MODE, bool JAC>
+__global__ __launch_bounds__(256) void reproj_small_kernel(ReprojParams p, float *AtA, float *Atb, float *stats)
+{
+  constexpr int D = MODE == 0 ? 13 + CS : 6;
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  p.rows = s_dyn;
+  p.serr = s_dyn + (size_t)2 * p.N * (D + 1);
+  p.sval = p.serr + p.N;
+  for (int idx = threadIdx.x; idx < p.N; idx += 256)
+    reproj_rows_body<CS, MODE, JAC>(p, idx);
+  __syncthreads();
+  if (JAC)
+  {
+    if constexpr (D * (D + 1) <= 256)
+    {
+      const size_t nf = (size_t)2 * p.N * (D + 1) + (size_t)2 * p.N;
+      double *s_part = reinterpret_cast<double *>(s_dyn + nf + (nf & 1)); // (8-byte aligned)
+      small_system_reduce<D>(p.rows, p.serr, p.sval, p.N, 2, p.weight, AtA, Atb, stats, s_part);
+    }
+  }
+  else
+  {
+    __shared__ double s_n[256], s_e[256];
+    const int tid = threadIdx.x;
+    double n_in = 0.0, se = 0.0;
+    for (int i = tid; i < p.N; i += 256)
+    {
+      n_in += (double)p.sval[i];
+      se += (double)p.serr[i];
+    }
+    s_n[tid] = n_in;
+    s_e[tid] = se;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1)
+    {
+      if (tid < off)
+      {
+        s_n[tid] += s_n[tid + off];
+        s_e[tid] += s_e[tid + off];
+      }
+      __syncthreads();
+    }
+    if (tid == 0)
+    {
+      stats[0] = s_n[0] > 0.0 ? (float)((double)p.weight * s_e[0] / s_n[0]) : p.weight * 10.0f;
+      stats[1] = (float)s_n[0];
+    }
+  }
 }
 
 // workgroup a: AtA[a][:] and Atb[a] = (weight/n) sum_rows J[row][a] * [J[row][:] | r[row]] in double; workgroup 0 also
@@ -214,6 +333,16 @@ static hipError_t reproj_impl(hipStream_t s, ReprojParams p, bool jac, float *sc
   p.serr = scratch + (size_t)2 * N * (D + 1);
   p.sval = p.serr + N;
   const int grid = (N + 255) / 256;
+  // small systems: one launch (rows in LDS, contracted by the same workgroup)
+  const size_t small_lds = ((size_t)2 * N * (D + 1) + (size_t)2 * N + 2) * sizeof(float) + (size_t)256 * sizeof(double);
+  if (D * (D + 1) <= 256 && N > 0 && small_lds <= 60 * 1024)
+  {
+    if (jac)
+      hipLaunchKernelGGL((reproj_small_kernel<CS, MODE, true>), dim3(1), dim3(256), small_lds, s, p, AtA, Atb, stats);
+    else
+      hipLaunchKernelGGL((reproj_small_kernel<CS, MODE, false>), dim3(1), dim3(256), small_lds, s, p, AtA, Atb, stats);
+    return hipGetLastError();
+  }
   if (jac)
   {
     if (grid > 0)
@@ -272,12 +401,9 @@ struct MgParams
 };
 
 template <int CS, int MODE, bool JAC>
-__global__ __launch_bounds__(256) void mg_rows_kernel(const MgParams p)
+__device__ __forceinline__ void mg_rows_body(const MgParams &p, int idx)
 {
   constexpr int D = MODE == 0 ? 14 + 2 * CS : (MODE == 1 ? 14 : (MODE == 2 ? 6 : 7));
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= p.N)
-    return;
   const float h0[3] = {p.homo0[3 * idx + 0], p.homo0[3 * idx + 1], p.homo0[3 * idx + 2]};
   const float h1[3] = {p.homo1[3 * idx + 0], p.homo1[3 * idx + 1], p.homo1[3 * idx + 2]};
   const float ss = p.scale0 + p.scale1;
@@ -421,6 +547,65 @@ __global__ __launch_bounds__(256) void mg_rows_kernel(const MgParams p)
   }
 }
 
+template <int CS, int MODE, bool JAC>
+__global__ __launch_bounds__(256) void mg_rows_kernel(const MgParams p)
+{
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < p.N)
+    mg_rows_body<CS, MODE, JAC>(p, idx);
+}
+
+// one launch for the small systems (see reproj_small_kernel)
+template <int CS, int MODE, bool JAC>
+__global__ __launch_bounds__(256) void mg_small_kernel(MgParams p, float *AtA, float *Atb, float *stats)
+{
+  constexpr int D = MODE == 0 ? 14 + 2 * CS : (MODE == 1 ? 14 : (MODE == 2 ? 6 : 7));
+  extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+  p.rows = s_dyn;
+  p.serr = s_dyn + (size_t)3 * p.N * (D + 1);
+  p.sval = p.serr + p.N;
+  for (int idx = threadIdx.x; idx < p.N; idx += 256)
+    mg_rows_body<CS, MODE, JAC>(p, idx);
+  __syncthreads();
+  if (JAC)
+  {
+    if constexpr (D * (D + 1) <= 256)
+    {
+      const size_t nf = (size_t)3 * p.N * (D + 1) + (size_t)2 * p.N;
+      double *s_part = reinterpret_cast<double *>(s_dyn + nf + (nf & 1));
+      small_system_reduce<D>(p.rows, p.serr, p.sval, p.N, 3, p.weight, AtA, Atb, stats, s_part);
+    }
+  }
+  else
+  {
+    __shared__ double s_n[256], s_e[256];
+    const int tid = threadIdx.x;
+    double n_in = 0.0, se = 0.0;
+    for (int i = tid; i < p.N; i += 256)
+    {
+      n_in += (double)p.sval[i];
+      se += (double)p.serr[i];
+    }
+    s_n[tid] = n_in;
+    s_e[tid] = se;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1)
+    {
+      if (tid < off)
+      {
+        s_n[tid] += s_n[tid + off];
+        s_e[tid] += s_e[tid + off];
+      }
+      __syncthreads();
+    }
+    if (tid == 0)
+    {
+      stats[0] = s_n[0] > 0.0 ? (float)((double)p.weight * s_e[0] / s_n[0]) : p.weight * 10.0f;
+      stats[1] = (float)s_n[0];
+    }
+  }
+}
+
 template <int CS, int MODE>
 static hipError_t mg_impl(hipStream_t s, MgParams p, bool jac, float *scratch, float *AtA, float *Atb, float *stats)
 {
@@ -430,6 +615,16 @@ static hipError_t mg_impl(hipStream_t s, MgParams p, bool jac, float *scratch, f
   p.serr = scratch + (size_t)3 * N * (D + 1);
   p.sval = p.serr + N;
   const int grid = (N + 255) / 256;
+  const size_t small_floats = (size_t)3 * N * (D + 1) + (size_t)2 * N;
+  const size_t small_lds = (small_floats + 2) * sizeof(float) + (size_t)256 * sizeof(double);
+  if (D * (D + 1) <= 256 && N > 0 && small_lds <= 60 * 1024)
+  {
+    if (jac)
+      hipLaunchKernelGGL((mg_small_kernel<CS, MODE, true>), dim3(1), dim3(256), small_lds, s, p, AtA, Atb, stats);
+    else
+      hipLaunchKernelGGL((mg_small_kernel<CS, MODE, false>), dim3(1), dim3(256), small_lds, s, p, AtA, Atb, stats);
+    return hipGetLastError();
+  }
   if (jac)
   {
     hipLaunchKernelGGL((mg_rows_kernel<CS, MODE, true>), dim3(grid), dim3(256), 0, s, p);
