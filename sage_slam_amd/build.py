@@ -17,7 +17,7 @@ OBJ = os.path.join(HERE, "csrc", "_obj")
 LIB = os.path.join(HERE, "libsage_ba.so")
 SOURCES = ["photo_kernels.hip", "geo_kernels.hip", "track_kernels.hip", "producers.hip", "keypoint_kernels.hip", "solve_kernels.hip", "operators.hip", "tracker.hip", "window.hip", "window_dist.hip", "window_factors.hip",
            "host_math.cpp", "shard_solve.cpp"]
-HEADERS = ["sage_device.h", "sage_internal.h", "host_math.h", "runtime_internal.h", os.path.join(ROOT, "include", "sage_ba.h")]
+HEADERS = ["sage_device.h", "sage_internal.h", "host_math.h", "runtime_internal.h", "finalize_bodies.h", os.path.join(ROOT, "include", "sage_ba.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HOSTCXX = os.environ.get("HOSTCXX", "/opt/rocm/lib/llvm/bin/clang++")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

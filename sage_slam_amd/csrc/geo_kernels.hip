@@ -13,6 +13,7 @@
 // Algorithmic bytes per source pixel: 4*(2CS + 9).
 #include "sage_device.h"
 #include "sage_internal.h"
+#include "finalize_bodies.h"
 
 #ifndef SAGE_GEO_WAVES
 #define SAGE_GEO_WAVES 2 // workgroups per CU the linearize kernel is register-budgeted for (x4 waves)
@@ -41,8 +42,6 @@ __device__ __forceinline__ int gload_loc(const void *loc, int is64, int n)
 {
   return is64 ? (int)reinterpret_cast<const long long *>(loc)[n] : reinterpret_cast<const int *>(loc)[n];
 }
-
-__device__ __forceinline__ int gsidx6(int i, int j) { return i * 6 - (i * (i - 1)) / 2 + (j - i); }
 
 // per-pixel hand-over from the geometry phase (lane = pixel) to the contraction phase (lane = (channel i, pixel k)):
 //   [0..3] tap byte offsets (int bits)  [4..7] sqrt(omega)*tap weights  [8] sqrt(omega)*kappa  [9] loc*CS*4 (int bits)
@@ -418,135 +417,12 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
 }
 
 // ------------------------------------------------------------------------------------------------
-struct GeoFinalizeParams
-{
-  GeoEdge single;
-  const GeoEdge *table;
-  const int32_t *edge_first;
-  const int32_t *edge_tiles;
-  const float *partials;
-  float *AtA, *Atb, *stats;
-  float weight;
-  int edge_base; // blockIdx.x = edge - edge_base
-  double *wide;  // optional [n_edges][D*D + D]: the results before rounding to fp32
-};
-
+// per-edge finalize (finalize_bodies.h), one workgroup per edge
 template <int CS>
 __global__ __launch_bounds__(kFinalizeBlock) void geo_finalize_kernel(const GeoFinalizeParams prm)
 {
-  constexpr int PP = geo_partial_floats(CS);
-  constexpr int D = 14 + 2 * CS;
-  constexpr int N16 = geo_n16(CS);
-  constexpr int NTT = N16 * (N16 + 1) / 2;
-  __shared__ double s[PP]; // partial sums and every derived product stay in double until the single final rounding
-  const int e = prm.edge_base + blockIdx.x, tid = threadIdx.x;
-  const GeoEdge &E = prm.table ? prm.table[e] : prm.single;
-  const float s0 = E.scale0 ? *E.scale0 : E.scale0_val;
-  const float s1 = E.scale1 ? *E.scale1 : E.scale1_val;
-  const int first = prm.edge_first[e], nt = prm.edge_tiles[e];
-  for (int idx = tid; idx < PP; idx += (int)blockDim.x)
-  {
-    double a = 0.0; // the per-workgroup partials are summed in double: free (a few dozen adds), and it keeps the
-                    // engine's accumulation noise below the reference's own fp32 floor
-    double a1 = 0.0, a2 = 0.0, a3 = 0.0; // four independent chains: the loads of a round are in flight together
-    const float *pp = prm.partials + (size_t)first * PP + idx;
-    int t = 0;
-    for (; t + 4 <= nt; t += 4)
-    {
-      const float v0 = pp[(size_t)t * PP], v1 = pp[(size_t)(t + 1) * PP], v2 = pp[(size_t)(t + 2) * PP],
-                  v3 = pp[(size_t)(t + 3) * PP];
-      a += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
-    }
-    for (; t < nt; ++t)
-      a += (double)pp[(size_t)t * PP];
-    s[idx] = (a + a1) + (a2 + a3);
-  }
-  __syncthreads();
-  const double n_in = s[45];
-  const bool ok = n_in > 0.0;
-  const double wn = ok ? (double)prm.weight / n_in : 0.0;
-  if (tid == 0)
-  {
-    prm.stats[2 * e + 0] = ok ? (float)(wn * s[44]) : 10.0f * prm.weight; // geometric_factor_kernels.cpp:934,944
-    prm.stats[2 * e + 1] = (float)n_in;
-  }
-  auto telem = [&](int tile, int row, int col) -> double {
-    return s[kGeoScalars + tile * 256 + (row & 3) * 64 + ((row >> 2) * 16 + col)];
-  };
-  // t index a in [0, 2CS): a < CS -> kappa*b0 channel a, else beta channel a-CS.  Operand block / row of a channel:
-  // CS = 32 loads channel pairs per lane (block = parity, row = channel/2), CS = 16 one channel per lane.
-  auto tblk = [&](int a) -> int { return CS == 32 ? (a / CS) * 2 + (a & 1) : a / CS; };
-  auto trow = [&](int a) -> int { return CS == 32 ? (a % CS) >> 1 : a % CS; };
-  auto TT = [&](int a, int b) -> double { // sum w t_a t_b
-    int bi = tblk(a), bj = tblk(b), ra = trow(a), rb = trow(b);
-    if (bi > bj || (bi == bj && ra > rb)) // always read the upper triangle: (w t_a) t_b != (w t_b) t_a in fp32
-    {
-      int t = bi; bi = bj; bj = t;
-      t = ra; ra = rb; rb = t;
-    }
-    const int tile = bi * N16 - (bi * (bi - 1)) / 2 + (bj - bi);
-    return telem(tile, ra, rb);
-  };
-  auto YT = [&](int r, int col) -> double { return telem(NTT + tblk(col), r, trow(col)); }; // sum w y_r t_col
-  auto YY = [&](int a, int b) -> double { // sum w y_a y_b, a,b in 0..8 (never both 8)
-    if (a > b)
-    {
-      const int t = a; a = b; b = t;
-    }
-    if (b < 6)
-      return s[gsidx6(a, b)];
-    if (b == 6)
-      return a < 6 ? s[21 + a] : s[33];
-    if (b == 7)
-      return a < 6 ? s[27 + a] : (a == 6 ? s[34] : s[35]);
-    return a < 6 ? s[36 + a] : (a == 6 ? s[42] : s[43]); // b == 8 (rho)
-  };
-  // column j -> (kind, index, coef): kind 0 = y entry, kind 1 = t entry
-  auto column = [&](int j, int &kind, int &idx, double &coef) {
-    if (j < 6) { kind = 0; idx = j; coef = 1.0; }
-    else if (j < 12) { kind = 0; idx = j - 6; coef = -1.0; }
-    else if (j < 12 + CS) { kind = 1; idx = j - 12; coef = (double)s0; }
-    else if (j < 12 + 2 * CS) { kind = 1; idx = j - 12; coef = -(double)s1; }
-    else if (j == 12 + 2 * CS) { kind = 0; idx = 6; coef = 1.0 / (double)s0; }
-    else { kind = 0; idx = 7; coef = -1.0 / (double)s1; }
-  };
-  float *AtA = prm.AtA + (size_t)e * D * D;
-  float *Atb = prm.Atb + (size_t)e * D;
-  for (int q = tid; q < D * D + D; q += (int)blockDim.x)
-  {
-    double val = 0.0;
-    if (ok)
-    {
-      if (q < D * D)
-      {
-        int ki, ii, kj, ij;
-        double ci, cj;
-        column(q / D, ki, ii, ci);
-        column(q % D, kj, ij, cj);
-        double mv;
-        if (ki == 0 && kj == 0)
-          mv = YY(ii, ij);
-        else if (ki == 1 && kj == 1)
-          mv = TT(ii, ij);
-        else
-          mv = ki == 0 ? YT(ii, ij) : YT(ij, ii);
-        val = wn * (ci * cj) * mv; // (ci*cj) first: exactly symmetric in (i, j)
-      }
-      else
-      {
-        int k, ii;
-        double c;
-        column(q - D * D, k, ii, c);
-        val = wn * c * (k == 0 ? YY(ii, 8) : YT(8, ii));
-      }
-    }
-    if (q < D * D)
-      AtA[q] = (float)val;
-    else
-      Atb[q - D * D] = (float)val;
-    if (prm.wide)
-      prm.wide[(size_t)e * (D * D + D) + q] = val;
-  }
+  __shared__ double s[geo_finalize_lds_doubles(CS)];
+  geo_finalize_body<CS>(prm, prm.edge_base + (int)blockIdx.x, s);
 }
 
 hipError_t launch_stats_finalize(hipStream_t s, const LaunchCommon &lc, float *stats, float fallback, float scale);

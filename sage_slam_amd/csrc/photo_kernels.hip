@@ -18,6 +18,7 @@
 
 #include "sage_device.h"
 #include "sage_internal.h"
+#include "finalize_bodies.h"
 
 namespace sage
 {
@@ -46,11 +47,6 @@ struct PhotoParams
 __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
 {
   return is64 ? (int)reinterpret_cast<const long long *>(loc)[n] : reinterpret_cast<const int *>(loc)[n];
-}
-
-__device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i <= j < 6
-{
-  return i * 6 - (i * (i - 1)) / 2 + (j - i);
 }
 
 #ifndef SAGE_PHOTO_ERR_WAVES
@@ -1188,159 +1184,12 @@ __global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WA
   }
 }
 
-// ------------------------------------------------------------------------------------------------
-// finalize: sum the workgroup partials of an edge in a fixed order (deterministic), expand the reduced
-// blocks into the reference layout [pose0 pose1 code0 scale0] (photometric_factor_kernels.cpp:350-364),
-// apply 1/num_inliers and the zero-overlap fallback (:1139-1161).
-// ------------------------------------------------------------------------------------------------
-struct PhotoFinalizeParams
-{
-  PhotoEdge single;
-  const PhotoEdge *table;
-  const int32_t *edge_first;
-  const int32_t *edge_tiles;
-  const float *partials;
-  float *AtA, *Atb, *stats;
-  float wsum;
-  int edge_base; // blockIdx.x = edge - edge_base
-  double *wide;  // optional [n_edges][D*D + D]: the results before rounding to fp32
-};
-
-__device__ __forceinline__ double tile_elem(const double *s, int base, int tile, int row, int col)
-{
-  return s[base + tile * 256 + (row & 3) * 64 + ((row >> 2) * 16 + col)];
-}
-
+// per-edge finalize (finalize_bodies.h), one workgroup per edge
 template <int CS>
 __global__ __launch_bounds__(kFinalizeBlock) void photo_finalize_kernel(const PhotoFinalizeParams prm)
 {
-  constexpr int PP = kPhotoScalars + photo_tiles(CS) * 256; // entries of a summed record
-  constexpr int D = 13 + CS;
-  __shared__ double s[PP]; // partial sums and every derived product stay in double until the single final rounding
-  const int e = prm.edge_base + blockIdx.x, tid = threadIdx.x;
-  const PhotoEdge &E = prm.table ? prm.table[e] : prm.single;
-  const float s0 = E.scale0 ? *E.scale0 : E.scale0_val;
-  const int first = prm.edge_first[e], nt = prm.edge_tiles[e];
-  // s[] keeps the historic index space: [0..39] scalars, then NT tiles of 256; the scalars and the cross tiles come from
-  // the double part of the records, the code-code tiles from the fp32 part
-  constexpr int NCCF = photo_cc_tiles(CS), DOFF = photo_partial_double_offset(CS), PF = photo_partial_floats(CS);
-  for (int idx = tid; idx < PP; idx += (int)blockDim.x)
-  {
-    const bool dbl = idx < kPhotoScalars || idx >= kPhotoScalars + NCCF * 256;
-    double a = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0; // four independent chains: the loads of a round are in flight together
-    int t = 0;
-    if (dbl)
-    {
-      const int di = idx < kPhotoScalars ? idx : idx - NCCF * 256;
-      const double *pp = reinterpret_cast<const double *>(prm.partials + (size_t)first * PF + DOFF) + di;
-      constexpr size_t STR = PF / 2; // record stride in doubles
-      for (; t + 4 <= nt; t += 4)
-      {
-        a += pp[(size_t)t * STR]; a1 += pp[(size_t)(t + 1) * STR]; a2 += pp[(size_t)(t + 2) * STR]; a3 += pp[(size_t)(t + 3) * STR];
-      }
-      for (; t < nt; ++t)
-        a += pp[(size_t)t * STR];
-    }
-    else
-    {
-      const float *pp = prm.partials + (size_t)first * PF + idx;
-      for (; t + 4 <= nt; t += 4)
-      {
-        const float v0 = pp[(size_t)t * PF], v1 = pp[(size_t)(t + 1) * PF], v2 = pp[(size_t)(t + 2) * PF], v3 = pp[(size_t)(t + 3) * PF];
-        a += (double)v0; a1 += (double)v1; a2 += (double)v2; a3 += (double)v3;
-      }
-      for (; t < nt; ++t)
-        a += (double)pp[(size_t)t * PF];
-    }
-    s[idx] = (a + a1) + (a2 + a3);
-  }
-  __syncthreads();
-  const double s0d = (double)s0;
-  const double n_in = s[36];
-  const bool ok = n_in > 0.0;
-  const double inv_n = ok ? 1.0 / n_in : 0.0;
-  float *AtA = prm.AtA + (size_t)e * D * D;
-  float *Atb = prm.Atb + (size_t)e * D;
-  if (tid == 0)
-  {
-    prm.stats[2 * e + 0] = ok ? (float)(s[35] * inv_n) : 10.0f * prm.wsum;
-    prm.stats[2 * e + 1] = (float)n_in;
-  }
-  // CS = 32: the contraction loads channel pairs per lane -> operand block = channel parity, row = channel / 2
-  auto X = [&](int row, int col) -> double { // sum_n a_n[row] * b_n[col]
-    if (CS == 32)
-      return tile_elem(s, kPhotoScalars, (col & 1) ? 4 : 3, row, col >> 1);
-    return tile_elem(s, kPhotoScalars, 1, row, col);
-  };
-  auto CC = [&](int i, int j) -> double { // sum_n sigma_n b_n[i] b_n[j], i <= j
-    if (CS == 32)
-    {
-      const int ti = i & 1, tj = j & 1;
-      if (ti <= tj)
-        return tile_elem(s, kPhotoScalars, ti + tj, i >> 1, j >> 1); // (0,0)->0 (0,1)->1 (1,1)->2
-      return tile_elem(s, kPhotoScalars, 1, j >> 1, i >> 1);
-    }
-    return tile_elem(s, kPhotoScalars, 0, i, j);
-  };
-  for (int idx = tid; idx < D * D + D; idx += (int)blockDim.x)
-  {
-    double val = 0.0;
-    if (ok)
-    {
-      if (idx < D * D)
-      {
-        int i = idx / D, j = idx % D;
-        if (i > j)
-        {
-          const int t = i;
-          i = j;
-          j = t;
-        }
-        // classes: pose (0..11), code (12..12+CS-1), scale (12+CS)
-        if (j < 12)
-        {
-          const double sg = ((i >= 6) != (j >= 6)) ? -1.0 : 1.0;
-          const int a = i % 6, b = j % 6;
-          val = sg * s[a <= b ? sidx6(a, b) : sidx6(b, a)];
-        }
-        else if (i < 12)
-        {
-          const double sg = (i >= 6) ? -1.0 : 1.0;
-          if (j < 12 + CS)
-            val = sg * s0d * X(i % 6, j - 12);
-          else
-            val = sg * s[21 + i % 6] / s0d;
-        }
-        else if (i < 12 + CS)
-        {
-          if (j < 12 + CS)
-            val = s0d * s0d * CC(i - 12, j - 12);
-          else
-            val = X(6, i - 12);
-        }
-        else
-          val = s[27] / (s0d * s0d);
-        val *= inv_n;
-      }
-      else
-      {
-        const int i = idx - D * D;
-        if (i < 12)
-          val = ((i >= 6) ? -1.0 : 1.0) * s[28 + i % 6];
-        else if (i < 12 + CS)
-          val = s0d * X(7, i - 12);
-        else
-          val = s[34] / s0d;
-        val *= inv_n;
-      }
-    }
-    if (idx < D * D)
-      AtA[idx] = (float)val;
-    else
-      Atb[idx - D * D] = (float)val;
-    if (prm.wide)
-      prm.wide[(size_t)e * (D * D + D) + idx] = val;
-  }
+  __shared__ double s[photo_finalize_lds_doubles(CS)];
+  photo_finalize_body<CS>(prm, prm.edge_base + (int)blockIdx.x, s);
 }
 
 // error-only finalize: stats[e] = {sum(err)/n_in or 10*wsum, n_in}   (:1049-1058)

@@ -1,6 +1,7 @@
 // window.hip -- the batched window engine: edge tables, work lists, deterministic assembly into block-sparse normal
 // equations, linearize / error pass / damped solve / LM iteration (no reference counterpart: SURVEY s8 "new").
 #include "runtime_internal.h"
+#include "finalize_bodies.h"
 
 namespace sage
 {
@@ -150,6 +151,30 @@ __global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
         p.tail_mirror[which * 2 + (photo ? 0 : 1)] = acc;
     }
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// per-edge finalize of BOTH factor types in one launch (a workgroup per edge and type): the geometric finalize no longer
+// sits between the two big kernels (18 us + a launch gap on the step's critical path, r04 timeline)
+// ------------------------------------------------------------------------------------------------
+struct WindowFinalizeParams
+{
+  PhotoFinalizeParams ph;
+  GeoFinalizeParams ge;
+  int n_p, n_g;
+};
+
+template <int CS>
+__global__ __launch_bounds__(kFinalizeBlock) void window_finalize_kernel(const WindowFinalizeParams prm)
+{
+  constexpr int LDS = photo_finalize_lds_doubles(CS) > geo_finalize_lds_doubles(CS) ? photo_finalize_lds_doubles(CS)
+                                                                                    : geo_finalize_lds_doubles(CS);
+  __shared__ double s[LDS];
+  const int bid = (int)blockIdx.x;
+  if (bid < prm.n_g) // (the longer finalize first)
+    geo_finalize_body<CS>(prm.ge, bid, s);
+  else
+    photo_finalize_body<CS>(prm.ph, bid - prm.n_g, s);
 }
 
 // error pass of a window in ONE tail kernel: per-edge statistics of both factor types from the workgroup partials
@@ -848,24 +873,43 @@ int window_linearize_set(SageWindow *w, int set)
                                 !(have_depth && w->dgrad_valid)));
     w->dpt_set = set;
     w->dgrad_valid = true;
-    // geometric first: its per-edge finalize (17 us) then hides between the two big kernels and only the shorter
-    // photometric finalize (9 us) sits between the last kernel and the assembly
+    // main kernels only (stage 1), then ONE finalize launch for both factor types (window_finalize_kernel)
+    LaunchCommon lcg = window_lc(w, false), lcp = window_lc(w, true, true);
+    lcg.stage = 1;
+    lcp.stage = 1;
     if (c.use_geo)
     {
       EdgeOut out{w->AtA_g.as<float>(), w->Atb_g.as<float>(), w->stats_g.as<float>(), w->wide_g.as<double>()};
-      LaunchCommon lc = window_lc(w, false);
-      prof_attach(w, 1, lc);
-      SAGE_HIP(launch_geo_linearize(w->stream, c.CS, nullptr, w->gtab[set].as<GeoEdge>(), lc, c.pyr.cam[0], c.eps,
+      prof_attach(w, 1, lcg);
+      SAGE_HIP(launch_geo_linearize(w->stream, c.CS, nullptr, w->gtab[set].as<GeoEdge>(), lcg, c.pyr.cam[0], c.eps,
                                     c.geo_loss_param, c.geo_weight, out));
     }
     if (c.use_photo)
     {
       EdgeOut out{w->AtA_p.as<float>(), w->Atb_p.as<float>(), w->stats_p.as<float>(), w->wide_p.as<double>()};
-      LaunchCommon lc = window_lc(w, true, true);
-      prof_attach(w, 0, lc);
-      SAGE_HIP(launch_photo_linearize(w->stream, c.CS, c.FS, nullptr, w->ptab[set].as<PhotoEdge>(), lc, c.pyr,
+      prof_attach(w, 0, lcp);
+      SAGE_HIP(launch_photo_linearize(w->stream, c.CS, c.FS, nullptr, w->ptab[set].as<PhotoEdge>(), lcp, c.pyr,
                                       c.photo_weights, c.eps, out));
     }
+    WindowFinalizeParams fp{};
+    fp.n_p = c.use_photo ? w->n_edges : 0;
+    fp.n_g = c.use_geo ? w->n_edges : 0;
+    fp.ph.table = w->ptab[set].as<PhotoEdge>();
+    fp.ph.edge_first = lcp.edge_first; fp.ph.edge_tiles = lcp.edge_tiles; fp.ph.partials = lcp.partials;
+    fp.ph.AtA = w->AtA_p.as<float>(); fp.ph.Atb = w->Atb_p.as<float>(); fp.ph.stats = w->stats_p.as<float>();
+    fp.ph.wide = w->wide_p.as<double>();
+    for (int l = 0; l < c.pyr.levels; ++l)
+      fp.ph.wsum += c.photo_weights[l];
+    fp.ge.table = w->gtab[set].as<GeoEdge>();
+    fp.ge.edge_first = lcg.edge_first; fp.ge.edge_tiles = lcg.edge_tiles; fp.ge.partials = lcg.partials;
+    fp.ge.AtA = w->AtA_g.as<float>(); fp.ge.Atb = w->Atb_g.as<float>(); fp.ge.stats = w->stats_g.as<float>();
+    fp.ge.wide = w->wide_g.as<double>();
+    fp.ge.weight = c.geo_weight;
+    if (c.CS == 32)
+      hipLaunchKernelGGL((window_finalize_kernel<32>), dim3(fp.n_p + fp.n_g), dim3(kFinalizeBlock), 0, w->stream, fp);
+    else
+      hipLaunchKernelGGL((window_finalize_kernel<16>), dim3(fp.n_p + fp.n_g), dim3(kFinalizeBlock), 0, w->stream, fp);
+    SAGE_HIP(hipGetLastError());
   }
   AssembleParams ap = window_assemble_params(w);
   // four workgroups of 512 threads per output block: one element per thread (the kernel is a chain of dependent
