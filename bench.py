@@ -446,42 +446,69 @@ def main():
     hist = []
     RESTART = 3   # the LM converges in ~3 steps on this scene: restart from the initial estimate every RESTART steps so
                   # the timed steps are live descent steps (a restart is one small H2D of the variables, inside the timing)
+    def run_steps(n_steps):
+        nonlocal damp
+        if dist is None or not py_steps:
+            # the engine's own loop: sage_window_lm_run drives the RESTART iterations between two restarts from C++ (no
+            # Python between the iterations being timed; a sharded window still enters Python for a gloo hook, never for RCCL)
+            i = 0
+            while i < n_steps:
+                win.reset()
+                damp = float(cfg.init_damp)
+                state.iters = 0
+                state.damp = damp
+                n = min(RESTART, n_steps - i)
+                for e0, e1, acc, d in win.lm_run(state, cfg, n):
+                    hist.append((float(e0), float(e1), bool(acc)))
+                damp = state.damp
+                i += n
+        else:
+            for i in range(n_steps):
+                if i % RESTART == 0:
+                    win.reset()
+                    damp = float(cfg.init_damp)
+                    state.iters = 0
+                hist.append(lm_step())
+
+    # instrumented pass FIRST (every hot kernel + the phase marks: eleven event records per step, 30-50 us of the
+    # stream's time): the other kernels' durations and phase_ms come from it.  It also brings the GPU / host clocks up:
+    # the step time of this loop settles only after ~25 steps (profiles/r04_step_series.txt: 2.2, 1.9, 1.88, 1.84 ...
+    # 1.78 ms), more than --warmup 5 covers.
+    win.set_profiling(1)
+    n_instr = min(max(args.steps, 1), 9 * RESTART)
+    run_steps(RESTART)
+    for which in range(4):
+        win.kernel_time(which)
+    win.phase_time()
+    barrier()
+    t1 = time.perf_counter()
+    run_steps(n_instr)
+    barrier()
+    ms_instr = 1e3 * (time.perf_counter() - t1) / max(1, n_instr)
+    ktime_full = [win.kernel_time(which) for which in range(4)]
+    phase, phase_n = win.phase_time()
+    del hist[:]
+    # W warm-up steps, then the timed region: HIP events around the dominant kernel only (the roofline's live launch
+    # duration: two event records per step)
+    win.set_profiling(2)
+    win.reset()
+    damp = float(cfg.init_damp)
+    state.iters = 0
+    state.damp = damp
     for i in range(args.warmup):
         hist.append(lm_step())
-    win.set_profiling(True)
     for which in range(4):
         win.kernel_time(which)
     barrier()
     t0 = time.perf_counter()
-    if dist is None or not py_steps:
-        # the engine's own loop: sage_window_lm_run drives the RESTART iterations between two restarts from C++ (no
-        # Python between the iterations being timed; a sharded window still enters Python for a gloo hook, never for RCCL)
-        i = 0
-        while i < args.steps:
-            win.reset()
-            damp = float(cfg.init_damp)
-            state.iters = 0
-            state.damp = damp
-            n = min(RESTART, args.steps - i)
-            for e0, e1, acc, d in win.lm_run(state, cfg, n):
-                hist.append((float(e0), float(e1), bool(acc)))
-            damp = state.damp
-            i += n
-    else:
-        for i in range(args.steps):
-            if i % RESTART == 0:
-                win.reset()
-                damp = float(cfg.init_damp)
-                state.iters = 0
-            hist.append(lm_step())
+    run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ktime = [win.kernel_time(which) for which in range(4)]
-    phase, phase_n = win.phase_time()
+    ktime = [win.kernel_time(0)] + ktime_full[1:]
     win.set_profiling(False)
     per_rank_ms = None
     if dist is not None:
@@ -509,8 +536,9 @@ def main():
         phase_ms = None
         if phase_n > 0:
             phase_ms = {k: v / phase_n for k, v in phase.items()}
-            phase_ms["host_idle"] = max(0.0, ms_per_step - sum(phase_ms.values()))
+            phase_ms["host_idle"] = max(0.0, ms_instr - sum(phase_ms.values()))
             phase_ms["iterations_sampled"] = phase_n
+            phase_ms["ms_per_step_instrumented"] = ms_instr  # the pass the marks were taken in (after the timed region)
         out = {
             "metric": f"M residuals/sec (+ LM iters/sec), {args.keyframes}-keyframe feature-metric BA @{args.height}x{args.width}",
             "value": residuals_per_step * args.steps / elapsed / 1e6,

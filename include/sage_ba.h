@@ -403,6 +403,8 @@ int sage_factor_cut_blocks(int type, int CS, const double *C, const float *Atb, 
  * the four hot kernels is bracketed by an event pair.  which: 0 photometric linearize, 1 geometric linearize,
  * 2 photometric error, 3 geometric error.  get_kernel_time synchronises, returns the accumulated milliseconds and
  * launch count since the last reset, and resets them. */
+/* on: 0 off, 1 every hot kernel + the phase marks, 2 the photometric linearize only (two event records per iteration
+ * instead of eleven: each record is a few microseconds of the stream's time). */
 int sage_window_set_profiling(SageWindow *w, int on);
 int sage_window_get_kernel_time(SageWindow *w, int which, double *total_ms, int *launches);
 /* phases of the LM iterations run through sage_window_lm_step / _lm_run since the last call (profiling on), on the

@@ -660,7 +660,8 @@ class Window:
         _chk(lib().sage_window_factor_error(self.h, type_, e, C.byref(v)), "sage_window_factor_error")
         return v.value
 
-    def set_profiling(self, on: bool):
+    def set_profiling(self, on):
+        """False / 0 off, True / 1 every hot kernel + phase marks, 2 the photometric linearize only."""
         _chk(lib().sage_window_set_profiling(self.h, int(on)), "sage_window_set_profiling")
 
     def kernel_time(self, which: int):

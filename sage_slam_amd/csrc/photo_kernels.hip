@@ -50,7 +50,8 @@ __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
 }
 
 #ifndef SAGE_PHOTO_ERR_WAVES
-#define SAGE_PHOTO_ERR_WAVES 3 // error pass: lower bound only, the kernel needs far fewer registers
+#define SAGE_PHOTO_ERR_WAVES 5 // error pass at FS = 16: 5 workgroups per CU (94 VGPRs, no spills; 4: 0.255 ms, 5: 0.246, 6 spills: 0.45);
+                               // FS = 32 lands at 102 VGPRs = 5 per SIMD on its own (asking for it costs 2 spills)
 #endif
 #ifndef SAGE_PHOTO_WAVES
 #define SAGE_PHOTO_WAVES 3 // workgroups per CU the linearize kernel is register-budgeted for (x4 waves)
@@ -206,7 +207,7 @@ struct TapBatch
 //      (lane = (channel pair i, pixel k): 16 lanes x dwordx2 = one 128-byte basis row; CS = 32: operand block 0 = even
 //      channels, block 1 = odd channels)
 template <int CS, int FS, bool JAC, int MODE>
-__global__ __launch_bounds__(kBlock, !JAC ? SAGE_PHOTO_ERR_WAVES : SAGE_PHOTO_WAVES) void photo_kernel(const PhotoParams prm)
+__global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3) : SAGE_PHOTO_WAVES) void photo_kernel(const PhotoParams prm)
 {
   constexpr bool PACKED = MODE >= 1;
   constexpr int NB = CS / 16;

@@ -289,7 +289,9 @@ struct SageWindow
   double phase_ms[4] = {0, 0, 0, 0}; // linearize, all-reduce, solve, error pass
   int phase_n = 0;
   bool profiling = false;
+  int prof_level = 0; // 1: all hot kernels + phase marks, 2: the photometric linearize only
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pending[4];
+  std::vector<hipEvent_t> ev_free; // recycled events (creating / destroying one per mark costs API time inside the region being profiled)
   double prof_ms[4] = {0, 0, 0, 0};
   int prof_n[4] = {0, 0, 0, 0};
 };

@@ -239,13 +239,34 @@ __global__ void mirror_totals_kernel(const double *__restrict__ tail, const doub
 }
 
 } // namespace sage
+static bool ev_get(SageWindow *w, hipEvent_t *e)
+{
+  if (!w->ev_free.empty())
+  {
+    *e = w->ev_free.back();
+    w->ev_free.pop_back();
+    return true;
+  }
+  return hipEventCreate(e) == hipSuccess;
+}
+static void ev_put(SageWindow *w, hipEvent_t e)
+{
+  if (e)
+    w->ev_free.push_back(e);
+}
+
 static void prof_attach(SageWindow *w, int which, LaunchCommon &lc)
 {
-  if (!w->profiling)
+  if (!w->profiling || (w->prof_level == 2 && which != 0))
     return;
   hipEvent_t a, b;
-  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess)
+  if (!ev_get(w, &a))
     return;
+  if (!ev_get(w, &b))
+  {
+    ev_put(w, a);
+    return;
+  }
   lc.ev_start = a;
   lc.ev_stop = b;
   w->pending[which].emplace_back(a, b);
@@ -253,7 +274,7 @@ static void prof_attach(SageWindow *w, int which, LaunchCommon &lc)
 
 void window_phase_mark(SageWindow *w, int which)
 {
-  if (!w->profiling)
+  if (!w->profiling || w->prof_level == 2)
     return;
   if (which == 0) // a new iteration: the previous one's marks are complete (or abandoned)
   {
@@ -264,12 +285,11 @@ void window_phase_mark(SageWindow *w, int which)
       w->phase_pending.push_back(w->phase_cur);
     else
       for (hipEvent_t e : w->phase_cur.ev)
-        if (e)
-          (void)hipEventDestroy(e);
+        ev_put(w, e);
     w->phase_cur = SageWindow::PhaseMarks{};
   }
   hipEvent_t e;
-  if (w->phase_cur.ev[which] || hipEventCreate(&e) != hipSuccess)
+  if (w->phase_cur.ev[which] || !ev_get(w, &e))
     return;
   (void)hipEventRecord(e, w->stream);
   w->phase_cur.ev[which] = e;
@@ -294,7 +314,7 @@ extern "C" int sage_window_get_phase_time(SageWindow *w, double *ms4, int *itera
       w->phase_n += 1;
     }
     for (hipEvent_t e : pm.ev)
-      (void)hipEventDestroy(e);
+      ev_put(w, e);
   }
   w->phase_pending.clear();
   for (int i = 0; i < 4; ++i)
@@ -313,6 +333,15 @@ extern "C" int sage_window_set_profiling(SageWindow *w, int on)
   if (!w)
     return SAGE_E_INVALID;
   w->profiling = on != 0;
+  w->prof_level = on;
+  // a stock of events up front: creating them inside the region being profiled costs API time there
+  while (w->profiling && w->ev_free.size() < 512)
+  {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess)
+      break;
+    w->ev_free.push_back(e);
+  }
   return SAGE_OK;
 }
 
@@ -329,8 +358,8 @@ extern "C" int sage_window_get_kernel_time(SageWindow *w, int which, double *tot
       w->prof_ms[which] += ms;
       w->prof_n[which] += 1;
     }
-    (void)hipEventDestroy(pr.first);
-    (void)hipEventDestroy(pr.second);
+    ev_put(w, pr.first);
+    ev_put(w, pr.second);
   }
   w->pending[which].clear();
   if (total_ms)
@@ -411,6 +440,14 @@ extern "C" void sage_window_destroy(SageWindow *w)
   for (hipEvent_t e : w->phase_cur.ev)
     if (e)
       (void)hipEventDestroy(e);
+  for (auto &pend : w->pending)
+    for (auto &pr : pend)
+    {
+      (void)hipEventDestroy(pr.first);
+      (void)hipEventDestroy(pr.second);
+    }
+  for (hipEvent_t e : w->ev_free)
+    (void)hipEventDestroy(e);
   delete w;
 }
 
