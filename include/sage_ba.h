@@ -207,6 +207,9 @@ int sage_damped_solve_qr_f32(const float *A, const float *b, int n, float damp, 
  * diagonal priors.  Returns SAGE_E_NOT_PSD if the damped matrix is not positive definite. */
 int sage_block_solve(const double *packed_host, int K, int nlinks, const int32_t *links, int B, double damp,
                      const double *diag_add, const double *g_add, double *delta);
+/* diagnostics: how many half-factorisations of split windows ran as two stages (a look-ahead thread + the chain
+ * through the previous row) in this process so far; the factor is the same bit for bit either way. */
+long long sage_solve_lookahead_count(void);
 
 /* ---- tracker LM (core/system/camera_tracker.cpp:1034-1310 / 1312-1672) ---- */
 typedef struct SageLmConfig

@@ -91,7 +91,7 @@ SYMBOLS = [
     "sage_tracker_photo_jac_error_calculate", "sage_tracker_photo_error_calculate",
     "sage_geometric_jac_error_calculate", "sage_geometric_error_calculate", "sage_depth_and_grad",
     "sage_gaussian_pyramid_with_grad", "sage_se3_exp", "sage_pose_retract", "sage_nearest_psd", "sage_nearest_psd_reference", "sage_factor_block_count", "sage_factor_hessian_blocks",
-    "sage_damped_solve_qr_f32", "sage_block_solve", "sage_lm_config_default", "sage_track_lm", "sage_track_frame",
+    "sage_damped_solve_qr_f32", "sage_block_solve", "sage_solve_lookahead_count", "sage_lm_config_default", "sage_track_lm", "sage_track_frame",
     "sage_window_create", "sage_window_destroy", "sage_window_add_keyframe", "sage_window_add_link", "sage_window_set_link_geo_loss",
     "sage_window_set_shard", "sage_window_finalize", "sage_window_num_keyframes", "sage_window_num_links",
     "sage_window_block_size", "sage_window_packed_count", "sage_window_packed_dev",
@@ -235,6 +235,12 @@ def block_solve(packed, K, links, B, damp, diag_add=None, g_add=None):
                                 C.c_double(damp), dp(da), dp(ga), delta.ctypes.data_as(C.POINTER(C.c_double))),
          "sage_block_solve")
     return delta
+
+
+def solve_lookahead_count() -> int:
+    f = lib().sage_solve_lookahead_count
+    f.restype = C.c_longlong
+    return int(f())
 
 
 def block_solve_domains(packed, K, links, B, damp, ndomains, diag_add=None, g_add=None):

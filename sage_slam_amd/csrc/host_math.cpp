@@ -1743,9 +1743,11 @@ static __attribute__((noinline)) bool wait_row_tickets(const BlockEnvelope &E, i
 // One pass over a range of block rows.  phase 0: factorise rows [lo,hi) ascending and forward-substitute y;
 // phase 1: back-substitute rows [lo,hi) descending.  Rows only touch the blocks of their own column ranges, so two
 // row ranges that do not reference each other can run on two cores.
+// role (phase 0 only): 0 one thread does everything; 1 / 2 the two stages of E.pipe (1: the chain through row i-1 and
+// the diagonal, 2: the look-ahead).  Rows with an A range are not split (no such rows in the halves of a plan).
 template <int NV>
 static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnvelope &E, double *T, double *X, double *y,
-                                                                 int phase, int lo, int hi)
+                                                                 int phase, int lo, int hi, int role = 0)
 {
   constexpr int BP = NV * 8, BB = BP * BP;
   const int K = E.K;
@@ -1761,18 +1763,33 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
     static const bool prof = sage::env_flag("SAGE_CHOL_PROFILE");
     unsigned long long tp[6] = {0, 0, 0, 0, 0, 0}, tl = __builtin_readcyclecounter();
 #define LAP(k) do { if (prof) { const unsigned long long t_ = __builtin_readcyclecounter(); tp[k] += t_ - tl; tl = t_; } } while (0)
+    BlockEnvelope::RowPipe *pipe = role ? E.pipe + (lo >= E.n1 && E.n1 > 0 ? 1 : 0) : nullptr;
+    auto pipe_wait = [&](std::atomic<int> &c, int need) -> bool { // false: the other stage gave up (negative count)
+      int v;
+      while ((v = c.load(std::memory_order_acquire)) < need)
+      {
+        if (v < 0)
+          return false;
+        __builtin_ia32_pause();
+      }
+      return true;
+    };
     for (int i = lo; i < hi; ++i)
     {
       LAP(5);
       if (E.before_row && E.before_row(E.user, i))
         return -2;
-      if (E.ready && !wait_row_tickets(E, i))
+      if (role != 1 && E.ready && !wait_row_tickets(E, i))
+      {
+        if (pipe)
+          pipe->early.store(-1, std::memory_order_release);
         return -2;
+      }
       LAP(0);
       // the column ranges of row i, in ascending order
       const int r0[2] = {afirst(i), row_first[i]}, r1[2] = {afirst(i) + acnt(i), i};
       RowPrefetch pf{nullptr, nullptr};
-      if (i + 1 < hi)
+      if (i + 1 < hi && role != 1)
       {
         // row i+1's blocks are contiguous in the storage: [A range | B range]
         const size_t b0 = (size_t)(acnt(i + 1) ? E.a_off[i + 1] : row_off[i + 1]);
@@ -1780,6 +1797,44 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
         pf.p = reinterpret_cast<const char *>(T + b0 * BB);
         pf.end = pf.p + nb * BB * sizeof(double);
       }
+      if (role == 2)
+      {
+        // look-ahead: needs the rows <= i-2 complete (and its own earlier rows)
+        if (!pipe_wait(pipe->late, i - 1 - lo))
+          return -2;
+        for (int j = row_first[i]; j < i; ++j)
+        {
+          double *CT = blk(i, j);
+          const int kend = j == i - 1 ? i - 2 : j; // (i, i-1): the product with row i-1's last block is the other stage's
+          for (int k = row_first[i]; k < kend; ++k)
+            if (has(j, k))
+              tn_sub<NV>(CT, blk(j, k), blk(i, k), false, pf);
+          if (j < i - 1)
+            apply_inverse<NV>(CT, X + (size_t)j * BB);
+        }
+        double *S = blk(i, i);
+        for (int k = row_first[i]; k < i - 1; ++k)
+          tn_sub<NV>(S, blk(i, k), blk(i, k), true, pf);
+        while (pf.p < pf.end) // (short rows: the prefetch of the next row's blocks is part of this stage's job)
+          pf.step();
+        pipe->early.store(i + 1 - lo, std::memory_order_release);
+        continue;
+      }
+      if (role == 1)
+      {
+        if (!pipe_wait(pipe->early, i + 1 - lo))
+          return -2;
+        if (i - 1 >= row_first[i])
+        {
+          double *CT = blk(i, i - 1);
+          if (i - 2 >= row_first[i] && has(i - 1, i - 2))
+            tn_sub<NV>(CT, blk(i - 1, i - 2), blk(i, i - 2), false, pf);
+          apply_inverse<NV>(CT, X + (size_t)(i - 1) * BB);
+          tn_sub<NV>(blk(i, i), CT, CT, true, pf);
+        }
+      }
+      else
+      {
       for (int rg = 0; rg < 2; ++rg)
         for (int j = r0[rg]; j < r1[rg]; ++j)
         {
@@ -1792,13 +1847,19 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
           apply_inverse<NV>(CT, X + (size_t)j * BB);
           LAP(2);
         }
-      double *S = blk(i, i);
+      double *S0 = blk(i, i);
       for (int rg = 0; rg < 2; ++rg)
         for (int k = r0[rg]; k < r1[rg]; ++k)
-          tn_sub<NV>(S, blk(i, k), blk(i, k), true, pf);
+          tn_sub<NV>(S0, blk(i, k), blk(i, k), true, pf);
+      } // role 0
+      double *S = blk(i, i);
       LAP(1);
       if (!factor_diag<NV>(S, X + (size_t)i * BB))
+      {
+        if (pipe)
+          pipe->late.store(-1, std::memory_order_release);
         return 1 + i;
+      }
       LAP(3);
       // forward substitution: y_i = L_ii^-1 (g_i - sum_k L_ik y_k)
       double w[BP];
@@ -1828,6 +1889,8 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
       for (int c = 0; c < BP; ++c)
         y[(size_t)i * BP + c] = yi[c];
       LAP(4);
+      if (pipe)
+        pipe->late.store(i + 1 - lo, std::memory_order_release);
       if (E.progress && i < E.n1 + E.n2)
         E.progress[i >= E.n1 ? 1 : 0].store(i + 1, std::memory_order_release);
     }
@@ -1897,15 +1960,15 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
 
 __attribute__((target_clones("avx512f", "avx2", "default"))) static int block_chol_40(const BlockEnvelope &E, double *T,
                                                                                       double *X, double *y, int phase,
-                                                                                      int lo, int hi)
+                                                                                      int lo, int hi, int role = 0)
 {
-  return block_chol_pass<5>(E, T, X, y, phase, lo, hi);
+  return block_chol_pass<5>(E, T, X, y, phase, lo, hi, role);
 }
 __attribute__((target_clones("avx512f", "avx2", "default"))) static int block_chol_24(const BlockEnvelope &E, double *T,
                                                                                       double *X, double *y, int phase,
-                                                                                      int lo, int hi)
+                                                                                      int lo, int hi, int role = 0)
 {
-  return block_chol_pass<3>(E, T, X, y, phase, lo, hi);
+  return block_chol_pass<3>(E, T, X, y, phase, lo, hi, role);
 }
 // Separator rows of a partial factorisation (domain decomposition, shard_solve.cpp): the rows [nI, K) get L_ij for
 // their columns j < nI; their blocks (i, j), nI <= j <= i, end as the Schur complement C_ij = A_ij - sum_{k<nI} L_ik L_jk^T
@@ -2380,15 +2443,17 @@ static SepPool *sep_pool()
   return p;
 }
 
-static int block_chol_range(const BlockEnvelope &E, double *T, double *X, double *y, int phase, int lo, int hi)
+static int block_chol_range(const BlockEnvelope &E, double *T, double *X, double *y, int phase, int lo, int hi,
+                            int role = 0)
 {
-  return E.Bp == 40 ? block_chol_40(E, T, X, y, phase, lo, hi) : block_chol_24(E, T, X, y, phase, lo, hi);
+  return E.Bp == 40 ? block_chol_40(E, T, X, y, phase, lo, hi, role) : block_chol_24(E, T, X, y, phase, lo, hi, role);
 }
 
-// The helper thread that takes the second half of a split window.  It sleeps on a condition variable, is woken by
-// block_chol_arm() (called while the caller still waits for the device), then spins for a job so that picking one up
-// costs no wake-up latency.  The caller never depends on it: a job the helper has not claimed by the time the caller
-// is done with its own half is claimed back and run by the caller.
+// Helper threads of a split window: [0] takes the second half, [1] / [2] are the look-ahead stages of the first / second
+// half (BlockEnvelope::RowPipe).  A helper sleeps on a condition variable, is woken by block_chol_arm() (called while the
+// caller still waits for the device), then spins for a job so that picking one up costs no wake-up latency.  Nobody
+// depends on a helper that has not claimed its job: the second half is claimed back and run by the caller, a half without
+// a look-ahead stage runs as one thread.
 struct CholHelper
 {
   std::mutex mu;
@@ -2402,33 +2467,124 @@ struct CholHelper
   std::atomic<bool> busy{false}; // one client at a time
   const BlockEnvelope *E = nullptr;
   double *T = nullptr, *X = nullptr, *y = nullptr;
+  int kind = 0; // 0: second half (factorisation, later the back substitution), 1: look-ahead stage of rows [lo, hi)
+  int lo = 0, hi = 0;
   std::thread th;
   pthread_t tid{};
   int near_cpu = -1;
   bool started = false;
   static void cpu_relax() { __builtin_ia32_pause(); }
-  void loop()
-  {
-    unsigned seen = 0;
-    for (;;)
+  void loop();
+};
+static CholHelper *chol_helper(int idx = 0)
+{
+  // deliberately leaked: the threads may still be parked on their condition variables when the process exits
+  static CholHelper **hs = [] {
+    CholHelper **v = new CholHelper *[3]{nullptr, nullptr, nullptr};
+    const unsigned hc = std::thread::hardware_concurrency();
+    for (int i = 0; i < 3; ++i)
     {
+      if (hc < (i == 0 ? 2u : 4u))
+        continue;
+      CholHelper *p = new CholHelper;
+      p->kind = i == 0 ? 0 : 1;
+      p->th = std::thread([p] { p->loop(); });
+      p->tid = p->th.native_handle();
+      p->th.detach();
+      v[i] = p;
+    }
+    return v;
+  }();
+  return hs[idx];
+}
+
+static std::atomic<long long> g_lookahead_count{0};
+
+// rows [lo, hi) can run as two stages: plain band rows (no A range, nothing left of lo), no per-row callback
+static bool rows_can_pipe(const BlockEnvelope &E, int lo, int hi)
+{
+  static const bool off = sage::env_flag("SAGE_SOLVE_NO_LOOKAHEAD");
+  if (off || E.before_row || !E.pipe || hi - lo < 4)
+    return false;
+  for (int i = lo; i < hi; ++i)
+    if ((E.a_cnt && E.a_cnt[i]) || E.row_first[i] < lo)
+      return false;
+  return true;
+}
+
+// hand rows [lo, hi) to look-ahead helper `idx`; true once the helper has claimed the job (it then WILL publish its
+// progress in E.pipe), false when there is no armed helper or it did not answer within a few microseconds
+static bool lookahead_engage(int idx, const BlockEnvelope &E, double *T, double *X, double *y, int lo, int hi)
+{
+  CholHelper *h = chol_helper(idx);
+  if (!h || !h->armed.load(std::memory_order_acquire) || !rows_can_pipe(E, lo, hi))
+    return false;
+  bool expect = false;
+  if (!h->busy.compare_exchange_strong(expect, true, std::memory_order_acq_rel))
+    return false;
+  h->E = &E; h->T = T; h->X = X; h->y = y; h->lo = lo; h->hi = hi;
+  h->p1_rc.store(-2, std::memory_order_relaxed);
+  h->claim.store(0, std::memory_order_release); // (a helper still looking at an older post claims only after the fields are set)
+  h->posted.fetch_add(1, std::memory_order_release);
+  const double t0 = mono_seconds();
+  unsigned spins = 0;
+  while (h->claim.load(std::memory_order_acquire) == 0)
+  {
+    CholHelper::cpu_relax();
+    if ((++spins & 63) == 0 && mono_seconds() - t0 > 20e-6)
+    {
+      int e0 = 0;
+      if (h->claim.compare_exchange_strong(e0, 2, std::memory_order_acq_rel))
       {
-        std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return armed.load(std::memory_order_acquire); });
+        h->busy.store(false, std::memory_order_release);
+        return false;
       }
-      const double t0 = mono_seconds();
-      unsigned spins = 0;
-      while (armed.load(std::memory_order_acquire))
+    }
+  }
+  g_lookahead_count.fetch_add(1, std::memory_order_relaxed);
+  return true;
+}
+static void lookahead_release(int idx)
+{
+  CholHelper *h = chol_helper(idx);
+  while (h->p1_rc.load(std::memory_order_acquire) == -2)
+    CholHelper::cpu_relax();
+  h->armed.store(false, std::memory_order_release);
+  h->busy.store(false, std::memory_order_release);
+}
+
+void CholHelper::loop()
+{
+  unsigned seen = 0;
+  for (;;)
+  {
+    {
+      std::unique_lock<std::mutex> lk(mu);
+      cv.wait(lk, [&] { return armed.load(std::memory_order_acquire); });
+    }
+    const double t0 = mono_seconds();
+    unsigned spins = 0;
+    while (armed.load(std::memory_order_acquire))
+    {
+      const unsigned p = posted.load(std::memory_order_acquire);
+      if (p != seen)
       {
-        const unsigned p = posted.load(std::memory_order_acquire);
-        if (p != seen)
+        seen = p;
+        int expect = 0;
+        if (claim.compare_exchange_strong(expect, 1, std::memory_order_acq_rel))
         {
-          seen = p;
-          int expect = 0;
-          if (claim.compare_exchange_strong(expect, 1, std::memory_order_acq_rel))
+          const BlockEnvelope &e = *E;
+          if (kind == 1)
           {
-            const BlockEnvelope &e = *E;
-            const int rc = block_chol_range(e, T, X, y, 0, e.n1, e.n1 + e.n2);
+            const int rc = block_chol_range(e, T, X, y, 0, lo, hi, 2);
+            p1_rc.store(rc == -2 ? -3 : rc, std::memory_order_release); // (-2 is the "not finished" value)
+          }
+          else
+          {
+            const bool piped = lookahead_engage(2, e, T, X, y, e.n1, e.n1 + e.n2);
+            const int rc = block_chol_range(e, T, X, y, 0, e.n1, e.n1 + e.n2, piped ? 1 : 0);
+            if (piped)
+              lookahead_release(2);
             p1_rc.store(rc, std::memory_order_release);
             int g;
             while ((g = go_p2.load(std::memory_order_acquire)) == 0)
@@ -2438,26 +2594,12 @@ struct CholHelper
             p2_done.store(1, std::memory_order_release);
           }
         }
-        cpu_relax();
-        if ((++spins & 1023) == 0 && mono_seconds() - t0 > 8e-3) // nobody came: back to sleep
-          armed.store(false, std::memory_order_release);
       }
+      cpu_relax();
+      if ((++spins & 1023) == 0 && mono_seconds() - t0 > 8e-3) // nobody came: back to sleep
+        armed.store(false, std::memory_order_release);
     }
   }
-};
-static CholHelper *chol_helper()
-{
-  // deliberately leaked: the thread may still be parked on the condition variable when the process exits
-  static CholHelper *h = [] {
-    if (std::thread::hardware_concurrency() < 2)
-      return (CholHelper *)nullptr;
-    CholHelper *p = new CholHelper;
-    p->th = std::thread([p] { p->loop(); });
-    p->tid = p->th.native_handle();
-    p->th.detach();
-    return p;
-  }();
-  return h;
 }
 } // namespace
 
@@ -2569,14 +2711,14 @@ static void pin_one(pthread_t t, int cpu)
   (void)pthread_setaffinity_np(t, sizeof(want), &want);
 }
 
-static void place_helper_near(CholHelper *h, int cpu)
+static void place_helper_near(CholHelper *h, int cpu, int slot)
 {
   if (cpu < 0 || cpu == h->near_cpu)
     return;
   h->near_cpu = cpu;
   const std::vector<int> &cores = ccx_cores_of(cpu, false);
-  if (!cores.empty())
-    pin_one(h->tid, cores[0]);
+  if ((int)cores.size() > slot)
+    pin_one(h->tid, cores[slot]);
 }
 
 static void place_pool_near(SepPool *q, int cpu)
@@ -2584,23 +2726,26 @@ static void place_pool_near(SepPool *q, int cpu)
   if (cpu < 0 || cpu == q->near_cpu)
     return;
   q->near_cpu = cpu;
-  // cores[0] is the helper's; more workers than cores left in the CCX continue on the other cores of the NUMA node
+  // cores[0..2] are the helpers'; more workers than cores left in the CCX continue on the other cores of the NUMA node
   const std::vector<int> &cores = ccx_cores_of(cpu, true);
-  for (size_t t = 0; t < q->tids.size() && t + 1 < cores.size(); ++t)
-    pin_one(q->tids[t], cores[t + 1]);
+  for (size_t t = 0; t < q->tids.size() && t + 3 < cores.size(); ++t)
+    pin_one(q->tids[t], cores[t + 3]);
 }
 
 void block_chol_arm(bool with_pool)
 {
-  CholHelper *h = chol_helper();
-  if (h && !h->armed.load(std::memory_order_acquire))
+  for (int idx = 0; idx < 3; ++idx)
   {
-    place_helper_near(h, sched_getcpu());
+    CholHelper *h = chol_helper(idx);
+    if (h && !h->armed.load(std::memory_order_acquire))
     {
-      std::lock_guard<std::mutex> lk(h->mu);
-      h->armed.store(true, std::memory_order_release);
+      place_helper_near(h, sched_getcpu(), idx);
+      {
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->armed.store(true, std::memory_order_release);
+      }
+      h->cv.notify_one();
     }
-    h->cv.notify_one();
   }
   if (!with_pool)
     return;
@@ -2870,6 +3015,8 @@ int block_chol_solve_tr(const BlockEnvelope &E0, double *T, double *X, double *y
       }
     }
   }
+  BlockEnvelope::RowPipe pipes[2];
+  E.pipe = pipes;
   CholHelper *h = chol_helper();
   bool shared = false;
   if (h && h->armed.load(std::memory_order_acquire))
@@ -2879,18 +3026,22 @@ int block_chol_solve_tr(const BlockEnvelope &E0, double *T, double *X, double *y
     {
       shared = true;
       h->E = &E; h->T = T; h->X = X; h->y = y;
-      h->claim.store(0, std::memory_order_relaxed);
       h->p1_rc.store(-2, std::memory_order_relaxed);
       h->go_p2.store(0, std::memory_order_relaxed);
       h->p2_done.store(0, std::memory_order_relaxed);
+      h->claim.store(0, std::memory_order_release);
       h->posted.fetch_add(1, std::memory_order_release);
     }
   }
+  // the first half as two stages when its look-ahead helper answers (the second half's thread asks for its own)
+  const bool piped = lookahead_engage(1, E, T, X, y, 0, E.n1);
   static const bool dbg = sage::env_flag("SAGE_DEBUG_TIMING");
   double tp[6] = {0, 0, 0, 0, 0, 0};
   if (dbg)
     tp[0] = mono_seconds();
-  int rc = block_chol_range(E, T, X, y, 0, 0, E.n1);
+  int rc = block_chol_range(E, T, X, y, 0, 0, E.n1, piped ? 1 : 0);
+  if (piped)
+    lookahead_release(1);
   if (dbg)
     tp[1] = mono_seconds();
   bool helper_has_it = false;
@@ -2980,6 +3131,8 @@ int block_chol_solve_tr(const BlockEnvelope &E0, double *T, double *X, double *y
   return rc;
 }
 } // namespace sage
+
+extern "C" long long sage_solve_lookahead_count(void) { return sage::g_lookahead_count.load(); }
 
 extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const int32_t *links, int B, double damp,
                                 const double *diag_add, const double *g_add, double *delta)

@@ -68,6 +68,16 @@ struct BlockEnvelope
   // back substitution: rows m >= bs_skip_from are left out of  sum_m L_mi^T x_m  (their part has been subtracted from y
   // beforehand, in parallel: the arrow rows of a loop-closure plan)
   int bs_skip_from = 0x7fffffff;
+  // optional (set by block_chol_solve_tr): two threads per half.  pipe[h] = {rows of half h whose EARLY part is done,
+  // rows that are complete}: a look-ahead thread forms, for row i, everything that only needs the rows <= i-2 (all
+  // blocks but (i, i-1) and their share of (i, i-1) / the diagonal), the half's own thread follows with the chain that
+  // needs row i-1 -- same blocks, same order of the sums, so the factor is the same bit for bit.
+  struct RowPipe
+  {
+    alignas(64) std::atomic<int> early{0};
+    alignas(64) std::atomic<int> late{0};
+  };
+  RowPipe *pipe = nullptr;
 };
 // In place: T becomes L^T blockwise, X (K*Bp*Bp) receives the inverses of the diagonal factors, y (K*Bp) the
 // right-hand side on entry and the solution on return.  Returns 0, or 1 + the block column of the first non-positive

@@ -161,10 +161,14 @@ __global__ __launch_bounds__(256) void solve_scatter_kernel(const SolvePlan P, c
         y[(size_t)i * Bp + r] = r < B ? g[r] + s_gadd[r] : 0.0;
     if (flags)
     {
-      __threadfence_system(); // the block (and its rhs rows) are visible to the host before the ticket is
+      // the block (and its rhs rows) are visible to the host before the ticket is: the workgroup barrier orders every
+      // lane's stores before lane 0's system-scope release (one cache write-back per block instead of one per wave)
       __syncthreads();
       if (tid == 0)
+      {
+        __threadfence_system();
         *reinterpret_cast<volatile unsigned *>(flags + b) = epoch;
+      }
     }
     else
       __syncthreads(); // s_dadd / s_gadd are reused by the next block

@@ -197,6 +197,49 @@ def test_block_solve_split_window_matches_dense(K, CS, window, monkeypatch):
         assert rel(out[0], out[-1]) < 1e-11
 
 
+_LOOKAHEAD_SNIPPET = r"""
+import sys, numpy as np
+from sage_slam_amd import capi
+K, CS, window = 40, 32, 3
+B = 7 + CS; n = K * B
+rng = np.random.default_rng(11)
+links = [(j, i) for i in range(K) for j in range(max(0, i - window), i)]
+mask = np.eye(K, dtype=bool)
+for a, b in links:
+    mask[a, b] = mask[b, a] = True
+J = rng.normal(size=(2 * n, n))
+Hs = (J.T @ J) * np.kron(mask, np.ones((B, B))) + 6 * n * np.eye(n)
+g = rng.normal(size=n)
+diag = np.stack([Hs[k * B:(k + 1) * B, k * B:(k + 1) * B] for k in range(K)])
+lnk = np.stack([Hs[a * B:(a + 1) * B, b * B:(b + 1) * B] for a, b in links])
+packed = np.concatenate([diag.reshape(-1), lnk.reshape(-1), g, np.zeros(4)])
+ref = np.linalg.solve(Hs + 1e-4 * np.diag(np.diag(Hs)), g)
+outs = [capi.block_solve(packed, K, links, B, 1e-4) for _ in range(12)]
+assert all(np.linalg.norm(d - ref) / np.linalg.norm(ref) < 1e-9 for d in outs)
+assert all(np.array_equal(outs[0], d) for d in outs)          # claimed / not claimed / piped: the same bits
+sys.stdout.write("%d %s" % (capi.solve_lookahead_count(), outs[0].tobytes().hex()))
+"""
+
+
+def test_block_solve_lookahead_is_bit_identical():
+    """the halves of a split window run as two stages (look-ahead thread + the chain through the previous row) when the
+    helper threads answer: same blocks, same order of the sums -> the same solution bit for bit as one thread per half"""
+    import subprocess, sys
+    res = {}
+    for name, extra in (("on", {}), ("off", {"SAGE_SOLVE_NO_LOOKAHEAD": "1"})):
+        env = dict(os.environ, **extra)
+        env.pop("SAGE_SOLVE_NO_LOOKAHEAD", None) if not extra else None
+        r = subprocess.run([sys.executable, "-c", _LOOKAHEAD_SNIPPET], capture_output=True, text=True, env=env,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        cnt, hexbytes = r.stdout.split()
+        res[name] = (int(cnt), hexbytes)
+    assert res["off"][0] == 0
+    assert res["on"][1] == res["off"][1]
+    if (os.cpu_count() or 1) >= 4:
+        assert res["on"][0] > 0, "the look-ahead helpers never answered"
+
+
 def test_tracker_lm_policy_with_oracle_backend(orc):
     """the product's LM driver (sage_track_lm) with the oracle as evaluation back-end: converges on a
     consistent scene, and its trace obeys the reference policy (camera_tracker.cpp:1156-1279)."""
