@@ -240,7 +240,9 @@ struct SageWindow
   SageShardPlan *shard = nullptr;
   DevBuf sepbuf;                        // device copy of the separator buffer (what the collective sums)
   std::vector<double> h_sep;
-  double *h_err = nullptr;              // pinned [8]: {linearize tail[4], error pass totals[4]} written by the kernels
+  double *h_err = nullptr;              // pinned [16]: {linearize tail[4], error pass totals[4], tickets of the totals[4]} written by the kernels
+  uint64_t err_epoch = 0;               // ticket value of the last error pass (a host thread can spin on the mirror
+                                        // instead of synchronising the stream: window_spin_totals)
   DevBuf pk;                            // engine-internal channel-group pyramids [K][3 (f,gx,gy)][FS/4][P][4]
   DevBuf f0s;                           // per keyframe: pre-sampled source features [L][FS/4][N][4]
   DevBuf ptab[2], gtab[2];              // edge tables per variable set
@@ -310,5 +312,5 @@ static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t s)
 }
 int window_upload_vars(SageWindow *w, int set);
 int window_linearize_set(SageWindow *w, int set);
-int window_sync_candidate(SageWindow *w);
+int window_sync_candidate(SageWindow *w, bool stream_idle = false);
 void window_phase_mark(SageWindow *w, int which); // profiling: record phase mark `which` on the window's stream

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kFinalizeBlock) void window_finalize_kernel(const W
 // (a wave-parallel sum in a fixed lane order) -- same summation orders, three launches and their gaps less on the step's critical path.
 
 __global__ __launch_bounds__(1024) void error_totals_kernel(const ErrorTotalsSide ph, const ErrorTotalsSide ge, double *out,
-                                                            double *mirror)
+                                                            double *mirror, double epoch)
 {
   for (int idx = threadIdx.x; idx < ph.n_edges + ge.n_edges; idx += blockDim.x)
   {
@@ -216,7 +216,12 @@ __global__ __launch_bounds__(1024) void error_totals_kernel(const ErrorTotalsSid
   {
     out[which * 2 + (photo ? 0 : 1)] = acc;
     if (mirror)
+    {
+      // the value, then its ticket: the host spins on the four tickets instead of synchronising the stream
       mirror[which * 2 + (photo ? 0 : 1)] = acc;
+      __threadfence_system();
+      *reinterpret_cast<volatile double *>(mirror + 4 + which * 2 + (photo ? 0 : 1)) = epoch;
+    }
   }
 }
 
@@ -810,8 +815,8 @@ extern "C" int sage_window_finalize(SageWindow *w)
   SAGE_HIP(hipMemsetAsync(w->errbuf.p, 0, 4 * sizeof(double), w->stream));
   if (!w->h_err)
   {
-    SAGE_HIP(hipHostMalloc(reinterpret_cast<void **>(&w->h_err), 8 * sizeof(double), hipHostMallocDefault));
-    std::memset(w->h_err, 0, 8 * sizeof(double));
+    SAGE_HIP(hipHostMalloc(reinterpret_cast<void **>(&w->h_err), 16 * sizeof(double), hipHostMallocDefault));
+    std::memset(w->h_err, 0, 16 * sizeof(double));
   }
   w->host_packed.assign(sage_window_packed_count(w), 0.0);
   w->delta.assign((size_t)K * w->B, 0.0);
@@ -1008,8 +1013,9 @@ extern "C" int sage_window_error(SageWindow *w, int which)
     ge = ErrorTotalsSide{lc.edge_first, lc.edge_tiles, lc.partials, w->stats_g.as<float>(), 10.0f * c.geo_weight,
                          c.geo_weight, w->n_edges, 2, 0, 1};
   }
+  w->err_epoch += 1;
   hipLaunchKernelGGL(error_totals_kernel, dim3(1), dim3(1024), 0, w->stream, ph, ge, w->errbuf.as<double>(),
-                     w->world == 1 && w->h_err ? w->h_err + 4 : nullptr);
+                     w->world == 1 && w->h_err ? w->h_err + 4 : nullptr, (double)w->err_epoch);
   SAGE_HIP(hipGetLastError());
   window_phase_mark(w, 4);
   return SAGE_OK;
@@ -1018,11 +1024,38 @@ extern "C" int sage_window_error(SageWindow *w, int which)
 // After a device solve the candidate variables / delta live in the solver's pinned buffers until the stream has
 // drained: refresh the host mirrors (set 1) here.  Returns SAGE_E_NOT_PSD when the factorisation hit a non-positive
 // pivot (the candidate is then meaningless).
-int window_sync_candidate(SageWindow *w)
+static int window_total_error(SageWindow *w, int from_linearize, double *err, bool stream_idle);
+
+// Single-rank windows: wait for the error pass by spinning on the tickets its totals kernel writes into the pinned mirror
+// (sage_window_error is the last thing in the stream then, and everything enqueued before it has landed too): a host
+// thread blocked in hipStreamSynchronize for more than a few dozen microseconds wakes up through an interrupt, 20-30 us
+// after the kernel has finished -- on the LM iteration's critical path.  false: no mirror / timed out (the caller
+// synchronises the stream as before).
+static bool window_spin_totals(SageWindow *w)
+{
+  if (w->world != 1 || !w->h_err || w->err_epoch == 0)
+    return false;
+  const volatile double *t = w->h_err + 8;
+  const double want = (double)w->err_epoch;
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (!(t[0] == want && t[1] == want && t[2] == want && t[3] == want))
+  {
+    __builtin_ia32_pause();
+    if ((++spins & 0x3ff) == 0 &&
+        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05)
+      return false;
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return true;
+}
+
+int window_sync_candidate(SageWindow *w, bool stream_idle)
 {
   if (!w->cand_pending)
     return SAGE_OK;
-  SAGE_HIP(hipStreamSynchronize(w->stream));
+  if (!stream_idle)
+    SAGE_HIP(hipStreamSynchronize(w->stream));
   w->cand_pending = false;
   const DeviceSolver *S = w->last_solver ? w->last_solver : w->solver;
   if (solver_host_status(S) != 0)
@@ -1088,10 +1121,16 @@ static double prior_error(const SageWindow *w, int set)
 
 extern "C" int sage_window_total_error(SageWindow *w, int from_linearize, double *err)
 {
+  return window_total_error(w, from_linearize, err, false);
+}
+
+// stream_idle: the caller has seen the error pass's tickets (window_spin_totals) -- nothing to synchronise
+static int window_total_error(SageWindow *w, int from_linearize, double *err, bool stream_idle)
+{
   if (!w || !w->finalized || !err)
     return SAGE_E_STATE;
   double t[4];
-  int rcs = window_sync_candidate(w);
+  int rcs = window_sync_candidate(w, stream_idle);
   if (rcs && rcs != SAGE_E_NOT_PSD)
     return rcs;
   // a failed factorisation only invalidates the CANDIDATE: the error at the linearisation point is still served
@@ -1099,7 +1138,8 @@ extern "C" int sage_window_total_error(SageWindow *w, int from_linearize, double
   if (w->world == 1 && w->h_err)
   {
     // single-rank window: the kernels mirrored the totals into pinned host memory
-    SAGE_HIP(hipStreamSynchronize(w->stream));
+    if (!stream_idle)
+      SAGE_HIP(hipStreamSynchronize(w->stream));
     const double *m = w->h_err + (from_linearize ? 0 : 4);
     *err = m[0] + m[1] + prior_error(w, from_linearize ? 0 : 1);
     return rc_out;
@@ -1689,9 +1729,10 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
     }
     else
     {
-      if (evals == 0 && (rc = sage_window_total_error(w, 1, &st->error)))
+      const bool idle = window_spin_totals(w);
+      if (evals == 0 && (rc = window_total_error(w, 1, &st->error, idle)))
         return rc;
-      rc = sage_window_total_error(w, 0, &st->candidate_error);
+      rc = window_total_error(w, 0, &st->candidate_error, idle);
       if (rc == SAGE_E_NOT_PSD)
         st->candidate_error = INFINITY;
       else if (rc)
