@@ -7,23 +7,19 @@
 // equations (keyframe blocks of B = 7+CS rows, coupled along factor-graph links) stay in HBM end to end:
 //
 //   scatter   packed [K diag blocks | link blocks | gradient] (double)  ->  block-envelope storage of the lower
-//             triangle (+ priors, LM damping, identity padding to BP rows)
-//   factor    ONE workgroup of 1024 lanes walks the block columns (right-looking): the column panel
-//             [C_jj ; C_ij (i in R_j) ; g_j^T] lives in registers and is eliminated column by column through an
-//             LDS broadcast buffer (one barrier per column), the trailing updates C_ii' -= L_ij L_i'j^T run as
-//             4x4 register tiles out of LDS.  The right-hand side rides along as an extra panel row, so the forward
-//             substitution is free; the back substitution follows in the same launch.
-//   retract   candidate variables = retract(current, delta)
+//             triangle (+ priors, LM damping, identity padding to BP rows), streamed into pinned host memory in the
+//             order the factorisation consumes it, a ticket per block
+//   factor    fixed-block Cholesky + substitutions on host cores (host_math.cpp: block_chol_solve_tr -- two halves and
+//             a separator, each half as two pipelined stages)
+//   retract   candidate variables = retract(current, delta), read zero-copy from the host's solution
 //
 // Everything is double: cond(H_damped) ~ 1e9 on the headline window.
 //
-// The factorisation is a dependency chain of K*B = 2.5 k pivots with ~27 M fused multiply-adds in total.  Measured on
-// MI355X (K = 64, B = 39): the one-workgroup device factorisation takes 4.2 ms (1.1 us per pivot: 16 waves re-issue the
-// panel update between two barriers), an AVX-512 host core does the same work in a fraction of that.  So the DEFAULT
-// is the hybrid: scatter on the device -> block storage D2H (pinned, 3 MB) -> fixed-block Cholesky on the host
-// (host_math.cpp: block_chol_solve_tr) -> solution H2D -> retract on the device.  SAGE_DEVICE_SOLVE=1 selects the
-// all-device factorisation (kept: it is exact to 1e-8 against the host solve and removes the last host round trip
-// once its pivot loop is restructured).
+// Why the factorisation is on the host: it is a dependency chain of K*B = 2.5 k pivots with ~27 M fused multiply-adds
+// in total.  A one-workgroup device factorisation took 4.2 ms on MI355X (K = 64, B = 39: 1.1 us per pivot, 16 waves
+// re-issue the panel update between two barriers; removed in r04), AVX-512 host cores do the same work in 0.13 ms.  So:
+// scatter on the device -> block storage over PCIe (pinned, 3.2 MB, overlapped with the factorisation) -> host
+// Cholesky -> retract on the device.
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -44,10 +40,6 @@ struct SolvePlan
   int K, B, Bp, nblk, nlinks;
   const int32_t *row_first; // [K] first block column of block row i
   const int32_t *row_off;   // [K] index of block (i, row_first[i]) in the block storage
-  const int32_t *col_ptr;   // [K+1]
-  const int32_t *col_rows;  // rows i > j with row_first[i] <= j, ascending
-  const int32_t *job_ptr;   // [K+1]
-  const int2 *jobs;         // trailing-update tile jobs of column j
   const int32_t *blk_row, *blk_col, *blk_src; // [nblk]; src = link index (bit 30: stored block is the link block
                                                // itself rather than its transpose) or -1
   const int32_t *perm, *pos; // elimination order: perm[position] = keyframe, pos[keyframe] = position
@@ -176,17 +168,6 @@ __global__ __launch_bounds__(256) void solve_scatter_kernel(const SolvePlan P, c
 }
 
 // ------------------------------------------------------------------------------------------------
-// factor + forward/back substitution: one workgroup
-// ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double readlane_f64(double v, int lane)
-{
-  const unsigned long long u = __double_as_longlong(v);
-  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(u & 0xffffffffull), lane);
-  const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(u >> 32), lane);
-  return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-
-// ------------------------------------------------------------------------------------------------
 // retract: candidate = current (+) delta   (gtsam_traits.h:45-70; tangent order [trans, rot], left update)
 // ------------------------------------------------------------------------------------------------
 __device__ inline void se3_exp_dev(const float *omega, const float *v, float *R, float *t) // mapping_utils.h:316-346
@@ -287,16 +268,13 @@ __global__ __launch_bounds__(1024) void solve_retract_kernel(const double *__res
 // ------------------------------------------------------------------------------------------------
 struct DeviceSolver
 {
-  int K = 0, B = 0, Bp = 0, nblk = 0, nlinks = 0, max_rows = 0;
+  int K = 0, B = 0, Bp = 0, nblk = 0, nlinks = 0;
   void *d_int = nullptr;   // all int tables in one allocation
-  void *d_dbg = nullptr;
-  void *d_L = nullptr, *d_y = nullptr; // one allocation: block storage, then the right-hand side (d_y = d_L + nblk*Bp*Bp)
-  void *d_tail = nullptr;              // device factorisation only: [unused double | status int]
   void *h_pinned = nullptr; // [K*VS floats | K*B doubles | tail double | status int]
   size_t h_vars_off = 0, h_delta_off = 0, h_tail_off = 0, h_status_off = 0, h_bytes = 0;
   SolvePlan plan{};
   int VS = 0;
-  void *h_T = nullptr, *h_y = nullptr;       // pinned, one allocation like d_L/d_y (hybrid path)
+  void *h_T = nullptr, *h_y = nullptr;       // pinned, one allocation: block storage, then the right-hand side
   std::vector<double> h_X;                   // inverses of the diagonal factors
   std::vector<int32_t> h_row_first, h_row_off, h_a_first, h_a_cnt, h_a_off, h_col_ptr, h_col_rows;
   int n1 = 0, n2 = 0; // two independent leading row ranges [0,n1) and [n1,n1+n2) of the elimination order (0: none)
@@ -330,30 +308,8 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   const std::vector<int32_t> &perm = bp.perm, &pos = bp.pos, &row_first = bp.row_first, &row_off = bp.row_off,
                              &a_first = bp.a_first, &a_cnt = bp.a_cnt, &a_off = bp.a_off, &blk_row = bp.blk_row,
                              &blk_col = bp.blk_col, &blk_src = bp.blk_src;
-  std::vector<int32_t> col_ptr(K + 1, 0), col_rows, job_ptr(K + 1, 0);
-  std::vector<int2> jobs;
-  int max_rows = 0;
-  for (int j = 0; j < K; ++j)
-  {
-    col_ptr[j] = (int)col_rows.size();
-    job_ptr[j] = (int)jobs.size();
-    std::vector<int> rows;
-    for (int i = j + 1; i < K; ++i)
-      if (row_first[i] <= j)
-        rows.push_back(i);
-    max_rows = std::max(max_rows, (int)rows.size());
-    for (int i : rows)
-      col_rows.push_back(i);
-  }
-  col_ptr[K] = (int)col_rows.size();
-  job_ptr[K] = (int)jobs.size();
-  if (col_rows.empty())
-    col_rows.push_back(0);
-  if (jobs.empty())
-    jobs.push_back(make_int2(0, 0));
-
   DeviceSolver *S = new DeviceSolver;
-  S->K = K; S->B = B; S->Bp = Bp; S->nblk = nblk; S->nlinks = (int)links.size(); S->max_rows = max_rows; S->VS = VS;
+  S->K = K; S->B = B; S->Bp = Bp; S->nblk = nblk; S->nlinks = (int)links.size(); S->VS = VS;
   // one allocation for the int tables
   std::vector<int32_t> all;
   auto put = [&](const std::vector<int32_t> &v) {
@@ -363,9 +319,8 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
       all.push_back(0);
     return off;
   };
-  const size_t o_rf = put(row_first), o_ro = put(row_off), o_cp = put(col_ptr), o_cr = put(col_rows),
-               o_jp = put(job_ptr), o_br = put(blk_row), o_bc = put(blk_col), o_bs = put(blk_src), o_pm = put(perm),
-               o_ps = put(pos);
+  const size_t o_rf = put(row_first), o_ro = put(row_off), o_br = put(blk_row), o_bc = put(blk_col),
+               o_bs = put(blk_src), o_pm = put(perm), o_ps = put(pos);
   // consumption order of the host factorisation: the two halves row by row side by side, the separator last
   std::vector<int32_t> order, pair_off;
   {
@@ -395,12 +350,6 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
         push_row(i);
   }
   const size_t o_ord = put(order);
-  const size_t o_jobs = all.size();
-  for (auto &jb : jobs)
-  {
-    all.push_back(jb.x);
-    all.push_back(jb.y);
-  }
   auto fail = [&](int rc) {
     solver_destroy(S);
     return rc;
@@ -412,12 +361,6 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   if (hipStreamSynchronize(stream) != hipSuccess)
     return fail((int)hipErrorUnknown);
   const size_t ty_doubles = (size_t)nblk * Bp * Bp + (size_t)K * Bp;
-  if (hipMalloc(&S->d_L, ty_doubles * sizeof(double)) != hipSuccess ||
-      hipMalloc(&S->d_tail, 2 * sizeof(double)) != hipSuccess)
-    return fail((int)hipErrorOutOfMemory);
-  S->d_y = reinterpret_cast<double *>(S->d_L) + (size_t)nblk * Bp * Bp;
-  if (sage::env_flag("SAGE_DEBUG_TIMING") && hipMalloc(&S->d_dbg, 8 * sizeof(unsigned long long)) != hipSuccess)
-    return fail((int)hipErrorOutOfMemory);
   S->h_row_first = row_first;
   S->h_row_off = row_off;
   S->h_a_first = a_first;
@@ -443,8 +386,7 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   const int32_t *base = reinterpret_cast<const int32_t *>(S->d_int);
   SolvePlan &P = S->plan;
   P.K = K; P.B = B; P.Bp = Bp; P.nblk = nblk; P.nlinks = (int)links.size();
-  P.row_first = base + o_rf; P.row_off = base + o_ro; P.col_ptr = base + o_cp; P.col_rows = base + o_cr;
-  P.job_ptr = base + o_jp; P.jobs = reinterpret_cast<const int2 *>(base + o_jobs);
+  P.row_first = base + o_rf; P.row_off = base + o_ro;
   P.blk_row = base + o_br; P.blk_col = base + o_bc; P.blk_src = base + o_bs; P.perm = base + o_pm; P.pos = base + o_ps;
   S->n1 = n1;
   S->n2 = n2;
@@ -461,7 +403,7 @@ void solver_destroy(DeviceSolver *S)
 {
   if (!S)
     return;
-  void *bufs[] = {S->d_int, S->d_L, S->d_tail, S->d_dbg};
+  void *bufs[] = {S->d_int};
   for (void *p : bufs)
     if (p)
       (void)hipFree(p);
