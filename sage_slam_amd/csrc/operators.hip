@@ -34,7 +34,6 @@ extern "C" void sage_workspace_destroy(SageWorkspace *ws)
   ws->stats.release();
   ws->misc.release();
   ws->dpt0.release();
-  ws->trk.release();
   ws->trk_dpts.release();
   ws->trk_kp_dpts.release();
   if (ws->host_stats)

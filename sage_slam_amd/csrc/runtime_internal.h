@@ -153,8 +153,9 @@ struct SageWorkspace
   // then ONE copy of everything into pinned memory and one synchronise.  Buffers persist across frames.
   bool defer_fetch = false;
   float *stats_ptr = nullptr;
-  DevBuf trk, trk_dpts, trk_kp_dpts; // trk: [pose 12 | photo AtA 49 Atb 7 | keypoint AtA 49 Atb 7 | stats 2 + 2 | pad]
-  float *trk_host = nullptr;         // pinned: [pose 12 | pad 4 | results 116]
+  DevBuf trk_dpts, trk_kp_dpts;      // dof 7: depths scaled for the evaluation
+  float *trk_host = nullptr;         // pinned: [pose 12 | pad 4 | photo AtA 49 Atb 7 | keypoint AtA 49 Atb 7 | stats 2 + 2 | ticket]
+  unsigned trk_epoch = 0;
 };
 
 static inline float *ws_stats(SageWorkspace *ws) { return ws->stats_ptr ? ws->stats_ptr : ws->stats.as<float>(); }

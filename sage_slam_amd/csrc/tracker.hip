@@ -12,9 +12,9 @@ struct TrackCtx
   int dof;
 };
 
-// layout of SageWorkspace::trk (floats) and of the pinned mirror trk_host
-constexpr int kTrkPose = 0, kTrkOut = 12, kTrkStats = 12 + 112, kTrkFloats = 12 + 112 + 4 + 4;
-constexpr int kTrkHostOut = 16; // results start here in trk_host ([0, 12) is the pose on its way to the device)
+// layout of the pinned evaluation buffer trk_host (floats)
+constexpr int kTrkPose = 0;
+constexpr int kTrkHostOut = 16; // results start here in trk_host ([0, 12) is the pose the kernels read; [16 + 116] the ticket)
 
 // depths the kernels of one evaluation read: dof 6 -> the caller's metric depths; dof 7 -> scale * unscaled
 // (camera_tracker.cpp:264, :273 candidate error; :431, :453 Jacobian)
@@ -40,12 +40,41 @@ int track_depths(TrackCtx *c, float scale, const float **photo, const float **kp
   return 0;
 }
 
-// the pose of the evaluation -> device (from pinned memory: a true asynchronous copy)
+// Zero-copy evaluation (r04): the kernels read the pose straight from the pinned mirror and write their 116 result
+// floats straight into it; a one-lane kernel posts a ticket behind them and the host spins on it.  Per evaluation this
+// replaces a host-to-device copy, a device-to-host copy and a blocking hipStreamSynchronize (each a 5-10 us round trip
+// through the runtime) by two PCIe accesses of the kernels themselves.
+__global__ void track_ticket_kernel(volatile unsigned *ticket, unsigned epoch)
+{
+  __threadfence_system();
+  *ticket = epoch;
+}
+
 static int track_upload_pose(SageWorkspace *ws, const float *pose12)
 {
-  std::memcpy(ws->trk_host, pose12, 12 * sizeof(float));
-  SAGE_HIP(hipMemcpyAsync(ws->trk.as<float>() + kTrkPose, ws->trk_host, 12 * sizeof(float), hipMemcpyHostToDevice,
-                          ws->stream));
+  std::memcpy(ws->trk_host, pose12, 12 * sizeof(float)); // (the previous evaluation has been waited for: nobody reads it)
+  return 0;
+}
+
+// enqueue the ticket and wait for it; falls back to a stream synchronise if it does not show up within 50 ms
+static int track_wait(SageWorkspace *ws)
+{
+  volatile unsigned *ticket = reinterpret_cast<volatile unsigned *>(ws->trk_host + kTrkHostOut + 116);
+  const unsigned epoch = ++ws->trk_epoch ? ws->trk_epoch : ++ws->trk_epoch;
+  hipLaunchKernelGGL(track_ticket_kernel, dim3(1), dim3(1), 0, ws->stream, ticket, epoch);
+  SAGE_HIP(hipGetLastError());
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (*ticket != epoch)
+  {
+    __builtin_ia32_pause();
+    if ((++spins & 0x3ff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05)
+    {
+      SAGE_HIP(hipStreamSynchronize(ws->stream));
+      break;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
   return 0;
 }
 
@@ -68,17 +97,17 @@ int track_lin_cb(void *vctx, const float *pose12, float scale, float *AtA, float
   TrackCtx *c = static_cast<TrackCtx *>(vctx);
   const SageTrackProblem *p = c->prob;
   SageWorkspace *ws = p->ws;
-  hipStream_t s = ws->stream;
   const int dof = c->dof;
   int rc = track_upload_pose(ws, pose12);
   if (rc)
     return rc;
-  const float *R = ws->trk.as<float>() + kTrkPose, *t = R + 9;
+  const float *R = ws->trk_host + kTrkPose, *t = R + 9; // (pinned, device-visible)
   const float *dp, *kdp;
   if ((rc = track_depths(c, scale, &dp, &kdp)))
     return rc;
-  float *dA = ws->trk.as<float>() + kTrkOut, *db = dA + 49, *dA2 = dA + 56, *db2 = dA2 + 49;
-  float *st = ws->trk.as<float>() + kTrkStats;
+  float *host = ws->trk_host + kTrkHostOut;
+  float *dA = host, *db = dA + 49, *dA2 = dA + 56, *db2 = dA2 + 49;
+  float *st = host + 112;
   {
     DeferGuard guard(ws);
     ws->stats_ptr = st;
@@ -102,9 +131,8 @@ int track_lin_cb(void *vctx, const float *pose12, float scale, float *AtA, float
         return rc;
     }
   }
-  float *host = ws->trk_host + kTrkHostOut;
-  SAGE_HIP(hipMemcpyAsync(host, dA, (112 + 4) * sizeof(float), hipMemcpyDeviceToHost, s));
-  SAGE_HIP(hipStreamSynchronize(s));
+  if ((rc = track_wait(ws)))
+    return rc;
   const float e_photo = p->use_photo ? host[112] : 0.f, e_kp = p->use_keypoints ? host[114] : 0.f;
   // AtA = zeros; AtA += photo_AtA; AtA += keypoint_AtA  (fp32 tensor adds, :296-318 / :344-364)
   for (int i = 0; i < dof * dof; ++i)
@@ -124,11 +152,12 @@ int track_err_cb(void *vctx, const float *pose12, float scale, float *error)
   int rc = track_upload_pose(ws, pose12);
   if (rc)
     return rc;
-  const float *R = ws->trk.as<float>() + kTrkPose, *t = R + 9;
+  const float *R = ws->trk_host + kTrkPose, *t = R + 9;
   const float *dp, *kdp;
   if ((rc = track_depths(c, scale, &dp, &kdp)))
     return rc;
-  float *st = ws->trk.as<float>() + kTrkStats;
+  float *host = ws->trk_host + kTrkHostOut;
+  float *st = host + 112;
   {
     DeferGuard guard(ws);
     ws->stats_ptr = st;
@@ -149,9 +178,8 @@ int track_err_cb(void *vctx, const float *pose12, float scale, float *error)
         return rc;
     }
   }
-  float *host = ws->trk_host + kTrkHostOut;
-  SAGE_HIP(hipMemcpyAsync(host + 112, st, 4 * sizeof(float), hipMemcpyDeviceToHost, ws->stream));
-  SAGE_HIP(hipStreamSynchronize(ws->stream));
+  if ((rc = track_wait(ws)))
+    return rc;
   *error = (p->use_photo ? host[112] : 0.f) + (p->use_keypoints ? host[114] : 0.f);
   return 0;
 }
@@ -178,10 +206,11 @@ extern "C" int sage_track_frame(const SageLmConfig *cfg, int dof, const SageTrac
   SageWorkspace *ws = prob->ws;
   int rc;
   // evaluation buffers of the workspace: allocated once, reused by every frame tracked through it
-  if ((rc = ws->trk.reserve(kTrkFloats * sizeof(float))))
-    return rc;
   if (!ws->trk_host)
+  {
     SAGE_HIP(hipHostMalloc((void **)&ws->trk_host, (kTrkHostOut + 112 + 4 + 12) * sizeof(float), hipHostMallocDefault));
+    std::memset(ws->trk_host, 0, (kTrkHostOut + 112 + 4 + 12) * sizeof(float));
+  }
   if (dof == 7 && ((prob->use_photo && (rc = ws->trk_dpts.reserve((size_t)prob->N * sizeof(float)))) ||
                    (prob->use_keypoints && (rc = ws->trk_kp_dpts.reserve((size_t)prob->NK * sizeof(float))))))
     return rc;
