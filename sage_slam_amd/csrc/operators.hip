@@ -19,6 +19,7 @@ extern "C" int sage_workspace_create(void *hip_stream, SageWorkspace **out)
     delete ws;
     return (int)e;
   }
+  std::memset(ws->host_stats, 0, 16 * sizeof(float));
   *out = ws;
   return SAGE_OK;
 }
@@ -31,7 +32,6 @@ extern "C" void sage_workspace_destroy(SageWorkspace *ws)
   ws->edge_first.release();
   ws->edge_tiles.release();
   ws->partials.release();
-  ws->stats.release();
   ws->misc.release();
   ws->dpt0.release();
   ws->trk_dpts.release();
@@ -62,8 +62,6 @@ static int ws_prepare(SageWorkspace *ws, int N, size_t partial_floats, LaunchCom
       return rc;
     if ((rc = ws->edge_tiles.reserve(sizeof(int32_t))))
       return rc;
-    if ((rc = ws->stats.reserve(4 * sizeof(float))))
-      return rc;
     SAGE_HIP(hipMemcpyAsync(ws->work.p, wl.work.data(), wl.work.size() * sizeof(WorkItem), hipMemcpyHostToDevice,
                             ws->stream));
     SAGE_HIP(hipMemcpyAsync(ws->edge_first.p, wl.edge_first.data(), sizeof(int32_t), hipMemcpyHostToDevice,
@@ -88,10 +86,41 @@ static int ws_prepare(SageWorkspace *ws, int N, size_t partial_floats, LaunchCom
   return SAGE_OK;
 }
 
+__global__ void ticket_kernel(volatile unsigned *ticket, unsigned epoch)
+{
+  __threadfence_system();
+  *ticket = epoch;
+}
+
+int ws_ticket_wait(SageWorkspace *ws)
+{
+  volatile unsigned *ticket = reinterpret_cast<volatile unsigned *>(ws->host_stats + 8);
+  if (++ws->ticket_epoch == 0)
+    ws->ticket_epoch = 1;
+  const unsigned epoch = ws->ticket_epoch;
+  hipLaunchKernelGGL(ticket_kernel, dim3(1), dim3(1), 0, ws->stream, ticket, epoch);
+  SAGE_HIP(hipGetLastError());
+  const auto t0 = std::chrono::steady_clock::now();
+  unsigned spins = 0;
+  while (*ticket != epoch)
+  {
+    __builtin_ia32_pause();
+    if ((++spins & 0x3ff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05)
+    {
+      SAGE_HIP(hipStreamSynchronize(ws->stream)); // (a long queue ahead of this operator: wait the ordinary way)
+      break;
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return SAGE_OK;
+}
+
+// the operator's kernels have written {error, inliers} into the pinned mirror themselves (ws_stats): wait for them
 static int ws_fetch_stats(SageWorkspace *ws, float *error_host, float *num_inliers_host)
 {
-  SAGE_HIP(hipMemcpyAsync(ws->host_stats, ws->stats.p, 2 * sizeof(float), hipMemcpyDeviceToHost, ws->stream));
-  SAGE_HIP(hipStreamSynchronize(ws->stream));
+  const int rc = ws_ticket_wait(ws);
+  if (rc)
+    return rc;
   if (error_host)
     *error_host = ws->host_stats[0];
   if (num_inliers_host)
@@ -146,7 +175,7 @@ extern "C" int sage_photometric_jac_error_calculate(
   e.homo = homo; e.loc = loc1d; e.loc_is_i64 = 1;
   e.R0 = R0; e.t0 = t0; e.R1 = R1; e.t1 = t1; e.R10 = R10; e.t10 = R10 ? t10 : nullptr;
   e.code0 = code0; e.scale0 = nullptr; e.scale0_val = scale0; e.N = N;
-  EdgeOut out{AtA_dev, Atb_dev, ws->stats.as<float>()};
+  EdgeOut out{AtA_dev, Atb_dev, ws_stats(ws)};
   SAGE_HIP(launch_photo_linearize(ws->stream, CS, FS, &e, nullptr, lc, *pyr, weights_host, eps, out));
   return ws_fetch_stats(ws, error_host, num_inliers_host);
 }
@@ -174,7 +203,7 @@ extern "C" int sage_photometric_error_calculate(
   e.feat0 = feat0; e.feat1 = feat1; e.grad1 = nullptr; e.bias0 = bias0; e.basis0 = basis0; e.mask1 = mask1;
   e.homo = homo; e.loc = loc1d; e.loc_is_i64 = 1;
   e.R10 = R10; e.t10 = t10; e.code0 = code0; e.scale0 = nullptr; e.scale0_val = scale0; e.N = N;
-  SAGE_HIP(launch_photo_error(ws->stream, CS, FS, &e, nullptr, lc, *pyr, weights_host, eps, ws->stats.as<float>()));
+  SAGE_HIP(launch_photo_error(ws->stream, CS, FS, &e, nullptr, lc, *pyr, weights_host, eps, ws_stats(ws)));
   return ws_fetch_stats(ws, error_host, num_inliers_host);
 }
 
@@ -197,8 +226,6 @@ static int track_common(SageWorkspace *ws, bool jac, int dof, float *AtA, float 
       work.push_back(WorkItem{0, tl});
     int rc;
     if ((rc = ws->work.reserve(work.size() * sizeof(WorkItem))))
-      return rc;
-    if ((rc = ws->stats.reserve(4 * sizeof(float))))
       return rc;
     SAGE_HIP(hipMemcpyAsync(ws->work.p, work.data(), work.size() * sizeof(WorkItem), hipMemcpyHostToDevice,
                             ws->stream));
@@ -276,7 +303,7 @@ extern "C" int sage_geometric_jac_error_calculate(
   e.homo = homo; e.loc = loc1d; e.loc_is_i64 = 0;
   e.R0 = R0; e.t0 = t0; e.R1 = R1; e.t1 = t1; e.R10 = R10; e.t10 = R10 ? t10 : nullptr;
   e.code0 = code0; e.scale0 = nullptr; e.scale1 = nullptr; e.scale0_val = scale0; e.scale1_val = scale1; e.N = N;
-  EdgeOut out{AtA_dev, Atb_dev, ws->stats.as<float>()};
+  EdgeOut out{AtA_dev, Atb_dev, ws_stats(ws)};
   SAGE_HIP(launch_geo_linearize(ws->stream, CS, &e, nullptr, lc, *cam, eps, loss_param, weight, out));
   return ws_fetch_stats(ws, error_host, num_inliers_host);
 }
@@ -301,7 +328,7 @@ extern "C" int sage_geometric_error_calculate(
   e.dpt0 = ws->dpt0.as<float>();
   e.bias0 = bias0; e.basis0 = basis0; e.dpt1 = dpt1; e.mask1 = mask1; e.homo = homo; e.loc = loc1d;
   e.loc_is_i64 = 0; e.R10 = R10; e.t10 = t10; e.code0 = code0; e.scale0_val = scale0; e.scale1_val = 1.f; e.N = N;
-  SAGE_HIP(launch_geo_error(ws->stream, CS, &e, nullptr, lc, *cam, eps, loss_param, weight, ws->stats.as<float>()));
+  SAGE_HIP(launch_geo_error(ws->stream, CS, &e, nullptr, lc, *cam, eps, loss_param, weight, ws_stats(ws)));
   return ws_fetch_stats(ws, error_host, num_inliers_host);
 }
 
@@ -333,7 +360,7 @@ static int reproj_common(SageWorkspace *ws, bool tracker, bool jac, float *AtA, 
     return SAGE_E_UNSUPPORTED;
   const int D = tracker ? 6 : 13 + CS;
   int rc;
-  if ((rc = ws->misc.reserve(reproj_scratch_floats(N, D) * sizeof(float))) || (rc = ws->stats.reserve(4 * sizeof(float))))
+  if ((rc = ws->misc.reserve(reproj_scratch_floats(N, D) * sizeof(float))))
     return rc;
   SAGE_HIP(launch_reproj(ws->stream, CS, tracker, jac, R10, t10, R0, t0, R1, t1, bias0, basis0, code0, loc, dpts0, homo,
                          matched, scale0, *cam, eps, loss_param, weight, N, ws->misc.as<float>(), AtA, Atb,
@@ -410,7 +437,7 @@ static int mg_common(SageWorkspace *ws, int mode, int loss, bool jac, float *AtA
     return SAGE_E_UNSUPPORTED;
   const int D = mode == 0 ? 14 + 2 * CS : (mode == 1 ? 14 : (mode == 2 ? 6 : 7));
   int rc;
-  if ((rc = ws->misc.reserve(mg_scratch_floats(N, D) * sizeof(float))) || (rc = ws->stats.reserve(4 * sizeof(float))))
+  if ((rc = ws->misc.reserve(mg_scratch_floats(N, D) * sizeof(float))))
     return rc;
   SAGE_HIP(launch_match_geom(ws->stream, mode, loss, CS, jac, R10, t10, R0, t0, R1, t1, bias0, bias1, basis0, basis1,
                              code0, code1, dpts0, dpts1, homo0, homo1, loc0, loc1, scale0, scale1, loss_param, weight, N,

@@ -143,8 +143,9 @@ using namespace sage_rt;
 struct SageWorkspace
 {
   hipStream_t stream = nullptr;
-  DevBuf work, edge_first, edge_tiles, partials, stats, misc, dpt0;
-  float *host_stats = nullptr; // pinned, 2 floats
+  DevBuf work, edge_first, edge_tiles, partials, misc, dpt0;
+  float *host_stats = nullptr; // pinned, 16 floats: [0, 4) the operator's {error, inliers}, written by its kernels; [8] the ticket
+  unsigned ticket_epoch = 0;
   int cached_N = -1;
   int n_work = 0;
   int tiles_per_block = 1;
@@ -154,11 +155,15 @@ struct SageWorkspace
   bool defer_fetch = false;
   float *stats_ptr = nullptr;
   DevBuf trk_dpts, trk_kp_dpts;      // dof 7: depths scaled for the evaluation
-  float *trk_host = nullptr;         // pinned: [pose 12 | pad 4 | photo AtA 49 Atb 7 | keypoint AtA 49 Atb 7 | stats 2 + 2 | ticket]
-  unsigned trk_epoch = 0;
+  float *trk_host = nullptr;         // pinned: [pose 12 | pad 4 | photo AtA 49 Atb 7 | keypoint AtA 49 Atb 7 | stats 2 + 2]
 };
 
-static inline float *ws_stats(SageWorkspace *ws) { return ws->stats_ptr ? ws->stats_ptr : ws->stats.as<float>(); }
+// where an operator's kernels put {error, inliers}: the tracker's evaluation buffer, or the workspace's pinned mirror (the
+// kernels write it over PCIe themselves: no device-to-host copy afterwards)
+static inline float *ws_stats(SageWorkspace *ws) { return ws->stats_ptr ? ws->stats_ptr : ws->host_stats; }
+// enqueue a one-lane kernel that posts a ticket behind everything in the workspace's stream and spin until it shows up
+// (instead of a blocking hipStreamSynchronize: operators.hip)
+int ws_ticket_wait(SageWorkspace *ws);
 
 
 // instantiated (CS, FS) combinations of the factor kernels

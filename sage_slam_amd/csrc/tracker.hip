@@ -14,7 +14,7 @@ struct TrackCtx
 
 // layout of the pinned evaluation buffer trk_host (floats)
 constexpr int kTrkPose = 0;
-constexpr int kTrkHostOut = 16; // results start here in trk_host ([0, 12) is the pose the kernels read; [16 + 116] the ticket)
+constexpr int kTrkHostOut = 16; // results start here in trk_host ([0, 12) is the pose the kernels read)
 
 // depths the kernels of one evaluation read: dof 6 -> the caller's metric depths; dof 7 -> scale * unscaled
 // (camera_tracker.cpp:264, :273 candidate error; :431, :453 Jacobian)
@@ -41,40 +41,12 @@ int track_depths(TrackCtx *c, float scale, const float **photo, const float **kp
 }
 
 // Zero-copy evaluation (r04): the kernels read the pose straight from the pinned mirror and write their 116 result
-// floats straight into it; a one-lane kernel posts a ticket behind them and the host spins on it.  Per evaluation this
+// floats straight into it; a one-lane kernel posts a ticket behind them and the host spins on it (ws_ticket_wait).  Per evaluation this
 // replaces a host-to-device copy, a device-to-host copy and a blocking hipStreamSynchronize (each a 5-10 us round trip
 // through the runtime) by two PCIe accesses of the kernels themselves.
-__global__ void track_ticket_kernel(volatile unsigned *ticket, unsigned epoch)
-{
-  __threadfence_system();
-  *ticket = epoch;
-}
-
 static int track_upload_pose(SageWorkspace *ws, const float *pose12)
 {
   std::memcpy(ws->trk_host, pose12, 12 * sizeof(float)); // (the previous evaluation has been waited for: nobody reads it)
-  return 0;
-}
-
-// enqueue the ticket and wait for it; falls back to a stream synchronise if it does not show up within 50 ms
-static int track_wait(SageWorkspace *ws)
-{
-  volatile unsigned *ticket = reinterpret_cast<volatile unsigned *>(ws->trk_host + kTrkHostOut + 116);
-  const unsigned epoch = ++ws->trk_epoch ? ws->trk_epoch : ++ws->trk_epoch;
-  hipLaunchKernelGGL(track_ticket_kernel, dim3(1), dim3(1), 0, ws->stream, ticket, epoch);
-  SAGE_HIP(hipGetLastError());
-  const auto t0 = std::chrono::steady_clock::now();
-  unsigned spins = 0;
-  while (*ticket != epoch)
-  {
-    __builtin_ia32_pause();
-    if ((++spins & 0x3ff) == 0 && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > 0.05)
-    {
-      SAGE_HIP(hipStreamSynchronize(ws->stream));
-      break;
-    }
-  }
-  std::atomic_thread_fence(std::memory_order_acquire);
   return 0;
 }
 
@@ -131,7 +103,7 @@ int track_lin_cb(void *vctx, const float *pose12, float scale, float *AtA, float
         return rc;
     }
   }
-  if ((rc = track_wait(ws)))
+  if ((rc = ws_ticket_wait(ws)))
     return rc;
   const float e_photo = p->use_photo ? host[112] : 0.f, e_kp = p->use_keypoints ? host[114] : 0.f;
   // AtA = zeros; AtA += photo_AtA; AtA += keypoint_AtA  (fp32 tensor adds, :296-318 / :344-364)
@@ -178,7 +150,7 @@ int track_err_cb(void *vctx, const float *pose12, float scale, float *error)
         return rc;
     }
   }
-  if ((rc = track_wait(ws)))
+  if ((rc = ws_ticket_wait(ws)))
     return rc;
   *error = (p->use_photo ? host[112] : 0.f) + (p->use_keypoints ? host[114] : 0.f);
   return 0;
