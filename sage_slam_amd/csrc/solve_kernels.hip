@@ -209,9 +209,34 @@ __global__ __launch_bounds__(1024) void solve_retract_kernel(const double *__res
                                                             int VS, const int32_t *__restrict__ pos,
                                                             const float *__restrict__ vars0,
                                                             float *__restrict__ vars1, float *__restrict__ h_vars,
-                                                            double *__restrict__ h_delta, double *__restrict__ h_tail)
+                                                            double *__restrict__ h_delta, double *__restrict__ h_tail,
+                                                            const volatile unsigned *go, unsigned epoch)
 {
   const int tid = threadIdx.x;
+  // The kernel is enqueued BEFORE the host factorises (right behind the scatter) and waits here for the host's word in
+  // pinned memory: the solution is there (go == epoch), or there is none (bit 31 set: non-positive pivot / abort).  The
+  // launch latency of a kernel issued into an idle queue (tens of microseconds on the step's critical path) is hidden
+  // behind the factorisation.  A watchdog (2 s of the 100 MHz wall clock) ends the wait if the host never answers.
+  __shared__ int s_go;
+  if (tid == 0)
+  {
+    const unsigned long long t0 = wall_clock64();
+    unsigned v;
+    while (((v = *go) & 0x7fffffffu) != epoch)
+    {
+      __builtin_amdgcn_s_sleep(4);
+      if (wall_clock64() - t0 > 200000000ull)
+      {
+        v = 0x80000000u;
+        break;
+      }
+    }
+    __threadfence_system();
+    s_go = (v & 0x80000000u) ? 0 : 1;
+  }
+  __syncthreads();
+  if (!s_go)
+    return;
   double nrm = 0.0;
   for (int idx = tid; idx < K * B; idx += blockDim.x)
   {
@@ -270,7 +295,9 @@ struct DeviceSolver
 {
   int K = 0, B = 0, Bp = 0, nblk = 0, nlinks = 0;
   void *d_int = nullptr;   // all int tables in one allocation
-  void *h_pinned = nullptr; // [K*VS floats | K*B doubles | tail double | status int]
+  void *h_pinned = nullptr; // [K*VS floats | K*B doubles | tail double | status int | go word of the pre-launched retract]
+  size_t h_go_off = 0;
+  unsigned go_epoch = 0;
   size_t h_vars_off = 0, h_delta_off = 0, h_tail_off = 0, h_status_off = 0, h_bytes = 0;
   SolvePlan plan{};
   int VS = 0;
@@ -380,7 +407,8 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   S->h_vars_off = 0;
   S->h_delta_off = ((size_t)K * VS * sizeof(float) + 15) / 16 * 16;
   S->h_tail_off = S->h_delta_off + (size_t)K * B * sizeof(double);
-  S->h_bytes = S->h_tail_off + 2 * sizeof(double);
+  S->h_go_off = S->h_tail_off + 2 * sizeof(double);
+  S->h_bytes = S->h_go_off + 2 * sizeof(double);
   if (hipHostMalloc(&S->h_pinned, S->h_bytes, hipHostMallocDefault) != hipSuccess)
     return fail((int)hipErrorOutOfMemory);
   const int32_t *base = reinterpret_cast<const int32_t *>(S->d_int);
@@ -414,8 +442,8 @@ void solver_destroy(DeviceSolver *S)
   delete S;
 }
 
-// enqueue: scatter -> factor/substitute -> retract -> D2H of {candidate variables, delta, |delta|^2, status}.
-// Nothing here synchronises; the results are valid after the stream has been synchronised.
+// enqueue scatter and retract, factorise on the host in between (the retract waits on the device for the host's word);
+// the candidate's host mirror is valid once the stream has drained (or a later kernel's ticket has been seen).
 int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, const float *vars0, float *vars1,
                int CS, double damp, double code_w, double scale_w, double pose_w, float scale_init0,
                const float *pose_init0)
@@ -449,6 +477,28 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
                        reinterpret_cast<double *>(S->h_y), S->d_order, S->h_flags, S->epoch, 0, S->nblk);
     if ((eh = hipGetLastError()) != hipSuccess)
       return (int)eh;
+    // the retract right behind the scatter: it waits on the device for this thread's word (solve_retract_kernel)
+    char *hp = reinterpret_cast<char *>(S->h_pinned);
+    volatile unsigned *go = reinterpret_cast<volatile unsigned *>(hp + S->h_go_off);
+    S->go_epoch = (S->go_epoch + 1) & 0x7fffffffu;
+    if (S->go_epoch == 0)
+      S->go_epoch = 1;
+    hipLaunchKernelGGL(solve_retract_kernel, dim3(1), dim3(1024), 0, stream,
+                       reinterpret_cast<const double *>(S->h_y), S->K, S->B, S->Bp, CS, S->VS, S->plan.pos, vars0, vars1,
+                       reinterpret_cast<float *>(hp + S->h_vars_off), reinterpret_cast<double *>(hp + S->h_delta_off),
+                       reinterpret_cast<double *>(hp + S->h_tail_off), go, S->go_epoch);
+    if ((eh = hipGetLastError()) != hipSuccess)
+      return (int)eh;
+    struct GoGuard // whatever happens below, the waiting kernel gets its word
+    {
+      volatile unsigned *go;
+      unsigned word;
+      ~GoGuard()
+      {
+        std::atomic_thread_fence(std::memory_order_release);
+        *go = word;
+      }
+    } guard{go, S->go_epoch | 0x80000000u};
     const auto t1 = std::chrono::steady_clock::now();
     BlockEnvelope env;
     env.K = S->K; env.Bp = S->Bp;
@@ -467,17 +517,9 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
       return SAGE_E_STATE; // the device never delivered a block (see block_chol_solve_tr)
     if (bad)
       return SAGE_E_NOT_PSD;
+    guard.word = S->go_epoch; // the solution is in h_y: go
     (void)eh;
   }
-  char *h = reinterpret_cast<char *>(S->h_pinned);
-  // (hybrid: the solution is read straight from the pinned buffer the host solved in)
-  hipLaunchKernelGGL(solve_retract_kernel, dim3(1), dim3(1024), 0, stream,
-                     reinterpret_cast<const double *>(S->h_y), S->K,
-                     S->B, S->Bp, CS, S->VS, S->plan.pos, vars0, vars1, reinterpret_cast<float *>(h + S->h_vars_off),
-                     reinterpret_cast<double *>(h + S->h_delta_off), reinterpret_cast<double *>(h + S->h_tail_off));
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess)
-    return (int)e;
   return SAGE_OK;
 }
 
