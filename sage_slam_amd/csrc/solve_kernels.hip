@@ -222,17 +222,22 @@ __global__ __launch_bounds__(1024) void solve_retract_kernel(const double *__res
   {
     const unsigned long long t0 = wall_clock64();
     unsigned v;
+    bool timed_out = false;
     while (((v = *go) & 0x7fffffffu) != epoch)
     {
       __builtin_amdgcn_s_sleep(4);
       if (wall_clock64() - t0 > 200000000ull)
       {
         v = 0x80000000u;
+        timed_out = true;
         break;
       }
     }
     __threadfence_system();
     s_go = (v & 0x80000000u) ? 0 : 1;
+    // status word of the host mirror (solver_host_status): 0 candidate written, 2 the host's word never came -- the
+    // caller then treats the evaluation as failed instead of reading a stale candidate
+    *reinterpret_cast<volatile int *>(h_tail + 1) = timed_out ? 2 : 0;
   }
   __syncthreads();
   if (!s_go)
