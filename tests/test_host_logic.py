@@ -240,6 +240,47 @@ def test_block_solve_lookahead_is_bit_identical():
         assert res["on"][0] > 0, "the look-ahead helpers never answered"
 
 
+def test_block_solve_concurrent_callers_share_the_helpers():
+    """several host threads factorise split windows at the same time: the helper threads (second half, look-ahead
+    stages, worker pool) serve one caller at a time, the others run their halves themselves -- every result is the
+    dense solve, and identical to the caller's own single-thread result"""
+    import threading
+    K, CS, window = 36, 32, 3
+    B = 7 + CS
+    n = K * B
+    rng = np.random.default_rng(5)
+    links = [(j, i) for i in range(K) for j in range(max(0, i - window), i)]
+    mask = np.eye(K, dtype=bool)
+    for a, b in links:
+        mask[a, b] = mask[b, a] = True
+    J = rng.normal(size=(2 * n, n))
+    Hs = (J.T @ J) * np.kron(mask, np.ones((B, B))) + 6 * n * np.eye(n)
+    g = rng.normal(size=n)
+    diag = np.stack([Hs[k * B:(k + 1) * B, k * B:(k + 1) * B] for k in range(K)])
+    lnk = np.stack([Hs[a * B:(a + 1) * B, b * B:(b + 1) * B] for a, b in links])
+    packed = np.concatenate([diag.reshape(-1), lnk.reshape(-1), g, np.zeros(4)])
+    ref = capi.block_solve(packed, K, links, B, 1e-4)
+    assert rel(ref, np.linalg.solve(Hs + 1e-4 * np.diag(np.diag(Hs)), g)) < 1e-9
+    errs = []
+
+    def worker():
+        try:
+            for _ in range(8):
+                d = capi.block_solve(packed, K, links, B, 1e-4)
+                if not np.array_equal(d, ref):
+                    errs.append("result differs")
+        except Exception as e:                                          # pragma: no cover
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker) for _ in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=120)
+    assert not any(t.is_alive() for t in ts), "a solve hung"
+    assert not errs, errs[:3]
+
+
 def test_tracker_lm_policy_with_oracle_backend(orc):
     """the product's LM driver (sage_track_lm) with the oracle as evaluation back-end: converges on a
     consistent scene, and its trace obeys the reference policy (camera_tracker.cpp:1156-1279)."""
