@@ -267,7 +267,8 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
       f32x4 o4[G + 1], w4[G + 1];
       float yi[G + 1], kap[G + 1];
       int locp[G + 1];
-      float tb[G + 1][NB], tq[G + 1][4][NB];
+      float tb[G + 1][NB], tq[G + 1][4][NB]; // CS = 16: one channel per lane
+      f32x2 tbp[G + 1], tqp[G + 1][4];         // CS = 32: a channel pair per lane, kept as register pairs
 // (macros, not lambdas: a buffer descriptor captured by a closure loses its provable uniformity and every load
 //  becomes a waterfall loop)
 #define SAGE_GEO_READ_STASH(g)                                                         \
@@ -287,15 +288,9 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
   {                                                                                                          \
     if (NB == 2)                                                                                             \
     {                                                                                                        \
-      const f32x2 vb_ = buf_load2(r_b0, (uint32_t)locp[g] + lane_off, 0);                                    \
-      tb[g][0] = vb_[0];                                                                                     \
-      tb[g][NB - 1] = vb_[1];                                                                                \
+      tbp[g] = buf_load2(r_b0, (uint32_t)locp[g] + lane_off, 0);                                             \
       _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                          \
-      {                                                                                                      \
-        const f32x2 vq_ = buf_load2(r_b1, (uint32_t)__float_as_int(o4[g][q]) + lane_off, 0);                 \
-        tq[g][q][0] = vq_[0];                                                                                \
-        tq[g][q][NB - 1] = vq_[1];                                                                           \
-      }                                                                                                      \
+          tqp[g][q] = buf_load2(r_b1, (uint32_t)__float_as_int(o4[g][q]) + lane_off, 0);                     \
     }                                                                                                        \
     else                                                                                                     \
     {                                                                                                        \
@@ -305,13 +300,27 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
     }                                                                                                        \
   }
 // operands of group g: t' = sqrt(omega) [kappa*b0 ; beta], both MFMA operands of the t t^T tiles
+// (CS = 32: the two channels of a lane as one register pair -- v_pk_mul / v_pk_fma with the tap weight broadcast:
+//  5 VALU instructions per group instead of 10; same products, same order of the sums)
 #define SAGE_GEO_STAGE_OPERANDS(g)                                                                             \
   {                                                                                                            \
-    _Pragma("unroll") for (int b = 0; b < NB; ++b)                                                             \
+    if (NB == 2)                                                                                               \
     {                                                                                                          \
-      bop[(g) & 1][b] = kap[g] * tb[g][b];                                                                     \
-      bop[(g) & 1][NB + b] = __builtin_fmaf(w4[g][3], tq[g][3][b], __builtin_fmaf(w4[g][2], tq[g][2][b],        \
-                             __builtin_fmaf(w4[g][1], tq[g][1][b], w4[g][0] * tq[g][0][b]))); /* beta (:592-595) */ \
+      const f32x2 kb_ = kap[g] * tbp[g];                                                                       \
+      f32x2 be_ = w4[g][0] * tqp[g][0];                                                                        \
+      be_ += w4[g][1] * tqp[g][1];                                                                             \
+      be_ += w4[g][2] * tqp[g][2];                                                                             \
+      be_ += w4[g][3] * tqp[g][3]; /* beta (:592-595) */                                                       \
+      bop[(g) & 1][0] = kb_[0];                                                                                \
+      bop[(g) & 1][NB - 1] = kb_[1];                                                                           \
+      bop[(g) & 1][NB] = be_[0];                                                                               \
+      bop[(g) & 1][2 * NB - 1] = be_[1];                                                                       \
+    }                                                                                                          \
+    else                                                                                                       \
+    {                                                                                                          \
+      bop[(g) & 1][0] = kap[g] * tb[g][0];                                                                     \
+      bop[(g) & 1][NB] = __builtin_fmaf(w4[g][3], tq[g][3][0], __builtin_fmaf(w4[g][2], tq[g][2][0],           \
+                         __builtin_fmaf(w4[g][1], tq[g][1][0], w4[g][0] * tq[g][0][0])));                      \
     }                                                                                                          \
     ygv[(g) & 1] = yi[g];                                                                                      \
   }
