@@ -233,14 +233,18 @@ __global__ void copy_floats_kernel(const float *__restrict__ src, float *__restr
 }
 
 // sharded windows: the reduced totals (tail of the packed buffer, error buffer) -> pinned host mirror
+// (one wave; the four tickets behind the values, like error_totals_kernel: the host spins on them)
 __global__ void mirror_totals_kernel(const double *__restrict__ tail, const double *__restrict__ err,
-                                     double *__restrict__ mirror)
+                                     double *__restrict__ mirror, double epoch)
 {
   const int t = threadIdx.x;
   if (t < 4)
     mirror[t] = tail[t];
   else if (t < 8)
     mirror[t] = err[t - 4];
+  __threadfence_system();
+  if (t < 4)
+    *reinterpret_cast<volatile double *>(mirror + 8 + t) = epoch;
 }
 
 } // namespace sage
@@ -1031,9 +1035,10 @@ static int window_total_error(SageWindow *w, int from_linearize, double *err, bo
 // thread blocked in hipStreamSynchronize for more than a few dozen microseconds wakes up through an interrupt, 20-30 us
 // after the kernel has finished -- on the LM iteration's critical path.  false: no mirror / timed out (the caller
 // synchronises the stream as before).
-static bool window_spin_totals(SageWindow *w)
+static bool window_spin_totals(SageWindow *w, bool reduced_mirror = false)
 {
-  if (w->world != 1 || !w->h_err || w->err_epoch == 0)
+  // (reduced_mirror: a sharded window whose reduced totals have just been mirrored by mirror_totals_kernel)
+  if ((w->world != 1 && !reduced_mirror) || !w->h_err || w->err_epoch == 0)
     return false;
   const volatile double *t = w->h_err + 8;
   const double want = (double)w->err_epoch;
@@ -1714,15 +1719,20 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
       if (w->allreduce(w->errbuf.as<double>(), 4, w->allreduce_user))
         return SAGE_E_STATE;
       hipLaunchKernelGGL(mirror_totals_kernel, dim3(1), dim3(64), 0, w->stream,
-                         w->packed.as<double>() + sage_window_packed_count(w) - 4, w->errbuf.as<double>(), w->h_err);
+                         w->packed.as<double>() + sage_window_packed_count(w) - 4, w->errbuf.as<double>(), w->h_err,
+                         (double)w->err_epoch);
+      // (the host spins on the mirror's tickets instead of blocking in a stream synchronise: with the kernels of a shard
+      //  8x shorter, the 20-30 us wake-up of a blocked thread would be 4 % of an iteration)
+      const bool idle = window_spin_totals(w, true);
       // a non-positive pivot of the damped system is a REJECTED evaluation (raise the damping), not a hard error; every
       // rank factors the same reduced system, so all of them take this branch together and the number of collectives
       // per iteration stays the same on every rank
-      rc = window_sync_candidate(w);
+      rc = window_sync_candidate(w, idle);
       if (rc && rc != SAGE_E_NOT_PSD)
         return rc;
       const bool not_psd = rc == SAGE_E_NOT_PSD;
-      SAGE_HIP(hipStreamSynchronize(w->stream));
+      if (!idle)
+        SAGE_HIP(hipStreamSynchronize(w->stream));
       if (evals == 0)
         st->error = w->h_err[0] + w->h_err[1] + prior_error(w, 0);
       st->candidate_error = not_psd ? INFINITY : w->h_err[4] + w->h_err[5] + prior_error(w, 1);
