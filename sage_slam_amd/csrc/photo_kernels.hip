@@ -147,26 +147,36 @@ __device__ __forceinline__ void pin6(f32x2 &a, f32x2 &b, f32x2 &c, f32x2 &d, f32
 // bounding box (floor() of it is then monotone in p, so the box of [min p, max p] contains every lane's taps)
 __device__ __forceinline__ float level_coord(float p, float ratio) { return __builtin_fmaf(p + 0.5f, ratio, -0.5f); }
 
-template <int CTRL, int ROW_MASK, bool IS_MIN>
-__device__ __forceinline__ float dpp_fminmax(float v, float identity)
-{
-  const int x = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
-  const float xf = __builtin_bit_cast(float, x);
-  return IS_MIN ? fminf(v, xf) : fmaxf(v, xf);
-}
-// wave64 float min / max, returned wave-uniform (same DPP ladder as wave_sum; lanes a masked step does not write keep `identity`)
+// wave64 float min / max, returned wave-uniform.  The DPP ladder of wave_sum with the min / max fused into the DPP
+// instruction itself: v = op(dpp(v), v), a lane whose DPP source is masked or out of range keeps its value.  Written as
+// asm because fminf / fmaxf through __builtin_amdgcn_update_dpp costs a v_mov_dpp, two canonicalising v_max and the
+// operation per step (100 VALU instructions for the four reductions of a sub-tile; 24 like this).  s_nop 1: a DPP read
+// of a VGPR the previous VALU instruction wrote needs two wait states, and the assembler does not insert them.
+#define SAGE_DPP_STEP(OP, CTRL) asm("s_nop 1\n\t" OP " %0, %0, %0 " CTRL : "+v"(v))
 template <bool IS_MIN>
 __device__ __forceinline__ float wave_fminmax(float v)
 {
-  const float id = IS_MIN ? __builtin_inff() : -__builtin_inff();
-  v = dpp_fminmax<0xB1, 0xF, IS_MIN>(v, id);
-  v = dpp_fminmax<0x4E, 0xF, IS_MIN>(v, id);
-  v = dpp_fminmax<0x141, 0xF, IS_MIN>(v, id);
-  v = dpp_fminmax<0x140, 0xF, IS_MIN>(v, id);
-  v = dpp_fminmax<0x142, 0xA, IS_MIN>(v, id);
-  v = dpp_fminmax<0x143, 0xC, IS_MIN>(v, id);
+  if (IS_MIN)
+  {
+    SAGE_DPP_STEP("v_min_f32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    SAGE_DPP_STEP("v_min_f32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    SAGE_DPP_STEP("v_min_f32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf");
+    SAGE_DPP_STEP("v_min_f32_dpp", "row_mirror row_mask:0xf bank_mask:0xf");
+    SAGE_DPP_STEP("v_min_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    SAGE_DPP_STEP("v_min_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  }
+  else
+  {
+    SAGE_DPP_STEP("v_max_f32_dpp", "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf");
+    SAGE_DPP_STEP("v_max_f32_dpp", "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf");
+    SAGE_DPP_STEP("v_max_f32_dpp", "row_half_mirror row_mask:0xf bank_mask:0xf");
+    SAGE_DPP_STEP("v_max_f32_dpp", "row_mirror row_mask:0xf bank_mask:0xf");
+    SAGE_DPP_STEP("v_max_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf");
+    SAGE_DPP_STEP("v_max_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf");
+  }
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+#undef SAGE_DPP_STEP
 
 // second-level accumulators of the noise-critical tiles (the two cross tiles and the pose tile: 3 x 4 floats per lane),
 // one region per wave (see "second level" in the kernel)
