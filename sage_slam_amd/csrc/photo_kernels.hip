@@ -528,7 +528,14 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       }
       // pre-sampled source quads [L][NG][N][4]: base of (level, group) wave-uniform, lane offset n * 16
       const uint32_t f0_vo = (uint32_t)(in_range ? n : 0) * 16u;
-      auto f0_base = [&](int l, int g) { return E.f0s + ((size_t)(l * NG + g) * (size_t)N) * 4; };
+      // (the 16 (level, group) bases are formed at their loads with scalar arithmetic from a laundered N: as loop invariants the
+      //  compiler keeps all of them in SGPRs across the sub-tile loop, spills them into VGPR lanes and pays two
+      //  v_readlane per load -- 32 VALU slots per sub-tile)
+      auto f0_base = [&](int l, int g) {
+        unsigned nq = (unsigned)N;
+        asm volatile("" : "+s"(nq)); // (volatile: stays next to the load that uses the base)
+        return E.f0s + (size_t)((unsigned)(l * NG + g) * nq) * 4;
+      };
       // per level and lane: the 4 tap weights and the LDS byte address a0 of the first tap (xf, yf); the others are
       // (xc, yf) = a0 + 16, (xf, yc) = a0 + row, (xc, yc) = a0 + row + 16 with row = 16 * box width (wave-uniform).  Inliers
       // are box-interior by construction; the clamp only matters for the other lanes (wild coordinates, weight x 0).  A
