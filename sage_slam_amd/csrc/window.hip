@@ -190,11 +190,26 @@ __global__ __launch_bounds__(1024) void error_totals_kernel(const ErrorTotalsSid
     const ErrorTotalsSide &sd = photo ? ph : ge;
     const int e = photo ? idx : idx - ph.n_edges;
     const int first = sd.edge_first[e], nt = sd.edge_tiles[e];
+    // same order of the sums as stats_finalize_kernel; eight records' loads in flight at a time (a chain of dependent
+    // cache misses otherwise: this one-workgroup kernel sits on the step's critical path)
     float se = 0.f, sn = 0.f;
-    for (int t = 0; t < nt; ++t)
+    for (int t0 = 0; t0 < nt; t0 += 8)
     {
-      se += sd.partials[(size_t)(first + t) * sd.stride + sd.err_off];
-      sn += sd.partials[(size_t)(first + t) * sd.stride + sd.cnt_off];
+      float ve[8], vn[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+      {
+        const int t = t0 + u < nt ? t0 + u : nt - 1;
+        ve[u] = sd.partials[(size_t)(first + t) * sd.stride + sd.err_off];
+        vn[u] = sd.partials[(size_t)(first + t) * sd.stride + sd.cnt_off];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (t0 + u < nt)
+        {
+          se += ve[u];
+          sn += vn[u];
+        }
     }
     sd.stats[2 * e + 0] = sn > 0.f ? sd.scale * se / sn : sd.fallback;
     sd.stats[2 * e + 1] = sn;
@@ -208,8 +223,20 @@ __global__ __launch_bounds__(1024) void error_totals_kernel(const ErrorTotalsSid
   const int which = wave >> 1;
   const ErrorTotalsSide &sd = photo ? ph : ge;
   double acc = 0.0;
-  for (int e = lane; e < sd.n_edges; e += 64)
-    acc += (double)sd.stats[2 * e + which];
+  for (int e0 = lane; e0 < sd.n_edges; e0 += 64 * 8) // (same order per lane; eight loads in flight)
+  {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+    {
+      const int e = e0 + 64 * u;
+      v[u] = sd.stats[2 * (e < sd.n_edges ? e : lane) + which];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (e0 + 64 * u < sd.n_edges)
+        acc += (double)v[u];
+  }
   for (int off = 32; off > 0; off >>= 1)
     acc += __shfl_down(acc, off);
   if (lane == 0)
