@@ -242,6 +242,113 @@ def edge_mode(capi, synth, torch):
             "edge": res}
 
 
+def shard_emulation(capi, torch, win, win_h, rank, world, steps, restart, ms_one_gpu_classic, compare_one_gpu=True):
+    """One rank of an N-rank job measured on a one-GPU box: a window holding rank `rank`'s links of
+    `world` (sage_window_set_shard), a REAL one-rank RCCL communicator on the window's stream (the launch cost of
+    ncclAllReduce, not its xGMI transfer), and the other ranks' share of every reduced system added from a table
+    (sage_window_emulate_peers) that is computed beforehand with the full window at the iterates of the job's own
+    trajectory -- so the rank solves the job's real reduced systems and takes its real accept / reject decisions.  What is
+    measured is this rank's critical path per LM iteration: its shard's kernels, the collective's launch, the replicated
+    host solve (uncontended: the other ranks' host threads are not there), the decision round trip.  Not in it: the
+    collective's transfer time over xGMI."""
+    K = len(win_h.keyframes)
+    classic = capi.lm_config_default(); classic.max_inner_evals = 1; classic.linearize_at_candidate = -1
+    st = capi.SageLmState()
+    win.set_profiling(0)
+    win.reset()
+    full, xs = [], []
+    for i in range(restart + 1):
+        win.linearize()
+        torch.cuda.synchronize()
+        full.append(win.packed_tensor().clone())
+        xs.append([win.get_keyframe(k) for k in range(K)])
+        if i < restart:
+            if i == 0:
+                st.iters = 0; st.damp = float(classic.init_damp)
+            win.lm_step(st, classic)
+            if not st.accepted:
+                return {"error": f"iterate {i} of the reference trajectory was rejected: no table to emulate with"}
+    comm = capi.rccl_comm_create(capi.rccl_unique_id(), 0, 1)
+    sw = capi.Window(win_h, rank=rank, world=world)
+    rest = torch.empty(restart + 1, sw.packed_count, dtype=torch.float64, device="cuda")
+    for i in range(restart + 1):
+        for k in range(K):
+            sw.set_keyframe(k, *xs[i][k])
+        sw.linearize()
+        torch.cuda.synchronize()
+        rest[i] = full[i] - sw.packed_tensor()
+    del full
+    sw.reset()
+    sw.use_rccl(comm)
+    sw.emulate_peers(rest)
+    cfg = capi.lm_config_default(); cfg.max_inner_evals = 1      # linearize_at_candidate 0 = automatic: reduced windows
+    state = capi.SageLmState()                                   # evaluate the candidate with the linearize kernels
+
+    def cycles(w, c, n_cycles, per_step):
+        acc = 0
+        for _ in range(n_cycles):
+            w.reset()
+            state.iters = 0; state.damp = float(c.init_damp)
+            tr, sec = w.lm_run_timed(state, c, restart)     # (C++ loop: no Python between the iterations)
+            for j in range(len(sec)):
+                per_step[j].append(float(sec[j]))
+                acc += int(tr[j][2])
+        return acc
+
+    n_cyc = max(2, (steps + restart - 1) // restart)
+    sw.set_profiling(1)
+    cycles(sw, cfg, 2, [[] for _ in range(restart)])
+    for which in range(4):
+        sw.kernel_time(which)
+    sw.phase_time()
+    cycles(sw, cfg, n_cyc, [[] for _ in range(restart)])
+    kt = [sw.kernel_time(which) for which in range(4)]
+    phase, phase_n = sw.phase_time()
+    sw.set_profiling(0)
+    cycles(sw, cfg, 3, [[] for _ in range(restart)])                       # warm-up without the event records
+    torch.cuda.synchronize()
+    ps = [[] for _ in range(restart)]
+    t0 = time.perf_counter()
+    acc = cycles(sw, cfg, n_cyc, ps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    steady = [x for j in range(1, restart) for x in ps[j]] or ps[0]
+    ms_steady = 1e3 * float(np.mean(steady))
+    # the same sequence (linearize-at-candidate) on the whole window: the one-GPU step the shard's is compared with
+    ms_one_same = float("nan")
+    if compare_one_gpu:
+        one = capi.lm_config_default(); one.max_inner_evals = 1; one.linearize_at_candidate = 1
+        cycles(win, one, 2, [[] for _ in range(restart)])
+        torch.cuda.synchronize()
+        p1 = [[] for _ in range(restart)]
+        cycles(win, one, n_cyc, p1)
+        torch.cuda.synchronize()
+        ms_one_same = 1e3 * float(np.mean([x for j in range(1, restart) for x in p1[j]] or p1[0]))
+    local_links = len(capi.shard_links(len(win_h.links), rank, world))
+    out = {"world": world, "rank": rank, "local_links": local_links, "links": len(win_h.links),
+           "ms_per_step": ms_steady,
+           "ms_first_step_after_restart": 1e3 * float(np.mean(ps[0])),
+           "ms_per_step_incl_restarts": 1e3 * wall / (n_cyc * restart),
+           "steps_timed": len(steady), "accepted_steps": acc, "steps": n_cyc * restart,
+           "lm": "linearize-at-candidate (automatic for reduced windows): per iteration 1 solve + 1 linearize of the shard + ONE "
+                 "all-reduce (packed system, error totals in its tail); `ms_per_step` = iterations 2.." + str(restart) +
+                 " after a restart (the first one also linearizes the initial estimate)",
+           "collective": "one-rank ncclAllReduce (RCCL) on the window's stream + the peers' share added from a precomputed "
+                         "table (sage_window_emulate_peers): launch cost measured, xGMI transfer time NOT included",
+           "host": "replicated host solve, uncontended (the other ranks' processes are not running)",
+           "one_gpu_ms_per_step_classic": ms_one_gpu_classic, "one_gpu_ms_per_step_same_sequence": ms_one_same,
+           "speedup_vs_one_gpu_classic": ms_one_gpu_classic / ms_steady,
+           "speedup_vs_one_gpu_same_sequence": ms_one_same / ms_steady,
+           "kernel_ms": {"photo_linearize": kt[0][0] / max(1, kt[0][1]), "geo_linearize": kt[1][0] / max(1, kt[1][1])}}
+    if phase_n > 0:
+        out["phase_ms"] = {k: v / phase_n for k, v in phase.items()}
+        out["phase_ms"]["iterations_sampled"] = phase_n
+    sw.close()
+    capi.rccl_comm_destroy(comm)
+    win.reset()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -255,10 +362,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config", type=int, default=0,
                     help="BASELINE.json configuration 1..5 (1 = tracker frame -> --mode edge; 3 = the headline window = default)")
-    ap.add_argument("--lm-variant", choices=["classic", "candidate"], default="classic",
-                    help="classic: linearize, solve, error pass at the candidate (SURVEY s8d's definition of an LM iteration, "
-                         "the default and the number quoted as `value`); candidate: SageLmConfig.linearize_at_candidate -- the "
-                         "candidate is evaluated by the linearize kernels, an accepted iteration has no separate error pass")
+    ap.add_argument("--lm-variant", choices=["auto", "classic", "candidate"], default="auto",
+                    help="classic: linearize, solve, error pass at the candidate (SURVEY s8d's definition of an LM iteration; "
+                         "what `value` is quoted on at --gpus 1); candidate: SageLmConfig.linearize_at_candidate -- the "
+                         "candidate is evaluated by the linearize kernels, an accepted iteration has no separate error pass; "
+                         "auto (default) = the engine's own choice: classic on one rank, candidate for windows reduced over "
+                         "ranks (one collective per iteration instead of two)")
+    ap.add_argument("--emulate-shard", default="0/8", metavar="R/N",
+                    help="single-GPU runs also measure rank R of an N-rank job on this one device (shard_emulation key of the "
+                         "line: one-rank RCCL communicator, the peers' share from a table); 'off' skips it")
     ap.add_argument("--mode", choices=["window", "edge"], default="window",
                     help="edge: latency of the drop-in per-edge operator API and of a full tracker frame (config 1)")
     args = ap.parse_args()
@@ -365,7 +477,9 @@ def main():
     packed = win.packed_tensor()
     errt = win.error_tensor()
     cfg = capi.lm_config_default()
-    cfg.linearize_at_candidate = 1 if args.lm_variant == "candidate" else 0
+    cfg.linearize_at_candidate = {"auto": 0, "classic": -1, "candidate": 1}[args.lm_variant]
+    classic_seq = args.lm_variant == "classic" or (args.lm_variant == "auto" and world == 1 and
+                                                   os.environ.get("SAGE_BENCH_FORCE_DIST") != "1")
     damp = float(cfg.init_damp)
 
     # totals over the whole job (all ranks): every link has 2 photometric + 2 geometric directed edges
@@ -538,7 +652,7 @@ def main():
             phase_ms = {k: v / phase_n for k, v in phase.items()}
             phase_ms["host_idle"] = max(0.0, ms_instr - sum(phase_ms.values()))
             phase_ms["iterations_sampled"] = phase_n
-            phase_ms["ms_per_step_instrumented"] = ms_instr  # the pass the marks were taken in (after the timed region)
+            phase_ms["ms_per_step_instrumented"] = ms_instr  # the pass the marks were taken in (BEFORE the warm-up and the timed region)
         out = {
             "metric": f"M residuals/sec (+ LM iters/sec), {args.keyframes}-keyframe feature-metric BA @{args.height}x{args.width}",
             "value": residuals_per_step * args.steps / elapsed / 1e6,
@@ -546,6 +660,8 @@ def main():
             "lm_iters_per_sec": args.steps / elapsed,
             "accepted_iters_per_sec": n_acc / elapsed,
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            # untimed steps this process ran before the W warm-up steps (instrumented pass: kernel events + phase marks)
+            "pre_timed_steps": RESTART + n_instr,
             "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -557,7 +673,7 @@ def main():
                        "collective": collective,
                        **({"per_rank_kernel_ms": per_rank_ms} if per_rank_ms else {}),
                        "lm": ("1 linearize + 1 solve (device scatter/retract, host block Cholesky) + 1 error pass per step"
-                              if args.lm_variant == "classic" else
+                              if classic_seq else
                               "linearize-at-candidate: per evaluation 1 solve + 1 linearize at the candidate (error and "
                               "system from one pass); no separate error pass; +1 linearize after every restart"),
                        "accepted_steps": n_acc,
@@ -579,6 +695,12 @@ def main():
         }
         if phase_ms:
             out["phase_ms"] = phase_ms
+        if world == 1 and args.emulate_shard != "off" and len(win_h.links) >= 8:
+            er, ew = (int(v) for v in args.emulate_shard.split("/"))
+            try:
+                out["shard_emulation"] = shard_emulation(capi, torch, win, win_h, er, ew, args.steps, RESTART, ms_per_step)
+            except Exception as exc:            # the headline line must not depend on the emulation
+                out["shard_emulation"] = {"error": repr(exc)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(win_h)
         os.write(json_fd, (json.dumps(out) + "\n").encode())

@@ -225,13 +225,16 @@ typedef struct SageLmConfig
   int max_inner_evals;       /* window LM only: cap on candidate evaluations per iteration (0 = reference policy: retry until accepted or max_damp) */
   float no_overlap_error;    /* tracker LM: > 0 -> stop with SAGE_E_NO_OVERLAP once the error at the current estimate is >= this
                               * (TrackFrame without the match-geometry term: 9.9 * sum(photo weights), camera_tracker.cpp:1515); 0 = off */
-  int linearize_at_candidate;/* window LM only (sage_window_lm_step), default 0.  1: the candidate is evaluated by the LINEARIZE
+  int linearize_at_candidate;/* window LM only (sage_window_lm_step).  1: the candidate is evaluated by the LINEARIZE
                               * kernels (error and normal equations from one pass, the system at the current estimate kept
                               * aside): an accepted iteration costs one linearize + one solve and no separate error pass, a
                               * rejected one costs a linearize instead of an error pass.  Same accept / reject rule and the
-                              * same iterates as the default sequence (the two kernels' errors agree to fp32 rounding).
+                              * same iterates as the classic sequence (the two kernels' errors agree to fp32 rounding).
                               * sage_window_get_edge then returns the per-edge results of the LAST evaluation (the
-                              * candidate's after a rejected one); the packed system is always the current estimate's. */
+                              * candidate's after a rejected one); the packed system is always the current estimate's.
+                              * 0 (default) = automatic: this sequence for windows that are reduced over ranks (one
+                              * collective per iteration instead of two and no error pass on the shard's critical path),
+                              * the classic sequence on a single rank.  -1: the classic sequence always. */
 } SageLmConfig;
 void sage_lm_config_default(SageLmConfig *cfg);
 
@@ -567,6 +570,11 @@ int sage_block_solve_domains(const double *packed_host, int K, int nlinks, const
  *   sage_window_use_rccl(win, comm)     -> the window's two all-reduces per LM iteration become
  *        ncclAllReduce(buf, buf, n, ncclDouble, ncclSum, comm, <the window's stream>)   -- no Python, no torch in the loop.
  * `comm` may equally be an ncclComm_t the host application already owns.  SAGE_E_UNSUPPORTED when no librccl is found. */
+/* Development aid (bench.py --emulate-shard; csrc/window_dist.hip): adds the share of ranks that are not there after every
+ * all-reduce of the window -- rest_dev = n_iterates packed systems (sage_window_packed_count doubles each, device memory,
+ * kept alive by the caller), entry i evaluated at the i-th LM iterate since sage_window_reset.  One rank of an N-rank
+ * job then walks the job's real trajectory on a one-GPU box with a one-rank communicator. */
+int sage_window_emulate_peers(SageWindow *w, const double *rest_dev, int n_iterates);
 #define SAGE_RCCL_ID_BYTES 128
 int sage_rccl_unique_id(unsigned char *id128);
 int sage_rccl_comm_create(const unsigned char *id128, int rank, int world, void **comm_out);
@@ -584,6 +592,10 @@ int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmConfig *cfg)
 /* n iterations of sage_window_lm_step in one call; trace (optional): n x {error, candidate_error, accepted, damp after the
  * step}; *done (optional) = iterations completed (an error code ends the run early). */
 int sage_window_lm_run(SageWindow *w, SageLmState *st, const SageLmConfig *cfg, int n, double *trace, int *done);
+/* the same + step_seconds[n]: host wall time of every iteration (entry of the call / return of the previous iteration ->
+ * this iteration's accept / reject decision) */
+int sage_window_lm_run_timed(SageWindow *w, SageLmState *st, const SageLmConfig *cfg, int n, double *trace, int *done,
+                             double *step_seconds);
 /* Sharded windows with the domain-decomposed solve (sage_shard_*: chosen at sage_window_finalize for world > 1 when
  * SAGE_SHARD_SCHUR=1, or by default from K >= 256 keyframes): sage_window_lm_step all-reduces the separator system
  * instead of the packed normal equations, and a rank only updates the keyframes its own links touch.  Call this (a

@@ -98,7 +98,7 @@ SYMBOLS = [
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_prepare_factors", "sage_factor_psd", "sage_factor_cut_blocks", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_get_phase_time", "sage_window_lm_step", "sage_window_lm_run", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_sort_locations", "sage_bind_thread_to_device",
+    "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_prepare_factors", "sage_factor_psd", "sage_factor_cut_blocks", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_get_phase_time", "sage_window_lm_step", "sage_window_lm_run", "sage_window_lm_run_timed", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_window_emulate_peers", "sage_sort_locations", "sage_bind_thread_to_device",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
@@ -596,6 +596,18 @@ class Window:
         """native RCCL all-reduce on the window's stream (sage_window_use_rccl); comm from rccl_comm_create()."""
         _chk(lib().sage_window_use_rccl(self.h, C.c_void_p(comm)), "sage_window_use_rccl")
 
+    def emulate_peers(self, rest):
+        """``sage_window_emulate_peers``: rest = [n_iterates, packed_count] float64 cuda tensor (kept alive here), the
+        packed systems of the ranks that are not there at the LM iterates since reset; None switches it off."""
+        if rest is None:
+            self._emu_rest = None
+            _chk(lib().sage_window_emulate_peers(self.h, None, 0), "sage_window_emulate_peers")
+            return
+        assert rest.is_cuda and rest.dim() == 2 and rest.shape[1] == self.packed_count and rest.is_contiguous()
+        self._emu_rest = rest
+        _chk(lib().sage_window_emulate_peers(self.h, C.c_void_p(rest.data_ptr()), int(rest.shape[0])),
+             "sage_window_emulate_peers")
+
     def lm_step(self, state: SageLmState, cfg: SageLmConfig):
         _chk(lib().sage_window_lm_step(self.h, C.byref(state), C.byref(cfg)), "sage_window_lm_step")
         return state
@@ -607,6 +619,14 @@ class Window:
         _chk(lib().sage_window_lm_run(self.h, C.byref(state), C.byref(cfg), n, tr.ctypes.data_as(C.POINTER(C.c_double)),
                                       C.byref(done)), "sage_window_lm_run")
         return tr[:done.value]
+
+    def lm_run_timed(self, state: SageLmState, cfg: SageLmConfig, n: int):
+        """lm_run + the host wall time of every iteration in seconds -> ([n, 4] trace, [n] seconds)."""
+        tr = np.zeros((n, 4), np.float64); sec = np.zeros(n, np.float64)
+        done = C.c_int()
+        _chk(lib().sage_window_lm_run_timed(self.h, C.byref(state), C.byref(cfg), n, tr.ctypes.data_as(C.POINTER(C.c_double)),
+                                            C.byref(done), sec.ctypes.data_as(C.POINTER(C.c_double))), "sage_window_lm_run_timed")
+        return tr[:done.value], sec[:done.value]
 
     def delta(self):
         d = np.zeros(self.K * self.B, np.float64)

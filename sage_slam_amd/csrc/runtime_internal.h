@@ -199,6 +199,7 @@ struct AssembleParams
   double *tail_mirror; // pinned host copy of the 4-double tail (single-rank windows), or null
   int K, nlinks, CS, n_edges_p, n_edges_g;
   int split;               // > 1: every output block is shared by `split` consecutive workgroups (small workgroups)
+  const int32_t *blocks;   // optional: the output blocks to assemble (ids 0..K-1 keyframes, K..K+nlinks-1 links, K+nlinks tail)
 };
 
 struct ErrorTotalsSide
@@ -246,7 +247,13 @@ struct SageWindow
   SageShardPlan *shard = nullptr;
   DevBuf sepbuf;                        // device copy of the separator buffer (what the collective sums)
   std::vector<double> h_sep;
-  double *h_err = nullptr;              // pinned [16]: {linearize tail[4], error pass totals[4], tickets of the totals[4]} written by the kernels
+  double *h_err = nullptr;              // pinned [16]: {linearize tail[4], error pass totals[4], tickets of error_totals_kernel[4],
+                                        // tickets of mirror_totals_kernel[4]} written by the kernels
+  uint64_t mirror_epoch = 0;            // ticket value of the last mirror_totals_kernel (its own slots: h_err[12..15])
+  // development aid (sage_window_emulate_peers): after every all-reduce the contribution of the ranks that are not there
+  // is added from a caller-provided table of packed systems (one per LM iterate since the last reset)
+  const double *emu_rest = nullptr;
+  int emu_n = 0, emu_cur = 0;           // emu_cur: index of the current iterate (reset -> 0, accept -> +1)
   uint64_t err_epoch = 0;               // ticket value of the last error pass (a host thread can spin on the mirror
                                         // instead of synchronising the stream: window_spin_totals)
   DevBuf pk;                            // engine-internal channel-group pyramids [K][3 (f,gx,gy)][FS/4][P][4]
@@ -271,7 +278,14 @@ struct SageWindow
   bool spec_err_valid = false;
   bool packed_reduced = false; // sharded windows: `packed` has been summed over the ranks since it was last assembled
   double spec_error = 0.0;                // total error at that linearisation point (priors included)
-  DevBuf packed_save;                     // the current system while the candidate's is being formed in `packed`
+  DevBuf packed_save;                     // linearize-at-candidate: the candidate's (reduced) system is formed here; an accepted
+                                          // candidate swaps it with `packed` (which always is the current estimate's system)
+  DevBuf packed_loc;                      // reduced windows: this rank's un-reduced share (only the blocks its edges touch are
+                                          // ever written, the rest stays zero), the send buffer of the out-of-place all-reduce
+  DevBuf asm_blocks;                      // ids of those blocks (keyframes, links, tail) for the assembly of packed_loc
+  int n_asm_blocks = 0;
+  // optional out-of-place form of the all-reduce hook (native RCCL: send != recv); without it: copy + in-place hook
+  int (*allreduce2)(const double *send, double *recv, size_t n, void *user) = nullptr;
   // f2: per-Values factor cache (sage_window_prepass): host copies of every local edge's results and the values
   // (all K keyframes) they were evaluated at
   struct FactorCache
@@ -285,12 +299,14 @@ struct SageWindow
     int psd_mode = -1;
   } fc;
   // optional kernel timing (HIP events on `stream`)
-  // phase marks of an LM iteration on the stream's timeline (profiling only): 0 start of the linearize, 1 system
+  // phase marks of an LM iteration on the stream's timeline (profiling only): 0 start of the iteration, 1 system
   // assembled, 2 all-reduce of the system enqueued / done, 3 candidate written (scatter + host factorisation + retract),
-  // 4 error pass done
+  // 4 error pass done.  An iteration is the list of marks in the order they were recorded (the classic sequence and the
+  // linearize-at-candidate one order them differently, a rejected evaluation repeats some): the time between two
+  // consecutive marks is booked to the phase the LATER mark closes
   struct PhaseMarks
   {
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    std::vector<std::pair<int, hipEvent_t>> ev; // (mark, event) in the order they were recorded
   };
   std::vector<PhaseMarks> phase_pending;
   PhaseMarks phase_cur;
@@ -317,6 +333,6 @@ static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t s)
   return 0;
 }
 int window_upload_vars(SageWindow *w, int set);
-int window_linearize_set(SageWindow *w, int set);
+int window_linearize_set(SageWindow *w, int set, double *dst = nullptr, bool local_blocks = false);
 int window_sync_candidate(SageWindow *w, bool stream_idle = false);
 void window_phase_mark(SageWindow *w, int which); // profiling: record phase mark `which` on the window's stream

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
   const int Dp = 13 + p.CS, Dg = 14 + 2 * p.CS;
   const int split = p.split > 1 ? p.split : 1;
   const int part = (int)blockIdx.x % split, bslot = (int)blockIdx.x / split;
-  const int blk = bslot;
+  const int blk = p.blocks ? p.blocks[bslot] : bslot;
   const int tstride = (int)blockDim.x * split, tfirst = part * (int)blockDim.x + (int)threadIdx.x; // element striding
   double *diag = p.packed;
   double *lnk = diag + (size_t)p.K * BB;
@@ -259,19 +259,32 @@ __global__ void copy_floats_kernel(const float *__restrict__ src, float *__restr
     dst[i] = src[i];
 }
 
-// sharded windows: the reduced totals (tail of the packed buffer, error buffer) -> pinned host mirror
-// (one wave; the four tickets behind the values, like error_totals_kernel: the host spins on them)
+// the (reduced) totals -- tail of the packed buffer, error buffer (may be null) -> pinned host mirror.  One wave; the values,
+// a workgroup barrier, then one system-scope release and the four tickets in the kernel's OWN slots (mirror[12..15];
+// error_totals_kernel owns mirror[8..11]): the host spins on them instead of synchronising the stream
 __global__ void mirror_totals_kernel(const double *__restrict__ tail, const double *__restrict__ err,
                                      double *__restrict__ mirror, double epoch)
 {
   const int t = threadIdx.x;
   if (t < 4)
     mirror[t] = tail[t];
-  else if (t < 8)
+  else if (t < 8 && err)
     mirror[t] = err[t - 4];
-  __threadfence_system();
-  if (t < 4)
-    *reinterpret_cast<volatile double *>(mirror + 8 + t) = epoch;
+  __syncthreads();
+  if (t == 0)
+  {
+    __threadfence_system();
+    for (int i = 0; i < 4; ++i)
+      *reinterpret_cast<volatile double *>(mirror + 12 + i) = epoch;
+  }
+}
+
+// dst += src (peer emulation: the contribution of the ranks that are not there)
+__global__ void add_doubles_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t n)
+{
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    dst[i] += src[i];
 }
 
 } // namespace sage
@@ -312,23 +325,30 @@ void window_phase_mark(SageWindow *w, int which)
 {
   if (!w->profiling || w->prof_level == 2)
     return;
-  if (which == 0) // a new iteration: the previous one's marks are complete (or abandoned)
+  if (which == 0) // a new iteration: the previous one's marks are complete
   {
-    bool complete = true;
-    for (hipEvent_t e : w->phase_cur.ev)
-      complete = complete && e != nullptr;
-    if (complete)
-      w->phase_pending.push_back(w->phase_cur);
+    if (w->phase_cur.ev.size() >= 2)
+    {
+      if (w->phase_pending.size() >= 1024) // nobody collects them: keep the newest
+      {
+        for (auto &m : w->phase_pending.front().ev)
+          ev_put(w, m.second);
+        w->phase_pending.erase(w->phase_pending.begin());
+      }
+      w->phase_pending.push_back(std::move(w->phase_cur));
+    }
     else
-      for (hipEvent_t e : w->phase_cur.ev)
-        ev_put(w, e);
+      for (auto &m : w->phase_cur.ev)
+        ev_put(w, m.second);
     w->phase_cur = SageWindow::PhaseMarks{};
   }
+  else if (w->phase_cur.ev.empty())
+    return; // (a mark outside an iteration: sage_window_solve / _error called on their own)
   hipEvent_t e;
-  if (w->phase_cur.ev[which] || !ev_get(w, &e))
+  if (w->phase_cur.ev.size() >= 64 || !ev_get(w, &e))
     return;
   (void)hipEventRecord(e, w->stream);
-  w->phase_cur.ev[which] = e;
+  w->phase_cur.ev.emplace_back(which, e);
 }
 
 extern "C" int sage_window_get_phase_time(SageWindow *w, double *ms4, int *iterations)
@@ -337,20 +357,31 @@ extern "C" int sage_window_get_phase_time(SageWindow *w, double *ms4, int *itera
     return SAGE_E_INVALID;
   SAGE_HIP(hipStreamSynchronize(w->stream));
   window_phase_mark(w, 0); // flush the iteration in progress
+  for (auto &m : w->phase_cur.ev) // (the mark the flush just recorded opens nothing)
+    ev_put(w, m.second);
+  w->phase_cur = SageWindow::PhaseMarks{};
   for (auto &pm : w->phase_pending)
   {
-    float d[4] = {0, 0, 0, 0};
+    // the time between two consecutive marks belongs to the phase the later one closes (1 linearize, 2 all-reduce,
+    // 3 solve, 4 error pass); every evaluation of an iteration counts
+    double d4[4] = {0, 0, 0, 0};
     bool ok = true;
-    for (int i = 0; i < 4; ++i)
-      ok = ok && hipEventElapsedTime(&d[i], pm.ev[i], pm.ev[i + 1]) == hipSuccess;
+    for (size_t i = 1; i < pm.ev.size() && ok; ++i)
+    {
+      float d = 0.f;
+      ok = hipEventElapsedTime(&d, pm.ev[i - 1].second, pm.ev[i].second) == hipSuccess;
+      const int ph = pm.ev[i].first;
+      if (ok && ph >= 1 && ph <= 4)
+        d4[ph - 1] += d;
+    }
     if (ok)
     {
       for (int i = 0; i < 4; ++i)
-        w->phase_ms[i] += d[i];
+        w->phase_ms[i] += d4[i];
       w->phase_n += 1;
     }
-    for (hipEvent_t e : pm.ev)
-      ev_put(w, e);
+    for (auto &m : pm.ev)
+      ev_put(w, m.second);
   }
   w->phase_pending.clear();
   for (int i = 0; i < 4; ++i)
@@ -456,7 +487,7 @@ extern "C" void sage_window_destroy(SageWindow *w)
 {
   if (!w)
     return;
-  DevBuf *bufs[] = {&w->packed_save, &w->rec_first_p, &w->rec_count_p, &w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
+  DevBuf *bufs[] = {&w->packed_save, &w->packed_loc, &w->asm_blocks, &w->rec_first_p, &w->rec_count_p, &w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
                     &w->pk, &w->f0s, &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
                     &w->work_g, &w->first_g, &w->tiles_g, &w->part_p, &w->part_g, &w->AtA_p, &w->Atb_p,
                     &w->stats_p, &w->AtA_g, &w->Atb_g, &w->stats_g, &w->adj_start, &w->adj, &w->link_edges,
@@ -470,12 +501,10 @@ extern "C" void sage_window_destroy(SageWindow *w)
   if (w->h_err)
     (void)hipHostFree(w->h_err);
   for (auto &pm : w->phase_pending)
-    for (hipEvent_t e : pm.ev)
-      if (e)
-        (void)hipEventDestroy(e);
-  for (hipEvent_t e : w->phase_cur.ev)
-    if (e)
-      (void)hipEventDestroy(e);
+    for (auto &m : pm.ev)
+      (void)hipEventDestroy(m.second);
+  for (auto &m : w->phase_cur.ev)
+    (void)hipEventDestroy(m.second);
   for (auto &pend : w->pending)
     for (auto &pr : pend)
     {
@@ -756,7 +785,9 @@ extern "C" int sage_window_finalize(SageWindow *w)
     long long total = 0;
     for (int n : Nedge)
       total += (n + kTile - 1) / kTile;
-    int tpb = total >= 8192 ? 16 : (total >= 2048 ? 8 : (total >= 512 ? 4 : 2));
+    // (r05, one rank's shard of the K = 64 window at world 8 = 2.9 k sub-tiles: runs of 8 leave 362 workgroups for 256 CUs --
+    //  85 us; runs of 4: 74 us, 2: 77 us; the full window's 23 k sub-tiles keep runs of 16)
+    int tpb = total >= 8192 ? 16 : (total >= 4096 ? 8 : (total >= 512 ? 4 : 2));
     if (const char *e = getenv("SAGE_GEO_TPB"))
       tpb = std::max(1, atoi(e));
     wl.build(Nedge, tpb);
@@ -842,6 +873,21 @@ extern "C" int sage_window_finalize(SageWindow *w)
   SAGE_HIP(hipStreamSynchronize(w->stream));
   if ((rc = w->packed.reserve(sage_window_packed_count(w) * sizeof(double))) || (rc = w->errbuf.reserve(4 * sizeof(double))))
     return rc;
+  {
+    // the output blocks this rank's edges contribute to (everything, on a single-rank window)
+    std::vector<int32_t> ids;
+    for (int k = 0; k < K; ++k)
+      if (!adjv[k].empty())
+        ids.push_back(k);
+    for (size_t l = 0; l < le.size(); ++l)
+      if (le[l].e_ab >= 0)
+        ids.push_back(K + (int32_t)l);
+    ids.push_back(K + (int32_t)w->links.size()); // the tail
+    w->n_asm_blocks = (int)ids.size();
+    if ((rc = upload(w->asm_blocks, ids, w->stream)))
+      return rc;
+    SAGE_HIP(hipStreamSynchronize(w->stream));
+  }
   SAGE_HIP(hipMemsetAsync(w->packed.p, 0, sage_window_packed_count(w) * sizeof(double), w->stream));
   SAGE_HIP(hipMemsetAsync(w->errbuf.p, 0, 4 * sizeof(double), w->stream));
   if (!w->h_err)
@@ -919,18 +965,21 @@ static AssembleParams window_assemble_params(SageWindow *w)
   ap.adj = w->adj.as<AdjEntry>();
   ap.links = w->link_edges.as<LinkEdges>();
   ap.packed = w->packed.as<double>();
-  ap.tail_mirror = w->world == 1 ? w->h_err : nullptr;
+  ap.tail_mirror = w->world == 1 && !w->allreduce ? w->h_err : nullptr; // (a reduced tail is mirrored after the sum)
   ap.K = w->K;
   ap.nlinks = (int)w->links.size();
   ap.CS = c.CS;
   ap.n_edges_p = w->n_edges;
   ap.n_edges_g = w->n_edges;
   ap.split = 1;
+  ap.blocks = nullptr;
   return ap;
 }
 
 // linearize every local edge at variable set `set` (0 = current estimate, 1 = candidate) and assemble the packed system
-int window_linearize_set(SageWindow *w, int set)
+// dst: where the packed system is assembled (default: w->packed); local_blocks: only the blocks this rank's edges touch
+// (dst then must hold zeros everywhere else: packed_loc)
+int window_linearize_set(SageWindow *w, int set, double *dst, bool local_blocks)
 {
   if (!w || !w->finalized)
     return SAGE_E_STATE;
@@ -940,7 +989,6 @@ int window_linearize_set(SageWindow *w, int set)
   {
     // depth maps of every keyframe at the current variables: both factor types read their sample depths from them
     // (an accepted candidate's maps from the error pass are still valid: only the gradients are missing then)
-    window_phase_mark(w, 0);
     const bool have_depth = w->dpt_set == set;
     SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[set].as<DepthItem>(), w->n_depth, H, W, !have_depth,
                                 !(have_depth && w->dgrad_valid)));
@@ -985,10 +1033,18 @@ int window_linearize_set(SageWindow *w, int set)
     SAGE_HIP(hipGetLastError());
   }
   AssembleParams ap = window_assemble_params(w);
+  if (dst)
+    ap.packed = dst;
   // four workgroups of 512 threads per output block: one element per thread (the kernel is a chain of dependent
   // gathers per element -- 17 us; one 1024-thread workgroup per block with two elements per thread took 27 us)
   ap.split = 4;
-  hipLaunchKernelGGL(assemble_kernel, dim3((w->K + ap.nlinks + 1) * ap.split), dim3(512), 0, w->stream, ap);
+  int nblocks = w->K + ap.nlinks + 1;
+  if (local_blocks && w->n_asm_blocks > 0)
+  {
+    ap.blocks = w->asm_blocks.as<int32_t>();
+    nblocks = w->n_asm_blocks;
+  }
+  hipLaunchKernelGGL(assemble_kernel, dim3(nblocks * ap.split), dim3(512), 0, w->stream, ap);
   SAGE_HIP(hipGetLastError());
   window_phase_mark(w, 1);
   w->have_lin = true;
@@ -998,7 +1054,12 @@ int window_linearize_set(SageWindow *w, int set)
   return SAGE_OK;
 }
 
-extern "C" int sage_window_linearize(SageWindow *w) { return window_linearize_set(w, 0); }
+extern "C" int sage_window_linearize(SageWindow *w)
+{
+  if (w)
+    window_phase_mark(w, 0); // a caller driving the iteration call by call: it starts here
+  return window_linearize_set(w, 0);
+}
 
 extern "C" int sage_window_error(SageWindow *w, int which)
 {
@@ -1046,7 +1107,7 @@ extern "C" int sage_window_error(SageWindow *w, int which)
   }
   w->err_epoch += 1;
   hipLaunchKernelGGL(error_totals_kernel, dim3(1), dim3(1024), 0, w->stream, ph, ge, w->errbuf.as<double>(),
-                     w->world == 1 && w->h_err ? w->h_err + 4 : nullptr, (double)w->err_epoch);
+                     w->world == 1 && !w->allreduce && w->h_err ? w->h_err + 4 : nullptr, (double)w->err_epoch);
   SAGE_HIP(hipGetLastError());
   window_phase_mark(w, 4);
   return SAGE_OK;
@@ -1064,11 +1125,13 @@ static int window_total_error(SageWindow *w, int from_linearize, double *err, bo
 // synchronises the stream as before).
 static bool window_spin_totals(SageWindow *w, bool reduced_mirror = false)
 {
-  // (reduced_mirror: a sharded window whose reduced totals have just been mirrored by mirror_totals_kernel)
-  if ((w->world != 1 && !reduced_mirror) || !w->h_err || w->err_epoch == 0)
+  // (reduced_mirror: the totals have just been mirrored by mirror_totals_kernel -- its own tickets and epoch)
+  if (!w->h_err)
     return false;
-  const volatile double *t = w->h_err + 8;
-  const double want = (double)w->err_epoch;
+  if (!reduced_mirror && (w->world != 1 || w->allreduce || w->err_epoch == 0))
+    return false;
+  const volatile double *t = w->h_err + (reduced_mirror ? 12 : 8);
+  const double want = (double)(reduced_mirror ? w->mirror_epoch : w->err_epoch);
   const auto t0 = std::chrono::steady_clock::now();
   unsigned spins = 0;
   while (!(t[0] == want && t[1] == want && t[2] == want && t[3] == want))
@@ -1080,6 +1143,58 @@ static bool window_spin_totals(SageWindow *w, bool reduced_mirror = false)
   }
   std::atomic_thread_fence(std::memory_order_acquire);
   return true;
+}
+
+// the window's all-reduce of n doubles + (peer emulation) the absent ranks' share from table entry `iterate`
+static int window_allreduce(SageWindow *w, double *buf, size_t n, int iterate)
+{
+  if (w->allreduce && w->allreduce(buf, n, w->allreduce_user))
+    return SAGE_E_STATE;
+  if (w->emu_rest && w->emu_n > 0)
+  {
+    const size_t np = sage_window_packed_count(w);
+    const double *rest = w->emu_rest + (size_t)(((iterate % w->emu_n) + w->emu_n) % w->emu_n) * np;
+    if (n == np)
+      hipLaunchKernelGGL(add_doubles_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, w->stream, rest, buf, np);
+    else if (n == 4) // error totals of a candidate: the tail of the absent ranks' system at that iterate
+      hipLaunchKernelGGL(add_doubles_kernel, dim3(1), dim3(64), 0, w->stream, rest + np - 4, buf, (size_t)4);
+    else
+      return SAGE_E_UNSUPPORTED;
+    SAGE_HIP(hipGetLastError());
+  }
+  return SAGE_OK;
+}
+
+// out of place: recv = sum over the ranks of send (n = the packed system).  Native RCCL reduces send -> recv directly; a
+// plain in-place hook gets a device copy first
+__global__ void copy_doubles_kernel(const double *__restrict__ src, double *__restrict__ dst, size_t n);
+static int window_allreduce_into(SageWindow *w, const double *send, double *recv, size_t n, int iterate)
+{
+  if (w->allreduce2)
+  {
+    if (w->allreduce2(send, recv, n, w->allreduce_user))
+      return SAGE_E_STATE;
+    SageAllReduceFn keep = w->allreduce;
+    w->allreduce = nullptr; // (the sum is done: window_allreduce below only adds the emulated peers' share)
+    const int rc = window_allreduce(w, recv, n, iterate);
+    w->allreduce = keep;
+    return rc;
+  }
+  hipLaunchKernelGGL(copy_doubles_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, w->stream, send, recv, n);
+  SAGE_HIP(hipGetLastError());
+  return window_allreduce(w, recv, n, iterate);
+}
+
+// enqueue the mirror of the (reduced) totals and their tickets
+static int window_mirror_totals(SageWindow *w, bool with_err, const double *system = nullptr)
+{
+  w->mirror_epoch += 1;
+  hipLaunchKernelGGL(mirror_totals_kernel, dim3(1), dim3(64), 0, w->stream,
+                     (system ? system : w->packed.as<double>()) + sage_window_packed_count(w) - 4,
+                     with_err ? w->errbuf.as<double>() : nullptr,
+                     w->h_err, (double)w->mirror_epoch);
+  SAGE_HIP(hipGetLastError());
+  return SAGE_OK;
 }
 
 int window_sync_candidate(SageWindow *w, bool stream_idle)
@@ -1304,6 +1419,7 @@ extern "C" int sage_window_accept(SageWindow *w)
   w->code[0] = w->code[1];
   w->scale[0] = w->scale[1];
   ++w->vars_epoch;
+  ++w->emu_cur;
   w->dpt_set = w->dpt_set == 1 ? 0 : -1; // depth maps evaluated at the candidate now belong to the current set
   // (a kernel, not hipMemcpyAsync: a device-to-device copy of 11 KB costs ~10 us of API time on the step's critical path)
   const int nv = w->K * w->VS;
@@ -1328,6 +1444,7 @@ extern "C" int sage_window_reset(SageWindow *w)
   if ((rc = window_upload_vars(w, 0)) || (rc = window_upload_vars(w, 1)))
     return rc;
   w->have_lin = false;
+  w->emu_cur = 0;
   return SAGE_OK;
 }
 
@@ -1552,81 +1669,89 @@ __global__ void copy_doubles_kernel(const double *__restrict__ src, double *__re
 
 // SageLmConfig::linearize_at_candidate: one LM iteration in which the candidate is evaluated by the linearize kernels.
 // `packed` holds the system at the current estimate (kept from the previous accepted iteration); per evaluation: damped
-// solve -> candidate; the current system is set aside (device copy, 3 MB); linearize at the candidate (its finalize
-// kernels deliver the error); accepted: the candidate's system IS the next iteration's, nothing is re-evaluated;
-// rejected: the saved system comes back and the damping goes up.  Decisions, damping schedule and iterates are those of
+// solve -> candidate; linearize at the candidate into a second buffer (its finalize kernels deliver the error); accepted:
+// the two buffers swap -- the candidate's system IS the next iteration's, nothing is re-evaluated or copied; rejected:
+// `packed` never left and the damping goes up.  Decisions, damping schedule and iterates are those of
 // the default sequence; sage_window_get_edge afterwards returns the per-edge results of the LAST evaluation.
 static int lm_step_at_candidate(SageWindow *w, SageLmState *st, const SageLmConfig *cfg, bool sharded)
 {
   int rc;
   auto clampd = [&](double d) { return std::min(std::max((double)cfg->min_damp, d), (double)cfg->max_damp); };
   const size_t np = sage_window_packed_count(w);
-  auto reduce_packed = [&]() -> int {
-    if (sharded && w->allreduce(w->packed.as<double>(), np, w->allreduce_user))
-      return SAGE_E_STATE;
-    w->packed_reduced = true;
-    return SAGE_OK;
+  if ((rc = w->packed_save.reserve(np * sizeof(double))))
+    return rc;
+  if (sharded && !w->packed_loc.p)
+  {
+    if ((rc = w->packed_loc.reserve(np * sizeof(double))))
+      return rc;
+    SAGE_HIP(hipMemsetAsync(w->packed_loc.p, 0, np * sizeof(double), w->stream)); // blocks of other ranks: zero for good
+  }
+  // one evaluation: linearize at variable set `set`, the (reduced) system into `dst`, its totals into the pinned mirror with
+  // their tickets -- the host never blocks in a stream synchronise on the iteration's critical path.  A reduced window
+  // assembles only the blocks its own edges touch (into packed_loc) and sums out of place into dst; the emulated peers'
+  // share of iterate `it` is added behind the sum.
+  auto evaluate = [&](int set, double *dst, int it) -> int {
+    int r;
+    if (!sharded)
+      return (r = window_linearize_set(w, set, dst)) ? r : window_mirror_totals(w, false, dst);
+    if ((r = window_linearize_set(w, set, w->packed_loc.as<double>(), true)) ||
+        (r = window_allreduce_into(w, w->packed_loc.as<double>(), dst, np, it)))
+      return r;
+    window_phase_mark(w, 2);
+    return window_mirror_totals(w, false, dst);
   };
   // the system at the current estimate is reused only if it is the GLOBAL one: sage_window_linearize / _prepass leave a
   // rank-local `packed` behind on a sharded window (every rank sees the same flags: same call sequence on all ranks)
+  bool mirrored_now = false;
   if (!(w->have_lin && w->lin_epoch == w->vars_epoch && (!sharded || w->packed_reduced)))
   {
-    if ((rc = window_linearize_set(w, 0)) || (rc = reduce_packed()))
+    if ((rc = evaluate(0, w->packed.as<double>(), w->emu_cur)))
       return rc;
+    w->packed_reduced = true;
+    w->spec_err_valid = false;
+    mirrored_now = true;
   }
   if (!w->spec_err_valid)
   {
-    if (sharded)
-    { // (the single-rank mirror h_err is not maintained for reduced totals: read the tail of the reduced buffer)
-      double t[4];
-      SAGE_HIP(hipMemcpyAsync(t, w->packed.as<double>() + np - 4, sizeof(t), hipMemcpyDeviceToHost, w->stream));
-      SAGE_HIP(hipStreamSynchronize(w->stream));
-      w->spec_error = t[0] + t[1] + prior_error(w, 0);
-    }
-    else if ((rc = sage_window_total_error(w, 1, &w->spec_error)))
+    // the totals at the current estimate: mirrored by the evaluation above -- or the system was left by
+    // sage_window_linearize (unsharded: mirror its tail now)
+    if (!mirrored_now && (rc = window_mirror_totals(w, false)))
       return rc;
+    if (!window_spin_totals(w, true))
+      SAGE_HIP(hipStreamSynchronize(w->stream));
+    w->spec_error = w->h_err[0] + w->h_err[1] + prior_error(w, 0);
     w->spec_err_valid = true;
   }
   st->error = w->spec_error;
-  if ((rc = w->packed_save.reserve(np * sizeof(double))))
-    return rc;
   int evals = 0;
   st->accepted = 0;
-  const bool mirror = !sharded && w->h_err != nullptr; // single-rank windows: totals mirrored into pinned host memory
   for (;;)
   {
     rc = sage_window_solve(w, st->damp, nullptr);
     bool not_psd = rc == SAGE_E_NOT_PSD;
     if (rc && !not_psd)
       return rc;
-    bool replaced = false;
     double cur_tot[4] = {0, 0, 0, 0};
     st->candidate_error = INFINITY;
     if (!not_psd)
     {
       const uint64_t lin_epoch = w->lin_epoch;
-      if (mirror)
-        std::memcpy(cur_tot, w->h_err, sizeof(cur_tot)); // (the stream drained at the end of the previous evaluation)
-      hipLaunchKernelGGL(copy_doubles_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, w->stream,
-                         w->packed.as<double>(), w->packed_save.as<double>(), np);
-      SAGE_HIP(hipGetLastError());
-      if ((rc = window_linearize_set(w, 1)) || (rc = reduce_packed()))
+      const bool was_reduced = w->packed_reduced;
+      std::memcpy(cur_tot, w->h_err, sizeof(cur_tot)); // (mirrored and seen at the end of the previous evaluation)
+      if ((rc = evaluate(1, w->packed_save.as<double>(), w->emu_cur + 1)))
         return rc;
-      replaced = true;
-      w->lin_epoch = lin_epoch; // (not the current variables' system unless accepted below)
+      w->lin_epoch = lin_epoch; // (`packed` still is the current estimate's system; the candidate's sits in packed_save)
+      w->packed_reduced = was_reduced;
       w->spec_err_valid = true; // spec_error still is the error at the current estimate
-      double t[4];
-      if (!mirror)
-        SAGE_HIP(hipMemcpyAsync(t, w->packed.as<double>() + np - 4, sizeof(t), hipMemcpyDeviceToHost, w->stream));
-      rc = window_sync_candidate(w); // a non-positive pivot of the factorisation shows up here
+      const bool idle = window_spin_totals(w, true);
+      rc = window_sync_candidate(w, idle); // a non-positive pivot of the factorisation shows up here
       if (rc && rc != SAGE_E_NOT_PSD)
         return rc;
       not_psd = rc == SAGE_E_NOT_PSD;
-      SAGE_HIP(hipStreamSynchronize(w->stream));
-      if (mirror)
-        std::memcpy(t, w->h_err, sizeof(t));
+      if (!idle)
+        SAGE_HIP(hipStreamSynchronize(w->stream));
       if (!not_psd)
-        st->candidate_error = t[0] + t[1] + prior_error(w, 1);
+        st->candidate_error = w->h_err[0] + w->h_err[1] + prior_error(w, 1);
     }
     ++evals;
     if (st->candidate_error < st->error)
@@ -1634,20 +1759,16 @@ static int lm_step_at_candidate(SageWindow *w, SageLmState *st, const SageLmConf
       st->accepted = 1;
       if ((rc = sage_window_accept(w)))
         return rc;
-      w->lin_epoch = w->vars_epoch; // `packed` is the system at the (new) current estimate
+      std::swap(w->packed.p, w->packed_save.p); // the candidate's system IS the next iteration's
+      std::swap(w->packed.cap, w->packed_save.cap);
+      w->lin_epoch = w->vars_epoch;
+      w->packed_reduced = true; // (summed over the ranks by evaluate(), or nothing to sum)
       w->spec_error = st->candidate_error;
       st->damp = clampd(st->damp / cfg->damp_dec_factor);
       break;
     }
-    if (replaced)
-    {
-      // rejected: the system at the current estimate comes back
-      hipLaunchKernelGGL(copy_doubles_kernel, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, w->stream,
-                         w->packed_save.as<double>(), w->packed.as<double>(), np);
-      SAGE_HIP(hipGetLastError());
-      if (mirror)
-        std::memcpy(w->h_err, cur_tot, sizeof(cur_tot));
-    }
+    // rejected: `packed` never left; the mirror goes back to the current estimate's totals
+    std::memcpy(w->h_err, cur_tot, sizeof(cur_tot));
     const bool give_up = st->damp >= cfg->max_damp || (cfg->max_inner_evals > 0 && evals >= cfg->max_inner_evals);
     st->damp = clampd(st->damp * cfg->damp_inc_factor);
     if (give_up)
@@ -1669,14 +1790,18 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
     st->damp = cfg->init_damp;
   auto clampd = [&](double d) { return std::min(std::max((double)cfg->min_damp, d), (double)cfg->max_damp); };
   const bool schur = sharded && w->shard != nullptr;
+  window_phase_mark(w, 0);
   // (rank-independent decision: the window's link count, not this rank's share of it -- a rank without links must
-  //  issue the same collectives as the others)
-  if (cfg->linearize_at_candidate && !schur && !w->links.empty())
+  //  issue the same collectives as the others).  linearize_at_candidate 0 = automatic: the sequence with one collective
+  //  and no separate error pass per iteration whenever the window is reduced over ranks (the shard's kernels are short
+  //  there, the second collective and its host round trip are not), the classic sequence on a single rank
+  const bool at_candidate = cfg->linearize_at_candidate > 0 || (cfg->linearize_at_candidate == 0 && sharded);
+  if (at_candidate && !schur && !w->links.empty())
     return lm_step_at_candidate(w, st, cfg, sharded);
-  if ((rc = sage_window_linearize(w)))
+  if ((rc = window_linearize_set(w, 0)))
     return rc;
-  if (sharded && !schur && w->allreduce(w->packed.as<double>(), sage_window_packed_count(w), w->allreduce_user))
-    return SAGE_E_STATE;
+  if (sharded && !schur && (rc = window_allreduce(w, w->packed.as<double>(), sage_window_packed_count(w), w->emu_cur)))
+    return rc;
   window_phase_mark(w, 2);
   int evals = 0;
   st->accepted = 0;
@@ -1743,11 +1868,8 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
       return rc;
     if (sharded)
     {
-      if (w->allreduce(w->errbuf.as<double>(), 4, w->allreduce_user))
-        return SAGE_E_STATE;
-      hipLaunchKernelGGL(mirror_totals_kernel, dim3(1), dim3(64), 0, w->stream,
-                         w->packed.as<double>() + sage_window_packed_count(w) - 4, w->errbuf.as<double>(), w->h_err,
-                         (double)w->err_epoch);
+      if ((rc = window_allreduce(w, w->errbuf.as<double>(), 4, w->emu_cur + 1)) || (rc = window_mirror_totals(w, true)))
+        return rc;
       // (the host spins on the mirror's tickets instead of blocking in a stream synchronise: with the kernels of a shard
       //  8x shorter, the 20-30 us wake-up of a blocked thread would be 4 % of an iteration)
       const bool idle = window_spin_totals(w, true);
@@ -1801,11 +1923,13 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
 // n LM iterations in one call (the loop a C++ caller writes around sage_window_lm_step; bench.py uses it so that no Python
 // runs between the iterations it times).  trace (optional): n x {error, candidate_error, accepted, damp after the step}.
 // Stops early on an error code; *done (optional) = iterations completed.
-extern "C" int sage_window_lm_run(SageWindow *w, SageLmState *st, const SageLmConfig *cfg, int n, double *trace, int *done)
+static int window_lm_run(SageWindow *w, SageLmState *st, const SageLmConfig *cfg, int n, double *trace, int *done,
+                         double *step_seconds)
 {
   if (!w || !st || !cfg || n < 0)
     return SAGE_E_INVALID;
   int i = 0, rc = SAGE_OK;
+  auto t_prev = std::chrono::steady_clock::now();
   for (; i < n; ++i)
   {
     if ((rc = sage_window_lm_step(w, st, cfg)))
@@ -1817,8 +1941,27 @@ extern "C" int sage_window_lm_run(SageWindow *w, SageLmState *st, const SageLmCo
       trace[4 * i + 2] = (double)st->accepted;
       trace[4 * i + 3] = st->damp;
     }
+    if (step_seconds)
+    {
+      const auto t = std::chrono::steady_clock::now();
+      step_seconds[i] = std::chrono::duration<double>(t - t_prev).count();
+      t_prev = t;
+    }
   }
   if (done)
     *done = i;
   return rc;
+}
+
+extern "C" int sage_window_lm_run(SageWindow *w, SageLmState *st, const SageLmConfig *cfg, int n, double *trace, int *done)
+{
+  return window_lm_run(w, st, cfg, n, trace, done, nullptr);
+}
+
+// the same with the host wall time of every iteration (step_seconds[n]: from the return of the previous iteration -- the
+// call's entry for the first -- to this one's; an iteration returns once its accept / reject decision is taken)
+extern "C" int sage_window_lm_run_timed(SageWindow *w, SageLmState *st, const SageLmConfig *cfg, int n, double *trace,
+                                        int *done, double *step_seconds)
+{
+  return window_lm_run(w, st, cfg, n, trace, done, step_seconds);
 }

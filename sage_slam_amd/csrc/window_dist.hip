@@ -123,6 +123,7 @@ extern "C" int sage_window_set_allreduce(SageWindow *w, SageAllReduceFn fn, void
   if (!w)
     return SAGE_E_INVALID;
   w->allreduce = fn;
+  w->allreduce2 = nullptr;
   w->allreduce_user = user;
   return SAGE_OK;
 }
@@ -187,6 +188,17 @@ int rccl_allreduce_cb(double *buf, size_t n, void *user)
   }
   return 0;
 }
+int rccl_allreduce2_cb(const double *send, double *recv, size_t n, void *user)
+{
+  RcclHook *h = static_cast<RcclHook *>(user);
+  const ncclResult_t r = rccl().AllReduce(send, recv, n, ncclDouble, ncclSum, h->comm, h->stream);
+  if (r != ncclSuccess)
+  {
+    fprintf(stderr, "[sage] ncclAllReduce: %s\n", rccl().GetErrorString ? rccl().GetErrorString(r) : "error");
+    return 1;
+  }
+  return 0;
+}
 } // namespace
 
 extern "C" int sage_rccl_unique_id(unsigned char *id128)
@@ -242,7 +254,23 @@ extern "C" int sage_window_use_rccl(SageWindow *w, void *nccl_comm)
   h->stream = w->stream;
   w->rccl_hook = h;
   w->allreduce = rccl_allreduce_cb;
+  w->allreduce2 = rccl_allreduce2_cb;
   w->allreduce_user = h;
+  return SAGE_OK;
+}
+
+// Development aid for boxes with fewer GPUs than ranks (bench.py --emulate-shard): the share of the ranks that are not
+// there.  rest_dev: n_iterates consecutive buffers of sage_window_packed_count doubles, entry i = the packed systems of all
+// OTHER ranks summed, evaluated at the i-th LM iterate since sage_window_reset; after every all-reduce of the window (the
+// real collective still runs: a one-rank communicator costs its launch, not its transfer) the entry of the iterate being
+// reduced is added on the window's stream.  nullptr switches it off.  The caller keeps the table alive.
+extern "C" int sage_window_emulate_peers(SageWindow *w, const double *rest_dev, int n_iterates)
+{
+  if (!w || (rest_dev && n_iterates < 1))
+    return SAGE_E_INVALID;
+  w->emu_rest = rest_dev;
+  w->emu_n = rest_dev ? n_iterates : 0;
+  w->emu_cur = 0;
   return SAGE_OK;
 }
 

@@ -8,7 +8,10 @@ ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name
 starts = [i for i, e in enumerate(ev) if marker in e[2]]
 if len(starts) < 8:
     sys.exit("not enough marker kernels")
-i0, i1 = starts[-6], starts[-4]          # one full step well inside steady state
+if marker == "depth_batch":
+    i0, i1 = starts[-6], starts[-4]      # one full step well inside steady state
+else:
+    i0, i1 = starts[-2], starts[-1]      # the last full span between two marker launches
 t0 = ev[i0][0]
 prev_end = t0
 for s, e, n in ev[i0:i1]:

@@ -34,11 +34,12 @@ def test_rccl_single_rank_lm_matches_plain_window():
     assert comm
     w = synth.make_window(K=6, H=48, W=64, FS=16, CS=32, L=3, n_samples=1500, seed=9)
 
-    def run(use_rccl):
+    def run(use_rccl, variant=-1):
         win = capi.Window(w)
         if use_rccl:
             win.use_rccl(comm)
         cfg = capi.lm_config_default(); cfg.max_inner_evals = 1
+        cfg.linearize_at_candidate = variant       # -1 classic, 0 automatic (reduced windows: linearize-at-candidate)
         st = capi.SageLmState()
         tr = []
         for _ in range(4):
@@ -54,6 +55,10 @@ def test_rccl_single_rank_lm_matches_plain_window():
     assert np.array_equal(t0[:, 2], t1[:, 2]) and t0[0, 2] == 1
     np.testing.assert_allclose(t1[:, :2], t0[:, :2], rtol=1e-12)        # sum over one rank = identity
     assert np.array_equal(p1, p0) and np.array_equal(d1, d0)
+    # automatic sequence of a reduced window (one collective per iteration): same decisions, errors to fp32 rounding
+    t2, _, _ = run(True, 0)
+    assert np.array_equal(t0[:, 2], t2[:, 2])
+    np.testing.assert_allclose(t2[:, :2], t0[:, :2], rtol=2e-6)
     # the raw collective on a device buffer of doubles
     import ctypes as C
     x = torch.arange(1000, dtype=torch.float64, device="cuda")
@@ -132,7 +137,7 @@ def test_rccl_multi_rank_lm_matches_single_rank(tmp_path, schur):
     ref = capi.Window(w)
     single = _trace(ref, capi, 4)
     assert np.array_equal(single[:, 2], tr[0][:, 2]) and tr[0][0, 2] == 1
-    np.testing.assert_allclose(tr[0][:, :2], single[:, :2], rtol=1e-6)
+    np.testing.assert_allclose(tr[0][:, :2], single[:, :2], rtol=2e-6)
     v_ref = _all_vars(ref, len(w.keyframes))
     for r in range(world):
         v = np.load(tmp_path / f"v_{int(schur)}_{r}.npy")

@@ -21,7 +21,7 @@ def _make():
 def _run(win, capi, steps, at_candidate=False):
     cfg = capi.lm_config_default()
     cfg.max_inner_evals = 1
-    cfg.linearize_at_candidate = 1 if at_candidate else 0
+    cfg.linearize_at_candidate = {True: 1, False: -1, None: 0}[at_candidate]   # None: the engine's automatic choice
     st = capi.SageLmState()
     trace = []
     for _ in range(steps):
@@ -53,6 +53,9 @@ def _worker(rank, world, port, out_dir):
     # the linearize-at-candidate variant through the same hook (reduced candidate systems, restored on a rejection)
     win.reset()
     np.save(os.path.join(out_dir, f"trace_c_{rank}.npy"), _run(win, capi, 6, at_candidate=True))
+    # automatic (linearize_at_candidate = 0): a reduced window takes the one-collective sequence by itself
+    win.reset()
+    np.save(os.path.join(out_dir, f"trace_a_{rank}.npy"), _run(win, capi, 6, at_candidate=None))
     dist.destroy_process_group()
 
 
@@ -76,6 +79,8 @@ def test_sharded_lm_step_matches_single_rank(tmp_path):
     fin = np.isfinite(single6[:, 1])
     np.testing.assert_allclose(c0[:, 0], single6[:, 0], rtol=2e-6)
     np.testing.assert_allclose(c0[fin, 1], single6[fin, 1], rtol=2e-6)
+    a0, a1 = (np.load(tmp_path / f"trace_a_{r}.npy") for r in range(world))
+    assert np.array_equal(a0, a1) and np.array_equal(a0, c0)      # automatic == forced, on every rank
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -12,7 +12,8 @@ import numpy as np
 import pytest
 
 from sage_slam_amd import synth
-from tests.helpers import presample_source, rel
+from tests.helpers import rel
+from tests.tracker_scene import HostScene
 
 pytestmark = pytest.mark.gpu
 
@@ -26,36 +27,14 @@ def capi():
     return c
 
 
-class Scene:
-    """frame 0 (tracked) -> frame 1 (reference keyframe) of a synthetic window, plus NK matched keypoints"""
+class Scene(HostScene):
+    """the host scene + its device buffers and the product-side problem description"""
 
-    def __init__(self, capi, orc, seed=31, NK=160, kp_noise_px=0.4, kp_noise_depth=0.002):
+    def __init__(self, capi, orc, **kw):
         import torch
-        self.capi, self.orc = capi, orc
-        w = synth.make_window(K=2, H=64, W=80, FS=16, CS=32, L=4, n_samples=3072, seed=seed, pose_noise=0.0)
-        self.w = w
-        a, b = w.keyframes[0], w.keyframes[1]
-        self.a, self.b = a, b
-        self.feat0s = presample_source(orc, w, a)
-        self.unscaled = (a.bias + a.basis @ a.code_true)[a.loc1d].astype(np.float32)       # dpt_map_0 / dpt_scale_0
-        self.s_true = np.float32(a.scale_true)
-        self.R10, self.t10 = synth.relative_pose(a.R_true, a.t_true, b.R_true, b.t_true)
-        rng = np.random.default_rng(seed + 1)
-        cam = w.cams[0]
-        xs = rng.integers(10, w.W - 10, NK); ys = rng.integers(10, w.H - 10, NK)
-        loc = ys * w.W + xs
-        self.kp_homo0 = np.stack([(xs - cam.cx) / cam.fx, (ys - cam.cy) / cam.fy, np.ones(NK)], 1).astype(np.float32)
-        self.kp_unscaled = (a.bias + a.basis @ a.code_true)[loc].astype(np.float32)
-        X1 = (self.R10.astype(np.float64) @ (float(self.s_true) * self.kp_unscaled[:, None] * self.kp_homo0).T).T + self.t10
-        self.kp_matched_2d = (np.stack([X1[:, 0] / X1[:, 2] * cam.fx + cam.cx, X1[:, 1] / X1[:, 2] * cam.fy + cam.cy], 1)
-                              + rng.normal(0, kp_noise_px, (NK, 2))).astype(np.float32)
-        self.kp_dpts1 = (X1[:, 2] + rng.normal(0, kp_noise_depth, NK)).astype(np.float32)
-        self.kp_homo1 = np.stack([X1[:, 0] / X1[:, 2] + rng.normal(0, kp_noise_px / cam.fx, NK),
-                                  X1[:, 1] / X1[:, 2] + rng.normal(0, kp_noise_px / cam.fy, NK), np.ones(NK)], 1).astype(np.float32)
-        self.NK = NK
-        self.reproj_loss_param = 1e-4 * w.W * w.W           # reproj_loss_param_factor * width^2 (camera_tracker.cpp:1076)
-        self.mg_loss_param = 0.1 * float(np.mean(a.bias ** 2))
-        self.reproj_weight, self.mg_weight = 0.05, 3.0
+        super().__init__(orc, **kw)
+        self.capi = capi
+        w, a, b = self.w, self.a, self.b
         # device side
         self.ws = capi.Workspace()
         self.pyr = capi.make_pyramid(w.cams[0], w.L)
@@ -82,58 +61,6 @@ class Scene:
         p.kp_loss_param = self.reproj_loss_param if dof == 6 else self.mg_loss_param
         p.kp_weight = self.reproj_weight if dof == 6 else self.mg_weight
         return p
-
-    def oracle_callbacks(self, dof, use_photo, use_kp):
-        """ComputeJacobianAndError / ComputeError restated over the oracle kernels: fp32 sums term by term"""
-        orc, w, a, b = self.orc, self.w, self.a, self.b
-        cam = w.cams[0]
-        F = np.float32
-
-        def depths(s):
-            if dof == 7:
-                return F(s) * self.unscaled, F(s) * self.kp_unscaled
-            return self.s_true * self.unscaled, self.s_true * self.kp_unscaled
-
-        def lin(p, s):
-            R, t = p[:9].reshape(3, 3), p[9:]
-            dp, kdp = depths(s)
-            A = np.zeros((dof, dof), F); g = np.zeros(dof, F); e = F(0)
-            if use_photo:
-                o = orc.tracker_photo_jac_error(dof, R, t, w.mask, dp, a.homo, self.feat0s, b.feat_pyr, b.grad_pyr,
-                                                w.level_offsets, w.cams, w.eps, w.photo_weights, scale0=s)
-                A = A + o["AtA"].astype(F); g = g + o["Atb"].astype(F); e = F(e + F(o["error"]))
-            if use_kp and dof == 6:
-                o = orc.tracker_reproj_jac_error(R, t, kdp, self.kp_homo0, self.kp_matched_2d, cam, w.eps,
-                                                 self.reproj_loss_param, self.reproj_weight)
-                A = A + o["AtA"].astype(F); g = g + o["Atb"].astype(F); e = F(e + F(o["error"]))
-            if use_kp and dof == 7:
-                o = orc.match_geom_jac_error(3, "fair", R, t, dpts0=kdp, dpts1=self.kp_dpts1, homo0=self.kp_homo0,
-                                             homo1=self.kp_homo1, scale0=s, loss_param=self.mg_loss_param,
-                                             weight=self.mg_weight)
-                A = A + o["AtA"].astype(F); g = g + o["Atb"].astype(F); e = F(e + F(o["error"]))
-            return A, g, float(e)
-
-        def err(p, s):
-            R, t = p[:9].reshape(3, 3), p[9:]
-            dp, kdp = depths(s)
-            e = F(0)
-            if use_photo:
-                e = F(e + F(orc.tracker_photo_error(R, t, w.mask, dp, a.homo, self.feat0s, b.feat_pyr, w.level_offsets,
-                                                    w.cams, w.eps, w.photo_weights)[0]))
-            if use_kp and dof == 6:
-                e = F(e + F(orc.tracker_reproj_error(R, t, kdp, self.kp_homo0, self.kp_matched_2d, cam, w.eps,
-                                                     self.reproj_loss_param, self.reproj_weight)[0]))
-            if use_kp and dof == 7:
-                e = F(e + F(orc.match_geom_error(2, "fair", R, t, dpts0=kdp, dpts1=self.kp_dpts1, homo0=self.kp_homo0,
-                                                 homo1=self.kp_homo1, loss_param=self.mg_loss_param,
-                                                 weight=self.mg_weight)))
-            return float(e)
-
-        return lin, err
-
-    def start_pose(self):
-        return self.capi.pack_pose(synth.so3_exp(np.array([0.004, -0.003, 0.002])) @ self.R10,
-                                   self.t10 + np.array([0.004, -0.003, 0.002], np.float32))
 
     def close(self):
         self.ws.close()
@@ -220,3 +147,39 @@ def test_track_frame_rejects_bad_problems(capi, scene):
     assert rc == -1                                                                     # "at least one factor should be enabled"
     rc = capi.track_frame(cfg, 5, scene.problem(6, True, False), scene.start_pose(), 1.0)[0]
     assert rc == -1
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# a8, independent oracle: sage_track_frame -- the product's policy over the HIP kernels -- against
+# the committed traces of oracle/track_lm.py (a restatement of camera_tracker.cpp's loop that shares no code with
+# sage_track_lm) over the C oracle's kernels: tests/golden/lm_trace_*.json, tests/golden/make_lm_trace_golden.py
+# ---------------------------------------------------------------------------------------------------------------------
+import glob
+import json
+import os
+
+_GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "lm_trace_*.json")))
+
+
+@pytest.mark.parametrize("path", _GOLDEN, ids=[os.path.basename(p)[9:-5] for p in _GOLDEN])
+def test_track_frame_matches_golden_lm_trace(capi, scene, path):
+    rec = json.load(open(path))
+    cfg = capi.lm_config_default()
+    for k, v in rec["config"].items():
+        setattr(cfg, k, v)
+    p0 = np.array(rec["start_pose"], np.float32)
+    rc, ph, sh, eh, ith, trh = capi.track_frame(cfg, rec["dof"], scene.problem(rec["dof"], rec["use_photo"], rec["use_keypoints"]),
+                                                p0, rec["start_scale"])
+    if rec["status"] == "no_overlap":
+        assert rc == -5 and ith == 0 and np.array_equal(ph, p0)
+        return
+    assert rc == 0 and ith == rec["iters"] and len(trh) == len(rec["trace"])
+    for g, w in zip(trh, rec["trace"]):
+        assert np.float32(g["damp"]) == np.float32(w["damp"])                        # the damping sequence, exactly
+        assert g["accepted"] == w["accepted"] and g["relinearized"] == w["relinearized"]
+        assert g["error"] == pytest.approx(w["error"], rel=2e-4)                     # HIP kernels vs the fp32 oracle's
+        assert g["candidate_error"] == pytest.approx(w["candidate_error"], rel=2e-4)
+    assert eh == pytest.approx(rec["final_error"], rel=1e-3)
+    assert rel(ph, np.array(rec["final_pose"], np.float32)) < 1e-4
+    if rec["dof"] == 7:
+        assert sh == pytest.approx(rec["final_scale"], rel=1e-4)
