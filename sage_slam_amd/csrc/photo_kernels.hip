@@ -67,6 +67,22 @@ __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
 #ifndef SAGE_PHOTO_LIN_GUNROLL
 #define SAGE_PHOTO_LIN_GUNROLL 8
 #endif
+// scripts/isa_census.py compiles this file with -DSAGE_PHASE_MARKERS: comment lines in the generated code that name the
+// phase which follows (a scheduling barrier on both sides keeps the instructions of a phase between its markers)
+#ifdef SAGE_PHASE_MARKERS
+#define SAGE_PHASE(name)                                 \
+  do                                                     \
+  {                                                      \
+    __builtin_amdgcn_sched_barrier(0);                   \
+    asm volatile("; SAGE_PHASE " name ::: "memory");     \
+    __builtin_amdgcn_sched_barrier(0);                   \
+  } while (0)
+#else
+#define SAGE_PHASE(name) \
+  do                     \
+  {                      \
+  } while (0)
+#endif
 
 // per-pixel hand-over from the sampling phase (lane = pixel) to the contraction phase (lane = (channel i, pixel k)):
 //   [0..7] rows of the cross tile: c(6) = S(0:6,6), sigma*d, u6      [8] sigma = S66     [9] loc*CS*4 (int bits)
@@ -315,6 +331,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     for (int t = NT + 1 - kPhotoL2Tiles; t < NT + 1; ++t)
       acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
+  SAGE_PHASE("A_warp");
   const int tile = wi.tile + sub;
   const int n = tile * kTile + tid;
   bool in_range = n < N;
@@ -400,18 +417,19 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   // the level's weight and its fx_l / fy_l scaling (h = (fx_l gx, fy_l gy)) applied once to the six sums of a step
   auto fold_step = [&](int l, const f32x2 &q00, const f32x2 &q01, const f32x2 &q11, const f32x2 &qa0, const f32x2 &qa1,
                        const f32x2 &qee) {
-    const float wl = prm.w[l];
+    // engine layout: the packed pyramids (and the pre-sampled source features) carry sqrt(w_l) and the gradient pyramids
+    // the level's focal lengths, h = sqrt(w_l) (fx_l d/dx, fy_l d/dy): every product is weighted already
+    const float wl = PACKED ? 1.0f : prm.w[l];
     err += wl * (qee[0] + qee[1]);
     if (JAC)
     {
       if (PACKED)
       {
-        // engine layout: the gradient pyramids hold h = (fx_l d/dx, fy_l d/dy) already (scaled once per keyframe)
-        G00 += wl * (q00[0] + q00[1]);
-        G01 += wl * (q01[0] + q01[1]);
-        G11 += wl * (q11[0] + q11[1]);
-        v0 += wl * (qa0[0] + qa0[1]);
-        v1 += wl * (qa1[0] + qa1[1]);
+        G00 += q00[0] + q00[1];
+        G01 += q01[0] + q01[1];
+        G11 += q11[0] + q11[1];
+        v0 += qa0[0] + qa0[1];
+        v1 += qa1[0] + qa1[1];
       }
       else
       {
@@ -426,6 +444,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     }
   };
   bool slice_live = true; // linearize, engine layout: false when no pixel of this wave's slice is an inlier
+  SAGE_PHASE("B_setup");
   if (PACKED)
   {
     // wave priority: a wave in its sampling phase goes ahead of the waves of its SIMD that are in their VALU / MFMA
@@ -570,6 +589,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
         dma16<3u * kStageCap0 * 16u + kStageCapC * 16u>(r_f1, lds0, voC, soff + pyr_bytes);
         dma16<3u * kStageCap0 * 16u + 2u * kStageCapC * 16u>(r_f1, lds0, voC, soff + 2u * pyr_bytes);
       };
+      SAGE_PHASE("B_taps");
       lgkm_wait0(); // the stash reads of the previous sub-tile's contraction are done before the region is rewritten
       // the source quads of a channel group live in a ring of four registers quads: quad l is reloaded with the next
       // group's level l right after its use, a full group (~4 level steps) before it is needed
@@ -591,11 +611,12 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
         t1[1] = lds_read16(a2 + 16u);     tx[1] = lds_read16(a2 + 16u + AS);
         t1[2] = lds_read16(a2);           tx[2] = lds_read16(a2 + AS);
         t1[3] = lds_read16(a0 + 16u);     tx[3] = lds_read16(a0 + 16u + AS);
-        f32x4 f1 = {0.f, 0.f, 0.f, 0.f}, gx = f1, gy = f1;
+        // nd = sum_k w_k t_k - f0 (the residual's subtraction rides in the interpolation chain: r = -nd)
+        f32x4 nd = -f0v, gx = {0.f, 0.f, 0.f, 0.f}, gy = gx;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
         {
-          f1 += tw[l][k] * t1[k];
+          nd += tw[l][k] * t1[k];
           gx += tw[l][k] * tx[k];
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -606,24 +627,21 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           gy += tw[l][k] * ty[k];
-        const f32x4 d4 = f0v - f1;
-        const f32x2 dl = {d4[0], d4[1]}, dh = {d4[2], d4[3]};
+        const f32x2 dl = {nd[0], nd[1]}, dh = {nd[2], nd[3]};
         const f32x2 xl = {gx[0], gx[1]}, xh = {gx[2], gx[3]}, yl = {gy[0], gy[1]}, yh = {gy[2], gy[3]};
-        f32x2 q00 = xl * xl, q01 = xl * yl, q11 = yl * yl, qa0 = xl * dl, qa1 = yl * dl, qee = dl * dl;
-        q00 += xh * xh;
-        q01 += xh * yh;
-        q11 += yh * yh;
-        qa0 += xh * dh;
-        qa1 += yh * dh;
-        qee += dh * dh;
-        // the level's weight, once per step and sum (the focal scalings h = (fx_l d/dx, fy_l d/dy) are in the pyramids)
-        const float wl = prm.w[l];
-        P00 += wl * q00;
-        P01 += wl * q01;
-        P11 += wl * q11;
-        Pv0 += wl * qa0;
-        Pv1 += wl * qa1;
-        Pee += wl * qee;
+        // the texels carry sqrt(w_l): the six sums take their weighted products directly (one v_pk_fma_f32 each)
+        P00 += xl * xl;
+        P00 += xh * xh;
+        P01 += xl * yl;
+        P01 += xh * yh;
+        P11 += yl * yl;
+        P11 += yh * yh;
+        Pv0 -= xl * dl;
+        Pv0 -= xh * dh;
+        Pv1 -= yl * dl;
+        Pv1 -= yh * dh;
+        Pee += dl * dl;
+        Pee += dh * dh;
       };
       // Straight-line over the channel groups (static wait counts, and no control-flow merge while a register is still in
       // flight: the compiler may place a register copy at a merge, ahead of the wait -- scripts/check_asm_loads.py walks
@@ -687,6 +705,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       v0 = Pv0[0] + Pv0[1];
       v1 = Pv1[0] + Pv1[1];
       err = Pee[0] + Pee[1];
+      SAGE_PHASE("B_end");
       }
       else
       {
@@ -729,16 +748,16 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
           {
             const uint32_t o = (uint32_t)j * kErrStageGroupBytes;
             const f32x4 t0 = lds_read16(a0 + o), t1 = lds_read16(a2 + 16u + o), t2 = lds_read16(a2 + o), t3 = lds_read16(a0 + 16u + o);
-            f32x4 f1 = tw[l][0] * t0;
-            f1 += tw[l][1] * t1;
-            f1 += tw[l][2] * t2;
-            f1 += tw[l][3] * t3;
-            const f32x4 d4 = f0v[l][j] - f1;
-            const f32x2 dl = {d4[0], d4[1]}, dh = {d4[2], d4[3]};
+            f32x4 nd = -f0v[l][j];
+            nd += tw[l][0] * t0;
+            nd += tw[l][1] * t1;
+            nd += tw[l][2] * t2;
+            nd += tw[l][3] * t3;
+            const f32x2 dl = {nd[0], nd[1]}, dh = {nd[2], nd[3]};
             qee += dl * dl;
             qee += dh * dh;
           }
-          Pee += prm.w[l] * qee;
+          Pee += qee; // (the texels carry sqrt(w_l))
         }
       }
       err = Pee[0] + Pee[1];
@@ -748,6 +767,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     {
       // ================= texture-path sampler: (level, channel group) steps, the 13 dwordx4 loads of a step issued
       // together, then reduced =================
+      SAGE_PHASE("B_texture_path");
       const f32x4 *f0s = reinterpret_cast<const f32x4 *>(E.f0s) + (in_range ? n : 0);
       for (int l = 0; l < nlev; ++l)
       {
@@ -864,6 +884,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     continue;
 
   // ---- per-pixel 7x7 reduced system ----
+  SAGE_PHASE("C_rows");
   __builtin_amdgcn_s_setprio(0);
   if (slice_live)
   {
@@ -949,6 +970,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
 
   // ---- MFMA contractions over this wave's 64 pixels, 4 pixels (K) per instruction; basis rows streamed from
   //      global memory in operand layout, AHEAD groups in flight ----
+  SAGE_PHASE("D_contract");
   {
 #if SAGE_PHOTO_ALT_ACC
     // extra accumulator sets of the three noise-critical tiles (live in this phase only): pixel group g goes to set g mod
@@ -959,6 +981,8 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       accb[u][0] = accb[u][1] = accb[u][2] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
     const int i = lane & 15, k = lane >> 4;
+    // rows 8..15 of the cross operand are zero: those lanes read slot 38 of the pixel's stash row (written as 0.f)
+    const int ai_slot = i < 8 ? i : 38;
     const uint32_t lane_off = (uint32_t)i * (NB == 2 ? 8u : 4u);
 #ifndef SAGE_PHOTO_AHEAD
 #define SAGE_PHOTO_AHEAD 6
@@ -969,7 +993,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
 #define SAGE_PHOTO_READ_STASH(g)                                                        \
   {                                                                                     \
     const float *p_ = st_w + ((g) * 4 + k) * kPhotoStashLD;                             \
-    ai[g] = p_[i & 7];                                                                  \
+    ai[g] = p_[ai_slot];                                                                \
     const f32x2 sl_ = *reinterpret_cast<const f32x2 *>(p_ + 8); /* sigma, loc */        \
     sg[g] = sl_[0];                                                                     \
     locp[g] = __float_as_int(sl_[1]);                                                   \
@@ -1000,7 +1024,6 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
 #pragma unroll
     for (int g = 0; g < AHEAD; ++g)
       SAGE_PHOTO_ISSUE(g)
-    const float asel = (i < 8) ? 1.f : 0.f; // rows 8..15 of the cross operand are zero
     SAGE_PHOTO_READ_POSE(0)
 #pragma unroll
     for (int g = 0; g < G; ++g)
@@ -1011,7 +1034,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
         SAGE_PHOTO_ISSUE(g + AHEAD)
       if (g + AHEAD + 1 < G)
         SAGE_PHOTO_READ_STASH(g + AHEAD + 1)
-      const float a = asel * ai[g];
+      const float a = ai[g];
 #if SAGE_PHOTO_ALT_ACC
       if (CS == 32 && (g % (SAGE_PHOTO_ALT_ACC + 1)) != 0)
       {
@@ -1060,6 +1083,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
 #endif
   }
   __builtin_amdgcn_wave_barrier(); // the stash is rewritten by the next sub-tile
+  SAGE_PHASE("E_second_level_flush");
   } // slice_live
   // ---- second level: the LM step's distance from the exact step is set by the fp32 accumulation chains of the two
   //      cross tiles (rows c, sigma d, u6: the code gradient and the pose-code blocks) and of the pose tile; the code-code
@@ -1176,6 +1200,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       sdd_acc = 0.f;
     }
   }
+  SAGE_PHASE("loop_end");
   } // sub-tile loop
 
   if (!JAC)

@@ -192,21 +192,25 @@ hipError_t launch_presample_source(hipStream_t s, float *f0s, const float *feat_
 
 // [C][P] channel-major -> [C/4][P][4] channel-group layout (engine-internal, once per keyframe).  axis 1 / 2: the texels of
 // pyramid level l are multiplied by fx_l / fy_l on the way -- the photometric linearize samples h = (fx_l d/dx, fy_l d/dy)
-// (photometric_factor_kernels.cpp:200-222 scales the sampled gradient by the level's focal lengths; here once per texel)
+// (photometric_factor_kernels.cpp:200-222 scales the sampled gradient by the level's focal lengths; here once per texel).
+// level_scale (optional, per level): one more factor on every texel of the level -- the window engine passes sqrt(w_l), so
+// that every product of two sampled quantities (h h^T, h r, r^2) carries the level's weight w_l (:1143-1149) by itself
 __global__ void repack_groups_kernel(float *__restrict__ dst, const float *__restrict__ src, int C, int P, int axis,
-                                     SagePyramid pyr)
+                                     SagePyramid pyr, RepackScale ls)
 {
   const int p = blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y;
   if (p >= P)
     return;
   float sc = 1.0f;
-  if (axis != 0)
+  if (axis != 0 || ls.on)
   {
     int l = 0;
     for (int i = 1; i < pyr.levels; ++i)
       l = p >= pyr.level_offsets[i] ? i : l;
-    sc = axis == 1 ? pyr.cam[l].fx : pyr.cam[l].fy;
+    sc = axis == 0 ? 1.0f : (axis == 1 ? pyr.cam[l].fx : pyr.cam[l].fy);
+    if (ls.on)
+      sc *= ls.s[l];
   }
   f32x4 v;
   v[0] = sc * src[(size_t)(4 * g + 0) * P + p];
@@ -216,12 +220,20 @@ __global__ void repack_groups_kernel(float *__restrict__ dst, const float *__res
   *reinterpret_cast<f32x4 *>(dst + ((size_t)g * P + p) * 4) = v;
 }
 
-hipError_t launch_repack_groups(hipStream_t s, float *dst, const float *src, int C, int P, int axis, const SagePyramid *pyr)
+hipError_t launch_repack_groups(hipStream_t s, float *dst, const float *src, int C, int P, int axis, const SagePyramid *pyr,
+                                const float *level_scale)
 {
   SagePyramid py{};
   if (pyr)
     py = *pyr;
-  hipLaunchKernelGGL(repack_groups_kernel, dim3((P + 255) / 256, C / 4), dim3(256), 0, s, dst, src, C, P, pyr ? axis : 0, py);
+  RepackScale ls{};
+  if (pyr && level_scale)
+  {
+    ls.on = 1;
+    for (int l = 0; l < pyr->levels; ++l)
+      ls.s[l] = level_scale[l];
+  }
+  hipLaunchKernelGGL(repack_groups_kernel, dim3((P + 255) / 256, C / 4), dim3(256), 0, s, dst, src, C, P, pyr ? axis : 0, py, ls);
   return hipGetLastError();
 }
 

@@ -178,8 +178,13 @@ struct DepthItem
 };
 hipError_t launch_presample_source(hipStream_t s, float *f0s, const float *feat_pk, const float *homo, int N, int FS,
                                    const SagePyramid &pyr);
+struct RepackScale // optional per-level factor of launch_repack_groups
+{
+  int on;
+  float s[SAGE_MAX_LEVELS];
+};
 hipError_t launch_repack_groups(hipStream_t s, float *dst, const float *src, int C, int P, int axis = 0,
-                                const SagePyramid *pyr = nullptr);
+                                const SagePyramid *pyr = nullptr, const float *level_scale = nullptr);
 // raster-order relayout of sampled locations (producers.hip)
 struct SortItem
 {
