@@ -24,6 +24,18 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
 
 
+def kernel_source_sha16() -> str:
+    """Hash of the dense factor kernels' sources: recorded next to rocprofv3 counter summaries (scripts/pmc_summary.py) and
+    compared by bench.py before it quotes committed per-launch counter constants -- instruction / byte counts belong to one
+    build of these files."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("photo_kernels.hip", "geo_kernels.hip", "sage_device.h", "sage_internal.h", "finalize_bodies.h"):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def _mtime(p):
     return os.path.getmtime(p) if os.path.exists(p) else 0.0
 

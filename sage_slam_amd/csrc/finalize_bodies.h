@@ -185,6 +185,11 @@ struct GeoFinalizeParams
   float weight;
   int edge_base; // blockIdx.x = edge - edge_base
   double *wide;  // optional [n_edges][D*D + D]: the results before rounding to fp32
+  // merged linearize (LaunchCommon::merge_geo_weight): the photometric launch's partial records of the same edges -- row 8
+  // of their cross tiles is  sum_n w_g omega kappa D b_n  (the scale1-code0 block; every other code0 block of the
+  // geometric edge rides in the photometric edge's result and reads zero here)
+  const float *photo_partials;
+  const int32_t *photo_rec_first, *photo_rec_count;
 };
 
 template <int CS>
@@ -287,6 +292,24 @@ __device__ __forceinline__ void geo_finalize_body(const GeoFinalizeParams &prm, 
         else
           mv = ki == 0 ? YT(ii, ij) : YT(ij, ii);
         val = wn * (ci * cj) * mv; // (ci*cj) first: exactly symmetric in (i, j)
+        if (prm.photo_partials && ki != kj)
+        {
+          // merged launch: (scale1, code0 channel c) = (1/n) (-1/s1) s0 * sum_n w_g omega kappa D b_n[c], summed over the
+          // photometric records of this edge in their fixed order (row 8 of the cross tile of channel c)
+          const int yrow = ki == 0 ? ii : ij, tcol = ki == 0 ? ij : ii;
+          if (yrow == 7 && tcol < CS)
+          {
+            constexpr int PF = photo_partial_floats(CS), DOFF = photo_partial_double_offset(CS);
+            const int xt = CS == 32 ? (tcol & 1) : 0, xc = CS == 32 ? (tcol >> 1) : tcol; // cross tile, column inside it
+            const int di = kPhotoScalars + xt * 256 + 32 + xc;                             // row 8 -> r = 0, 16-block 2
+            const int pf = prm.photo_rec_first[e], pn = prm.photo_rec_count[e];
+            const double *pp = reinterpret_cast<const double *>(prm.photo_partials + (size_t)pf * PF + DOFF) + di;
+            double r8 = 0.0;
+            for (int t = 0; t < pn; ++t)
+              r8 += pp[(size_t)t * (PF / 2)];
+            val = (1.0 / n_in) * (ci * cj) * r8;
+          }
+        }
       }
       else
       {

@@ -37,6 +37,9 @@ struct GeoParams
   int width, height; // cam.w / cam.h as integers: scalar (SGPR) values for the buffer descriptors
   int n_work;
 };
+// MERGE (linearize only; LaunchCommon::merge_geo_weight): the blocks that involve code0 only through t0 = kappa*b0 -- the
+// 3 t0 t0^T tiles and the 2 y t0^T tiles of 15 at CS = 32 -- are contracted by the photometric kernel of the same pair,
+// which gets {omega, D, grad D} of every pixel through GeoEdge::px_out; their accumulators stay zero here
 
 __device__ __forceinline__ int gload_loc(const void *loc, int is64, int n)
 {
@@ -91,7 +94,7 @@ __device__ __forceinline__ void geo_scalar_rc(int k, int &r, int &c)
 // with packed f32 math, and the y operand is zero-padded in the stash instead of being masked.
 constexpr int kGeoLinBlock = kBlock;
 
-template <int CS, bool JAC>
+template <int CS, bool JAC, bool MERGE = false>
 __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(const GeoParams prm)
 {
   constexpr int NW = kWaves;
@@ -116,6 +119,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
   E.basis1 = uni(E.basis1); E.mask1 = uni(E.mask1); E.homo = uni(E.homo); E.loc = uni(E.loc);
   E.R0 = uni(E.R0); E.t0 = uni(E.t0); E.R1 = uni(E.R1); E.t1 = uni(E.t1); E.R10 = uni(E.R10); E.t10 = uni(E.t10);
   E.N = uni(E.N); E.loc_is_i64 = uni(E.loc_is_i64);
+  E.px_out = uni(E.px_out);
   const int N = E.N;
   const float loss_param = E.loss_param > 0.f ? E.loss_param : prm.loss_param; // per-link parameter (mapper.cpp:369)
 
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
     const bool live = vm != 0.f;
     float y[9];
     float kappa;
+    float gD_out[2] = {0.f, 0.f};
     {
       float gD[2] = {0.f, 0.f};
       const float *gx = E.dgrad1, *gy = E.dgrad1 + (size_t)W * H;
@@ -222,12 +227,16 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
       const float qx = fx * (rh[0] * inv_z - X[0] * rh[2] * inv_z * inv_z); // :681-682
       const float qy = fy * (rh[1] * inv_z - X[1] * rh[2] * inv_z * inv_z);
       kappa = rh[2] - (gD[0] * qx + gD[1] * qy); // :684-685
+      gD_out[0] = gD[0];
+      gD_out[1] = gD[1];
       y[6] = kappa * d0;
       y[7] = Ds;
       y[8] = rho;
     }
     // sqrt_cauchy_weight = m / sqrt(rho^2 + c)  (:690);  omega = its square
     const float om = live ? (m * m) / (rho * rho + loss_param) : 0.f;
+    if (MERGE && in_range)
+      reinterpret_cast<f32x4 *>(E.px_out)[n] = f32x4{om, Ds, gD_out[0], gD_out[1]};
     if (!live)
     {
 #pragma unroll
@@ -350,12 +359,18 @@ __global__ __launch_bounds__(kBlock, JAC ? SAGE_GEO_WAVES : 4) void geo_kernel(c
 #pragma unroll
           for (int bj = bi; bj < N16; ++bj)
           {
+            if (MERGE && bj < NB)
+              continue; // t0 t0^T: in the photometric kernel's code-code tiles
             const int t = bi * N16 - (bi * (bi - 1)) / 2 + (bj - bi);
             acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bop[g & 1][bi], bop[g & 1][bj], acc[t], 0, 0, 0);
           }
 #pragma unroll
         for (int bj = 0; bj < N16; ++bj)
+        {
+          if (MERGE && bj < NB)
+            continue; // y t0^T: in the photometric kernel's cross tiles
           acc[NTT + bj] = __builtin_amdgcn_mfma_f32_16x16x4f32(ygv[g & 1], bop[g & 1][bj], acc[NTT + bj], 0, 0, 0);
+        }
         acc[NT] = __builtin_amdgcn_mfma_f32_16x16x4f32(ygv[g & 1], ygv[g & 1], acc[NT], 0, 0, 0);
       }
     }
@@ -457,7 +472,10 @@ static hipError_t geo_lin_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   {
     if (lc.ev_start)
       (void)hipEventRecord(lc.ev_start, s);
-    hipLaunchKernelGGL((geo_kernel<CS, true>), dim3(lc.n_work), dim3(kGeoLinBlock), 0, s, p);
+    if (lc.merge_geo_weight > 0.f)
+      hipLaunchKernelGGL((geo_kernel<CS, true, true>), dim3(lc.n_work), dim3(kGeoLinBlock), 0, s, p);
+    else
+      hipLaunchKernelGGL((geo_kernel<CS, true, false>), dim3(lc.n_work), dim3(kGeoLinBlock), 0, s, p);
     if (lc.ev_stop)
       (void)hipEventRecord(lc.ev_stop, s);
   }
@@ -475,6 +493,9 @@ static hipError_t geo_lin_impl(hipStream_t s, const GeoEdge *single, const GeoEd
   f.stats = out.stats;
   f.wide = out.wide;
   f.weight = weight;
+  f.photo_partials = lc.merge_geo_weight > 0.f ? lc.merge_photo_partials : nullptr;
+  f.photo_rec_first = lc.merge_photo_rec_first;
+  f.photo_rec_count = lc.merge_photo_rec_count;
   f.edge_base = lc.stage == 2 ? lc.edge_base : 0;
   const int n_fin = lc.stage == 2 ? lc.edge_count : lc.n_edges;
   if (n_fin > 0)

@@ -42,6 +42,7 @@ struct PhotoParams
   // flush == tiles_per_block is the plain "one record per work item"
   const int32_t *rec_first;
   int flush;
+  float merge_w; // > 0: merged linearize (LaunchCommon::merge_geo_weight) -- the geometric factor weight w_g
 };
 
 __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
@@ -217,6 +218,7 @@ struct TapBatch
 };
 
 // MODE 0: reference layout [FS][P] / [2][FS][P], dword gathers, source features sampled in-kernel (per-edge operator API)
+// MODE 2: MODE 1 + the merged linearize (the geometric edge's code0 blocks ride in this kernel's contractions; linearize only)
 // MODE 1: engine layout [FS/4][P][4] (one dwordx4 per tap and channel group, 1 KiB contiguous per wave) with the
 //         source features pre-sampled per keyframe; the (level, group) steps are software-pipelined: the 13 loads of
 //         step it+1 are in flight while step it is reduced (two register batches).
@@ -236,6 +238,7 @@ template <int CS, int FS, bool JAC, int MODE>
 __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3) : SAGE_PHOTO_WAVES) void photo_kernel(const PhotoParams prm)
 {
   constexpr bool PACKED = MODE >= 1;
+  constexpr bool MERGE = JAC && MODE == 2; // engine layout + the geometric edge's code0 blocks (LaunchCommon::merge_geo_weight)
   constexpr int NB = CS / 16;
   constexpr int NG = FS / 4;
   // channel groups of a level unrolled together (linearize: all; error pass: at most SAGE_PHOTO_ERR_GUNROLL)
@@ -263,6 +266,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   E.R0 = uni(E.R0); E.t0 = uni(E.t0); E.R1 = uni(E.R1); E.t1 = uni(E.t1); E.R10 = uni(E.R10); E.t10 = uni(E.t10);
   E.N = uni(E.N); E.loc_is_i64 = uni(E.loc_is_i64); E.f0s = uni(E.f0s);
   E.dpt1_geo = uni(E.dpt1_geo);
+  E.geo_px = uni(E.geo_px);
   const int N = E.N;
 
   // ---- poses (wave-uniform) ----
@@ -889,6 +893,10 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   if (slice_live)
   {
   const bool live = vm != 0.0f;
+  // merged linearize (LaunchCommon::merge_geo_weight): the geometric kernel's hand-over for this pixel, asked for first
+  f32x4 gp = {0.f, 0.f, 0.f, 0.f};
+  if (MERGE)
+    gp = reinterpret_cast<const f32x4 *>(E.geo_px)[in_range ? n : 0];
   const float vm2 = vm * vm; // gradient and residual both carry m (:200, :234)
   G00 *= vm2;
   G01 *= vm2;
@@ -896,6 +904,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   v0 *= vm2;
   v1 *= vm2;
   float Q[2][7];
+  float dXz[6]; // z-row of dX/dT0 (merged linearize: the geometric edge's pose row starts from it)
   {
     // world-from-keyframe poses (wave-uniform scalar loads), re-read per sub-tile behind an opaque pointer: held across the
     // sampling phase their 24 SGPRs were spilled to VGPR lanes and every use paid a v_readlane
@@ -930,6 +939,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     {
       Q[0][j] = inv_z * dX[0][j] + jx * dX[2][j];
       Q[1][j] = inv_z * dX[1][j] + jy * dX[2][j];
+      dXz[j] = dX[2][j];
     }
     Q[0][6] = rh[0] * inv_z - X[0] * rh[2] * inv_z * inv_z; // :324-325 without fx, fy
     Q[1][6] = rh[1] * inv_z - X[1] * rh[2] * inv_z * inv_z;
@@ -950,7 +960,30 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     for (int i = 0; i < 7; ++i)
       S6[i] = Q[0][i] * GQ0[6] + Q[1][i] * GQ1[6];
     u6 = Q[0][6] * v0 + Q[1][6] * v1;
-    sdd_acc += S6[6] * d * d;
+    sdd_acc += S6[6] * d * d; // (the photometric sigma only: the geometric edge keeps its own scale0-scale0 entry)
+    float row8 = 0.f;
+    if (MERGE)
+    {
+      // merged linearize: the geometric edge of the same pair (geometric_factor_kernels.cpp:671-716) at the same pixel --
+      // {omega, D, grad D} from its kernel; a = dX_z/dT0 - gradD^T Jpi dX/dT0 and kappa = r_z - gradD^T dpi/dd in terms of
+      // this kernel's own Q (Jpi's unit-focal form: P = diag(fx, fy) Q).  Its code0 column is kappa s0 b_n, so every block it
+      // enters has the form of one the photometric contraction carries -- sigma b b^T, (c, sigma d, u6) b^T: the weights are
+      // added and contracted once.  With wk = w_g omega kappa and g = (fx dD/dx, fy dD/dy):
+      //   c_r  += wk a_r = wk dXz_r - Q0r (wk g_x) - Q1r (wk g_y)     (r < 6; the same form with dXz_6 := r_z gives sigma)
+      //   u6   += wk rho,   row 8 = wk D  (the scale1-code0 block, read by the geometric finalize)
+      // omega is zero for every pixel the geometric kernel found dead (the same pixels as here: same warp, same mask)
+      const float om = in_range ? gp[0] : 0.f;
+      const float gx = gp[2] * fx0, gy = gp[3] * fy0;
+      const float kap = rh[2] - (gx * Q[0][6] + gy * Q[1][6]);
+      const float wk = (prm.merge_w * om) * kap;
+      const float wgx = wk * gx, wgy = wk * gy;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+        S6[r] += wk * dXz[r] - (Q[0][r] * wgx + Q[1][r] * wgy);
+      S6[6] += wk * kap;
+      u6 += wk * (gp[1] - X[2]);
+      row8 = wk * gp[1];
+    }
     // stash: the rows that multiply b_n (c (6), sigma*d, u6), sigma and the byte offset of the basis row, then the
     // operands of the pose tile
     f32x4 *st = reinterpret_cast<f32x4 *>(st_w + lane * kPhotoStashLD);
@@ -963,7 +996,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     st[6] = f32x4{Q[0][0], Q[0][1], Q[0][2], Q[0][3]};
     st[7] = f32x4{Q[0][4], Q[0][5], Q[1][0], Q[1][1]};
     st[8] = f32x4{Q[1][2], Q[1][3], Q[1][4], Q[1][5]};
-    st[9] = f32x4{Q[0][6] * d, Q[1][6] * d, 0.f, 0.f};
+    st[9] = f32x4{Q[0][6] * d, Q[1][6] * d, row8, 0.f};
   }
   __builtin_amdgcn_wave_barrier(); // same-wave LDS hand-over (in-order LDS pipe): no workgroup barrier needed
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -981,8 +1014,9 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       accb[u][0] = accb[u][1] = accb[u][2] = f32x4{0.f, 0.f, 0.f, 0.f};
 #endif
     const int i = lane & 15, k = lane >> 4;
-    // rows 8..15 of the cross operand are zero: those lanes read slot 38 of the pixel's stash row (written as 0.f)
-    const int ai_slot = i < 8 ? i : 38;
+    // rows 9..15 of the cross operand are zero: those lanes read slot 39 of the pixel's stash row (written as 0.f); row 8
+    // (slot 38) is the merged linearize's scale1-code0 row, zero otherwise
+    const int ai_slot = i < 8 ? i : (i == 8 ? 38 : 39);
     const uint32_t lane_off = (uint32_t)i * (NB == 2 ? 8u : 4u);
 #ifndef SAGE_PHOTO_AHEAD
 #define SAGE_PHOTO_AHEAD 6
@@ -1294,6 +1328,7 @@ static PhotoParams make_params(const PhotoEdge *single, const PhotoEdge *table, 
   p.n_work = lc.n_work;
   p.rec_first = lc.flush > 0 ? lc.edge_first : nullptr;
   p.flush = lc.flush > 0 ? lc.flush : lc.tiles_per_block;
+  p.merge_w = lc.merge_geo_weight;
   for (int l = 0; l < pyr.levels; ++l)
   {
     p.rx[l] = pyr.cam[l].fx / pyr.cam[0].fx; // same fp32 quotient the kernels used to form per pixel
@@ -1316,7 +1351,9 @@ static hipError_t photo_lin_impl(hipStream_t s, const PhotoEdge *single, const P
   {
     if (lc.ev_start)
       (void)hipEventRecord(lc.ev_start, s);
-    if (lc.packed)
+    if (lc.packed && lc.merge_geo_weight > 0.f)
+      hipLaunchKernelGGL((photo_kernel<CS, FS, true, 2>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
+    else if (lc.packed)
       hipLaunchKernelGGL((photo_kernel<CS, FS, true, 1>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
     else
       hipLaunchKernelGGL((photo_kernel<CS, FS, true, 0>), dim3(lc.n_work), dim3(kBlock), 0, s, p);

@@ -256,6 +256,8 @@ struct SageWindow
   int emu_n = 0, emu_cur = 0;           // emu_cur: index of the current iterate (reset -> 0, accept -> +1)
   uint64_t err_epoch = 0;               // ticket value of the last error pass (a host thread can spin on the mirror
                                         // instead of synchronising the stream: window_spin_totals)
+  DevBuf geo_px;                        // merged linearize: per local edge and source pixel {omega, D, dD/dx, dD/dy} (geo -> photo)
+  bool merge_ok = false;                // both factor types on, geometric weight > 0, not switched off (SAGE_NO_MERGE)
   DevBuf pk;                            // engine-internal channel-group pyramids [K][3 (f,gx,gy)][FS/4][P][4]
   DevBuf f0s;                           // per keyframe: pre-sampled source features [L][FS/4][N][4]
   DevBuf ptab[2], gtab[2];              // edge tables per variable set
@@ -333,6 +335,6 @@ static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t s)
   return 0;
 }
 int window_upload_vars(SageWindow *w, int set);
-int window_linearize_set(SageWindow *w, int set, double *dst = nullptr, bool local_blocks = false);
+int window_linearize_set(SageWindow *w, int set, double *dst = nullptr, bool local_blocks = false, bool merge = false);
 int window_sync_candidate(SageWindow *w, bool stream_idle = false);
 void window_phase_mark(SageWindow *w, int which); // profiling: record phase mark `which` on the window's stream

@@ -36,6 +36,10 @@ struct PhotoEdge
   // error (geometric_factor_kernels.cpp:127-218: same warp, same mask lookup) and no separate geometric launch runs
   const float *dpt1_geo;
   float geo_loss; // > 0: the geometric edge's own Cauchy parameter (GeoEdge::loss_param), else the launch's
+  // merged linearize (LaunchCommon::merge_geo_weight): per-pixel hand-over from the geometric kernel of the same
+  // (kf0, kf1) pair, [N][4] = {omega, D, dD/dx, dD/dy} -- the photometric kernel folds the geometric edge's code0 blocks
+  // into its own contractions (GeoEdge::px_out is the same buffer)
+  const float *geo_px;
   const float *bias0;   // [H*W]
   const float *basis0;  // [H*W,CS]
   const float *mask1;   // [H,W]
@@ -71,6 +75,7 @@ struct GeoEdge
   int32_t loc_is_i64;
   float loss_param; // > 0: this edge's Cauchy parameter (the mapper's geo_loss_param_factor * avg_squared_dpt_bias of the
                     // link's newer keyframe, mapper.cpp:369), else the launch's
+  float *px_out;    // merged linearize: [N][4] = {omega, D, dD/dx, dD/dy} per source pixel (PhotoEdge::geo_px)
 };
 
 // Tracker edge (a3): relative pose only, pre-sampled source features.
@@ -137,6 +142,19 @@ struct LaunchCommon
   // photometric linearize: > 0 -> one partial record per `flush` sub-tiles (edge_first / edge_tiles then count RECORDS:
   // record = edge_first[edge] + tile / flush); 0 -> one record per work item
   int32_t flush = 0;
+  // merged linearize of a window's two factor types (r05): > 0 = the geometric factor weight.  Both factor types of a link
+  // see the same source pixels, the same warp and -- pixel by pixel -- the same inliers, and every block of the geometric
+  // edge that involves code0 only through t0 = kappa*b0 has the form  sum_n (weight_n) x b_n^T  the photometric kernel
+  // contracts anyway: the geometric kernel hands {omega, D, grad D} of every pixel to the photometric kernel
+  // (GeoEdge::px_out = PhotoEdge::geo_px), drops its 5 code0 tiles (of 15 at CS = 32), and the photometric kernel adds
+  // w_g omega kappa^2 to its code-code weight, w_g omega kappa [a; rho] to its cross rows and carries one more cross row
+  // (w_g omega kappa D: the scale1-code0 block, read back by the geometric finalize).  The per-edge results are then
+  // MIXED (the photometric edge holds the pair's code0 blocks, the geometric edge zeros there); their sum -- what the
+  // assembly forms -- is the same normal equations.
+  float merge_geo_weight = 0.f;
+  // geometric finalize of a merged launch: the photometric launch's partial records (row 8 of the cross tiles)
+  const float *merge_photo_partials = nullptr;
+  const int32_t *merge_photo_rec_first = nullptr, *merge_photo_rec_count = nullptr;
 };
 
 // per-edge results, reference layouts

@@ -487,7 +487,7 @@ extern "C" void sage_window_destroy(SageWindow *w)
 {
   if (!w)
     return;
-  DevBuf *bufs[] = {&w->packed_save, &w->packed_loc, &w->asm_blocks, &w->rec_first_p, &w->rec_count_p, &w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
+  DevBuf *bufs[] = {&w->packed_save, &w->packed_loc, &w->asm_blocks, &w->geo_px, &w->rec_first_p, &w->rec_count_p, &w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
                     &w->pk, &w->f0s, &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
                     &w->work_g, &w->first_g, &w->tiles_g, &w->part_p, &w->part_g, &w->AtA_p, &w->Atb_p,
                     &w->stats_p, &w->AtA_g, &w->Atb_g, &w->stats_g, &w->adj_start, &w->adj, &w->link_edges,
@@ -718,6 +718,21 @@ extern "C" int sage_window_finalize(SageWindow *w)
                                      c.pyr));
   // ---- local edges
   w->n_edges = 2 * (int)w->local_links.size();
+  // merged linearize (LaunchCommon::merge_geo_weight): the geometric kernel's per-pixel hand-over to the photometric one
+  std::vector<size_t> px_off((size_t)w->n_edges + 1, 0);
+  for (size_t li = 0; li < w->local_links.size(); ++li)
+  {
+    const int l = w->local_links[li];
+    px_off[2 * li + 1] = px_off[2 * li] + (size_t)std::max(1, w->views[w->links[l].first].N);
+    px_off[2 * li + 2] = px_off[2 * li + 1] + (size_t)std::max(1, w->views[w->links[l].second].N);
+  }
+  w->merge_ok = c.use_photo && c.use_geo && c.geo_weight > 0.f && !sage::env_flag("SAGE_NO_MERGE");
+  if (w->merge_ok)
+  {
+    if ((rc = w->geo_px.reserve(std::max<size_t>(1, px_off[w->n_edges]) * 4 * sizeof(float))))
+      return rc;
+    SAGE_HIP(hipMemsetAsync(w->geo_px.p, 0, std::max<size_t>(1, px_off[w->n_edges]) * 4 * sizeof(float), w->stream));
+  }
   std::vector<LinkEdges> le(w->links.size(), LinkEdges{-1, -1});
   std::vector<int> Nedge(w->n_edges);
   std::vector<std::vector<AdjEntry>> adjv(K);
@@ -746,6 +761,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
         pe.dpt0 = w->dpt.as<float>() + (size_t)k0 * HW;
         pe.dpt1_geo = (c.use_photo && c.use_geo) ? w->dpt.as<float>() + (size_t)k1 * HW : nullptr;
         pe.geo_loss = w->link_geo_loss[l];
+        pe.geo_px = w->merge_ok ? w->geo_px.as<float>() + 4 * px_off[e] : nullptr;
         pe.basis0 = v0.basis; pe.mask1 = c.mask_dev; pe.homo = v0.homo; pe.loc = v0.loc1d; pe.loc_is_i64 = 1;
         pe.R0 = x0; pe.t0 = x0 + 9; pe.R1 = x1; pe.t1 = x1 + 9; pe.R10 = nullptr; pe.t10 = nullptr;
         pe.code0 = x0 + 13; pe.scale0 = x0 + 12; pe.N = v0.N;
@@ -758,6 +774,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
         ge.R0 = x0; ge.t0 = x0 + 9; ge.R1 = x1; ge.t1 = x1 + 9; ge.R10 = nullptr; ge.t10 = nullptr;
         ge.code0 = x0 + 13; ge.scale0 = x0 + 12; ge.scale1 = x1 + 12; ge.N = v0.N;
         ge.loss_param = w->link_geo_loss[l];
+        ge.px_out = w->merge_ok ? w->geo_px.as<float>() + 4 * px_off[e] : nullptr;
         gt[e] = ge;
         if (s == 0)
         {
@@ -994,7 +1011,9 @@ static AssembleParams window_assemble_params(SageWindow *w)
 // linearize every local edge at variable set `set` (0 = current estimate, 1 = candidate) and assemble the packed system
 // dst: where the packed system is assembled (default: w->packed); local_blocks: only the blocks this rank's edges touch
 // (dst then must hold zeros everywhere else: packed_loc)
-int window_linearize_set(SageWindow *w, int set, double *dst, bool local_blocks)
+// merge: the merged linearize of the two factor types (LaunchCommon::merge_geo_weight) -- the per-edge results are then
+// mixed (sage_window_get_edge), the assembled system is the same
+int window_linearize_set(SageWindow *w, int set, double *dst, bool local_blocks, bool merge)
 {
   if (!w || !w->finalized)
     return SAGE_E_STATE;
@@ -1013,6 +1032,8 @@ int window_linearize_set(SageWindow *w, int set, double *dst, bool local_blocks)
     LaunchCommon lcg = window_lc(w, false), lcp = window_lc(w, true, true);
     lcg.stage = 1;
     lcp.stage = 1;
+    merge = merge && w->merge_ok;
+    lcg.merge_geo_weight = lcp.merge_geo_weight = merge ? c.geo_weight : 0.f;
     if (c.use_geo)
     {
       EdgeOut out{w->AtA_g.as<float>(), w->Atb_g.as<float>(), w->stats_g.as<float>(), w->wide_g.as<double>()};
@@ -1041,6 +1062,12 @@ int window_linearize_set(SageWindow *w, int set, double *dst, bool local_blocks)
     fp.ge.AtA = w->AtA_g.as<float>(); fp.ge.Atb = w->Atb_g.as<float>(); fp.ge.stats = w->stats_g.as<float>();
     fp.ge.wide = w->wide_g.as<double>();
     fp.ge.weight = c.geo_weight;
+    if (merge)
+    {
+      fp.ge.photo_partials = lcp.partials;
+      fp.ge.photo_rec_first = lcp.edge_first;
+      fp.ge.photo_rec_count = lcp.edge_tiles;
+    }
     if (c.CS == 32)
       hipLaunchKernelGGL((window_finalize_kernel<32>), dim3(fp.n_p + fp.n_g), dim3(kFinalizeBlock), 0, w->stream, fp);
     else
@@ -1708,8 +1735,8 @@ static int lm_step_at_candidate(SageWindow *w, SageLmState *st, const SageLmConf
   auto evaluate = [&](int set, double *dst, int it) -> int {
     int r;
     if (!sharded)
-      return (r = window_linearize_set(w, set, dst)) ? r : window_mirror_totals(w, false, dst);
-    if ((r = window_linearize_set(w, set, w->packed_loc.as<double>(), true)) ||
+      return (r = window_linearize_set(w, set, dst, false, true)) ? r : window_mirror_totals(w, false, dst);
+    if ((r = window_linearize_set(w, set, w->packed_loc.as<double>(), true, true)) ||
         (r = window_allreduce_into(w, w->packed_loc.as<double>(), dst, np, it)))
       return r;
     window_phase_mark(w, 2);
@@ -1813,7 +1840,7 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
   const bool at_candidate = cfg->linearize_at_candidate > 0 || (cfg->linearize_at_candidate == 0 && sharded);
   if (at_candidate && !schur && !w->links.empty())
     return lm_step_at_candidate(w, st, cfg, sharded);
-  if ((rc = window_linearize_set(w, 0)))
+  if ((rc = window_linearize_set(w, 0, nullptr, false, true)))
     return rc;
   if (sharded && !schur && (rc = window_allreduce(w, w->packed.as<double>(), sage_window_packed_count(w), w->emu_cur)))
     return rc;

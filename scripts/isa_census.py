@@ -6,7 +6,7 @@ markers by class.  The sub-tile loop body is straight-line per 64-pixel wave sli
 groups of the contraction are unrolled), so the static count of a phase IS its count per slice; the markers' scheduling
 barriers cost the marked build a few instructions of freedom (the unmarked build's total is printed next to it).
 
-usage: python scripts/isa_census.py [CS FS] [-o profiles/r05_photo_isa_census.txt]
+usage: python scripts/isa_census.py [CS FS [MODE]] [-o profiles/r05_photo_isa_census.txt]
 """
 import os
 import re
@@ -57,8 +57,8 @@ def classify(op):
     return "other"
 
 
-def kernel_body(asm, CS, FS):
-    key = f"photo_kernelILi{CS}ELi{FS}ELb1ELi1EE"
+def kernel_body(asm, CS, FS, MODE=1):
+    key = f"photo_kernelILi{CS}ELi{FS}ELb1ELi{MODE}EE"
     lines = asm.split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + key + r"\w*:", l))
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
@@ -86,12 +86,17 @@ def census(body):
     return phases, ops
 
 
-def vgprs(lines, CS, FS):
-    key = f"photo_kernelILi{CS}ELi{FS}ELb1ELi1EE"
+def vgprs(lines, CS, FS, MODE=1):
+    """(VGPRs, VGPR spills, SGPR spills) from the kernel's metadata record"""
+    key = f"photo_kernelILi{CS}ELi{FS}ELb1ELi{MODE}EE"
     txt = "\n".join(lines)
-    m = re.search(key + r"[\s\S]*?\.vgpr_count:\s*(\d+)", txt)
-    m2 = re.search(key + r"[\s\S]*?\.vgpr_spill_count:\s*(\d+)", txt)
-    return (int(m.group(1)) if m else -1, int(m2.group(1)) if m2 else -1)
+    i = txt.find(".name:", txt.find("amdhsa.kernels"))
+    m = re.search(r"\.name:\s+_Z\w*" + key + r"\w*\n([\s\S]*?)\.wavefront_size", txt)
+    if not m:
+        return (-1, -1, -1)
+    blk = m.group(1)
+    g = lambda k: int(re.search(k + r":\s*(\d+)", blk).group(1))
+    return (g(r"\.vgpr_count"), g(r"\.vgpr_spill_count"), g(r"\.sgpr_spill_count"))
 
 
 def main():
@@ -101,15 +106,16 @@ def main():
         out_path = sys.argv[sys.argv.index("-o") + 1]
         args = [a for a in args if a != out_path]
     CS, FS = (int(args[0]), int(args[1])) if len(args) >= 2 else (32, 16)
+    MODE = int(args[2]) if len(args) >= 3 else 1
     extra = [a for a in sys.argv[1:] if a.startswith("-D")]
-    body, lines = kernel_body(compile_asm(True, extra), CS, FS)
+    body, lines = kernel_body(compile_asm(True, extra), CS, FS, MODE)
     phases, ops = census(body)
-    plain_body, plain_lines = kernel_body(compile_asm(False, extra), CS, FS)
+    plain_body, plain_lines = kernel_body(compile_asm(False, extra), CS, FS, MODE)
     plain, _ = census(plain_body)
     cols = ["valu", "valu_pk", "valu_dpp", "valu_lane", "mfma", "lds", "vmem", "salu", "smem", "wait_nop", "branch"]
     rows = []
-    rows.append(f"photo_kernel<{CS},{FS},true,1> -- instructions per phase (static = per 64-pixel wave slice inside the sub-tile loop)")
-    rows.append(f"marked build: VGPRs / spills {vgprs(lines, CS, FS)}; unmarked build: {vgprs(plain_lines, CS, FS)}")
+    rows.append(f"photo_kernel<{CS},{FS},true,{MODE}> -- instructions per phase (static = per 64-pixel wave slice inside the sub-tile loop)")
+    rows.append(f"(VGPRs, VGPR spills, SGPR spills): marked build {vgprs(lines, CS, FS, MODE)}; unmarked build {vgprs(plain_lines, CS, FS, MODE)}")
     rows.append(f"{'phase':24s}" + "".join(f"{c:>10s}" for c in cols) + f"{'VALU all':>10s}")
     tot = Counter()
     loop = Counter()

@@ -176,6 +176,22 @@ def window_vs_oracle(capi, orc, w, label, gold, live=("f32", "f64")):
     st = capi.SageLmState()
     win.lm_step(st, cfg)
     assert st.accepted == 1 and st.candidate_error < st.error
+    # r05: sage_window_lm_step linearizes with the MERGED kernels (the geometric edges' code0 blocks contracted by the
+    # photometric kernel of the same pair) -- what bench.py times.  The classic sequence leaves the system of the iteration's
+    # linearisation point in `packed`: the same normal equations as the separate kernels' above, and its LM step holds
+    # the same bars against the committed fp32-oracle / exact deltas.
+    pm = win.packed_host().astype(np.float64)
+    Hm, gm = add_priors(*capi.unpack_dense(pm, K, w.links, CS)[:2], w, CS)
+    dm = damped_delta(Hm, gm, DAMP)
+    m_h64, m_h32 = rel(dm, d64), rel(dm, d32)
+    summary_line(f"[{label}] merged linearize (LM iteration): packed vs separate kernels {rel(pm[:-4], packed[:-4]):.1e}; LM delta "
+                 f"hip-fp32oracle {m_h32:.2e}  hip-exact {m_h64:.2e}  merged-vs-separate {rel(dm, dh):.2e}")
+    assert rel(pm[:-4], packed[:-4]) < 2e-6 and np.array_equal(pm[-4:], packed[-4:])
+    assert m_h32 < TOL_DELTA, (label, m_h32)
+    if r_3264 < 0.75 * TOL_DELTA:
+        assert m_h64 < TOL_DELTA, (label, m_h64)
+    else:
+        assert m_h64 < r_3264 + TOL_DELTA, (label, m_h64, r_3264)
     win.close()
     return r_h64, r_h32, r_3264
 

@@ -451,7 +451,9 @@ def test_linearize_at_candidate_lm_matches_classic(capi, dec, inner):
     np.testing.assert_allclose(t1[:, 3], t0[:, 3], rtol=1e-12)
     assert rel(v1, v0) < 1e-5
     assert rel(pf1, pf0) < 1e-5
-    assert rel(pl1, pf1) < 1e-12                         # what the variant keeps IS the linearisation at the current estimate
+    # what the variant keeps IS the linearisation at the current estimate -- formed by the merged kernels of the LM iteration
+    # (r05), win.linearize() by the separate ones: the same normal equations to fp32 accumulation order (measured 2e-9)
+    assert rel(pl1, pf1) < 1e-7
 
 
 @pytest.mark.parametrize("use_photo,use_geo", [(True, False), (False, True)])
