@@ -12,8 +12,10 @@ A "step" is one LM iteration = one pass of the hot path over the whole window:
 Inputs are resident in HBM before the timed region.  Residuals per step = E_photo*L*N*FS + E_geo*N
 (linearisation residuals only; the error-evaluation pass is not double counted).
 
-Multi-GPU: factor-graph links are sharded over ranks (rank r owns the contiguous link range [r*n/world, (r+1)*n/world)), keyframes replicated, one
-all-reduce of the packed normal equations and one of the 4-double error tail per step (strong scaling).
+Multi-GPU: factor-graph links are sharded over ranks (rank r owns the contiguous link range [r*n/world, (r+1)*n/world)),
+keyframes replicated; a reduced window runs the one-collective LM sequence (linearize at the candidate: ONE all-reduce of
+the packed normal equations per step, the error totals in its tail; strong scaling).  Single-GPU runs also measure one rank
+of an 8-rank job on this device (`shard_emulation`: one-rank RCCL communicator, the peers' share from a table).
 
 Prints ONE JSON line on rank 0.
 """
@@ -33,17 +35,32 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 # Counter constants of the K = 64 headline window (rocprofv3 --pmc, separate passes, scripts/pmc_run.sh ->
-# profiles/r04_v2_pmc_summary.txt; bench.py cannot collect PMC counters itself, null for any other workload).  They are
+# profiles/r05_v3_pmc_summary.txt; bench.py cannot collect PMC counters itself, null for any other workload).  They are
 # per-launch INSTRUCTION / BYTE counts of one build on one workload -- fixed by the code, not by the box -- and are combined
-# below with the launch durations measured live in this run.
+# below with the launch durations measured live in this run.  They belong to ONE build of the kernel sources: the summary
+# records sage_slam_amd.build.kernel_source_sha16() of the tree it was taken from, and the constants are quoted only while
+# the tree still hashes to it (a stale constant used to go out silently).
+#   kernels: the LM iteration's merged pair -- photo_kernel<32,16,true,2> and geo_kernel<32,true,true>
 #   traffic: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane reads on gfx950, + WRITE_SIZE
 PMC_K64 = {
-    "source": "profiles/r04_v2_pmc_summary.txt",
-    "photo": {"fetch_size_kb": 726920.0, "write_size_kb": 43930.0, "insts_vmem_rd": 7.85302e6, "insts_valu": 1.77356e8,
-              "insts_mfma": 8.96938e6, "lds_idx_active": 1.37959e8, "lds_bank_conflict": 3.24344e7},
-    "geo": {"insts_vmem_rd": 9.07303e6, "insts_valu": 7.49784e7, "insts_mfma": 2.24234e7, "lds_idx_active": 3.23551e7},
+    "source": "profiles/r05_v3_pmc_summary.txt",
+    "kernel_source_sha16": "8edd2a1e956d6a52",
+    "photo": {"fetch_size_kb": 764042.0, "write_size_kb": 43888.0, "insts_vmem_rd": 7.95836e6, "insts_valu": 1.64295e8,
+              "insts_mfma": 8.96938e6, "lds_idx_active": 1.41346e8, "lds_bank_conflict": 3.54242e7},
+    "geo": {"insts_vmem_rd": 9.07898e6, "insts_valu": 6.70424e7, "insts_mfma": 1.4949e7, "lds_idx_active": 3.31144e7},
 }
 PMC_TRAFFIC_BYTES_K64 = {"hbm_bytes_per_launch": (2 * PMC_K64["photo"]["fetch_size_kb"] + PMC_K64["photo"]["write_size_kb"]) * 1024.0}
+
+
+def pmc_constants_current():
+    """True while the kernel sources still are the ones the committed counters were taken from."""
+    try:
+        from sage_slam_amd.build import kernel_source_sha16
+        return kernel_source_sha16() == PMC_K64["kernel_source_sha16"]
+    except Exception:
+        return False
+
+
 N_CU, N_SIMD, CLK_HZ = 256, 1024, 2.4e9          # MI355X: 256 CUs x 4 SIMDs, 2.4 GHz peak engine clock
 L1_PEAK_GBS = N_CU * 64 * CLK_HZ / 1e9         # CU texture path: 64 B / clk / CU  (39.3 TB/s)
 MFMA_F32_PEAK_TFLOPS = 157.3                    # dense f32 matrix peak (= the f32 vector peak on this part)
@@ -313,7 +330,9 @@ def shard_emulation(capi, torch, win, win_h, rank, world, steps, restart, ms_one
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     steady = [x for j in range(1, restart) for x in ps[j]] or ps[0]
-    ms_steady = 1e3 * float(np.mean(steady))
+    # median of the steady iterations (a host thread that is descheduled for a few hundred microseconds once in a run would
+    # otherwise be the result); the mean and the spread are reported next to it
+    ms_steady = 1e3 * float(np.median(steady))
     # the same sequence (linearize-at-candidate) on the whole window: the one-GPU step the shard's is compared with
     ms_one_same = float("nan")
     if compare_one_gpu:
@@ -323,11 +342,13 @@ def shard_emulation(capi, torch, win, win_h, rank, world, steps, restart, ms_one
         p1 = [[] for _ in range(restart)]
         cycles(win, one, n_cyc, p1)
         torch.cuda.synchronize()
-        ms_one_same = 1e3 * float(np.mean([x for j in range(1, restart) for x in p1[j]] or p1[0]))
+        ms_one_same = 1e3 * float(np.median([x for j in range(1, restart) for x in p1[j]] or p1[0]))
     local_links = len(capi.shard_links(len(win_h.links), rank, world))
     out = {"world": world, "rank": rank, "local_links": local_links, "links": len(win_h.links),
            "ms_per_step": ms_steady,
-           "ms_first_step_after_restart": 1e3 * float(np.mean(ps[0])),
+           "ms_per_step_mean": 1e3 * float(np.mean(steady)),
+           "ms_per_step_p10_p90": [1e3 * float(np.percentile(steady, 10)), 1e3 * float(np.percentile(steady, 90))],
+           "ms_first_step_after_restart": 1e3 * float(np.median(ps[0])),
            "ms_per_step_incl_restarts": 1e3 * wall / (n_cyc * restart),
            "steps_timed": len(steady), "accepted_steps": acc, "steps": n_cyc * restart,
            "lm": "linearize-at-candidate (automatic for reduced windows): per iteration 1 solve + 1 linearize of the shard + ONE "
@@ -644,6 +665,7 @@ def main():
         ach = px_launch * bytes_photo_px / (ms_photo * 1e-3) / 1e9 if ms_photo > 0 else 0.0
         ach_geo = px_launch * bytes_geo_px / (ms_geo * 1e-3) / 1e9 if ms_geo > 0 else 0.0
         headline = world == 1 and args.keyframes == 64 and args.height == 128 and args.fs == 16 and args.cs == 32
+        pmc_ok = headline and pmc_constants_current()
         n_acc = int(sum(1 for h in hist[args.warmup:] if h[2]))
         # phases of an iteration on rank 0's stream timeline (HIP events); "host_idle" = the rest of the step: accept /
         # reject decision, the error totals' all-reduce, launch gaps
@@ -678,16 +700,33 @@ def main():
                               "system from one pass); no separate error pass; +1 linearize after every restart"),
                        "accepted_steps": n_acc,
                        "error_first_last": [hist[0][0], hist[-1][1]]},
-            "roofline": {"bound": "hbm", "kernel": "photo_kernel<CS,FS,true> (fused photometric linearize)",
+            "roofline": {"bound": "hbm",
+                         "kernel": "photo_kernel<CS,FS,true,2> (fused photometric linearize of the LM iteration; since r05 it also "
+                                   "contracts the geometric edge's code0 blocks of the same pair -- the merged linearize)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                         "bound_note": "the HBM figure is SURVEY s8(d)'s algorithmic-byte roofline; what binds the kernel is VALU + MFMA issue (see issue)",
-                         "traffic": PMC_TRAFFIC_BYTES_K64["hbm_bytes_per_launch"] if headline else None,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, " + PMC_K64["source"],
-                         "issue": issue_roofline(PMC_K64["photo"], ms_photo) if headline else None,
+                         "bound_note": "the HBM figure is SURVEY s8(d)'s algorithmic-byte roofline of the PHOTOMETRIC factor alone "
+                                       "(492 B per source pixel at FS 16 / CS 32) over this kernel's launch time, although the kernel "
+                                       "now does a third of the geometric factor's contractions as well; `linearize_pair` prices "
+                                       "both factor types' algorithmic bytes against both kernels' time.  What binds the kernel is "
+                                       "VALU + MFMA issue and the LDS pipe (see issue), not HBM",
+                         # both linearize kernels of a step as one unit: (B_photo + B_geo) per source pixel over t_photo + t_geo
+                         # (r04, separate kernels: 4.70 GB / (0.639 + 0.494 ms) = 4.15 TB/s = 0.519)
+                         "linearize_pair": {"achieved": px_launch * (bytes_photo_px + bytes_geo_px) / ((ms_photo + ms_geo) * 1e-3) / 1e9
+                                            if ms_photo + ms_geo > 0 else 0.0,
+                                            "frac": px_launch * (bytes_photo_px + bytes_geo_px) / ((ms_photo + ms_geo) * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                            if ms_photo + ms_geo > 0 else 0.0,
+                                            "bytes_per_launch_pair": px_launch * (bytes_photo_px + bytes_geo_px),
+                                            "ms": ms_photo + ms_geo},
+                         "traffic": PMC_TRAFFIC_BYTES_K64["hbm_bytes_per_launch"] if pmc_ok else None,
+                         "traffic_source": ("rocprofv3 --pmc FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, " + PMC_K64["source"]
+                                            if pmc_ok else "none: " + ("the kernel sources no longer hash to the committed counter "
+                                            "summary's build (" + PMC_K64["source"] + ")" if headline else "counters are committed "
+                                            "for the headline workload only")),
+                         "issue": issue_roofline(PMC_K64["photo"], ms_photo) if pmc_ok else None,
                          "bytes_per_launch": px_launch * bytes_photo_px, "avg_launch_ms": ms_photo,
                          "geo_kernel": {"achieved": ach_geo, "frac": ach_geo / HBM_PEAK_GBS, "avg_launch_ms": ms_geo,
                                         "bytes_per_launch": px_launch * bytes_geo_px,
-                                        "issue": issue_roofline(PMC_K64["geo"], ms_geo) if headline else None},
+                                        "issue": issue_roofline(PMC_K64["geo"], ms_geo) if pmc_ok else None},
                          # (the window's error pass evaluates both factor types in the photometric error kernel: no
                          #  separate geometric launch)
                          "error_pass_ms": {"photo+geo" if ktime[3][1] == 0 else "photo": ktime[2][0] / max(1, ktime[2][1]),

@@ -69,6 +69,10 @@ typedef struct SagePyramid
 } SagePyramid;
 
 /* CameraPyramid ctor: level i = level i-1 resized to (size_t)(w/2),(size_t)(h/2). Host only. */
+/* (The photometric entry points and sage_window_create accept pyramids whose per-level focal ratios fx_l/fx_0, fy_l/fy_0 are
+ * powers of two -- what this function and the reference's CameraPyramid build -- and return SAGE_E_UNSUPPORTED otherwise: the
+ * kernels form a level's coordinate with the host-side quotient, which is only then bit-identical to the reference's
+ * ((p + 0.5) * fx_l) / fx_0 - 0.5, photometric_factor_kernels.cpp:101-103.) */
 int sage_camera_pyramid(const SageCamera *base, int levels, SagePyramid *out);
 
 const char *sage_version(void);
@@ -370,7 +374,11 @@ int sage_window_set_keyframe(SageWindow *w, int kf, const float *pose12, const f
 int sage_window_get_delta(const SageWindow *w, double *delta);
 /* host copy of per-edge results of the last linearize, reference layouts (for parity tests):
  * type 0 = photometric (D=13+CS), 1 = geometric (D=14+2CS); edge index e in [0, 2*nlinks): link e/2,
- * direction e%2 (0: a->b, 1: b->a). */
+ * direction e%2 (0: a->b, 1: b->a).  After sage_window_linearize / sage_window_prepass: one factor type per result,
+ * exactly the reference's per-edge AtA / Atb.  After sage_window_lm_step (windows with both factor types): the iteration's
+ * MERGED linearize -- the geometric edge's blocks that involve code0 through kappa*b0 (code0-code0, pose-code0, scale0-code0,
+ * code0 gradient) ride in the PHOTOMETRIC edge's result of the same pair and read zero in the geometric one; the sum of
+ * the two -- what the assembly forms -- is the same normal equations. */
 int sage_window_get_edge(const SageWindow *w, int type, int e, float *AtA, float *Atb, float *err, float *n_in);
 
 /* f2 (core/gtsam/photometric_factor.cpp:72-219, geometric_factor.cpp:41-233, mapper.cpp:544-551): the
@@ -582,7 +590,9 @@ void sage_rccl_comm_destroy(void *comm);
 int sage_window_use_rccl(SageWindow *w, void *nccl_comm);
 
 /* one full LM iteration: linearize -> (all-reduce) -> solve -> error at candidate -> (all-reduce) -> accept/reject
- * (policy of camera_tracker.cpp:1156-1279).  Sharded windows need sage_window_set_allreduce first. */
+ * (policy of camera_tracker.cpp:1156-1279); windows that are reduced over ranks take the one-collective sequence
+ * solve -> linearize at the candidate -> all-reduce -> accept/reject by themselves (SageLmConfig::linearize_at_candidate).
+ * Sharded windows need sage_window_set_allreduce / sage_window_use_rccl first. */
 typedef struct SageLmState
 {
   double damp, error, candidate_error;

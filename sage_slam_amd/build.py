@@ -30,7 +30,7 @@ def kernel_source_sha16() -> str:
     build of these files."""
     import hashlib
     h = hashlib.sha256()
-    for f in ("photo_kernels.hip", "geo_kernels.hip", "sage_device.h", "sage_internal.h", "finalize_bodies.h"):
+    for f in ("photo_kernels.hip", "geo_kernels.hip", "sage_device.h", "sage_internal.h"):
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

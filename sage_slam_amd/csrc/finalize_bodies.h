@@ -14,7 +14,7 @@ __device__ __forceinline__ int sidx6(int i, int j) // upper-triangular index, i 
 __device__ __forceinline__ int gsidx6(int i, int j) { return sidx6(i, j); }
 
 __host__ __device__ constexpr int photo_finalize_lds_doubles(int CS) { return kPhotoScalars + photo_tiles(CS) * 256; }
-__host__ __device__ constexpr int geo_finalize_lds_doubles(int CS) { return geo_partial_floats(CS); }
+__host__ __device__ constexpr int geo_finalize_lds_doubles(int CS) { return geo_partial_floats(CS) + CS; } // + row 8 of a merged launch
 
 // ------------------------------------------------------------------------------------------------
 // photometric finalize: sum the workgroup partials of an edge in a fixed order (deterministic), expand the reduced
@@ -205,11 +205,47 @@ __device__ __forceinline__ void geo_finalize_body(const GeoFinalizeParams &prm, 
   const float s0 = E.scale0 ? *E.scale0 : E.scale0_val;
   const float s1 = E.scale1 ? *E.scale1 : E.scale1_val;
   const int first = prm.edge_first[e], nt = prm.edge_tiles[e];
-  for (int idx = tid; idx < PP; idx += (int)blockDim.x)
+  for (int idx = tid; idx < PP + (prm.photo_partials ? CS : 0); idx += (int)blockDim.x)
   {
     double a = 0.0; // the per-workgroup partials are summed in double: free (a few dozen adds), and it keeps the
                     // engine's accumulation noise below the reference's own fp32 floor
     double a1 = 0.0, a2 = 0.0, a3 = 0.0; // four independent chains: the loads of a round are in flight together
+    if (idx >= PP)
+    {
+      // merged launch: s[PP + c] = sum over the photometric records of this edge of  sum_n w_g omega kappa D b_n[c]  (row 8
+      // of the cross tile of channel c; doubles), in the records' fixed order
+      constexpr int PF = photo_partial_floats(CS), DOFF = photo_partial_double_offset(CS);
+      const int c = idx - PP;
+      const int xt = CS == 32 ? (c & 1) : 0, xc = CS == 32 ? (c >> 1) : c; // cross tile, column inside it
+      const int di = kPhotoScalars + xt * 256 + 32 + xc;                   // row 8 -> r = 0, 16-block 2
+      const int pn = prm.photo_rec_count[e];
+      const double *pp = reinterpret_cast<const double *>(prm.photo_partials + (size_t)prm.photo_rec_first[e] * PF + DOFF) + di;
+      constexpr size_t STR = PF / 2;
+      int t = 0;
+      for (; t + 4 <= pn; t += 4)
+      {
+        a += pp[(size_t)t * STR]; a1 += pp[(size_t)(t + 1) * STR]; a2 += pp[(size_t)(t + 2) * STR]; a3 += pp[(size_t)(t + 3) * STR];
+      }
+      for (; t < pn; ++t)
+        a += pp[(size_t)t * STR];
+      s[idx] = (a + a1) + (a2 + a3);
+      continue;
+    }
+    if (prm.photo_partials && idx >= kGeoScalars)
+    {
+      // merged launch: the t0 t0^T and y t0^T tiles were not contracted here (exact zeros in the records): not read
+      constexpr int NBm = CS / 16;
+      const int tile = (idx - kGeoScalars) >> 8;
+      bool skipped = tile >= NTT && tile < NTT + NBm; // y t0^T
+      for (int bi = 0; bi < NBm; ++bi)
+        for (int bj = bi; bj < NBm; ++bj)
+          skipped = skipped || tile == bi * N16 - (bi * (bi - 1)) / 2 + (bj - bi);
+      if (skipped)
+      {
+        s[idx] = 0.0;
+        continue;
+      }
+    }
     const float *pp = prm.partials + (size_t)first * PP + idx;
     int t = 0;
     for (; t + 4 <= nt; t += 4)
@@ -299,14 +335,7 @@ __device__ __forceinline__ void geo_finalize_body(const GeoFinalizeParams &prm, 
           const int yrow = ki == 0 ? ii : ij, tcol = ki == 0 ? ij : ii;
           if (yrow == 7 && tcol < CS)
           {
-            constexpr int PF = photo_partial_floats(CS), DOFF = photo_partial_double_offset(CS);
-            const int xt = CS == 32 ? (tcol & 1) : 0, xc = CS == 32 ? (tcol >> 1) : tcol; // cross tile, column inside it
-            const int di = kPhotoScalars + xt * 256 + 32 + xc;                             // row 8 -> r = 0, 16-block 2
-            const int pf = prm.photo_rec_first[e], pn = prm.photo_rec_count[e];
-            const double *pp = reinterpret_cast<const double *>(prm.photo_partials + (size_t)pf * PF + DOFF) + di;
-            double r8 = 0.0;
-            for (int t = 0; t < pn; ++t)
-              r8 += pp[(size_t)t * (PF / 2)];
+            const double r8 = s[PP + tcol];
             val = (1.0 / n_in) * (ci * cj) * r8;
           }
         }

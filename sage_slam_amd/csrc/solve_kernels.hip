@@ -223,8 +223,19 @@ __global__ __launch_bounds__(1024) void solve_retract_kernel(const double *__res
     const unsigned long long t0 = wall_clock64();
     unsigned v;
     bool timed_out = false;
-    while (((v = *go) & 0x7fffffffu) != epoch)
+    for (;;)
     {
+      v = *go;
+      // the word carries the epoch of the LAST solve the host answered: mine -> go / abort (bit 31); a NEWER one (the host
+      // gave up on this solve -- its own word was overwritten before this kernel ran) -> abort; an older one -> keep waiting
+      const unsigned d = ((v & 0x7fffffffu) - epoch) & 0x7fffffffu;
+      if (d == 0u)
+        break;
+      if (d < 0x40000000u && (v & 0x7fffffffu) != 0u)
+      {
+        v = 0x80000000u;
+        break;
+      }
       __builtin_amdgcn_s_sleep(4);
       if (wall_clock64() - t0 > 200000000ull)
       {
@@ -235,9 +246,10 @@ __global__ __launch_bounds__(1024) void solve_retract_kernel(const double *__res
     }
     __threadfence_system();
     s_go = (v & 0x80000000u) ? 0 : 1;
-    // status word of the host mirror (solver_host_status): 0 candidate written, 2 the host's word never came -- the
-    // caller then treats the evaluation as failed instead of reading a stale candidate
-    *reinterpret_cast<volatile int *>(h_tail + 1) = timed_out ? 2 : 0;
+    // status word of the host mirror (solver_host_status): 0 candidate written, 1 no candidate (the host aborted the solve:
+    // non-positive pivot / error), 2 the host's word never came -- the caller then treats the evaluation as failed instead
+    // of reading a stale candidate
+    *reinterpret_cast<volatile int *>(h_tail + 1) = timed_out ? 2 : (s_go ? 0 : 1);
   }
   __syncthreads();
   if (!s_go)

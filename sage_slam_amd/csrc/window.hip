@@ -468,7 +468,7 @@ extern "C" int sage_window_create(const SageWindowConfig *cfg, void *hip_stream,
 {
   if (!cfg || !out || !cfg->mask_dev)
     return SAGE_E_INVALID;
-  if (!supported(cfg->CS, cfg->FS) || cfg->pyr.levels < 1 || cfg->pyr.levels > SAGE_MAX_LEVELS)
+  if (!supported(cfg->CS, cfg->FS) || cfg->pyr.levels < 1 || cfg->pyr.levels > SAGE_MAX_LEVELS || !pyramid_is_dyadic(cfg->pyr))
     return SAGE_E_UNSUPPORTED;
   int ndev = 0;
   SAGE_HIP(hipGetDeviceCount(&ndev));

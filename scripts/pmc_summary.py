@@ -4,7 +4,7 @@ import csv, glob, os, sys, collections
 root = sys.argv[1]
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sage_slam_amd.build import kernel_source_sha16
-print("# kernel_source_sha16:", kernel_source_sha16(), "(photo_kernels.hip geo_kernels.hip sage_device.h sage_internal.h finalize_bodies.h)")
+print("# kernel_source_sha16:", kernel_source_sha16(), "(photo_kernels.hip geo_kernels.hip sage_device.h sage_internal.h)")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True):
     with open(f) as fh:

@@ -15,7 +15,7 @@ if [ "$CFG" = "4" ]; then export KBENCH_ARGS="16 3 256 320 32 32"; fi
 if [ "$CFG" = "2" ]; then export KBENCH_ARGS="16 3 128 160 16 32"; fi
 timeout 900 python bench.py $BARGS --steps 40 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- python $R/bench.py $BARGS --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- python $R/bench.py $BARGS --steps 20 --warmup 3 --no-cpu-baseline --emulate-shard off > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 DB=$(find $OUT/trace -name "*.db" | head -1)
 python $R/scripts/rocpd_summary.py $DB $OUT/kernel_stats.csv
 bash $R/scripts/pmc_run.sh $TAG "FETCH_SIZE GRBM_GUI_ACTIVE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \

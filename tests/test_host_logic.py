@@ -525,3 +525,21 @@ def test_block_solve_ring_closure_cover_plan_matches_dense():
         bad = packed.copy(); bad[(K // 3) * B * B] = -1e6
         with pytest.raises(capi.SageError):
             capi.block_solve(bad, K, links, B, 0.0)
+
+
+def test_non_dyadic_pyramids_are_refused():
+    """the kernels form a level's coordinate with the host-side quotient fx_l / fx_0 (exact for the halving
+    pyramids sage_camera_pyramid / the reference's CameraPyramid build); a pyramid whose level ratios are not powers of two
+    could land one texel off at floor() boundaries and is refused up front -- before any device is touched."""
+    import ctypes as C
+    cam = capi.SageCamera(100.0, 100.0, 40.0, 32.0, 80.0, 64.0)
+    pyr = capi.make_pyramid(cam, 3)
+    assert [pyr.cam[l].fx / pyr.cam[0].fx for l in range(3)] == [1.0, 0.5, 0.25]
+    cfg = capi.SageWindowConfig()
+    cfg.pyr = pyr; cfg.FS, cfg.CS = 16, 32
+    cfg.mask_dev = 1                                     # never dereferenced: the checks come first
+    bad = capi.SageWindowConfig.from_buffer_copy(cfg)
+    bad.pyr.cam[1].fx = 100.0 / 3.0                      # a 1/3 level
+    h = C.c_void_p()
+    assert capi.lib().sage_window_create(C.byref(bad), None, C.byref(h)) == -2          # SAGE_E_UNSUPPORTED
+    assert not h.value
