@@ -286,6 +286,9 @@ def shard_emulation(capi, torch, win, win_h, rank, world, steps, restart, ms_one
             if not st.accepted:
                 return {"error": f"iterate {i} of the reference trajectory was rejected: no table to emulate with"}
     comm = capi.rccl_comm_create(capi.rccl_unique_id(), 0, 1)
+    # (the replicated solve: the domain-decomposed one -- default from K >= 256 -- all-reduces a separator system whose peer
+    #  contributions cannot be tabulated beforehand)
+    os.environ["SAGE_SHARD_SCHUR"] = "0"
     sw = capi.Window(win_h, rank=rank, world=world)
     rest = torch.empty(restart + 1, sw.packed_count, dtype=torch.float64, device="cuda")
     for i in range(restart + 1):

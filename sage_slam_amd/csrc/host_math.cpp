@@ -1433,6 +1433,9 @@ namespace
 struct RowPrefetch // (plain aggregate: the multi-versioned callers must not need an out-of-line constructor)
 {
   const char *p, *end;
+  // two more ranges, taken up when the first is through (r05, arrow-row chains: besides the chain's own next block the
+  // half's blocks and inverse of the NEXT column -- written by another core, 64 KB a chain used to wait for column by column)
+  const char *p2 = nullptr, *end2 = nullptr, *p3 = nullptr, *end3 = nullptr;
   inline __attribute__((always_inline)) void step()
   {
     if (p < end)
@@ -1440,6 +1443,18 @@ struct RowPrefetch // (plain aggregate: the multi-versioned callers must not nee
       __builtin_prefetch(p, 0, 3);
       __builtin_prefetch(p + 64, 0, 3);
       p += 128;
+    }
+    else if (p2 < end2)
+    {
+      __builtin_prefetch(p2, 0, 3);
+      __builtin_prefetch(p2 + 64, 0, 3);
+      p2 += 128;
+    }
+    else if (p3 < end3)
+    {
+      __builtin_prefetch(p3, 0, 3);
+      __builtin_prefetch(p3 + 64, 0, 3);
+      p3 += 128;
     }
   }
 };
@@ -1713,13 +1728,24 @@ static double mono_seconds()
   clock_gettime(CLOCK_MONOTONIC, &ts);
   return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
 }
-static __attribute__((noinline)) bool wait_row_tickets(const BlockEnvelope &E, int i)
+// from_col: only the blocks (i, j >= from_col) -- the others have been consumed already (the arrow-row tasks take their
+// blocks one by one).  Structural fill blocks (E.fill) are zeroed here instead of waited for: this is their first touch.
+static __attribute__((noinline)) bool wait_row_tickets(const BlockEnvelope &E, int i, double *T, int from_col = 0)
 {
   const int na = E.a_cnt ? E.a_cnt[i] : 0;
   const int b0[2] = {na ? E.a_off[i] : 0, E.row_off[i]}, nb[2] = {na, i - E.row_first[i] + 1};
+  const int c0[2] = {na ? E.a_first[i] : 0, E.row_first[i]};
+  const size_t BB = (size_t)E.Bp * E.Bp;
   for (int rg = 0; rg < 2; ++rg)
     for (int q = 0; q < nb[rg]; ++q)
     {
+      if (c0[rg] + q < from_col)
+        continue;
+      if (E.fill && E.fill[b0[rg] + q])
+      {
+        std::memset(T + (size_t)(b0[rg] + q) * BB, 0, BB * sizeof(double));
+        continue;
+      }
       const volatile unsigned *f = E.ready + b0[rg] + q;
       if (*f == E.epoch)
         continue;
@@ -1779,7 +1805,7 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
       LAP(5);
       if (E.before_row && E.before_row(E.user, i))
         return -2;
-      if (role != 1 && E.ready && !wait_row_tickets(E, i))
+      if (role != 1 && E.ready && !wait_row_tickets(E, i, T))
       {
         if (pipe)
           pipe->early.store(-1, std::memory_order_release);
@@ -2039,7 +2065,16 @@ __attribute__((target_clones("avx512f", "avx2", "default"))) static void block_s
 struct SepTaskA
 {
   int row, half, j0, j1; // columns [j0, j1)
+  // r05: a long chain may carry a PARTNER row of the same half and column range (the partner's own entry is a `slave`: its
+  // slots are filled by the master's thread): the two rows share the loads of the half's blocks column by column, and the
+  // number of long chains fits the cores of the halves' L3 domain (a chain on another domain runs ~30 % slower and the
+  // separator then waits a millisecond for it: config 5, 3 cover rows x 2 halves on 4 free cores)
+  int partner = -1;
+  bool slave = false;
 };
+// set by the calling thread's role: pool workers outside the caller's L3 domain do not take the long arrow-row chains
+static thread_local bool tl_fast_thread = true;
+static std::atomic<int> g_fast_pool_threads{-1}; // pool workers on the caller's L3 domain (-1: unknown / no pool)
 struct SepTaskB
 {
   int i, i2, half, k0, k1; // common columns [k0, k1), i2 < i
@@ -2053,12 +2088,16 @@ struct SepJob
   std::vector<SepTaskB> tb;
   std::vector<double> Sd, wd, Pp; // [ta][BB], [ta][Bp], [tb][BB]
   std::atomic<int> nextA{0}, doneA{0}, nextB{0}, doneB{0};
+  std::atomic<int> nextLong{0};
+  std::vector<int> long_tasks, short_tasks; // indices into ta: chains of > 16 columns (masters only) / the rest
   std::atomic<int> abort{0};
   std::atomic<int> progress[2];
   // phase C (back substitution): y_i -= sum over the separator rows m of L_mi^T x_m for the rows i of the halves, in
   // chunks of rows -- after the separator rows' x are known (goC: 0 wait, 1 go, 2 skip)
   std::vector<std::pair<int, int>> tc;
   std::atomic<int> goC{0}, nextC{0}, doneC{0};
+  double t_start = 0.0; // (SAGE_DEBUG_TIMING)
+  int dbg_waits[64] = {};
 };
 
 static void sep_job_build(SepJob &J)
@@ -2088,8 +2127,40 @@ static void sep_job_build(SepJob &J)
     }
   // longest first: the long arrow rows start early, the short middle-separator rows fill the gaps
   std::stable_sort(J.ta.begin(), J.ta.end(), [](const SepTaskA &x, const SepTaskA &y) { return x.j1 - x.j0 > y.j1 - y.j0; });
+  {
+    // pair long chains of the same half and range until they fit the fast threads (the pool workers on the caller's L3
+    // domain + the caller and the second half's helper join only after their halves: not counted)
+    const int fast = g_fast_pool_threads.load(std::memory_order_acquire);
+    auto is_long = [&](const SepTaskA &a) { return a.j1 - a.j0 > 16; };
+    int n_long = 0;
+    for (auto &a : J.ta)
+      n_long += is_long(a) ? 1 : 0;
+    if (fast > 0 && !sage::env_flag("SAGE_SOLVE_NO_PAIRING"))
+      for (size_t t = 0; t < J.ta.size() && n_long > fast; ++t)
+      {
+        SepTaskA &a = J.ta[t];
+        if (!is_long(a) || a.slave || a.partner >= 0)
+          continue;
+        for (size_t u = J.ta.size(); u-- > t + 1;) // (the last rows first: they are the ones that used to end up off-domain)
+        {
+          SepTaskA &b = J.ta[u];
+          if (is_long(b) && !b.slave && b.partner < 0 && b.half == a.half && b.j0 >= a.j0 && b.j1 == a.j1)
+          {
+            a.partner = (int)u;
+            b.slave = true;
+            --n_long;
+            break;
+          }
+        }
+      }
+    for (size_t t = 0; t < J.ta.size(); ++t)
+      if (!J.ta[t].slave)
+        (is_long(J.ta[t]) ? J.long_tasks : J.short_tasks).push_back((int)t);
+  }
+  // (i2 == i, r05: the row's own  sum_k L_ik L_ik^T  -- its share of the diagonal block -- as pair products too: it is not on
+  //  the chain's recurrence, and one product less per column lets the arrow-row chains keep closer to the halves)
   for (int i = sep0; i < K; ++i)
-    for (int i2 = sep0; i2 < i; ++i2)
+    for (int i2 = sep0; i2 <= i; ++i2)
       for (int h = 0; h < 2; ++h)
       {
         int a, b, a2, b2;
@@ -2163,14 +2234,16 @@ static inline __attribute__((always_inline)) void sep_run_a(SepJob &J, int t)
   const BlockEnvelope &E = *J.E;
   double *T = J.T, *X = J.X, *y = J.y;
   const SepTaskA &a = J.ta[t];
-  const int i = a.row;
   auto afirst = [&](int r) { return E.a_cnt ? E.a_first[r] : 0; };
   auto acnt = [&](int r) { return E.a_cnt ? E.a_cnt[r] : 0; };
   auto has = [&](int r, int c) { return (c >= E.row_first[r] && c <= r) || (c >= afirst(r) && c < afirst(r) + acnt(r)); };
   auto blk = [&](int r, int c) {
     return T + (size_t)(c < E.row_first[r] ? E.a_off[r] + c - E.a_first[r] : E.row_off[r] + c - E.row_first[r]) * BB;
   };
-  double *Sd = J.Sd.data() + (size_t)t * BB, *wd = J.wd.data() + (size_t)t * BP;
+  // the rows this thread carries: the task's own and, for a paired chain, its partner's (same half, same columns)
+  const int rows[2] = {a.row, a.partner >= 0 ? J.ta[a.partner].row : -1};
+  const int row_j0[2] = {a.j0, a.partner >= 0 ? J.ta[a.partner].j0 : 0}; // (a partner may join at a later column)
+  double *wds[2] = {J.wd.data() + (size_t)t * BP, a.partner >= 0 ? J.wd.data() + (size_t)a.partner * BP : nullptr};
   RowPrefetch pf{nullptr, nullptr};
   for (int j = a.j0; j < a.j1; ++j)
   {
@@ -2182,39 +2255,59 @@ static inline __attribute__((always_inline)) void sep_run_a(SepJob &J, int t)
       if ((++spins & 0xff) == 0 && J.abort.load(std::memory_order_acquire))
         return;
     }
-    if (E.ready) // this block of row i has arrived from the device
-    {
-      const volatile unsigned *f = E.ready + (blk(i, j) - T) / BB;
-      const double t0 = mono_seconds();
-      spins = 0;
-      while (*f != E.epoch)
-      {
-        __builtin_ia32_pause();
-        if ((++spins & 0xfff) == 0 && (J.abort.load(std::memory_order_acquire) || mono_seconds() - t0 > 2.0))
-        {
-          J.abort.store(2, std::memory_order_release);
-          return;
-        }
-      }
-      std::atomic_thread_fence(std::memory_order_acquire);
-    }
-    double *CT = blk(i, j);
+    if (spins)
+      ++J.dbg_waits[t & 63]; // (SAGE_DEBUG_TIMING: columns at which this chain had caught up with its half)
     if (j + 1 < a.j1)
     {
-      pf.p = reinterpret_cast<const char *>(blk(i, j + 1));
-      pf.end = pf.p + BB * sizeof(double);
+      // the half's row j + 1 (its blocks are contiguous in the storage) and its inverse: asked for now, used next column
+      const int r1 = j + 1;
+      pf.p2 = reinterpret_cast<const char *>(T + (size_t)E.row_off[r1] * BB);
+      pf.end2 = pf.p2 + (size_t)(r1 - E.row_first[r1] + 1) * BB * sizeof(double);
+      pf.p3 = reinterpret_cast<const char *>(X + (size_t)r1 * BB);
+      pf.end3 = pf.p3 + BB * sizeof(double);
     }
-    for (int k = std::max(a.j0, (int)E.row_first[j]); k < j; ++k) // (row j is a half row: its columns are [row_first[j], j])
-      if (has(j, k))
-        tn_sub<NV>(CT, blk(j, k), blk(i, k), false, pf);
-    apply_inverse<NV>(CT, X + (size_t)j * BB);
-    tn_sub<NV>(Sd, CT, CT, true, pf);
-    const double *yk = y + (size_t)j * BP;
-    for (int tt = 0; tt < BP; ++tt)
+    for (int q = 0; q < 2 && rows[q] >= 0; ++q)
     {
-      const double f = yk[tt];
-      for (int r = 0; r < BP; ++r)
-        wd[r] -= f * CT[tt * BP + r];
+      const int i = rows[q];
+      if (j < row_j0[q])
+        continue;
+      if (E.ready && E.fill && E.fill[(blk(i, j) - T) / BB])
+        std::memset(blk(i, j), 0, BB * sizeof(double)); // structural fill: not delivered, zeroed at its first touch
+      else if (E.ready) // this block of row i has arrived from the device
+      {
+        const volatile unsigned *f = E.ready + (blk(i, j) - T) / BB;
+        const double t0 = mono_seconds();
+        spins = 0;
+        while (*f != E.epoch)
+        {
+          __builtin_ia32_pause();
+          if ((++spins & 0xfff) == 0 && (J.abort.load(std::memory_order_acquire) || mono_seconds() - t0 > 2.0))
+          {
+            J.abort.store(2, std::memory_order_release);
+            return;
+          }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+      }
+      double *CT = blk(i, j);
+      if (j + 1 < a.j1)
+      {
+        pf.p = reinterpret_cast<const char *>(blk(i, j + 1));
+        pf.end = pf.p + BB * sizeof(double);
+      }
+      for (int k = std::max(row_j0[q], (int)E.row_first[j]); k < j; ++k) // (row j is a half row: its columns are [row_first[j], j])
+        if (has(j, k))
+          tn_sub<NV>(CT, blk(j, k), blk(i, k), false, pf);
+      apply_inverse<NV>(CT, X + (size_t)j * BB);
+      // (the diagonal share  sum_j CT_j CT_j^T  is a pair product of phase B since r05: not on this chain's recurrence)
+      const double *yk = y + (size_t)j * BP;
+      double *wd = wds[q];
+      for (int tt = 0; tt < BP; ++tt)
+      {
+        const double f = yk[tt];
+        for (int r = 0; r < BP; ++r)
+          wd[r] -= f * CT[tt * BP + r];
+      }
     }
   }
 }
@@ -2232,7 +2325,7 @@ static inline __attribute__((always_inline)) void sep_run_b(SepJob &J, int t)
   double *P = J.Pp.data() + (size_t)t * BB;
   RowPrefetch pf{nullptr, nullptr};
   for (int k = b.k0; k < b.k1; ++k)
-    tn_sub<NV>(P, blk(b.i2, k), blk(b.i, k), false, pf);
+    tn_sub<NV>(P, blk(b.i2, k), blk(b.i, k), b.i2 == b.i, pf); // (a row with itself: the upper triangle is all the factorisation reads)
 }
 
 // the separator block: rows [sep0, K) with the partial sums of the tasks folded in; then their back substitution
@@ -2249,7 +2342,8 @@ static inline __attribute__((always_inline)) int sep_finish(SepJob &J)
   RowPrefetch pf{nullptr, nullptr};
   for (int i = sep0; i < K; ++i)
   {
-    if (E.ready && !wait_row_tickets(E, i))
+    // (the blocks of the columns < sep0 went through the arrow-row tasks one by one)
+    if (E.ready && !wait_row_tickets(E, i, T, sep0))
       return -2;
     const int c0 = std::max((int)E.row_first[i], sep0);
     for (int j = c0; j < i; ++j)
@@ -2270,12 +2364,17 @@ static inline __attribute__((always_inline)) int sep_finish(SepJob &J)
     double w[BP];
     for (int r = 0; r < BP; ++r)
       w[r] = y[(size_t)i * BP + r];
+    for (size_t t = 0; t < J.tb.size(); ++t) // the row's own pair products (fixed order: deterministic)
+      if (J.tb[t].i == i && J.tb[t].i2 == i)
+      {
+        const double *P = J.Pp.data() + t * BB;
+        for (int o = 0; o < BB; ++o)
+          S[o] += P[o];
+      }
     for (size_t t = 0; t < J.ta.size(); ++t)
       if (J.ta[t].row == i)
       {
-        const double *Sd = J.Sd.data() + t * BB, *wd = J.wd.data() + t * BP;
-        for (int o = 0; o < BB; ++o)
-          S[o] += Sd[o];
+        const double *wd = J.wd.data() + t * BP;
         for (int r = 0; r < BP; ++r)
           w[r] += wd[r];
       }
@@ -2317,19 +2416,37 @@ __attribute__((target_clones("avx512f", "avx2", "default"))) static void sep_run
 __attribute__((target_clones("avx512f", "avx2", "default"))) static int sep_finish_40(SepJob &J) { return sep_finish<5>(J); }
 __attribute__((target_clones("avx512f", "avx2", "default"))) static int sep_finish_24(SepJob &J) { return sep_finish<3>(J); }
 
-// take tasks until none is left (called by the pool's workers, the helper after its half, and the caller)
+// take tasks until none is left (called by the pool's workers, the helper after its half, and the caller).  Long chains go
+// to the threads of the caller's L3 domain only (tl_fast_thread), longest first; everybody takes the short ones.
 static void sep_work(SepJob &J)
 {
   const bool b40 = J.E->Bp == 40;
   const int nA = (int)J.ta.size(), nB = (int)J.tb.size();
-  for (;;)
-  {
-    const int t = J.nextA.fetch_add(1, std::memory_order_acq_rel);
-    if (t >= nA)
-      break;
+  static const bool dbg_a = sage::env_flag("SAGE_DEBUG_TIMING");
+  auto run_a = [&](int t) {
+    const double ta0 = dbg_a ? mono_seconds() : 0.0;
     if (!J.abort.load(std::memory_order_acquire))
       b40 ? sep_run_a_40(J, t) : sep_run_a_24(J, t);
-    J.doneA.fetch_add(1, std::memory_order_acq_rel);
+    if (dbg_a && J.ta[t].j1 - J.ta[t].j0 > 16)
+      fprintf(stderr, "[sage arrow task] row %d%s half %d cols %d: %.0f us on cpu %d (ends %.0f us after job start; caught up with its half at %d columns)\n",
+              J.ta[t].row, J.ta[t].partner >= 0 ? " (+ a partner row)" : "", J.ta[t].half, J.ta[t].j1 - J.ta[t].j0,
+              1e6 * (mono_seconds() - ta0), sched_getcpu(), 1e6 * (mono_seconds() - J.t_start), J.dbg_waits[t & 63]);
+    J.doneA.fetch_add(J.ta[t].partner >= 0 ? 2 : 1, std::memory_order_acq_rel);
+  };
+  if (tl_fast_thread)
+    for (;;)
+    {
+      const int q = J.nextLong.fetch_add(1, std::memory_order_acq_rel);
+      if (q >= (int)J.long_tasks.size())
+        break;
+      run_a(J.long_tasks[q]);
+    }
+  for (;;)
+  {
+    const int q = J.nextA.fetch_add(1, std::memory_order_acq_rel);
+    if (q >= (int)J.short_tasks.size())
+      break;
+    run_a(J.short_tasks[q]);
   }
   while (J.doneA.load(std::memory_order_acquire) < nA) // phase B reads the rows phase A completes
     __builtin_ia32_pause();
@@ -2381,8 +2498,9 @@ struct SepPool
   std::atomic<bool> busy{false};
   std::atomic<SepJob *> job{nullptr};
   std::vector<pthread_t> tids;
+  std::vector<char> fast; // per worker: pinned to a core of the caller's L3 domain (place_pool_near)
   int near_cpu = -1;
-  void loop()
+  void loop(int idx)
   {
     unsigned seen = posted.load(std::memory_order_acquire);
     for (;;)
@@ -2407,6 +2525,7 @@ struct SepPool
           if (open.load(std::memory_order_seq_cst))
           {
             SepJob *j = job.load(std::memory_order_acquire);
+            tl_fast_thread = (size_t)idx < fast.size() ? fast[idx] != 0 : true;
             sep_work(*j);
             sep_work_c(*j, true);
           }
@@ -2436,7 +2555,7 @@ static SepPool *sep_pool()
     SepPool *q = new SepPool;
     for (int i = 0; i < n; ++i)
     {
-      std::thread th([q] { q->loop(); });
+      std::thread th([q, i] { q->loop(i); });
       q->tids.push_back(th.native_handle());
       th.detach();
     }
@@ -2730,8 +2849,16 @@ static void place_pool_near(SepPool *q, int cpu)
   q->near_cpu = cpu;
   // cores[0..2] are the helpers'; more workers than cores left in the CCX continue on the other cores of the NUMA node
   const std::vector<int> &cores = ccx_cores_of(cpu, true);
+  const size_t n_ccx = ccx_cores_of(cpu, false).size();
+  q->fast.assign(q->tids.size(), 0);
+  int n_fast = 0;
   for (size_t t = 0; t < q->tids.size() && t + 3 < cores.size(); ++t)
+  {
     pin_one(q->tids[t], cores[t + 3]);
+    q->fast[t] = t + 3 < n_ccx ? 1 : 0;
+    n_fast += q->fast[t];
+  }
+  g_fast_pool_threads.store(n_fast, std::memory_order_release);
 }
 
 void block_chol_arm(bool with_pool)
@@ -3003,6 +3130,7 @@ int block_chol_solve_tr(const BlockEnvelope &E0, double *T, double *X, double *y
   {
     job.E = &E; job.T = T; job.X = X; job.y = y;
     sep_job_build(job);
+    job.t_start = mono_seconds();
     E.progress = job.progress;
     pool = sep_pool();
     if (pool && pool->armed.load(std::memory_order_acquire))
@@ -3071,6 +3199,9 @@ int block_chol_solve_tr(const BlockEnvelope &E0, double *T, double *X, double *y
     sep_work(job); // the caller takes tasks too (all of them when no pool thread is around)
     while (job.doneB.load(std::memory_order_acquire) < (int)job.tb.size())
       CholHelper::cpu_relax();
+    if (dbg)
+      fprintf(stderr, "[sage block chol] arrow tasks (%zu row chains, %zu pair products) done %.0f us after the halves\n",
+              job.ta.size(), job.tb.size(), 1e6 * (mono_seconds() - tp[2]));
     if (rc == 0 && job.abort.load(std::memory_order_acquire))
       rc = -2;
     if (rc == 0)

@@ -53,6 +53,11 @@ struct BlockEnvelope
   // delivered by the device; a row is only touched after all its blocks have arrived
   const volatile unsigned *ready = nullptr;
   unsigned epoch = 0;
+  // optional, with `ready`: fill[b] != 0 marks a block that is structural fill-in (no link behind it, off the diagonal):
+  // the device does not deliver it -- whoever touches it first zeroes it instead of waiting for a ticket (r05: the arrow
+  // rows of a loop-closure plan are ~1500 such blocks, 19 MB of zeros that used to cross PCIe behind everything else while
+  // the arrow-row tasks waited for them)
+  const uint8_t *fill = nullptr;
   // optional: called before row i is waited for / touched (the pipelined window solve launches the device work that
   // produces the next rows from here); a non-zero return aborts the factorisation with -2
   int (*before_row)(void *user, int row) = nullptr;

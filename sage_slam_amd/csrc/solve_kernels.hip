@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void solve_scatter_kernel(const SolvePlan P, c
                                                             const SolvePriors pri, double damp, int transposed,
                                                             double *__restrict__ L, double *__restrict__ y,
                                                             const int32_t *__restrict__ order, unsigned *flags,
-                                                            unsigned epoch, int first, int count)
+                                                            unsigned epoch, int first, int count, int deliver_fill)
 {
   const int tid = threadIdx.x;
   const int B = P.B, Bp = P.Bp, BB = B * B;
@@ -92,6 +92,8 @@ __global__ __launch_bounds__(256) void solve_scatter_kernel(const SolvePlan P, c
     const int i = P.blk_row[b], j = P.blk_col[b], srcf = P.blk_src[b];
     const int src = srcf < 0 ? -1 : (srcf & 0x3fffffff);
     const bool flip = srcf >= 0 && (srcf & 0x40000000);
+    if (flags && src < 0 && i != j && !deliver_fill)
+      continue; // structural fill-in: the host zeroes it at its first touch (BlockEnvelope::fill) -- nothing to deliver
     const int kf = P.perm[i]; // keyframe of this block row
     const double *diag = packed + (size_t)kf * BB;
     const double *lnk = packed + (size_t)P.K * BB + (size_t)(src < 0 ? 0 : src) * BB;
@@ -329,6 +331,7 @@ struct DeviceSolver
   unsigned epoch = 0;
   int scatter_wgs = 32;
   std::vector<int32_t> h_pos, h_perm; // elimination order (host copies)
+  std::vector<uint8_t> h_fill;        // per block: structural fill-in (not delivered by the scatter kernel: BlockEnvelope::fill)
   std::vector<int32_t> h_pair_off;    // order-list offset of "pair row" t (row t of the first half + row t of the second);
                                       // entry T = start of the separator rows, entry T+1 = nblk
 };
@@ -438,7 +441,12 @@ int solver_create(DeviceSolver **out, int K, int B, int VS, const std::vector<st
   S->d_order = base + o_ord;
   S->h_pos = pos;
   S->h_perm = perm;
+  S->h_fill.assign((size_t)nblk, 0);
+  for (int b = 0; b < nblk; ++b)
+    S->h_fill[b] = (blk_src[b] < 0 && blk_row[b] != blk_col[b]) ? 1 : 0;
   S->h_pair_off = pair_off;
+  if (const char *e = getenv("SAGE_SCATTER_WGS")) // (diagnostic: workgroups of the scatter kernel)
+    S->scatter_wgs = std::max(1, atoi(e));
   std::memset(S->h_pinned, 0, S->h_bytes);
   *out = S;
   return SAGE_OK;
@@ -491,7 +499,8 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
       S->epoch = 1;
     hipLaunchKernelGGL(solve_scatter_kernel, dim3(std::min(S->scatter_wgs, S->nblk)), dim3(256), 0, stream, S->plan,
                        packed_dev, vars0, S->VS, CS, pri, damp, 1, reinterpret_cast<double *>(S->h_T),
-                       reinterpret_cast<double *>(S->h_y), S->d_order, S->h_flags, S->epoch, 0, S->nblk);
+                       reinterpret_cast<double *>(S->h_y), S->d_order, S->h_flags, S->epoch, 0, S->nblk,
+                       sage::env_flag("SAGE_SCATTER_FILL") ? 1 : 0); // (diagnostic: ship the zero fill blocks as r04 did)
     if ((eh = hipGetLastError()) != hipSuccess)
       return (int)eh;
     // the retract right behind the scatter: it waits on the device for this thread's word (solve_retract_kernel)
@@ -524,6 +533,7 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
     env.col_ptr = S->h_col_ptr.data(); env.col_rows = S->h_col_rows.data();
     env.n1 = S->n1; env.n2 = S->n2;
     env.ready = S->h_flags; env.epoch = S->epoch;
+    env.fill = S->h_fill.data();
     const int bad = block_chol_solve_tr(env, reinterpret_cast<double *>(S->h_T), S->h_X.data(),
                                         reinterpret_cast<double *>(S->h_y));
     const auto t2 = std::chrono::steady_clock::now();

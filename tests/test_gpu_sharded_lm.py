@@ -137,3 +137,52 @@ def test_schur_sharded_lm_step_matches_single_rank(tmp_path, world):
     for r in range(world):
         v = np.load(tmp_path / f"svars_{r}.npy")
         assert np.abs(v - v_ref).max() < 2e-5 * max(1.0, np.abs(v_ref).max())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# r05: peer emulation (sage_window_emulate_peers; bench.py's shard_emulation): ONE rank of a 3-rank job on one device, a
+# one-rank RCCL communicator on its stream, the other ranks' share of every reduced system from a table that was computed
+# beforehand at the iterates of the job's own trajectory -- the rank must walk the single-rank window's trajectory
+# (same accept / reject decisions, errors and iterates to the reduction's rounding)
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rank", [0, 2])
+def test_emulated_peers_walk_the_real_trajectory(rank):
+    import torch
+    from sage_slam_amd import capi
+    w = _make()
+    K, world, steps = len(w.keyframes), 3, 3
+    classic = capi.lm_config_default(); classic.max_inner_evals = 1; classic.linearize_at_candidate = -1
+    full = capi.Window(w)
+    st = capi.SageLmState()
+    table, xs, ref = [], [], []
+    for i in range(steps + 1):
+        full.linearize()
+        torch.cuda.synchronize()
+        table.append(full.packed_tensor().clone())
+        xs.append([full.get_keyframe(k) for k in range(K)])
+        if i < steps:
+            full.lm_step(st, classic)
+            assert st.accepted == 1
+            ref.append((st.error, st.candidate_error, int(st.accepted), st.damp))
+    v_ref = _all_vars(full, K)
+    full.close()
+    comm = capi.rccl_comm_create(capi.rccl_unique_id(), 0, 1)
+    sh = capi.Window(w, rank=rank, world=world)
+    rest = torch.empty(steps + 1, sh.packed_count, dtype=torch.float64, device="cuda")
+    for i in range(steps + 1):
+        for k in range(K):
+            sh.set_keyframe(k, *xs[i][k])
+        sh.linearize()
+        torch.cuda.synchronize()
+        rest[i] = table[i] - sh.packed_tensor()
+    sh.reset()
+    sh.use_rccl(comm)
+    sh.emulate_peers(rest)
+    got = _run(sh, capi, steps, at_candidate=None)            # automatic: the one-collective sequence of a reduced window
+    ref = np.array(ref)
+    assert np.array_equal(got[:, 2], ref[:, 2]) and np.array_equal(got[:, 3], ref[:, 3])
+    np.testing.assert_allclose(got[:, :2], ref[:, :2], rtol=2e-6)
+    v = _all_vars(sh, K)
+    assert np.abs(v - v_ref).max() < 2e-5 * max(1.0, np.abs(v_ref).max())
+    sh.close()
+    capi.rccl_comm_destroy(comm)
