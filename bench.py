@@ -743,6 +743,16 @@ def main():
                 out["shard_emulation"] = shard_emulation(capi, torch, win, win_h, er, ew, args.steps, RESTART, ms_per_step)
             except Exception as exc:            # the headline line must not depend on the emulation
                 out["shard_emulation"] = {"error": repr(exc)}
+            se = out["shard_emulation"]
+            if classic_seq and se.get("one_gpu_ms_per_step_same_sequence", 0) == se.get("one_gpu_ms_per_step_same_sequence", float("nan")):
+                # the same window with the engine's other LM sequence (SageLmConfig.linearize_at_candidate = 1: the candidate is
+                # evaluated by the linearize kernels, an accepted iteration has no separate error pass; identical iterates and
+                # decisions) -- reported next to `value`, which stays on the classic sequence of SURVEY s8d
+                ms_c = se["one_gpu_ms_per_step_same_sequence"]
+                out["linearize_at_candidate"] = {"ms_per_step": ms_c, "lm_iters_per_sec": 1e3 / ms_c,
+                                                 "value": residuals_per_step / (ms_c * 1e-3) / 1e6, "unit": "Mresiduals/s",
+                                                 "note": "median of the iterations 2..3 after each restart (every timed iteration "
+                                                         "accepted); a rejected iteration costs a linearize here instead of an error pass"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(win_h)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
