@@ -2500,6 +2500,7 @@ struct SepPool
   std::vector<pthread_t> tids;
   std::vector<char> fast; // per worker: pinned to a core of the caller's L3 domain (place_pool_near)
   int near_cpu = -1;
+  size_t near_off = 0;
   void loop(int idx)
   {
     unsigned seen = posted.load(std::memory_order_acquire);
@@ -2625,7 +2626,7 @@ static std::atomic<long long> g_lookahead_count{0};
 static bool rows_can_pipe(const BlockEnvelope &E, int lo, int hi)
 {
   static const bool off = sage::env_flag("SAGE_SOLVE_NO_LOOKAHEAD");
-  if (off || E.before_row || !E.pipe || hi - lo < 4)
+  if (off || E.no_lookahead || E.before_row || !E.pipe || hi - lo < 4)
     return false;
   for (int i = lo; i < hi; ++i)
     if ((E.a_cnt && E.a_cnt[i]) || E.row_first[i] < lo)
@@ -2842,33 +2843,47 @@ static void place_helper_near(CholHelper *h, int cpu, int slot)
     pin_one(h->tid, cores[slot]);
 }
 
-static void place_pool_near(SepPool *q, int cpu)
+static void place_pool_near(SepPool *q, int cpu, size_t off)
 {
-  if (cpu < 0 || cpu == q->near_cpu)
+  if (cpu < 0 || (cpu == q->near_cpu && off == q->near_off))
     return;
   q->near_cpu = cpu;
-  // cores[0..2] are the helpers'; more workers than cores left in the CCX continue on the other cores of the NUMA node
+  q->near_off = off;
+  // cores[0..off) are the helpers' (off = 3: second half + two look-ahead stages; 1: no look-ahead stages); more workers than
+  // cores left in the CCX continue on the other cores of the NUMA node
   const std::vector<int> &cores = ccx_cores_of(cpu, true);
   const size_t n_ccx = ccx_cores_of(cpu, false).size();
   q->fast.assign(q->tids.size(), 0);
   int n_fast = 0;
-  for (size_t t = 0; t < q->tids.size() && t + 3 < cores.size(); ++t)
+  for (size_t t = 0; t < q->tids.size() && t + off < cores.size(); ++t)
   {
-    pin_one(q->tids[t], cores[t + 3]);
-    q->fast[t] = t + 3 < n_ccx ? 1 : 0;
+    pin_one(q->tids[t], cores[t + off]);
+    q->fast[t] = t + off < n_ccx ? 1 : 0;
     n_fast += q->fast[t];
   }
   g_fast_pool_threads.store(n_fast, std::memory_order_release);
 }
 
-void block_chol_arm(bool with_pool)
+bool block_chol_arm(bool with_pool, int long_arrow_chains)
 {
-  for (int idx = 0; idx < 3; ++idx)
+  static const bool no_la_env = sage::env_flag("SAGE_SOLVE_NO_LOOKAHEAD");
+  const int cpu = sched_getcpu();
+  // r05: a loop-closure plan's long arrow-row chains run ~30 % slower on another L3 domain and the separator then waits for
+  // them (config 5: six chains, four cores left next to the two halves and their look-ahead stages: 1.1-1.4 ms).  When the
+  // chains fit the domain only without the look-ahead stages, those two cores go to the chains: the halves take twice as
+  // long per row, but everything ends together (config 5 solve phase 3.9 -> 3.5 ms)
+  bool no_la = no_la_env;
+  if (!no_la && with_pool && long_arrow_chains > 0 && !sage::env_flag("SAGE_SOLVE_KEEP_LOOKAHEAD"))
+  {
+    const int n_ccx = (int)ccx_cores_of(cpu, false).size(); // cores of the domain without the caller's
+    no_la = long_arrow_chains > n_ccx - 3 && long_arrow_chains <= n_ccx - 1;
+  }
+  for (int idx = 0; idx < (no_la ? 1 : 3); ++idx)
   {
     CholHelper *h = chol_helper(idx);
     if (h && !h->armed.load(std::memory_order_acquire))
     {
-      place_helper_near(h, sched_getcpu(), idx);
+      place_helper_near(h, cpu, idx);
       {
         std::lock_guard<std::mutex> lk(h->mu);
         h->armed.store(true, std::memory_order_release);
@@ -2877,17 +2892,35 @@ void block_chol_arm(bool with_pool)
     }
   }
   if (!with_pool)
-    return;
+    return no_la;
   SepPool *q = sep_pool();
   if (q && !q->armed.load(std::memory_order_acquire))
   {
-    place_pool_near(q, sched_getcpu());
+    place_pool_near(q, cpu, no_la ? 1 : 3);
     {
       std::lock_guard<std::mutex> lk(q->mu);
       q->armed.store(true, std::memory_order_release);
     }
     q->cv.notify_all();
   }
+  return no_la;
+}
+
+// rows of the separator part whose ranges run far along a half (> 16 columns): the chains the pool's fast threads carry
+int block_plan_long_arrow_chains(const BlockEnvelope &E)
+{
+  if (E.n1 <= 0 || E.n2 <= 0 || !E.a_cnt)
+    return 0;
+  const int sep0 = E.n1 + E.n2;
+  int n = 0;
+  for (int i = sep0; i < E.K; ++i)
+  {
+    if (E.a_cnt[i] > 16)
+      ++n;
+    if (sep0 - std::min((int)E.row_first[i], sep0) > 16)
+      ++n;
+  }
+  return n;
 }
 
 bool block_plan_has_arrow_rows(const BlockEnvelope &E)
@@ -3357,7 +3390,7 @@ extern "C" int sage_block_solve(const double *packed, int K, int nlinks, const i
     env.n1 = bp.n1; env.n2 = bp.n2;
     env.col_ptr = bp.col_ptr.data(); env.col_rows = bp.col_rows.data();
     if (bp.n1 > 0)
-      sage::block_chol_arm(sage::block_plan_has_arrow_rows(env));
+      env.no_lookahead = sage::block_chol_arm(sage::block_plan_has_arrow_rows(env), sage::block_plan_long_arrow_chains(env));
     const int rcf = sage::block_chol_solve_tr(env, T.data(), X.data(), y.data());
     if (dbg2)
       fprintf(stderr, "[sage block_solve] fixed-block Cholesky + substitution %.3f ms\n",

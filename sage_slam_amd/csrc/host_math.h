@@ -58,6 +58,9 @@ struct BlockEnvelope
   // rows of a loop-closure plan are ~1500 such blocks, 19 MB of zeros that used to cross PCIe behind everything else while
   // the arrow-row tasks waited for them)
   const uint8_t *fill = nullptr;
+  // set from block_chol_arm's return value: the halves run WITHOUT their look-ahead stages, whose two cores carry arrow-row
+  // chains instead (loop-closure plans with more long chains than the halves' L3 domain has cores left: r05)
+  bool no_lookahead = false;
   // optional: called before row i is waited for / touched (the pipelined window solve launches the device work that
   // produces the next rows from here); a non-zero return aborts the factorisation with -2
   int (*before_row)(void *user, int row) = nullptr;
@@ -97,7 +100,11 @@ int block_chol_partial_back(const BlockEnvelope &env, double *T, double *X, doub
 // Wake the helper thread ahead of a block_chol_solve_tr call with n1 > 0 (it then spins for the job for a few
 // milliseconds at most); call it when the system is about to be produced, e.g. before waiting on the D2H copy.
 // with_pool: also wake the worker pool that shares the long separator ("arrow") rows of a loop-closure plan.
-void block_chol_arm(bool with_pool = false);
+// Returns true when the solve should run its halves without look-ahead stages (BlockEnvelope::no_lookahead): a plan whose
+// long arrow-row chains (block_plan_long_arrow_chains) do not fit the cores the look-ahead stages leave free in the caller's
+// L3 domain but do fit with those two cores.
+bool block_chol_arm(bool with_pool = false, int long_arrow_chains = 0);
+int block_plan_long_arrow_chains(const BlockEnvelope &env);
 // true when the separator rows of the plan reach far into the halves (cover keyframes of loop closures): the
 // factorisation then wants the worker pool
 bool block_plan_has_arrow_rows(const BlockEnvelope &env);

@@ -483,6 +483,7 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
     // tickets each one, so the host works on row 0 while the rest is still crossing PCIe (no D2H copy, no stream sync).
     static const bool dbgt = sage::env_flag("SAGE_DEBUG_TIMING");
     hipError_t eh;
+    bool no_lookahead = false;
     if (S->n1 > 0)
     {
       // the helper core (and, for loop-closure plans with long separator rows, the worker pool) wakes up while this
@@ -492,7 +493,7 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
       pe.row_first = S->h_row_first.data(); pe.row_off = S->h_row_off.data();
       pe.a_first = S->h_a_first.data(); pe.a_cnt = S->h_a_cnt.data(); pe.a_off = S->h_a_off.data();
       pe.n1 = S->n1; pe.n2 = S->n2;
-      block_chol_arm(block_plan_has_arrow_rows(pe));
+      no_lookahead = block_chol_arm(block_plan_has_arrow_rows(pe), block_plan_long_arrow_chains(pe));
     }
     S->epoch += 1;
     if (S->epoch == 0) // wrapped: 0 is the "never written" value
@@ -534,6 +535,7 @@ int solver_run(DeviceSolver *S, hipStream_t stream, const double *packed_dev, co
     env.n1 = S->n1; env.n2 = S->n2;
     env.ready = S->h_flags; env.epoch = S->epoch;
     env.fill = S->h_fill.data();
+    env.no_lookahead = no_lookahead;
     const int bad = block_chol_solve_tr(env, reinterpret_cast<double *>(S->h_T), S->h_X.data(),
                                         reinterpret_cast<double *>(S->h_y));
     const auto t2 = std::chrono::steady_clock::now();
