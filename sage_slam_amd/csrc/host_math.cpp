@@ -2072,9 +2072,11 @@ struct SepTaskA
   int partner = -1;
   bool slave = false;
 };
-// set by the calling thread's role: pool workers outside the caller's L3 domain do not take the long arrow-row chains
-static thread_local bool tl_fast_thread = true;
-static std::atomic<int> g_fast_pool_threads{-1}; // pool workers on the caller's L3 domain (-1: unknown / no pool)
+// Which long arrow-row chains a thread takes: domain 0 = the caller's L3 domain (first half), 1 = the second half's own L3
+// domain of a two-domain placement, -1 = a pool worker elsewhere on the node (short tasks and pair products only)
+static thread_local int tl_domain = 0;
+static std::atomic<int> g_domain_threads[2] = {{-1}, {0}}; // pool workers per domain (-1: unknown / no pool)
+static std::atomic<bool> g_two_domains{false};             // the second half, its look-ahead and its chains sit on domain 1
 struct SepTaskB
 {
   int i, i2, half, k0, k1; // common columns [k0, k1), i2 < i
@@ -2088,8 +2090,8 @@ struct SepJob
   std::vector<SepTaskB> tb;
   std::vector<double> Sd, wd, Pp; // [ta][BB], [ta][Bp], [tb][BB]
   std::atomic<int> nextA{0}, doneA{0}, nextB{0}, doneB{0};
-  std::atomic<int> nextLong{0};
-  std::vector<int> long_tasks, short_tasks; // indices into ta: chains of > 16 columns (masters only) / the rest
+  std::atomic<int> nextLong[2];
+  std::vector<int> long_tasks[2], short_tasks; // indices into ta: chains of > 16 columns by half (masters only) / the rest
   std::atomic<int> abort{0};
   std::atomic<int> progress[2];
   // phase C (back substitution): y_i -= sum over the separator rows m of L_mi^T x_m for the rows i of the halves, in
@@ -2130,16 +2132,24 @@ static void sep_job_build(SepJob &J)
   {
     // pair long chains of the same half and range until they fit the fast threads (the pool workers on the caller's L3
     // domain + the caller and the second half's helper join only after their halves: not counted)
-    const int fast = g_fast_pool_threads.load(std::memory_order_acquire);
+    const bool two = g_two_domains.load(std::memory_order_acquire);
+    const int fast0 = g_domain_threads[0].load(std::memory_order_acquire), fast1 = g_domain_threads[1].load(std::memory_order_acquire);
     auto is_long = [&](const SepTaskA &a) { return a.j1 - a.j0 > 16; };
-    int n_long = 0;
+    int n_long[2] = {0, 0};
     for (auto &a : J.ta)
-      n_long += is_long(a) ? 1 : 0;
-    if (fast > 0 && !sage::env_flag("SAGE_SOLVE_NO_PAIRING"))
-      for (size_t t = 0; t < J.ta.size() && n_long > fast; ++t)
+      if (is_long(a))
+        ++n_long[a.half];
+    // capacity per half: its own domain's workers (two domains), or the one domain's workers shared by both halves
+    auto over = [&](int h) {
+      if (fast0 <= 0)
+        return false;
+      return two ? n_long[h] > std::max(1, h == 0 ? fast0 : fast1) : n_long[0] + n_long[1] > fast0;
+    };
+    if (!sage::env_flag("SAGE_SOLVE_NO_PAIRING"))
+      for (size_t t = 0; t < J.ta.size(); ++t)
       {
         SepTaskA &a = J.ta[t];
-        if (!is_long(a) || a.slave || a.partner >= 0)
+        if (!is_long(a) || a.slave || a.partner >= 0 || !over(a.half))
           continue;
         for (size_t u = J.ta.size(); u-- > t + 1;) // (the last rows first: they are the ones that used to end up off-domain)
         {
@@ -2148,14 +2158,22 @@ static void sep_job_build(SepJob &J)
           {
             a.partner = (int)u;
             b.slave = true;
-            --n_long;
+            --n_long[a.half];
             break;
           }
         }
       }
+    J.nextLong[0].store(0, std::memory_order_relaxed);
+    J.nextLong[1].store(0, std::memory_order_relaxed);
     for (size_t t = 0; t < J.ta.size(); ++t)
       if (!J.ta[t].slave)
-        (is_long(J.ta[t]) ? J.long_tasks : J.short_tasks).push_back((int)t);
+      {
+        if (is_long(J.ta[t]))
+          J.long_tasks[J.ta[t].half].push_back((int)t);
+        else
+          J.short_tasks.push_back((int)t);
+      }
+
   }
   // (i2 == i, r05: the row's own  sum_k L_ik L_ik^T  -- its share of the diagonal block -- as pair products too: it is not on
   //  the chain's recurrence, and one product less per column lets the arrow-row chains keep closer to the halves)
@@ -2417,7 +2435,7 @@ __attribute__((target_clones("avx512f", "avx2", "default"))) static int sep_fini
 __attribute__((target_clones("avx512f", "avx2", "default"))) static int sep_finish_24(SepJob &J) { return sep_finish<3>(J); }
 
 // take tasks until none is left (called by the pool's workers, the helper after its half, and the caller).  Long chains go
-// to the threads of the caller's L3 domain only (tl_fast_thread), longest first; everybody takes the short ones.
+// to the threads of the halves' L3 domains only (tl_domain >= 0), longest first; everybody takes the short ones.
 static void sep_work(SepJob &J)
 {
   const bool b40 = J.E->Bp == 40;
@@ -2433,14 +2451,23 @@ static void sep_work(SepJob &J)
               1e6 * (mono_seconds() - ta0), sched_getcpu(), 1e6 * (mono_seconds() - J.t_start), J.dbg_waits[t & 63]);
     J.doneA.fetch_add(J.ta[t].partner >= 0 ? 2 : 1, std::memory_order_acq_rel);
   };
-  if (tl_fast_thread)
-    for (;;)
+  if (tl_domain >= 0)
+  {
+    // its own half's chains first; then whatever is left of the other half's (a chain nobody has started is better run
+    // across domains than not at all: liveness does not depend on the placement)
+    const int first = g_two_domains.load(std::memory_order_acquire) ? (tl_domain & 1) : 0;
+    for (int pass = 0; pass < 2; ++pass)
     {
-      const int q = J.nextLong.fetch_add(1, std::memory_order_acq_rel);
-      if (q >= (int)J.long_tasks.size())
-        break;
-      run_a(J.long_tasks[q]);
+      const int h = pass == 0 ? first : 1 - first;
+      for (;;)
+      {
+        const int q = J.nextLong[h].fetch_add(1, std::memory_order_acq_rel);
+        if (q >= (int)J.long_tasks[h].size())
+          break;
+        run_a(J.long_tasks[h][q]);
+      }
     }
+  }
   for (;;)
   {
     const int q = J.nextA.fetch_add(1, std::memory_order_acq_rel);
@@ -2498,9 +2525,9 @@ struct SepPool
   std::atomic<bool> busy{false};
   std::atomic<SepJob *> job{nullptr};
   std::vector<pthread_t> tids;
-  std::vector<char> fast; // per worker: pinned to a core of the caller's L3 domain (place_pool_near)
+  std::vector<int> dom; // per worker: 0 / 1 = pinned to a core of the first / second half's L3 domain, -1 elsewhere (place_pool)
   int near_cpu = -1;
-  size_t near_off = 0;
+  int near_mode = -1;
   void loop(int idx)
   {
     unsigned seen = posted.load(std::memory_order_acquire);
@@ -2526,7 +2553,7 @@ struct SepPool
           if (open.load(std::memory_order_seq_cst))
           {
             SepJob *j = job.load(std::memory_order_acquire);
-            tl_fast_thread = (size_t)idx < fast.size() ? fast[idx] != 0 : true;
+            tl_domain = (size_t)idx < dom.size() ? dom[idx] : 0;
             sep_work(*j);
             sep_work_c(*j, true);
           }
@@ -2593,7 +2620,7 @@ struct CholHelper
   int lo = 0, hi = 0;
   std::thread th;
   pthread_t tid{};
-  int near_cpu = -1;
+  int near_cpu = -1, near_mode = -1;
   bool started = false;
   static void cpu_relax() { __builtin_ia32_pause(); }
   void loop();
@@ -2833,57 +2860,144 @@ static void pin_one(pthread_t t, int cpu)
   (void)pthread_setaffinity_np(t, sizeof(want), &want);
 }
 
-static void place_helper_near(CholHelper *h, int cpu, int slot)
+// cores of ANOTHER L3 domain of the caller's NUMA node (the next one with at least `want` free physical cores), or empty
+static std::vector<int> second_domain_cores_uncached(int cpu, size_t want);
+static std::vector<int> second_domain_cores(int cpu, size_t want)
 {
-  if (cpu < 0 || cpu == h->near_cpu)
-    return;
-  h->near_cpu = cpu;
-  const std::vector<int> &cores = ccx_cores_of(cpu, false);
-  if ((int)cores.size() > slot)
-    pin_one(h->tid, cores[slot]);
+  // (sysfs is read once per caller CPU and size: the arm call sits at the start of every solve)
+  static std::mutex mu;
+  static std::map<std::pair<int, size_t>, std::vector<int>> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find({cpu, want});
+  if (it != cache.end())
+    return it->second;
+  return cache.emplace(std::make_pair(cpu, want), second_domain_cores_uncached(cpu, want)).first->second;
+}
+static std::vector<int> second_domain_cores_uncached(int cpu, size_t want)
+{
+  char path[128];
+  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+  const std::vector<int> l3a = read_cpu_list(path);
+  cpu_set_t allowed;
+  if (l3a.empty() || sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
+    return {};
+  std::vector<int> seen = l3a;
+  for (int c : node_cpus_of(cpu))
+  {
+    if (std::find(seen.begin(), seen.end(), c) != seen.end() || c >= CPU_SETSIZE || !CPU_ISSET(c, &allowed))
+      continue;
+    snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", c);
+    const std::vector<int> l3b = read_cpu_list(path);
+    if (l3b.empty())
+      continue;
+    seen.insert(seen.end(), l3b.begin(), l3b.end());
+    std::vector<int> cores = sibling_free_cores(l3b, cpu, allowed);
+    if (cores.size() >= want)
+      return cores;
+  }
+  return {};
 }
 
-static void place_pool_near(SepPool *q, int cpu, size_t off)
+// mode 0: everything on the caller's L3 domain A -- A[0] second half, A[1] / A[2] look-ahead stages, pool from A[3] on;
+// mode 1: no look-ahead stages -- A[0] second half, pool from A[1] on;
+// mode 2 (two domains): A[0] look-ahead of the first half, pool workers for the first half's chains from A[1] on;
+//         B[0] second half, B[1] its look-ahead stage, pool workers for the second half's chains from B[2] on
+static void place_helper(CholHelper *h, int cpu, int idx, int mode, const std::vector<int> &B)
 {
-  if (cpu < 0 || (cpu == q->near_cpu && off == q->near_off))
+  if (cpu < 0 || (cpu == h->near_cpu && mode == h->near_mode))
+    return;
+  h->near_cpu = cpu;
+  h->near_mode = mode;
+  const std::vector<int> &A = ccx_cores_of(cpu, false);
+  if (mode == 2)
+  {
+    const int core = idx == 0 ? (B.size() > 0 ? B[0] : -1) : idx == 1 ? (A.size() > 0 ? A[0] : -1) : (B.size() > 1 ? B[1] : -1);
+    if (core >= 0)
+      pin_one(h->tid, core);
+    return;
+  }
+  if ((int)A.size() > idx)
+    pin_one(h->tid, A[idx]);
+}
+
+static void place_pool(SepPool *q, int cpu, int mode, const std::vector<int> &B, int chains_per_half)
+{
+  if (cpu < 0 || (cpu == q->near_cpu && mode == q->near_mode))
     return;
   q->near_cpu = cpu;
-  q->near_off = off;
-  // cores[0..off) are the helpers' (off = 3: second half + two look-ahead stages; 1: no look-ahead stages); more workers than
-  // cores left in the CCX continue on the other cores of the NUMA node
-  const std::vector<int> &cores = ccx_cores_of(cpu, true);
+  q->near_mode = mode;
+  const std::vector<int> &cores = ccx_cores_of(cpu, true); // domain A first, then the rest of the NUMA node
   const size_t n_ccx = ccx_cores_of(cpu, false).size();
-  q->fast.assign(q->tids.size(), 0);
-  int n_fast = 0;
-  for (size_t t = 0; t < q->tids.size() && t + off < cores.size(); ++t)
+  q->dom.assign(q->tids.size(), -1);
+  int n0 = 0, n1 = 0;
+  if (mode == 2)
   {
-    pin_one(q->tids[t], cores[t + off]);
-    q->fast[t] = t + off < n_ccx ? 1 : 0;
-    n_fast += q->fast[t];
+    size_t t = 0;
+    for (size_t c = 1; c < n_ccx && (int)c <= chains_per_half && t < q->tids.size(); ++c, ++t, ++n0)
+    {
+      pin_one(q->tids[t], cores[c]);
+      q->dom[t] = 0;
+    }
+    for (size_t c = 2; c < B.size() && (int)c - 1 <= chains_per_half && t < q->tids.size(); ++c, ++t, ++n1)
+    {
+      pin_one(q->tids[t], B[c]);
+      q->dom[t] = 1;
+    }
+    // the rest: the remaining cores of domain A, then of the node (short tasks, pair products, back substitution)
+    for (size_t c = 1 + (size_t)n0; t < q->tids.size() && c < cores.size(); ++c)
+    {
+      if (std::find(B.begin(), B.end(), cores[c]) != B.end())
+        continue;
+      pin_one(q->tids[t++], cores[c]);
+    }
   }
-  g_fast_pool_threads.store(n_fast, std::memory_order_release);
+  else
+  {
+    const size_t off = mode == 1 ? 1 : 3;
+    for (size_t t = 0; t < q->tids.size() && t + off < cores.size(); ++t)
+    {
+      pin_one(q->tids[t], cores[t + off]);
+      q->dom[t] = t + off < n_ccx ? 0 : -1;
+      n0 += q->dom[t] == 0 ? 1 : 0;
+    }
+  }
+  g_domain_threads[0].store(n0, std::memory_order_release);
+  g_domain_threads[1].store(n1, std::memory_order_release);
+  g_two_domains.store(mode == 2, std::memory_order_release);
 }
 
 bool block_chol_arm(bool with_pool, int long_arrow_chains)
 {
   static const bool no_la_env = sage::env_flag("SAGE_SOLVE_NO_LOOKAHEAD");
   const int cpu = sched_getcpu();
-  // r05: a loop-closure plan's long arrow-row chains run ~30 % slower on another L3 domain and the separator then waits for
-  // them (config 5: six chains, four cores left next to the two halves and their look-ahead stages: 1.1-1.4 ms).  When the
-  // chains fit the domain only without the look-ahead stages, those two cores go to the chains: the halves take twice as
-  // long per row, but everything ends together (config 5 solve phase 3.9 -> 3.5 ms)
-  bool no_la = no_la_env;
-  if (!no_la && with_pool && long_arrow_chains > 0 && !sage::env_flag("SAGE_SOLVE_KEEP_LOOKAHEAD"))
+  // r05: a loop-closure plan's long arrow-row chains run ~30 % slower on another L3 domain than their half and the separator
+  // then waits for them (config 5: six chains, four cores left next to the two halves and their look-ahead stages: 1.1-1.4 ms).
+  // The two halves do not reference each other: when the chains do not fit domain A, the SECOND half moves to a domain B of
+  // its own with its look-ahead stage and its chains (mode 2) -- every chain then sits next to the half it follows.  Without
+  // a second domain the look-ahead stages' cores go to the chains when that makes them fit (mode 1).
+  int mode = no_la_env ? 1 : 0;
+  std::vector<int> B;
+  const int per_half = (long_arrow_chains + 1) / 2;
+  if (mode == 0 && with_pool && long_arrow_chains > 0 && !sage::env_flag("SAGE_SOLVE_KEEP_LOOKAHEAD"))
   {
-    const int n_ccx = (int)ccx_cores_of(cpu, false).size(); // cores of the domain without the caller's
-    no_la = long_arrow_chains > n_ccx - 3 && long_arrow_chains <= n_ccx - 1;
+    const int n_ccx = (int)ccx_cores_of(cpu, false).size(); // cores of domain A without the caller's
+    if (long_arrow_chains > n_ccx - 3)
+    {
+      if (!sage::env_flag("SAGE_SOLVE_ONE_DOMAIN"))
+        B = second_domain_cores(cpu, (size_t)(2 + per_half));
+      if (!B.empty() && n_ccx >= 1 + per_half)
+        mode = 2;
+      else if (long_arrow_chains <= n_ccx - 1)
+        mode = 1;
+    }
   }
+  const bool no_la = mode == 1;
   for (int idx = 0; idx < (no_la ? 1 : 3); ++idx)
   {
     CholHelper *h = chol_helper(idx);
     if (h && !h->armed.load(std::memory_order_acquire))
     {
-      place_helper_near(h, cpu, idx);
+      place_helper(h, cpu, idx, mode, B);
       {
         std::lock_guard<std::mutex> lk(h->mu);
         h->armed.store(true, std::memory_order_release);
@@ -2896,7 +3010,7 @@ bool block_chol_arm(bool with_pool, int long_arrow_chains)
   SepPool *q = sep_pool();
   if (q && !q->armed.load(std::memory_order_acquire))
   {
-    place_pool_near(q, cpu, no_la ? 1 : 3);
+    place_pool(q, cpu, mode, B, per_half);
     {
       std::lock_guard<std::mutex> lk(q->mu);
       q->armed.store(true, std::memory_order_release);
