@@ -241,6 +241,50 @@ def test_block_solve_lookahead_is_bit_identical():
     print(f"look-ahead engaged in {res['on'][0]} half-factorisations of 12 solves")
 
 
+_ARROW_SNIPPET = r"""
+import sys, numpy as np
+from sage_slam_amd import capi
+K, CS, window = 72, 32, 3
+B = 7 + CS; n = K * B
+rng = np.random.default_rng(17)
+links = [(j, i) for i in range(K) for j in range(max(0, i - window), i)] + [(0, 71), (1, 70), (2, 69), (0, 36)]
+mask = np.eye(K, dtype=bool)
+for a, b in links:
+    mask[a, b] = mask[b, a] = True
+J = rng.normal(size=(2 * n, n))
+Hs = (J.T @ J) * np.kron(mask, np.ones((B, B))) + 6 * n * np.eye(n)
+g = rng.normal(size=n)
+diag = np.stack([Hs[k * B:(k + 1) * B, k * B:(k + 1) * B] for k in range(K)])
+lnk = np.stack([Hs[a * B:(a + 1) * B, b * B:(b + 1) * B] for a, b in links])
+packed = np.concatenate([diag.reshape(-1), lnk.reshape(-1), g, np.zeros(4)])
+ref = np.linalg.solve(Hs + 1e-4 * np.diag(np.diag(Hs)), g)
+outs = [capi.block_solve(packed, K, links, B, 1e-4) for _ in range(6)]
+assert all(np.linalg.norm(d - ref) / np.linalg.norm(ref) < 1e-9 for d in outs)
+assert all(np.array_equal(outs[0], d) for d in outs)
+sys.stdout.write(outs[0].tobytes().hex())
+"""
+
+
+def test_loop_closure_solve_is_bit_identical_in_every_placement():
+    """r05: a loop-closure plan (cover keyframes -> arrow rows over both halves) under every thread placement the solve can
+    choose -- the second half on an L3 domain of its own (when the host has one), everything on the caller's domain, halves
+    without look-ahead stages, paired / unpaired arrow chains, a two-worker pool: who runs a task changes, the order of every
+    sum does not -> the same solution bit for bit (and the dense solve to 1e-9 in each)"""
+    import subprocess, sys
+    outs = {}
+    for name, extra in (("default", {}), ("one_domain", {"SAGE_SOLVE_ONE_DOMAIN": "1"}),
+                        ("keep_lookahead", {"SAGE_SOLVE_ONE_DOMAIN": "1", "SAGE_SOLVE_KEEP_LOOKAHEAD": "1"}),
+                        ("no_lookahead", {"SAGE_SOLVE_NO_LOOKAHEAD": "1"}), ("no_pairing", {"SAGE_SOLVE_NO_PAIRING": "1"}),
+                        ("pool2", {"SAGE_SOLVE_POOL": "2"})):
+        env = {k: v for k, v in os.environ.items() if not k.startswith("SAGE_SOLVE_")}
+        env.update(extra)
+        r = subprocess.run([sys.executable, "-c", _ARROW_SNIPPET], capture_output=True, text=True, env=env,
+                           cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=600)
+        assert r.returncode == 0, (name, r.stderr[-2000:])
+        outs[name] = r.stdout.strip()
+    assert len(set(outs.values())) == 1, {k: v[:16] for k, v in outs.items()}
+
+
 def test_block_solve_concurrent_callers_share_the_helpers():
     """several host threads factorise split windows at the same time: the helper threads (second half, look-ahead
     stages, worker pool) serve one caller at a time, the others run their halves themselves -- every result is the
