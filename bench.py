@@ -12,7 +12,7 @@ A "step" is one LM iteration = one pass of the hot path over the whole window:
 Inputs are resident in HBM before the timed region.  Residuals per step = E_photo*L*N*FS + E_geo*N
 (linearisation residuals only; the error-evaluation pass is not double counted).
 
-Multi-GPU: factor-graph links are sharded over ranks (rank r owns the contiguous link range [r*n/world, (r+1)*n/world)),
+Multi-GPU: factor-graph links are sharded over ranks (rank r owns the contiguous range [r*2n/world, (r+1)*2n/world) of the directed edges),
 keyframes replicated; a reduced window runs the one-collective LM sequence (linearize at the candidate: ONE all-reduce of
 the packed normal equations per step, the error totals in its tail; strong scaling).  Single-GPU runs also measure one rank
 of an 8-rank job on this device (`shard_emulation`: one-rank RCCL communicator, the peers' share from a table).
@@ -346,8 +346,8 @@ def shard_emulation(capi, torch, win, win_h, rank, world, steps, restart, ms_one
         cycles(win, one, n_cyc, p1)
         torch.cuda.synchronize()
         ms_one_same = 1e3 * float(np.median([x for j in range(1, restart) for x in p1[j]] or p1[0]))
-    local_links = len(capi.shard_links(len(win_h.links), rank, world))
-    out = {"world": world, "rank": rank, "local_links": local_links, "links": len(win_h.links),
+    local_edges = len(capi.shard_edges(len(win_h.links), rank, world))
+    out = {"world": world, "rank": rank, "local_directed_edges": local_edges, "directed_edges": 2 * len(win_h.links),
            "ms_per_step": ms_steady,
            "ms_per_step_mean": 1e3 * float(np.mean(steady)),
            "ms_per_step_p10_p90": [1e3 * float(np.percentile(steady, 10)), 1e3 * float(np.percentile(steady, 90))],
@@ -661,8 +661,10 @@ def main():
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
         # dominant kernel: the fused photometric linearize; algorithmic bytes of ONE launch on this rank
-        local_links = len(capi.shard_links(len(win_h.links), rank, world))
-        px_launch = 2 * local_links * N
+        # (windows that take the domain-decomposed solve shard by whole links, the others by directed edge)
+        schur = world > 1 and (os.environ.get("SAGE_SHARD_SCHUR", "1" if args.keyframes >= 256 else "0") not in ("0", ""))
+        px_launch = (2 * len(capi.shard_links(len(win_h.links), rank, world)) if schur else
+                     len(capi.shard_edges(len(win_h.links), rank, world))) * N
         ms_photo = ktime[0][0] / max(1, ktime[0][1])
         ms_geo = ktime[1][0] / max(1, ktime[1][1])
         ach = px_launch * bytes_photo_px / (ms_photo * 1e-3) / 1e9 if ms_photo > 0 else 0.0

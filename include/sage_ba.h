@@ -334,8 +334,11 @@ int sage_window_add_link(SageWindow *w, int kf_a, int kf_b);
 /* the Cauchy parameter of ONE link's two geometric edges (before finalize; 0 = the window's geo_loss_param): the mapper
  * derives it per link from the newer keyframe, geo_loss_param_factor * kf->avg_squared_dpt_bias (mapper.cpp:367-373) */
 int sage_window_set_link_geo_loss(SageWindow *w, int link, float loss_param);
-/* edge sharding for multi-GPU: this process evaluates the contiguous range [rank*n/world, (rank+1)*n/world) of the
- * n links (in the order they were added). Default (0,1). */
+/* edge sharding for multi-GPU: this process evaluates the contiguous range [rank*2n/world, (rank+1)*2n/world) of the 2n
+ * DIRECTED edges (edge 2l = link l a -> b, 2l + 1 = b -> a, links in the order they were added; both factor types of a
+ * direction together) -- r05: the two directions of a link may sit on two ranks (42 links on 8 ranks are 5 or 6 each, 84
+ * directed edges 10 or 11).  Windows that use the domain-decomposed solve (SAGE_SHARD_SCHUR, default from 256 keyframes)
+ * shard by whole links, [rank*n/world, (rank+1)*n/world), as sage_shard_plan_create assumes.  Default (0,1). */
 int sage_window_set_shard(SageWindow *w, int rank, int world);
 /* must be called once after the last add_keyframe/add_link and before linearize/error. */
 int sage_window_finalize(SageWindow *w);

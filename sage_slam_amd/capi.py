@@ -794,9 +794,16 @@ def rccl_comm_destroy(comm: int):
 
 
 def shard_links(nlinks: int, rank: int, world: int) -> List[int]:
-    """link ownership rule of ``sage_window_set_shard``: rank r owns the contiguous range
-    [r*n/world, (r+1)*n/world) of the link list."""
+    """link ownership rule of windows that use the domain-decomposed solve (``SAGE_SHARD_SCHUR`` / K >= 256) and of
+    ``sage_shard_plan_create``: rank r owns the contiguous range [r*n/world, (r+1)*n/world) of the link list."""
     return list(range(nlinks * rank // world, nlinks * (rank + 1) // world))
+
+
+def shard_edges(nlinks: int, rank: int, world: int) -> List[int]:
+    """ownership rule of ``sage_window_set_shard`` (r05): rank r owns the contiguous range [r*2n/world, (r+1)*2n/world) of
+    the DIRECTED edges 2*link + direction (both factor types of a direction together); the two directions of a link may
+    belong to two ranks."""
+    return list(range(2 * nlinks * rank // world, 2 * nlinks * (rank + 1) // world))
 
 
 def edge_col(type_: int, role: int, bi: int, CS: int) -> int:

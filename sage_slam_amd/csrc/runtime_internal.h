@@ -245,7 +245,9 @@ struct SageWindow
   std::vector<float> code_init, scale_init, pose_init;
   std::vector<float> code_added; // codes as added (code_init is the zero prior mean)
   std::vector<std::pair<int, int>> links; // (a, b) with a < b
-  std::vector<int> local_links;           // indices into links
+  std::vector<int> local_links;           // indices into links (links with at least one local directed edge)
+  std::vector<int> local_edges;           // this rank's directed edges, global ids 2 * link + direction, ascending (local edge
+                                          // index = position in this list; a single-rank window: the identity)
   int n_edges = 0;                        // local directed edges per factor type (= 2 * local links)
   // device
   DevBuf vars[2];                       // [K][VS]: pose 12, scale 1, code CS
@@ -352,6 +354,7 @@ static int upload(DevBuf &b, const std::vector<T> &v, hipStream_t s)
   return 0;
 }
 int window_upload_vars(SageWindow *w, int set);
+int window_local_edge(const SageWindow *w, int global_edge); // local index of directed edge 2 * link + dir, or -1
 int window_linearize_set(SageWindow *w, int set, double *dst = nullptr, bool local_blocks = false, bool merge = false);
 int window_sync_candidate(SageWindow *w, bool stream_idle = false);
 void window_phase_mark(SageWindow *w, int which); // profiling: record phase mark `which` on the window's stream

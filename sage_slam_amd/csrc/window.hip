@@ -104,7 +104,6 @@ __global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
     {
       const int bi = idx / B, bj = idx % B; // bi indexes keyframe a (older), bj keyframe b
       double acc = 0.0;
-      if (le.e_ab >= 0)
       {
         for (int type = 0; type < 2; ++type)
         {
@@ -116,12 +115,12 @@ __global__ __launch_bounds__(1024) void assemble_kernel(const AssembleParams p)
           const size_t ws = (size_t)D * D + D;
           // edge a->b : a has role 0, b has role 1
           int ci = edge_col(type, 0, bi, p.CS), cj = edge_col(type, 1, bj, p.CS);
-          if (ci >= 0 && cj >= 0)
+          if (le.e_ab >= 0 && ci >= 0 && cj >= 0) // (each direction on its own: the other one may belong to another rank)
             acc += Wd ? Wd[(size_t)le.e_ab * ws + (size_t)ci * D + cj] : (double)A[(size_t)le.e_ab * D * D + (size_t)ci * D + cj];
           // edge b->a : b has role 0, a has role 1
           ci = edge_col(type, 1, bi, p.CS);
           cj = edge_col(type, 0, bj, p.CS);
-          if (ci >= 0 && cj >= 0)
+          if (le.e_ba >= 0 && ci >= 0 && cj >= 0)
             acc += Wd ? Wd[(size_t)le.e_ba * ws + (size_t)ci * D + cj] : (double)A[(size_t)le.e_ba * D * D + (size_t)ci * D + cj];
         }
       }
@@ -587,15 +586,42 @@ extern "C" int sage_window_finalize(SageWindow *w)
   }
   if ((rc = w->dpt.reserve((size_t)K * HW * sizeof(float))) || (rc = w->dgrad.reserve((size_t)K * 2 * HW * sizeof(float))))
     return rc;
-  // ---- local links: rank r owns the contiguous range [r*n/world, (r+1)*n/world) of the link list.  Links are added
-  //      keyframe by keyframe, so a contiguous range touches ~K/world + (back links) keyframes: only those need depth
-  //      maps on this rank
+  // ---- local edges.  A link is two directed edges per factor type (a -> b, b -> a: global ids 2l, 2l + 1).  r05: rank r owns
+  //      the contiguous range [r*2n/world, (r+1)*2n/world) of the DIRECTED edges -- the two directions of a link may sit on
+  //      two ranks (both factor types of a direction stay together: the merged linearize pairs them).  With whole links, 42
+  //      links on 8 ranks are 5 or 6 per rank, 20 % imbalance (BASELINE config 4: the 6-link ranks set the job's pace at 4.6x
+  //      where the 5-link ranks reach 6x); 84 directed edges are 10 or 11.  Links are added keyframe by keyframe, so a
+  //      contiguous range touches ~K/world + (back links) keyframes: only those need depth maps on this rank.  The
+  //      domain-decomposed solve (shard_solve.cpp) derives its domains from whole links: windows that will use it
+  //      (SAGE_SHARD_SCHUR / K >= 256) keep the link granularity.
   w->local_links.clear();
+  w->local_edges.clear();
   {
     const long long nl = (long long)w->links.size();
-    const int lo = (int)(nl * w->rank / w->world), hi = (int)(nl * (w->rank + 1) / w->world);
-    for (int l = lo; l < hi; ++l)
-      w->local_links.push_back(l);
+    bool by_link = sage::env_flag("SAGE_SHARD_BY_LINK");
+    if (w->world > 1)
+    {
+      const char *e = getenv("SAGE_SHARD_SCHUR");
+      by_link = by_link || (e ? atoi(e) != 0 : w->K >= 256);
+    }
+    if (by_link)
+    {
+      const int lo = (int)(nl * w->rank / w->world), hi = (int)(nl * (w->rank + 1) / w->world);
+      for (int l = lo; l < hi; ++l)
+      {
+        w->local_edges.push_back(2 * l);
+        w->local_edges.push_back(2 * l + 1);
+      }
+    }
+    else
+    {
+      const int lo = (int)(2 * nl * w->rank / w->world), hi = (int)(2 * nl * (w->rank + 1) / w->world);
+      for (int ge = lo; ge < hi; ++ge)
+        w->local_edges.push_back(ge);
+    }
+    for (int ge : w->local_edges)
+      if (w->local_links.empty() || w->local_links.back() != ge / 2)
+        w->local_links.push_back(ge / 2);
   }
   std::vector<char> needed(K, 0);
   for (int l : w->local_links)
@@ -717,14 +743,14 @@ extern "C" int sage_window_finalize(SageWindow *w)
                                      w->pk.as<float>() + (size_t)k * 3 * plane_f, w->views[k].homo, w->views[k].N, FS,
                                      c.pyr));
   // ---- local edges
-  w->n_edges = 2 * (int)w->local_links.size();
+  w->n_edges = (int)w->local_edges.size();
   // merged linearize (LaunchCommon::merge_geo_weight): the geometric kernel's per-pixel hand-over to the photometric one
   std::vector<size_t> px_off((size_t)w->n_edges + 1, 0);
-  for (size_t li = 0; li < w->local_links.size(); ++li)
+  for (int e = 0; e < w->n_edges; ++e)
   {
-    const int l = w->local_links[li];
-    px_off[2 * li + 1] = px_off[2 * li] + (size_t)std::max(1, w->views[w->links[l].first].N);
-    px_off[2 * li + 2] = px_off[2 * li + 1] + (size_t)std::max(1, w->views[w->links[l].second].N);
+    const int ge = w->local_edges[e], l = ge / 2;
+    const int k0 = ge % 2 == 0 ? w->links[l].first : w->links[l].second; // the source keyframe of the direction
+    px_off[(size_t)e + 1] = px_off[e] + (size_t)std::max(1, w->views[k0].N);
   }
   w->merge_ok = c.use_photo && c.use_geo && c.geo_weight > 0.f && !sage::env_flag("SAGE_NO_MERGE");
   if (w->merge_ok)
@@ -742,13 +768,12 @@ extern "C" int sage_window_finalize(SageWindow *w)
   {
     std::vector<PhotoEdge> pt(w->n_edges);
     std::vector<GeoEdge> gt(w->n_edges);
-    for (size_t li = 0; li < w->local_links.size(); ++li)
+    for (int e = 0; e < w->n_edges; ++e)
     {
-      const int l = w->local_links[li];
+      const int l = w->local_edges[e] / 2;
       const int ab[2] = {w->links[l].first, w->links[l].second};
-      for (int dir = 0; dir < 2; ++dir)
       {
-        const int e = 2 * (int)li + dir;
+        const int dir = w->local_edges[e] % 2;
         const int k0 = ab[dir], k1 = ab[1 - dir];
         const SageKeyframeView &v0 = w->views[k0], &v1 = w->views[k1];
         const float *x0 = w->vars[s].as<float>() + (size_t)k0 * w->VS;
@@ -796,7 +821,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
         }
       }
       if (s == 0)
-        le[l] = LinkEdges{2 * (int)li, 2 * (int)li + 1};
+        (w->local_edges[e] % 2 == 0 ? le[l].e_ab : le[l].e_ba) = e;
     }
     if ((rc = upload(w->ptab[s], pt, w->stream)) || (rc = upload(w->gtab[s], gt, w->stream)))
       return rc;
@@ -839,6 +864,11 @@ extern "C" int sage_window_finalize(SageWindow *w)
     // (r03, one rank's shard of the K = 64 window at world 8 / 4 = 2.9 k / 5.8 k sub-tiles: runs of 4 / 8 are 19 % / 8 % faster
     //  than the 1 / 2 the first heuristic picked; >= ~3 workgroups per CU stay in flight)
     int tpb = total >= 4096 ? 8 : (total >= 1536 ? 4 : (total >= 768 ? 2 : 1));
+    // (r05, one rank's shard of BASELINE config 4 at world 8 -- FS = 32, 10 or 11 edges of 252 sub-tiles: with runs of 4 the
+    //  11-edge shard's 693 workgroups take 0.231 ms where the 10-edge shard's 630 take 0.163; runs of 6: 0.187 / 0.163, runs
+    //  of 7 / 9 / 12 worse for both.  At FS = 16 the same range wants runs of 4 (K = 64 shard: 0.084 ms; 5-8: 0.11-0.12))
+    if (FS == 32 && total >= 1536 && total < 4096)
+      tpb = 6;
     {
       // even runs: an edge of T sub-tiles is cut into ceil(T / tpb) workgroups of ceil(T / that) sub-tiles each -- with
       // T = 12 (3072 samples: the reference's default) runs of 8 leave a half-length second workgroup per edge and the
@@ -912,7 +942,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
       if (!adjv[k].empty())
         ids.push_back(k);
     for (size_t l = 0; l < le.size(); ++l)
-      if (le[l].e_ab >= 0)
+      if (le[l].e_ab >= 0 || le[l].e_ba >= 0)
         ids.push_back(K + (int32_t)l);
     ids.push_back(K + (int32_t)w->links.size()); // the tail
     w->n_asm_blocks = (int)ids.size();
@@ -957,6 +987,12 @@ extern "C" int sage_window_finalize(SageWindow *w)
   }
   w->finalized = true;
   return SAGE_OK;
+}
+
+int window_local_edge(const SageWindow *w, int global_edge)
+{
+  const auto it = std::lower_bound(w->local_edges.begin(), w->local_edges.end(), global_edge);
+  return it != w->local_edges.end() && *it == global_edge ? (int)(it - w->local_edges.begin()) : -1;
 }
 
 static LaunchCommon window_lc(SageWindow *w, bool photo, bool photo_linearize = false)

@@ -8,14 +8,9 @@ extern "C" int sage_window_get_edge(const SageWindow *w, int type, int e, float 
   if (!w || !w->finalized || (type != 0 && type != 1))
     return SAGE_E_INVALID;
   // e is the global directed-edge index: link e/2, direction e%2 ; map to the local index
-  const int l = e / 2, dir = e % 2;
-  int li = -1;
-  for (size_t i = 0; i < w->local_links.size(); ++i)
-    if (w->local_links[i] == l)
-      li = (int)i;
-  if (li < 0)
+  const int le = window_local_edge(w, e);
+  if (le < 0)
     return SAGE_E_INVALID;
-  const int le = 2 * li + dir;
   const size_t D = type == 0 ? 13 + w->cfg.CS : 14 + 2 * w->cfg.CS;
   const DevBuf &A = type == 0 ? w->AtA_p : w->AtA_g, &b = type == 0 ? w->Atb_p : w->Atb_g,
                &st = type == 0 ? w->stats_p : w->stats_g;
@@ -39,14 +34,7 @@ extern "C" int sage_window_get_edge(const SageWindow *w, int type, int e, float 
 // launches, .item() syncs and a NearestPsd (photometric_factor.cpp:72-219, geometric_factor.cpp:41-233).  Here the first
 // factor that sees new values triggers ONE sage_window_linearize (or sage_window_error) for the whole window and one
 // device-to-host copy of the per-edge results; every other factor is served from the host cache.
-static int local_edge_index(const SageWindow *w, int e)
-{
-  const int l = e / 2, dir = e % 2;
-  for (size_t i = 0; i < w->local_links.size(); ++i)
-    if (w->local_links[i] == l)
-      return 2 * (int)i + dir;
-  return -1;
-}
+static int local_edge_index(const SageWindow *w, int e) { return window_local_edge(w, e); }
 
 extern "C" int sage_window_prepass(SageWindow *w, const float *pose12, const float *codes, const float *scales,
                                    int jacobians, int *recomputed)

@@ -8,5 +8,5 @@ for r in $(seq 0 $((N-1))); do
   EMU_COMPARE=0 python scripts/shard_emu_probe.py $CFG $r/$N 30 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('config $CFG rank %d/%d: links %3d  ms_per_step %.4f (p10-p90 %.4f-%.4f)  one-GPU classic %.4f  speedup %.2f  photo %.4f geo %.4f' % (d['rank'], d['world'], d['local_links'], d['ms_per_step'], d['ms_per_step_p10_p90'][0], d['ms_per_step_p10_p90'][1], d['one_gpu_ms_per_step_classic'], d['speedup_vs_one_gpu_classic'], d['kernel_ms']['photo_linearize'], d['kernel_ms']['geo_linearize']))"
+print('config $CFG rank %d/%d: directed edges %3d  ms_per_step %.4f (p10-p90 %.4f-%.4f)  one-GPU classic %.4f  speedup %.2f  photo %.4f geo %.4f' % (d['rank'], d['world'], d['local_directed_edges'], d['ms_per_step'], d['ms_per_step_p10_p90'][0], d['ms_per_step_p10_p90'][1], d['one_gpu_ms_per_step_classic'], d['speedup_vs_one_gpu_classic'], d['kernel_ms']['photo_linearize'], d['kernel_ms']['geo_linearize']))"
 done

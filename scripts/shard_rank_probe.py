@@ -18,6 +18,6 @@ for r in [int(a) for a in sys.argv[3:]]:
     res = {}
     for i, nm in enumerate(["photo_lin", "geo_lin"]):
         ms, c = win.kernel_time(i); res[nm] = round(ms / max(1, c), 4)
-    links = capi.shard_links(len(w.links), r, world)
-    print(f"config {cfgn} rank {r}/{world}: links {[w.links[l] for l in links]}", json.dumps(res), flush=True)
+    edges = capi.shard_edges(len(w.links), r, world)
+    print(f"config {cfgn} rank {r}/{world}: {len(edges)} directed edges", json.dumps(res), flush=True)
     win.close()

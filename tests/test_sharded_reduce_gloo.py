@@ -22,6 +22,18 @@ def _free_port():
     return p
 
 
+def _edge_results_directed(orc, w, edges_owned):
+    """per-edge oracle results of DIRECTED edges 2 * link + direction (the window engine's ownership unit since r05)"""
+    res = {}
+    for ge in edges_owned:
+        l, d = ge // 2, ge % 2
+        a, b = w.links[l]
+        k0, k1 = (a, b) if d == 0 else (b, a)
+        res[(0, l, d)] = oracle_photo(orc, w, k0, k1)
+        res[(1, l, d)] = oracle_geo(orc, w, k0, k1)
+    return res
+
+
 def _edge_results(orc, w, links_owned):
     res = {}
     for l in links_owned:
@@ -41,8 +53,8 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     w = synth.make_window(K=4, H=16, W=20, FS=16, CS=16, L=2, seed=3, back_links=2, border=1, erode=2)
     K, CS, B = len(w.keyframes), w.CS, 7 + w.CS
-    owned = capi.shard_links(len(w.links), rank, world)
-    packed = capi.assemble_packed(K, w.links, CS, _edge_results(orc, w, owned))
+    owned = capi.shard_edges(len(w.links), rank, world)   # directed edges: a link's two directions may sit on two ranks
+    packed = capi.assemble_packed(K, w.links, CS, _edge_results_directed(orc, w, owned))
     t = torch.from_numpy(packed.copy())
     dist.all_reduce(t)                                   # the one data-path collective (sum, double)
     delta = capi.block_solve(t.numpy(), K, w.links, B, 1e-3, diag_add=np.full(K * B, 1e-3))
@@ -58,8 +70,9 @@ def test_two_rank_shard_equals_single_rank(orc, tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     w = synth.make_window(K=4, H=16, W=20, FS=16, CS=16, L=2, seed=3, back_links=2, border=1, erode=2)
     K, CS, B = len(w.keyframes), w.CS, 7 + w.CS
-    owned = [capi.shard_links(len(w.links), r, world) for r in range(world)]
-    assert sorted(owned[0] + owned[1]) == list(range(len(w.links))) and not set(owned[0]) & set(owned[1])
+    owned = [capi.shard_edges(len(w.links), r, world) for r in range(world)]
+    assert sorted(owned[0] + owned[1]) == list(range(2 * len(w.links))) and not set(owned[0]) & set(owned[1])
+    assert len(w.links) % 2 == 1 and owned[0][-1] // 2 == owned[1][0] // 2      # (the odd link is split between the ranks)
     full = capi.assemble_packed(K, w.links, CS, _edge_results(orc, w, range(len(w.links))))
     ref = capi.block_solve(full, K, w.links, B, 1e-3, diag_add=np.full(K * B, 1e-3))
     d0, d1 = (np.load(tmp_path / f"delta_{r}.npy") for r in range(world))
