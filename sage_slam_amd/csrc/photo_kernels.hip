@@ -160,6 +160,46 @@ __device__ __forceinline__ void pin6(f32x2 &a, f32x2 &b, f32x2 &c, f32x2 &d, f32
   asm volatile("" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f));
 }
 
+// Two world-from-keyframe poses (wave-uniform addresses) through the scalar cache: eight s_load issued together, ONE wait.
+// (r05: written as loads of a uniform address + v_readfirstlane the compiler made them per-lane flat loads through one
+// register quad -- seven serialised L2 round trips and 21 VALU slots per 64-pixel slice.)  The pointers are not assumed
+// contiguous (the per-edge operators pass separate tensors).
+__device__ __forceinline__ void sload_pose_pair(const float *R0, const float *t0, const float *R1, const float *t1, Pose &p0,
+                                                Pose &p1)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  f32x8 a8, b8;
+  f32x2 at2, bt2;
+  float a1, b1, at1, bt1;
+  asm volatile("s_load_dwordx8 %0, %8, 0x0\n\t"
+               "s_load_dword %1, %8, 0x20\n\t"
+               "s_load_dwordx2 %2, %9, 0x0\n\t"
+               "s_load_dword %3, %9, 0x8\n\t"
+               "s_load_dwordx8 %4, %10, 0x0\n\t"
+               "s_load_dword %5, %10, 0x20\n\t"
+               "s_load_dwordx2 %6, %11, 0x0\n\t"
+               "s_load_dword %7, %11, 0x8\n\t"
+               "s_waitcnt lgkmcnt(0)"
+               : "=&s"(a8), "=&s"(a1), "=&s"(at2), "=&s"(at1), "=&s"(b8), "=&s"(b1), "=&s"(bt2), "=&s"(bt1)
+               : "s"(R0), "s"(t0), "s"(R1), "s"(t1)
+               : "memory");
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+  {
+    p0.R[i] = a8[i];
+    p1.R[i] = b8[i];
+  }
+  p0.R[8] = a1;
+  p1.R[8] = b1;
+  p0.t[0] = at2[0]; p0.t[1] = at2[1]; p0.t[2] = at1;
+  p1.t[0] = bt2[0]; p1.t[1] = bt2[1]; p1.t[2] = bt1;
+#else
+  p0 = load_pose2(R0, t0);
+  p1 = load_pose2(R1, t1);
+#endif
+}
+
 // level-l pixel coordinate of a level-0 coordinate (:101-103, :142-144): ONE rounding sequence for the lanes and for the
 // bounding box (floor() of it is then monotone in p, so the box of [min p, max p] contains every lane's taps)
 __device__ __forceinline__ float level_coord(float p, float ratio) { return __builtin_fmaf(p + 0.5f, ratio, -0.5f); }
@@ -285,7 +325,33 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     for (int i = 0; i < 3; ++i)
       p10.t[i] = uni(p10.t[i]);
   }
+  if (JAC && PACKED)
+  {
+    // r05: the linearize has register room (140 of the 168 VGPRs three waves per SIMD allow) and no SGPRs left -- the 12 values
+    // lived in spilled SGPRs and cost 24 v_readlane + their wait states per slice (warp in phase A, again in phase C): as
+    // (opaque) VGPRs they are plain operands
+#pragma unroll
+    for (int i = 0; i < 9; ++i)
+      asm volatile("" : "+v"(p10.R[i]));
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      asm volatile("" : "+v"(p10.t[i]));
+  }
 
+  // per-lane constants of the staged sampler's box computation (see "the 16 coordinates" below): lane 4 l + c, c = x0, x1, y0, y1
+  float box_ratio = 0.f;
+  int box_hi = 0;
+  if (PACKED)
+  {
+    const int bc = lane & 3;
+#pragma unroll
+    for (int l = 0; l < kStageLevels; ++l)
+      if ((lane >> 2) == l || (l == kStageLevels - 1 && (lane >> 2) >= kStageLevels))
+      {
+        box_ratio = bc < 2 ? prm.rx[l] : prm.ry[l];
+        box_hi = (bc < 2 ? prm.lw[l] : prm.lh[l]) - 1 + (bc & 1);
+      }
+  }
   const SagePyramid &pyr = prm.pyr;
   const float fx0 = pyr.cam[0].fx, fy0 = pyr.cam[0].fy, cx0 = pyr.cam[0].cx, cy0 = pyr.cam[0].cy;
   const int W0 = prm.width, H0 = prm.height;
@@ -473,21 +539,27 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     int cnt0 = 0, cntC = 0;
     if (slice_live && nlev == kStageLevels)
     {
+      // (floor coordinate of the first tap .. second tap, NOT clamped to the image: columns -1 / W_l and rows -1 / H_l
+      //  are part of the box when an inlier's taps reach them -- those taps carry weight 0 and are filled with a
+      //  repeated border texel -- so that every inlier's four taps sit at a0, a0 + 16, a0 + row, a0 + row + 16):
+      //    x0 = min(max(floor(c_l(pmn)), -1), W_l - 1)      x1 = max(min(floor(c_l(pmx)) + 1, W_l), x0 + 1)     (y alike)
+      // r05: the 16 coordinates (4 levels x {x0, x1, y0, y1}) are formed in ONE pass, lane 4 l + c taking coordinate c of
+      // level l with its ratio and upper clamp from two per-lane constants (box_ratio, box_hi) -- as uniform values on the
+      // vector unit they cost ~100 of a slice's VALU slots.  Same operations per value, same integers.  (The lower clamp -1
+      // is harmless for x1 / y1: a value below it is replaced by x0 + 1 >= 0 either way.)
+      const int bc = lane & 3, odd = bc & 1;
+      const float bsel = (bc & 2) ? (odd ? qmx : qmn) : (odd ? pmx : pmn);
+      int bw = min(max((int)floorf(level_coord(bsel, box_ratio)) + odd, -1), box_hi);
+      bw = max(bw, __builtin_amdgcn_update_dpp(0, bw, 0xA0, 0xf, 0xf, false) + odd); // (x1, y1 read x0, y0: quad_perm [0,0,2,2])
 #pragma unroll
       for (int l = 0; l < kStageLevels; ++l)
       {
-        // (floor coordinate of the first tap .. second tap, NOT clamped to the image: columns -1 / W_l and rows -1 / H_l
-        //  are part of the box when an inlier's taps reach them -- those taps carry weight 0 and are filled with a
-        //  repeated border texel -- so that every inlier's four taps sit at a0, a0 + 16, a0 + row, a0 + row + 16)
-        const int Wl = prm.lw[l], Hl = prm.lh[l];
-        const int x0 = min(max((int)floorf(level_coord(pmn, prm.rx[l])), -1), Wl - 1);
-        const int x1 = max(min((int)floorf(level_coord(pmx, prm.rx[l])) + 1, Wl), x0 + 1);
-        const int y0 = min(max((int)floorf(level_coord(qmn, prm.ry[l])), -1), Hl - 1);
-        const int y1 = max(min((int)floorf(level_coord(qmx, prm.ry[l])) + 1, Hl), y0 + 1);
-        bx0[l] = uni(x0);
-        by0[l] = uni(y0);
-        bwd[l] = uni(x1 - x0 + 1);
-        bhd[l] = uni(y1 - y0 + 1);
+        const int x0 = __builtin_amdgcn_readlane(bw, 4 * l + 0), x1 = __builtin_amdgcn_readlane(bw, 4 * l + 1);
+        const int y0 = __builtin_amdgcn_readlane(bw, 4 * l + 2), y1 = __builtin_amdgcn_readlane(bw, 4 * l + 3);
+        bx0[l] = x0;
+        by0[l] = y0;
+        bwd[l] = x1 - x0 + 1;
+        bhd[l] = y1 - y0 + 1;
         const int c = bwd[l] * bhd[l];
         if (l == 0)
         {
@@ -615,8 +687,9 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
         t1[1] = lds_read16(a2 + 16u);     tx[1] = lds_read16(a2 + 16u + AS);
         t1[2] = lds_read16(a2);           tx[2] = lds_read16(a2 + AS);
         t1[3] = lds_read16(a0 + 16u);     tx[3] = lds_read16(a0 + 16u + AS);
-        // nd = sum_k w_k t_k - f0 (the residual's subtraction rides in the interpolation chain: r = -nd)
-        f32x4 nd = -f0v, gx = {0.f, 0.f, 0.f, 0.f}, gy = gx;
+        // nd = sum_k w_k t_k - f0 (the residual's subtraction rides in the interpolation chain: r = -nd; the chain starts
+        // from the pre-sampled quad, which the producer stores negated -- r05: 2 v_xor per step less)
+        f32x4 nd = f0v, gx = {0.f, 0.f, 0.f, 0.f}, gy = gx; // (f0s holds the NEGATED source features)
 #pragma unroll
         for (int k = 0; k < 4; ++k)
         {
@@ -752,7 +825,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
           {
             const uint32_t o = (uint32_t)j * kErrStageGroupBytes;
             const f32x4 t0 = lds_read16(a0 + o), t1 = lds_read16(a2 + 16u + o), t2 = lds_read16(a2 + o), t3 = lds_read16(a0 + 16u + o);
-            f32x4 nd = -f0v[l][j];
+            f32x4 nd = f0v[l][j]; // (negated at the producer)
             nd += tw[l][0] * t0;
             nd += tw[l][1] * t1;
             nd += tw[l][2] * t2;
@@ -788,7 +861,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
         {
           const uint32_t soff = (uint32_t)g * plane * 4u;
           TapBatch<JAC> B;
-          B.f0 = f0s[((size_t)l * NG + g) * N];
+          B.f0 = -f0s[((size_t)l * NG + g) * N]; // (stored negated for the staged sampler's FMA chain)
 #pragma unroll
           for (int k = 0; k < 4; ++k)
           {
@@ -906,11 +979,10 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   float Q[2][7];
   float dXz[6]; // z-row of dX/dT0 (merged linearize: the geometric edge's pose row starts from it)
   {
-    // world-from-keyframe poses (wave-uniform scalar loads), re-read per sub-tile behind an opaque pointer: held across the
-    // sampling phase their 24 SGPRs were spilled to VGPR lanes and every use paid a v_readlane
-    const float *R0p = E.R0, *R1p = E.R1;
-    asm volatile("" : "+s"(R0p), "+s"(R1p));
-    const Pose p0 = load_pose2(R0p, E.t0), p1 = load_pose2(R1p, E.t1);
+    // world-from-keyframe poses, re-read per sub-tile through the scalar cache: held across the sampling phase their 24 SGPRs
+    // were spilled to VGPR lanes and every use paid a v_readlane
+    Pose p0, p1;
+    sload_pose_pair(E.R0, E.t0, E.R1, E.t1, p0, p1);
     // (engine layout: the homogeneous coordinates are read again and the warp of phase A recomputed -- same operations,
     //  same values -- instead of ten registers staying live across the sampling phase)
     if (PACKED)

@@ -156,7 +156,7 @@ hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev,
   return hipGetLastError();
 }
 
-// pre-sampled source features f0s[l][g][n][0:4] = 4-tap bilinear sample of the keyframe's own pyramid at its sampled
+// pre-sampled source features f0s[l][g][n][0:4] = MINUS the 4-tap bilinear sample of the keyframe's own pyramid at its sampled
 // pixels, with the Jacobian kernel's source coordinates (photometric_factor_kernels.cpp:101-139) -- pose independent,
 // built once per keyframe (the tracker's cat_sampled_features_0, camera_tracker.cpp:1104-1123)
 __global__ void presample_source_kernel(float *__restrict__ f0s, const float *__restrict__ feat_pk,
@@ -177,7 +177,8 @@ __global__ void presample_source_kernel(float *__restrict__ f0s, const float *__
 #pragma unroll
   for (int k = 0; k < 4; ++k)
     f += ts.w[k] * src[ts.off[k]];
-  reinterpret_cast<f32x4 *>(f0s)[((size_t)l * G + g) * N + n] = f;
+  // stored NEGATED: the samplers start their interpolation chain from it (sum_k w_k t_k - f0)
+  reinterpret_cast<f32x4 *>(f0s)[((size_t)l * G + g) * N + n] = -f;
 }
 
 hipError_t launch_presample_source(hipStream_t s, float *f0s, const float *feat_pk, const float *homo, int N, int FS,

@@ -278,7 +278,7 @@ struct SageWindow
   DevBuf geo_px;                        // merged linearize: per local edge and source pixel {omega, D, dD/dx, dD/dy} (geo -> photo)
   bool merge_ok = false;                // both factor types on, geometric weight > 0, not switched off (SAGE_NO_MERGE)
   DevBuf pk;                            // engine-internal channel-group pyramids [K][3 (f,gx,gy)][FS/4][P][4]
-  DevBuf f0s;                           // per keyframe: pre-sampled source features [L][FS/4][N][4]
+  DevBuf f0s;                           // per keyframe: pre-sampled source features, negated [L][FS/4][N][4]
   DevBuf ptab[2], gtab[2];              // edge tables per variable set
   DevBuf work_p, first_p, tiles_p, work_g, first_g, tiles_g;
   DevBuf rec_first_p, rec_count_p;      // photometric linearize: partial RECORDS per edge (flush_p sub-tiles each)

@@ -29,7 +29,8 @@ struct PhotoEdge
   // pyramids pre-multiplied by their level's focal lengths)
   const float *feat0_pk, *feat1_pk;
   // pose-independent pre-sampled source features of the source keyframe [L][FS/4][N][4] (what the reference's
-  // tracker calls cat_sampled_features_0, camera_tracker.cpp:1104-1123), built once per keyframe
+  // tracker calls cat_sampled_features_0, camera_tracker.cpp:1104-1123), built once per keyframe -- stored NEGATED (the
+  // samplers start their interpolation chain sum_k w_k t_k - f0 from it)
   const float *f0s;
   const float *dpt0;    // [H,W]   s0*(bias0+basis0*code0): depth map of the SOURCE keyframe at the evaluated variables
   // window error pass only: depth map of the DESTINATION keyframe -> the error kernel also forms the geometric edge's
