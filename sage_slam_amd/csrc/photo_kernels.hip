@@ -148,6 +148,34 @@ __device__ __forceinline__ f32x4 gload16(const float *sbase, uint32_t voff)
   asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(v) : "v"(voff), "s"(sbase) : "memory");
   return v;
 }
+// basis rows of the contraction phase: same discipline (the compiler batches tracked loads four at a time and waits for the
+// first right behind the fourth -- two pixel groups of cover; as hand-tracked loads they stay SAGE_PHOTO_AHEAD groups ahead)
+__device__ __forceinline__ f32x2 bload8(__amdgpu_buffer_rsrc_t r, uint32_t voff)
+{
+  f32x2 v;
+  asm volatile("s_nop 4\n\tbuffer_load_dwordx2 %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(r));
+  return v;
+}
+__device__ __forceinline__ float bload4(__amdgpu_buffer_rsrc_t r, uint32_t voff)
+{
+  float v;
+  asm volatile("s_nop 4\n\tbuffer_load_dword %0, %1, %2, 0 offen" : "=v"(v) : "v"(voff), "s"(r));
+  return v;
+}
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+  if constexpr (I < N)
+  {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+template <int N>
+__device__ __forceinline__ void vm_wait_keep2(f32x2 &v)
+{
+  asm volatile("s_waitcnt vmcnt(%1)" : "+v"(v) : "n"(N));
+}
 template <int N>
 __device__ __forceinline__ void vm_wait_keep(f32x4 &v)
 {
@@ -1095,6 +1123,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
 #endif
     constexpr int G = 16, AHEAD = SAGE_PHOTO_AHEAD;
     float bl[G], bh[G], ai[G], sg[G], ya[G], yb[G];
+    f32x2 vb[G]; // the loaded pairs stay whole until their wait (a half copied out earlier would be read before it landed)
     int locp[G];
 #define SAGE_PHOTO_READ_STASH(g)                                                        \
   {                                                                                     \
@@ -1113,16 +1142,9 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
 #define SAGE_PHOTO_ISSUE(g)                                                             \
   {                                                                                     \
     if (NB == 2)                                                                        \
-    {                                                                                   \
-      const f32x2 vb_ = buf_load2(r_b0, (uint32_t)locp[g] + lane_off, 0);               \
-      bl[g] = vb_[0];                                                                   \
-      bh[g] = vb_[1];                                                                   \
-    }                                                                                   \
+      vb[g] = bload8(r_b0, (uint32_t)locp[g] + lane_off);                               \
     else                                                                                \
-    {                                                                                   \
-      bl[g] = buf_load(r_b0, (uint32_t)locp[g] + lane_off, 0);                          \
-      bh[g] = 0.f;                                                                      \
-    }                                                                                   \
+      vb[g][0] = bload4(r_b0, (uint32_t)locp[g] + lane_off);                            \
   }
 #pragma unroll
     for (int g = 0; g < AHEAD + 1; ++g)
@@ -1131,15 +1153,18 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     for (int g = 0; g < AHEAD; ++g)
       SAGE_PHOTO_ISSUE(g)
     SAGE_PHOTO_READ_POSE(0)
-#pragma unroll
-    for (int g = 0; g < G; ++g)
-    {
+    static_for<0, G>([&](auto gc) {
+      constexpr int g = decltype(gc)::value; // (compile-time: the wait counts below are template arguments)
       if (g + 1 < G)
         SAGE_PHOTO_READ_POSE(g + 1) // LDS only: one group ahead is enough
       if (g + AHEAD < G)
         SAGE_PHOTO_ISSUE(g + AHEAD)
       if (g + AHEAD + 1 < G)
         SAGE_PHOTO_READ_STASH(g + AHEAD + 1)
+      // (one load per group: younger than group g's are the groups up to g + AHEAD)
+      vm_wait_keep2<(G - 1 - g < AHEAD ? G - 1 - g : AHEAD)>(vb[g]);
+      bl[g] = vb[g][0];
+      bh[g] = NB == 2 ? vb[g][1] : 0.f;
       const float a = ai[g];
 #if SAGE_PHOTO_ALT_ACC
       if (CS == 32 && (g % (SAGE_PHOTO_ALT_ACC + 1)) != 0)
@@ -1152,7 +1177,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
         acc[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bh[g], bh[g], acc[2], 0, 0, 0);
         accb[u][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bl[g], accb[u][0], 0, 0, 0);
         accb[u][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bh[g], accb[u][1], 0, 0, 0);
-        continue;
+        return;
       }
 #endif
       acc[YY] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[g], yb[g], acc[YY], 0, 0, 0);
@@ -1169,7 +1194,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bl[g], bl[g], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bl[g], acc[1], 0, 0, 0);
       }
-    }
+    });
 #if SAGE_PHOTO_ALT_ACC
     if (CS == 32)
     {

@@ -1,6 +1,6 @@
 """Build-time check of the hand-tracked loads of the photometric linearize (photo_kernels.hip: gload16 / vm_wait_keep).
 
-The inline-asm `global_load_dwordx4` of the staged sampler are invisible to the compiler's wait-count bookkeeping: the
+The inline-asm `global_load_dwordx4` of the staged sampler (and, r05, the `buffer_load_dwordx2` basis-row loads of the contraction phase) are invisible to the compiler's wait-count bookkeeping: the
 destination registers are only valid after the next inline-asm `s_waitcnt vmcnt`.  The compiler is free to copy or spill a
 register between the two statements (it believes the value exists); this script compiles the kernel file to assembly and
 fails if any instruction between such a load and the following inline-asm wait touches the destination registers.
@@ -25,6 +25,14 @@ def regs_of(text):
     return out
 
 
+def is_tracked_load(line):
+    """inline-asm loads with a VGPR destination: gload16 (global_load_dwordx4) and the basis-row loads of the contraction
+    phase (buffer_load_dword / dwordx2 ... offen); the LDS-direct buffer loads of the sampler have no destination register"""
+    if "global_load_dwordx4" in line:
+        return True
+    return bool(re.search(r"\bbuffer_load_dword(x2)?\s", line)) and " lds" not in line
+
+
 def check(asm_text):
     """Walks the control-flow graph from every hand-tracked load to the inline-asm waits that cover it."""
     lines = asm_text.split("\n")
@@ -41,9 +49,9 @@ def check(asm_text):
         if "#ASMSTART" not in ln:
             continue
         k = i + 1
-        while k < len(lines) and "#ASMEND" not in lines[k] and "global_load_dwordx4" not in lines[k]:
+        while k < len(lines) and "#ASMEND" not in lines[k] and not is_tracked_load(lines[k]):
             k += 1
-        if k >= len(lines) or "global_load_dwordx4" not in lines[k]:
+        if k >= len(lines) or not is_tracked_load(lines[k]):
             continue
         dst = regs_of(lines[k].split(",")[0])
         n_loads += 1
