@@ -1010,7 +1010,18 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     // world-from-keyframe poses, re-read per sub-tile through the scalar cache: held across the sampling phase their 24 SGPRs
     // were spilled to VGPR lanes and every use paid a v_readlane
     Pose p0, p1;
-    sload_pose_pair(E.R0, E.t0, E.R1, E.t1, p0, p1);
+    if constexpr (FS >= 32)
+    {
+      // FS = 32 (BASELINE config 4) is bound by the memory side (fetch 1.58 x the algorithmic bytes, L2 hit rate 35 %): there
+      // the kernel runs 4 % FASTER with the per-lane loads the compiler makes of this (seven round trips in series that
+      // hold the wave back from its next burst of requests) than with the scalar loads -- measured, r05_kernel_ab_experiments
+      const float *R0p = E.R0, *R1p = E.R1;
+      asm volatile("" : "+s"(R0p), "+s"(R1p));
+      p0 = load_pose2(R0p, E.t0);
+      p1 = load_pose2(R1p, E.t1);
+    }
+    else
+      sload_pose_pair(E.R0, E.t0, E.R1, E.t1, p0, p1);
     // (engine layout: the homogeneous coordinates are read again and the warp of phase A recomputed -- same operations,
     //  same values -- instead of ten registers staying live across the sampling phase)
     if (PACKED)
@@ -1121,7 +1132,8 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
 #ifndef SAGE_PHOTO_AHEAD
 #define SAGE_PHOTO_AHEAD 6
 #endif
-    constexpr int G = 16, AHEAD = SAGE_PHOTO_AHEAD;
+    // (FS = 32: one group ahead -- the memory-side-bound configuration loses 4 % with six, see phase C)
+    constexpr int G = 16, AHEAD = FS >= 32 ? 1 : SAGE_PHOTO_AHEAD;
     float bl[G], bh[G], ai[G], sg[G], ya[G], yb[G];
     f32x2 vb[G]; // the loaded pairs stay whole until their wait (a half copied out earlier would be read before it landed)
     int locp[G];
