@@ -1139,7 +1139,14 @@ extern "C" int sage_window_linearize(SageWindow *w)
   return window_linearize_set(w, 0);
 }
 
-extern "C" int sage_window_error(SageWindow *w, int which)
+static int window_error_pass(SageWindow *w, int which, bool speculate_gradients);
+extern "C" int sage_window_error(SageWindow *w, int which) { return window_error_pass(w, which, false); }
+
+// speculate_gradients (the LM iteration's candidate evaluation, one GPU): the depth-map gradients of the evaluated set are
+// launched right behind the totals -- the stream is idle while the host takes the accept / reject decision, and an accepted
+// candidate's next linearize then finds maps AND gradients in place (one launch and 13 us off the accepted iteration; a
+// rejected candidate's gradients are never read: the next evaluation rebuilds the maps)
+static int window_error_pass(SageWindow *w, int which, bool speculate_gradients)
 {
   if (!w || !w->finalized || which < 0 || which > 1)
     return SAGE_E_STATE;
@@ -1188,6 +1195,11 @@ extern "C" int sage_window_error(SageWindow *w, int which)
                      w->world == 1 && !w->allreduce && w->h_err ? w->h_err + 4 : nullptr, (double)w->err_epoch);
   SAGE_HIP(hipGetLastError());
   window_phase_mark(w, 4);
+  if (speculate_gradients && has && c.use_geo && w->dpt_set == which && !w->dgrad_valid)
+  {
+    SAGE_HIP(launch_depth_batch(w->stream, c.CS, w->depth_items[which].as<DepthItem>(), w->n_depth, H, W, false, true));
+    w->dgrad_valid = true;
+  }
   return SAGE_OK;
 }
 
@@ -1942,7 +1954,7 @@ extern "C" int sage_window_lm_step(SageWindow *w, SageLmState *st, const SageLmC
     }
     if (rc)
       return rc;
-    if ((rc = sage_window_error(w, 1)))
+    if ((rc = window_error_pass(w, 1, !sharded)))
       return rc;
     if (sharded)
     {
