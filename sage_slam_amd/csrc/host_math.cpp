@@ -2786,6 +2786,99 @@ static std::vector<int> read_cpu_list(const char *path)
   return out;
 }
 
+// ---- which CPUs the solve's threads may be placed on.  Default: the calling thread's affinity mask.  r05: a GPU box is a
+// slice of a node whose other GPUs run other jobs -- their host threads sit on CPUs of the same NUMA node, and a helper
+// pinned onto a core another tenant saturates runs its half of the factorisation at half speed for the life of the
+// process (~1 process in 8 measured +60..200 us per solve).  sage_bind_thread_to_device therefore samples /proc/stat and
+// hands over the CPUs of QUIET physical cores (placement_set_allowed); the caller's own mask may be narrower than that
+// (its L3 domain), the loop-closure plans' second domain is looked for in the handed-over set.
+static std::mutex g_place_mu;
+static bool g_place_override = false;
+static cpu_set_t g_place_allowed;
+static std::map<std::pair<int, bool>, std::vector<int>> g_ccx_cache;
+static std::map<std::pair<int, size_t>, std::vector<int>> g_dom2_cache;
+
+void placement_set_allowed(const cpu_set_t *allowed)
+{
+  std::lock_guard<std::mutex> lk(g_place_mu);
+  g_place_override = allowed != nullptr;
+  if (allowed)
+    g_place_allowed = *allowed;
+  g_ccx_cache.clear();
+  g_dom2_cache.clear();
+}
+
+static bool placement_allowed(cpu_set_t *out) // (g_place_mu held)
+{
+  if (g_place_override)
+  {
+    *out = g_place_allowed;
+    return true;
+  }
+  return sched_getaffinity(0, sizeof(*out), out) == 0;
+}
+
+// CPUs that were busy (> 25 % non-idle) during a window of `ms` milliseconds; empty when /proc/stat cannot be read
+std::vector<int> placement_busy_cpus(int ms)
+{
+  auto snap = [](std::map<int, std::pair<unsigned long long, unsigned long long>> &m) {
+    FILE *f = fopen("/proc/stat", "r");
+    if (!f)
+      return false;
+    char line[512];
+    while (fgets(line, sizeof(line), f))
+    {
+      int cpu;
+      unsigned long long v[8] = {0};
+      if (sscanf(line, "cpu%d %llu %llu %llu %llu %llu %llu %llu %llu", &cpu, &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6],
+                 &v[7]) >= 5)
+      {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 8; ++i)
+          tot += v[i];
+        m[cpu] = {tot, v[3] + v[4]};
+      }
+    }
+    fclose(f);
+    return !m.empty();
+  };
+  std::map<int, std::pair<unsigned long long, unsigned long long>> a, b;
+  std::vector<int> out;
+  if (!snap(a))
+    return out;
+  std::this_thread::sleep_for(std::chrono::milliseconds(ms));
+  if (!snap(b))
+    return out;
+  for (const auto &kv : a)
+  {
+    auto it = b.find(kv.first);
+    if (it == b.end())
+      continue;
+    const double tot = (double)(it->second.first - kv.second.first), idle = (double)(it->second.second - kv.second.second);
+    if (tot >= 4.0 && 1.0 - idle / tot > 0.25) // (USER_HZ ticks: at least 4 in the window)
+      out.push_back(kv.first);
+  }
+  return out;
+}
+
+// hardware threads of the physical core of `cpu`
+std::vector<int> placement_core_siblings(int cpu)
+{
+  char path[128];
+  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list", cpu);
+  std::vector<int> sib = read_cpu_list(path);
+  if (sib.empty())
+    sib.push_back(cpu);
+  return sib;
+}
+
+std::vector<int> placement_l3_domain(int cpu)
+{
+  char path[128];
+  snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
+  return read_cpu_list(path);
+}
+
 // Thread placement of the solve: the caller, the helper of the second half and the worker pool each get their own
 // PHYSICAL core of the caller's CCX (cores that share its L3): the halves and the arrow-row tasks then work out of one
 // cache and one NUMA node (a helper on the far socket takes ~35 % longer for its half), and no two of them share a core
@@ -2827,21 +2920,20 @@ static std::vector<int> node_cpus_of(int cpu)
   return {};
 }
 
-// (sysfs is read once per caller CPU: the arm call sits at the start of every solve)
-static const std::vector<int> &ccx_cores_of(int cpu, bool with_node)
+// (sysfs is read once per caller CPU: the arm call sits at the start of every solve; returned by value -- the cache is
+//  cleared when the allowed set changes)
+static std::vector<int> ccx_cores_of(int cpu, bool with_node)
 {
-  static std::mutex mu;
-  static std::map<std::pair<int, bool>, std::vector<int>> cache;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = cache.find({cpu, with_node});
-  if (it != cache.end())
+  std::lock_guard<std::mutex> lk(g_place_mu);
+  auto it = g_ccx_cache.find({cpu, with_node});
+  if (it != g_ccx_cache.end())
     return it->second;
   std::vector<int> cores;
   char path[128];
   snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
   const std::vector<int> l3 = read_cpu_list(path);
   cpu_set_t allowed;
-  if (!l3.empty() && sched_getaffinity(0, sizeof(allowed), &allowed) == 0)
+  if (!l3.empty() && placement_allowed(&allowed))
   {
     cores = sibling_free_cores(l3, cpu, allowed);
     if (with_node)
@@ -2849,7 +2941,7 @@ static const std::vector<int> &ccx_cores_of(int cpu, bool with_node)
         if (std::find(cores.begin(), cores.end(), c) == cores.end())
           cores.push_back(c);
   }
-  return cache.emplace(std::make_pair(cpu, with_node), std::move(cores)).first->second;
+  return g_ccx_cache.emplace(std::make_pair(cpu, with_node), std::move(cores)).first->second;
 }
 
 static void pin_one(pthread_t t, int cpu)
@@ -2865,13 +2957,11 @@ static std::vector<int> second_domain_cores_uncached(int cpu, size_t want);
 static std::vector<int> second_domain_cores(int cpu, size_t want)
 {
   // (sysfs is read once per caller CPU and size: the arm call sits at the start of every solve)
-  static std::mutex mu;
-  static std::map<std::pair<int, size_t>, std::vector<int>> cache;
-  std::lock_guard<std::mutex> lk(mu);
-  auto it = cache.find({cpu, want});
-  if (it != cache.end())
+  std::lock_guard<std::mutex> lk(g_place_mu);
+  auto it = g_dom2_cache.find({cpu, want});
+  if (it != g_dom2_cache.end())
     return it->second;
-  return cache.emplace(std::make_pair(cpu, want), second_domain_cores_uncached(cpu, want)).first->second;
+  return g_dom2_cache.emplace(std::make_pair(cpu, want), second_domain_cores_uncached(cpu, want)).first->second;
 }
 static std::vector<int> second_domain_cores_uncached(int cpu, size_t want)
 {
@@ -2879,7 +2969,7 @@ static std::vector<int> second_domain_cores_uncached(int cpu, size_t want)
   snprintf(path, sizeof(path), "/sys/devices/system/cpu/cpu%d/cache/index3/shared_cpu_list", cpu);
   const std::vector<int> l3a = read_cpu_list(path);
   cpu_set_t allowed;
-  if (l3a.empty() || sched_getaffinity(0, sizeof(allowed), &allowed) != 0)
+  if (l3a.empty() || !placement_allowed(&allowed))
     return {};
   std::vector<int> seen = l3a;
   for (int c : node_cpus_of(cpu))

@@ -5,6 +5,7 @@
 
 #include <utility>
 #include <atomic>
+#include <sched.h>
 #include <vector>
 
 namespace sage
@@ -104,6 +105,11 @@ int block_chol_partial_back(const BlockEnvelope &env, double *T, double *X, doub
 // long arrow-row chains (block_plan_long_arrow_chains) do not fit the cores the look-ahead stages leave free in the caller's
 // L3 domain but do fit with those two cores.
 bool block_chol_arm(bool with_pool = false, int long_arrow_chains = 0);
+// placement of the solve's threads (host_math.cpp "which CPUs the solve's threads may be placed on")
+void placement_set_allowed(const cpu_set_t *allowed); // nullptr: back to the calling thread's affinity mask
+std::vector<int> placement_busy_cpus(int ms);
+std::vector<int> placement_core_siblings(int cpu);
+std::vector<int> placement_l3_domain(int cpu);
 int block_plan_long_arrow_chains(const BlockEnvelope &env);
 // true when the separator rows of the plan reach far into the halves (cover keyframes of loop closures): the
 // factorisation then wants the worker pool

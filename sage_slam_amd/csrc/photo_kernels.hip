@@ -1167,11 +1167,11 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     SAGE_PHOTO_READ_POSE(0)
     static_for<0, G>([&](auto gc) {
       constexpr int g = decltype(gc)::value; // (compile-time: the wait counts below are template arguments)
-      if (g + 1 < G)
+      if constexpr (g + 1 < G)
         SAGE_PHOTO_READ_POSE(g + 1) // LDS only: one group ahead is enough
-      if (g + AHEAD < G)
+      if constexpr (g + AHEAD < G)
         SAGE_PHOTO_ISSUE(g + AHEAD)
-      if (g + AHEAD + 1 < G)
+      if constexpr (g + AHEAD + 1 < G)
         SAGE_PHOTO_READ_STASH(g + AHEAD + 1)
       // (one load per group: younger than group g's are the groups up to g + AHEAD)
       vm_wait_keep2<(G - 1 - g < AHEAD ? G - 1 - g : AHEAD)>(vb[g]);
@@ -1179,7 +1179,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       bh[g] = NB == 2 ? vb[g][1] : 0.f;
       const float a = ai[g];
 #if SAGE_PHOTO_ALT_ACC
-      if (CS == 32 && (g % (SAGE_PHOTO_ALT_ACC + 1)) != 0)
+      if constexpr (CS == 32 && (g % (SAGE_PHOTO_ALT_ACC + 1)) != 0)
       {
         constexpr int NS = SAGE_PHOTO_ALT_ACC + 1;
         const int u = g % NS - 1;
@@ -1193,7 +1193,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       }
 #endif
       acc[YY] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[g], yb[g], acc[YY], 0, 0, 0);
-      if (CS == 32)
+      if constexpr (CS == 32)
       {
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bl[g], bl[g], acc[0], 0, 0, 0);
         acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(sg[g] * bl[g], bh[g], acc[1], 0, 0, 0);

@@ -110,6 +110,82 @@ extern "C" int sage_bind_thread_to_device(int device)
       cpus = groups[((size_t)my_pos * stride) % groups.size()];
     }
   }
+  // r05: the box is a slice of a node whose other GPUs run other tenants' jobs on CPUs of the same NUMA node.  Look at the
+  // load (250 ms of /proc/stat), keep to physical cores that are quiet on all their hardware threads, and -- alone on the node
+  // -- move to the L3 domain with the most of them; the solve's helper threads are placed on quiet cores only
+  // (placement_set_allowed: the whole node's quiet CPUs, so that a loop-closure plan still finds its second domain).
+  if (!sage::env_flag("SAGE_BIND_NO_PROBE"))
+  {
+    const std::vector<int> busy = sage::placement_busy_cpus(250);
+    std::vector<char> noisy(CPU_SETSIZE, 0);
+    for (int b : busy)
+      for (int sib : sage::placement_core_siblings(b))
+        if (sib < CPU_SETSIZE)
+          noisy[sib] = 1;
+    // the node's quiet CPUs (of the CPUs this process may use)
+    cpu_set_t quiet_node;
+    CPU_ZERO(&quiet_node);
+    int n_quiet_node = 0;
+    for (int c : parse_cpulist(buf))
+      if (c < CPU_SETSIZE && CPU_ISSET(c, &allowed) && !noisy[c])
+      {
+        CPU_SET(c, &quiet_node);
+        ++n_quiet_node;
+      }
+    auto quiet_cores_of = [&](const std::vector<int> &set) {
+      int n = 0;
+      std::vector<char> seen(CPU_SETSIZE, 0);
+      for (int c : set)
+      {
+        if (c >= CPU_SETSIZE || seen[c] || noisy[c] || !CPU_ISSET(c, &allowed))
+          continue;
+        for (int sib : sage::placement_core_siblings(c))
+          if (sib < CPU_SETSIZE)
+            seen[sib] = 1;
+        ++n;
+      }
+      return n;
+    };
+    std::vector<int> pick = cpus;
+    if (on_node <= 1)
+    {
+      // L3 domains of the node: the one with the most quiet physical cores (ties: the first)
+      std::vector<char> seen(CPU_SETSIZE, 0);
+      int best = -1;
+      for (int c : cpus)
+      {
+        if (seen[c])
+          continue;
+        std::vector<int> dom = sage::placement_l3_domain(c);
+        if (dom.empty())
+          dom.push_back(c);
+        for (int x : dom)
+          if (x < CPU_SETSIZE)
+            seen[x] = 1;
+        std::vector<int> in;
+        for (int x : dom)
+          if (std::find(cpus.begin(), cpus.end(), x) != cpus.end())
+            in.push_back(x);
+        const int q = quiet_cores_of(in);
+        if (q > best)
+        {
+          best = q;
+          pick = in;
+        }
+      }
+    }
+    std::vector<int> quiet_pick;
+    for (int c : pick)
+      if (!noisy[c])
+        quiet_pick.push_back(c);
+    if (quiet_cores_of(quiet_pick) >= 4 && n_quiet_node >= 8)
+    {
+      cpus = quiet_pick;
+      sage::placement_set_allowed(&quiet_node);
+    }
+    else
+      sage::placement_set_allowed(nullptr); // too little room: placement as before
+  }
   CPU_ZERO(&want);
   for (int c : cpus)
     CPU_SET(c, &want);
