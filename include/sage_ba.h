@@ -172,8 +172,17 @@ int sage_gaussian_pyramid_with_grad(SageWorkspace *ws, float *pyr_dev, float *gr
  * function), intersected with the thread's current affinity mask.  The hybrid window solve reads 3 MB of freshly DMA'd
  * normal equations per LM iteration and the pinned buffers live on the device's node: from the far socket of a
  * two-socket host the iteration is ~10 % slower.  Opt-in (one process per GPU: call it once from the thread that
- * drives the window); returns the number of CPUs bound to, 0 if the topology is not exposed, < 0 on error. */
+ * drives the window); returns the number of CPUs bound to, 0 if the topology is not exposed, < 0 on error.
+ * r05: the call also watches the host's load for 250 ms (/proc/stat) and keeps to physical cores that are quiet on all their
+ * hardware threads -- alone on the NUMA node it narrows the thread's mask to the L3 domain with the most of them -- and the
+ * solve's helper threads are placed on quiet cores only (SAGE_BIND_NO_PROBE=1: the plain NUMA-node binding). */
 int sage_bind_thread_to_device(int device);
+/* Diagnostics of the hybrid solve's thread placement: the CPUs its (up to three) helper threads are pinned to (-1: not
+ * placed yet; returns how many entries were written), and how often the placement monitor has moved a helper off a core
+ * that another process crowded (a background thread looks at the helpers' run-queue delay and at the load on their cores'
+ * other hardware threads every 250 ms; SAGE_PLACEMENT_MONITOR=0 turns it off). */
+int sage_solver_helper_cpus(int *cpus, int n);
+int sage_solver_placement_moves(void);
 
 /* se3_exp (core/mapping/mapping_utils.h:316-346): R[9], t[3] from omega[3], v[3]. */
 void sage_se3_exp(const float *omega, const float *v, float *R, float *t);

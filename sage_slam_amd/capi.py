@@ -98,7 +98,7 @@ SYMBOLS = [
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_prepare_factors", "sage_factor_psd", "sage_factor_cut_blocks", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_get_phase_time", "sage_window_lm_step", "sage_window_lm_run", "sage_window_lm_run_timed", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_window_emulate_peers", "sage_sort_locations", "sage_bind_thread_to_device",
+    "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_prepare_factors", "sage_factor_psd", "sage_factor_cut_blocks", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_get_phase_time", "sage_window_lm_step", "sage_window_lm_run", "sage_window_lm_run_timed", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_window_emulate_peers", "sage_sort_locations", "sage_bind_thread_to_device", "sage_solver_helper_cpus", "sage_solver_placement_moves",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
@@ -904,6 +904,18 @@ def _dptr(t):
 def bind_thread_to_device(device: int = 0) -> int:
     """``sage_bind_thread_to_device``: keep the calling thread on the GPU's NUMA node (returns the number of CPUs)."""
     return int(lib().sage_bind_thread_to_device(int(device)))
+
+
+def solver_helper_cpus():
+    """``sage_solver_helper_cpus``: CPUs the hybrid solve's helper threads are pinned to (-1: not placed yet)."""
+    buf = (C.c_int * 3)()
+    n = int(lib().sage_solver_helper_cpus(buf, 3))
+    return [int(buf[i]) for i in range(n)]
+
+
+def solver_placement_moves() -> int:
+    """``sage_solver_placement_moves``: helpers the placement monitor has moved off crowded cores so far."""
+    return int(lib().sage_solver_placement_moves())
 
 
 def sort_locations(ws, loc1d, homo, H, W):

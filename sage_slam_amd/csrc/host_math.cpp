@@ -20,6 +20,8 @@
 #include <ctime>
 #include <pthread.h>
 #include <sched.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 #include <mutex>
 #include <numeric>
 #include <random>
@@ -2620,6 +2622,8 @@ struct CholHelper
   int lo = 0, hi = 0;
   std::thread th;
   pthread_t tid{};
+  std::atomic<int> ktid{0};    // kernel thread id (its /proc/self/task entry: the placement monitor reads its run-queue delay)
+  std::atomic<int> cpu{-1};    // the CPU it is pinned to (-1: not pinned)
   int near_cpu = -1, near_mode = -1;
   bool started = false;
   static void cpu_relax() { __builtin_ia32_pause(); }
@@ -2637,7 +2641,10 @@ static CholHelper *chol_helper(int idx = 0)
         continue;
       CholHelper *p = new CholHelper;
       p->kind = i == 0 ? 0 : 1;
-      p->th = std::thread([p] { p->loop(); });
+      p->th = std::thread([p] {
+        p->ktid.store((int)syscall(SYS_gettid), std::memory_order_release);
+        p->loop();
+      });
       p->tid = p->th.native_handle();
       p->th.detach();
       v[i] = p;
@@ -2988,6 +2995,150 @@ static std::vector<int> second_domain_cores_uncached(int cpu, size_t want)
   return {};
 }
 
+// ---- placement monitor (r05).  The box's other tenants move: a core that was quiet when the helpers were placed may carry
+// somebody else's thread a minute later, and a helper that shares its hardware thread (it then waits on the run queue when the
+// solve wakes it) or its physical core (SMT: ~2/3 speed) slows every solve of the process from then on.  A background thread
+// looks every 250 ms at (a) the run-queue delay of the three helper threads (/proc/self/task/<tid>/schedstat) and (b) the load
+// on the OTHER hardware threads of their cores (/proc/stat); a helper that is crowded in two consecutive looks is moved to
+// a core of the caller's L3 domain (else of its NUMA node) that is idle on all its hardware threads.  The arrow-row pool of the
+// loop-closure plans is not watched.  SAGE_PLACEMENT_MONITOR=0 turns it off; SAGE_DEBUG_TIMING prints the moves.
+static std::atomic<bool> g_monitor_started{false};
+static std::atomic<int> g_monitor_moves{0};
+static std::mutex g_pin_mu;
+
+static long long read_run_delay_ns(int ktid)
+{
+  char path[96];
+  snprintf(path, sizeof(path), "/proc/self/task/%d/schedstat", ktid);
+  FILE *f = fopen(path, "r");
+  if (!f)
+    return -1;
+  unsigned long long run = 0, delay = 0;
+  const int n = fscanf(f, "%llu %llu", &run, &delay);
+  fclose(f);
+  return n == 2 ? (long long)delay : -1;
+}
+
+static bool stat_snapshot(std::map<int, std::pair<unsigned long long, unsigned long long>> &m)
+{
+  FILE *f = fopen("/proc/stat", "r");
+  if (!f)
+    return false;
+  char line[512];
+  while (fgets(line, sizeof(line), f))
+  {
+    int cpu;
+    unsigned long long v[8] = {0};
+    if (sscanf(line, "cpu%d %llu %llu %llu %llu %llu %llu %llu %llu", &cpu, &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6],
+               &v[7]) >= 5)
+    {
+      unsigned long long tot = 0;
+      for (int i = 0; i < 8; ++i)
+        tot += v[i];
+      m[cpu] = {tot, v[3] + v[4]};
+    }
+  }
+  fclose(f);
+  return !m.empty();
+}
+
+static void placement_monitor_loop()
+{
+  const bool verbose = sage::env_flag("SAGE_DEBUG_TIMING");
+  std::map<int, std::pair<unsigned long long, unsigned long long>> prev, cur;
+  long long prev_delay[3] = {-1, -1, -1};
+  int strikes[3] = {0, 0, 0};
+  stat_snapshot(prev);
+  for (;;)
+  {
+    std::this_thread::sleep_for(std::chrono::milliseconds(250));
+    cur.clear();
+    if (!stat_snapshot(cur))
+      continue;
+    auto busy = [&](int c) {
+      auto a = prev.find(c), b = cur.find(c);
+      if (a == prev.end() || b == cur.end())
+        return 0.0;
+      const double tot = (double)(b->second.first - a->second.first), idle = (double)(b->second.second - a->second.second);
+      return tot >= 4.0 ? 1.0 - idle / tot : 0.0;
+    };
+    CholHelper *hs[3] = {chol_helper(0), chol_helper(1), chol_helper(2)};
+    for (int idx = 0; idx < 3; ++idx)
+    {
+      CholHelper *h = hs[idx];
+      if (!h)
+        continue;
+      const int c = h->cpu.load(std::memory_order_acquire), kt = h->ktid.load(std::memory_order_acquire);
+      if (c < 0 || kt <= 0)
+        continue;
+      const long long d = read_run_delay_ns(kt);
+      const long long dd = (d >= 0 && prev_delay[idx] >= 0) ? d - prev_delay[idx] : 0;
+      prev_delay[idx] = d;
+      bool crowded = dd > 2000000; // > 2 ms on the run queue in a quarter second: somebody shares the hardware thread
+      double sib_busy = 0.0;
+      for (int sib : placement_core_siblings(c))
+        if (sib != c)
+          sib_busy = std::max(sib_busy, busy(sib));
+      crowded = crowded || sib_busy > 0.3;
+      strikes[idx] = crowded ? strikes[idx] + 1 : 0;
+      if (strikes[idx] < 2)
+        continue;
+      // a quiet core: the caller's L3 domain first, then its node; idle on all hardware threads, not used by another helper
+      const int near = h->near_cpu;
+      if (near < 0)
+        continue;
+      int target = -1;
+      for (int cand : ccx_cores_of(near, true))
+      {
+        bool ok = true;
+        for (int sib : placement_core_siblings(cand))
+          ok = ok && busy(sib) < 0.1;
+        for (int j = 0; j < 3 && ok; ++j)
+          ok = !(hs[j] && hs[j]->cpu.load(std::memory_order_acquire) == cand);
+        if (ok)
+        {
+          target = cand;
+          break;
+        }
+      }
+      if (target < 0)
+        continue;
+      {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        pin_one(h->tid, target);
+        h->cpu.store(target, std::memory_order_release);
+      }
+      g_monitor_moves.fetch_add(1, std::memory_order_relaxed);
+      strikes[idx] = 0;
+      if (verbose)
+        fprintf(stderr, "[sage placement] helper %d: cpu %d crowded (run-queue delay %.1f ms, sibling load %.0f %%) -> cpu %d\n", idx, c,
+                dd * 1e-6, 100.0 * sib_busy, target);
+    }
+    prev.swap(cur);
+  }
+}
+
+static void placement_monitor_start()
+{
+  bool expect = false;
+  if (!g_monitor_started.compare_exchange_strong(expect, true))
+    return;
+  if (const char *e = getenv("SAGE_PLACEMENT_MONITOR"))
+    if (atoi(e) == 0)
+      return;
+  std::thread(placement_monitor_loop).detach();
+}
+
+int placement_helper_cpus(int *cpus, int n)
+{
+  int k = 0;
+  for (int idx = 0; idx < 3 && k < n; ++idx)
+    if (CholHelper *h = chol_helper(idx))
+      cpus[k++] = h->cpu.load(std::memory_order_acquire);
+  return k;
+}
+int placement_monitor_moves() { return g_monitor_moves.load(std::memory_order_relaxed); }
+
 // mode 0: everything on the caller's L3 domain A -- A[0] second half, A[1] / A[2] look-ahead stages, pool from A[3] on;
 // mode 1: no look-ahead stages -- A[0] second half, pool from A[1] on;
 // mode 2 (two domains): A[0] look-ahead of the first half, pool workers for the first half's chains from A[1] on;
@@ -3003,11 +3154,19 @@ static void place_helper(CholHelper *h, int cpu, int idx, int mode, const std::v
   {
     const int core = idx == 0 ? (B.size() > 0 ? B[0] : -1) : idx == 1 ? (A.size() > 0 ? A[0] : -1) : (B.size() > 1 ? B[1] : -1);
     if (core >= 0)
+    {
       pin_one(h->tid, core);
+      h->cpu.store(core, std::memory_order_release);
+    }
+    placement_monitor_start();
     return;
   }
   if ((int)A.size() > idx)
+  {
     pin_one(h->tid, A[idx]);
+    h->cpu.store(A[idx], std::memory_order_release);
+  }
+  placement_monitor_start();
 }
 
 static void place_pool(SepPool *q, int cpu, int mode, const std::vector<int> &B, int chains_per_half)

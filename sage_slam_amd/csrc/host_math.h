@@ -110,6 +110,8 @@ void placement_set_allowed(const cpu_set_t *allowed); // nullptr: back to the ca
 std::vector<int> placement_busy_cpus(int ms);
 std::vector<int> placement_core_siblings(int cpu);
 std::vector<int> placement_l3_domain(int cpu);
+int placement_helper_cpus(int *cpus, int n); // CPUs the solve's (up to three) helper threads are pinned to
+int placement_monitor_moves();              // helpers moved off crowded cores so far (placement monitor)
 int block_plan_long_arrow_chains(const BlockEnvelope &env);
 // true when the separator rows of the plan reach far into the halves (cover keyframes of loop closures): the
 // factorisation then wants the worker pool

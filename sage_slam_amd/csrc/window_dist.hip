@@ -194,6 +194,9 @@ extern "C" int sage_bind_thread_to_device(int device)
   return (int)cpus.size();
 }
 
+extern "C" int sage_solver_helper_cpus(int *cpus, int n) { return cpus && n > 0 ? sage::placement_helper_cpus(cpus, n) : 0; }
+extern "C" int sage_solver_placement_moves(void) { return sage::placement_monitor_moves(); }
+
 extern "C" int sage_window_set_allreduce(SageWindow *w, SageAllReduceFn fn, void *user)
 {
   if (!w)

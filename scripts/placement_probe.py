@@ -55,7 +55,21 @@ cpu1 = getcpu()
 dur = busy(a, b)
 busy_pre = sorted(c for c in allowed if pre.get(c, 0) > 0.2)
 hot = sorted(c for c in dur if dur[c] > 0.5)
-out = dict(ms_per_step=round(ms, 4), cpu_start=cpu0, cpu_end=cpu1, l3=l3_of(cpu1), allowed=f"{allowed[0]}..{allowed[-1]} ({len(allowed)})",
+hog_trace = None
+if len(sys.argv) > 1 and sys.argv[1] == "hog":
+    # crowd the helpers' cores with busy loops and watch the placement monitor move them (DESIGN s7)
+    import subprocess
+    before = [c for c in capi.solver_helper_cpus() if c >= 0]
+    hogs = [subprocess.Popen([sys.executable, "-c", "import os\nos.sched_setaffinity(0, {%d})\nwhile True: pass" % c]) for c in set(before)]
+    hog_trace = []
+    try:
+        for _ in range(8):
+            t0 = time.perf_counter(); run(120); torch.cuda.synchronize()
+            hog_trace.append((round(1e3 * (time.perf_counter() - t0) / 120, 4), capi.solver_helper_cpus(), capi.solver_placement_moves()))
+    finally:
+        for h in hogs:
+            h.kill()
+out = dict(ms_per_step=round(ms, 4), helper_cpus=capi.solver_helper_cpus(), monitor_moves=capi.solver_placement_moves(), hog_trace=hog_trace, cpu_start=cpu0, cpu_end=cpu1, l3=l3_of(cpu1), allowed=f"{allowed[0]}..{allowed[-1]} ({len(allowed)})",
            busy_before_in_mask=busy_pre, n_busy_before_all=sum(1 for v in pre.values() if v > 0.2),
            hot_during=hot, loadavg=open("/proc/loadavg").read().split()[:3])
 os.write(_fd, (json.dumps(out) + "\n").encode())

@@ -241,6 +241,44 @@ def test_block_solve_lookahead_is_bit_identical():
     print(f"look-ahead engaged in {res['on'][0]} half-factorisations of 12 solves")
 
 
+_MONITOR_SNIPPET = _LOOKAHEAD_SNIPPET.split("ref = np.linalg.solve")[0] + r"""
+import os, subprocess, time
+def solve_for(sec):
+    t0 = time.time()
+    while time.time() - t0 < sec:
+        capi.block_solve(packed, K, links, B, 1e-4)
+solve_for(0.6)
+before = [c for c in capi.solver_helper_cpus() if c >= 0]
+hogs = [subprocess.Popen([sys.executable, "-c", "import os\nos.sched_setaffinity(0, {%d})\nwhile True: pass" % c]) for c in set(before)]
+try:
+    for _ in range(10):
+        solve_for(0.5)
+        if capi.solver_placement_moves() > 0:
+            break
+finally:
+    for h in hogs:
+        h.kill()
+after = [c for c in capi.solver_helper_cpus() if c >= 0]
+sys.stdout.write("%d %d %d" % (len(before), capi.solver_placement_moves(), len(set(before) & set(after))))
+"""
+
+
+def test_placement_monitor_moves_helpers_off_crowded_cores():
+    """r05: a helper thread of the hybrid solve whose core another process saturates is moved to a quiet core by the
+    placement monitor (run-queue delay of the helper / load on its core's other hardware threads, looked at every 250 ms).
+    A child process solves in a loop, pins one busy loop onto every helper's CPU and waits for the monitor."""
+    import subprocess, sys
+    if (os.cpu_count() or 1) < 8 or not os.path.exists("/proc/self/schedstat") or len(os.sched_getaffinity(0)) < 8:
+        pytest.skip("needs >= 8 CPUs and /proc schedstat")
+    r = subprocess.run([sys.executable, "-c", _MONITOR_SNIPPET], capture_output=True, text=True,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    n_helpers, moves, still_crowded = (int(v) for v in r.stdout.split())
+    if n_helpers == 0:
+        pytest.skip("no helper threads were placed on this host (topology not exposed)")
+    assert moves >= 1 and still_crowded < n_helpers, (n_helpers, moves, still_crowded)
+
+
 _ARROW_SNIPPET = r"""
 import sys, numpy as np
 from sage_slam_amd import capi
