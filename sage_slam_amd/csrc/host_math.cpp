@@ -8,6 +8,7 @@
 //   sage_track_lm            core/system/camera_tracker.cpp:1156-1279 (+ LMConvergence :527-573)
 #include <algorithm>
 #include <map>
+#include <memory>
 #include <atomic>
 #include <chrono>
 #include <cmath>
@@ -2527,6 +2528,7 @@ struct SepPool
   std::atomic<bool> busy{false};
   std::atomic<SepJob *> job{nullptr};
   std::vector<pthread_t> tids;
+  std::unique_ptr<std::atomic<int>[]> ktid, cpu; // per worker: kernel thread id, CPU it is pinned to (-1: none) -- placement monitor
   std::vector<int> dom; // per worker: 0 / 1 = pinned to a core of the first / second half's L3 domain, -1 elsewhere (place_pool)
   int near_cpu = -1;
   int near_mode = -1;
@@ -2571,6 +2573,7 @@ struct SepPool
     }
   }
 };
+static std::atomic<SepPool *> g_sep_pool_made{nullptr}; // (the placement monitor must not CREATE the pool by asking for it)
 static SepPool *sep_pool()
 {
   // deliberately leaked, like the helper
@@ -2583,12 +2586,23 @@ static SepPool *sep_pool()
     if (n < 1)
       return (SepPool *)nullptr;
     SepPool *q = new SepPool;
+    q->ktid.reset(new std::atomic<int>[n]);
+    q->cpu.reset(new std::atomic<int>[n]);
     for (int i = 0; i < n; ++i)
     {
-      std::thread th([q, i] { q->loop(i); });
+      q->ktid[i].store(0);
+      q->cpu[i].store(-1);
+    }
+    for (int i = 0; i < n; ++i)
+    {
+      std::thread th([q, i] {
+        q->ktid[i].store((int)syscall(SYS_gettid), std::memory_order_release);
+        q->loop(i);
+      });
       q->tids.push_back(th.native_handle());
       th.detach();
     }
+    g_sep_pool_made.store(q, std::memory_order_release);
     return q;
   }();
   return p;
@@ -3000,8 +3014,8 @@ static std::vector<int> second_domain_cores_uncached(int cpu, size_t want)
 // solve wakes it) or its physical core (SMT: ~2/3 speed) slows every solve of the process from then on.  A background thread
 // looks every 250 ms at (a) the run-queue delay of the three helper threads (/proc/self/task/<tid>/schedstat) and (b) the load
 // on the OTHER hardware threads of their cores (/proc/stat); a helper that is crowded in two consecutive looks is moved to
-// a core of the caller's L3 domain (else of its NUMA node) that is idle on all its hardware threads.  The arrow-row pool of the
-// loop-closure plans is not watched.  SAGE_PLACEMENT_MONITOR=0 turns it off; SAGE_DEBUG_TIMING prints the moves.
+// a core of its own L3 domain (else the caller's, else the NUMA node) that is idle on all its hardware threads; the workers of
+// the loop-closure plans' arrow-row pool are watched the same way once the pool exists.  SAGE_PLACEMENT_MONITOR=0 turns it off; SAGE_DEBUG_TIMING prints the moves.
 static std::atomic<bool> g_monitor_started{false};
 static std::atomic<int> g_monitor_moves{0};
 static std::mutex g_pin_mu;
@@ -3046,8 +3060,9 @@ static void placement_monitor_loop()
 {
   const bool verbose = sage::env_flag("SAGE_DEBUG_TIMING");
   std::map<int, std::pair<unsigned long long, unsigned long long>> prev, cur;
-  long long prev_delay[3] = {-1, -1, -1};
-  int strikes[3] = {0, 0, 0};
+  // watched threads: slots 0..2 the helpers, 3.. the arrow-row pool's workers (once a loop-closure plan has made the pool)
+  std::vector<long long> prev_delay(3, -1);
+  std::vector<int> strikes(3, 0);
   stat_snapshot(prev);
   for (;;)
   {
@@ -3063,38 +3078,61 @@ static void placement_monitor_loop()
       return tot >= 4.0 ? 1.0 - idle / tot : 0.0;
     };
     CholHelper *hs[3] = {chol_helper(0), chol_helper(1), chol_helper(2)};
-    for (int idx = 0; idx < 3; ++idx)
+    SepPool *q = g_sep_pool_made.load(std::memory_order_acquire);
+    const int nq = q ? (int)q->tids.size() : 0;
+    prev_delay.resize(3 + nq, -1);
+    strikes.resize(3 + nq, 0);
+    auto slot_cpu = [&](int i) -> std::atomic<int> * { return i < 3 ? (hs[i] ? &hs[i]->cpu : nullptr) : &q->cpu[i - 3]; };
+    auto slot_ktid = [&](int i) { return i < 3 ? (hs[i] ? hs[i]->ktid.load(std::memory_order_acquire) : 0) : q->ktid[i - 3].load(std::memory_order_acquire); };
+    auto slot_thread = [&](int i) { return i < 3 ? hs[i]->tid : q->tids[i - 3]; };
+    const int near = hs[0] ? hs[0]->near_cpu : (q ? q->near_cpu : -1);
+    for (int i = 0; i < 3 + nq; ++i)
     {
-      CholHelper *h = hs[idx];
-      if (!h)
+      std::atomic<int> *pc = slot_cpu(i);
+      if (!pc)
         continue;
-      const int c = h->cpu.load(std::memory_order_acquire), kt = h->ktid.load(std::memory_order_acquire);
+      const int c = pc->load(std::memory_order_acquire), kt = slot_ktid(i);
       if (c < 0 || kt <= 0)
         continue;
       const long long d = read_run_delay_ns(kt);
-      const long long dd = (d >= 0 && prev_delay[idx] >= 0) ? d - prev_delay[idx] : 0;
-      prev_delay[idx] = d;
+      const long long dd = (d >= 0 && prev_delay[i] >= 0) ? d - prev_delay[i] : 0;
+      prev_delay[i] = d;
       bool crowded = dd > 2000000; // > 2 ms on the run queue in a quarter second: somebody shares the hardware thread
       double sib_busy = 0.0;
       for (int sib : placement_core_siblings(c))
         if (sib != c)
           sib_busy = std::max(sib_busy, busy(sib));
       crowded = crowded || sib_busy > 0.3;
-      strikes[idx] = crowded ? strikes[idx] + 1 : 0;
-      if (strikes[idx] < 2)
+      strikes[i] = crowded ? strikes[i] + 1 : 0;
+      if (strikes[i] < 2 || near < 0)
         continue;
-      // a quiet core: the caller's L3 domain first, then its node; idle on all hardware threads, not used by another helper
-      const int near = h->near_cpu;
-      if (near < 0)
-        continue;
-      int target = -1;
-      for (int cand : ccx_cores_of(near, true))
+      // a quiet core: the thread's own L3 domain first (a pool worker of the second half's domain stays there), then the
+      // caller's domain and node; idle on all hardware threads, not used by another watched thread
+      std::vector<int> cands = placement_l3_domain(c);
+      for (int x : ccx_cores_of(near, true))
+        cands.push_back(x);
+      cpu_set_t allowed;
       {
+        std::lock_guard<std::mutex> lk(g_place_mu);
+        if (!placement_allowed(&allowed))
+          continue;
+      }
+      const std::vector<int> near_sib = placement_core_siblings(near);
+      int target = -1;
+      for (int cand : cands)
+      {
+        if (cand >= CPU_SETSIZE || !CPU_ISSET(cand, &allowed) || std::find(near_sib.begin(), near_sib.end(), cand) != near_sib.end())
+          continue;
         bool ok = true;
         for (int sib : placement_core_siblings(cand))
+        {
           ok = ok && busy(sib) < 0.1;
-        for (int j = 0; j < 3 && ok; ++j)
-          ok = !(hs[j] && hs[j]->cpu.load(std::memory_order_acquire) == cand);
+          for (int j = 0; j < 3 + nq && ok; ++j)
+          {
+            std::atomic<int> *pj = slot_cpu(j);
+            ok = !(pj && pj->load(std::memory_order_acquire) == sib);
+          }
+        }
         if (ok)
         {
           target = cand;
@@ -3105,14 +3143,14 @@ static void placement_monitor_loop()
         continue;
       {
         std::lock_guard<std::mutex> lk(g_pin_mu);
-        pin_one(h->tid, target);
-        h->cpu.store(target, std::memory_order_release);
+        pin_one(slot_thread(i), target);
+        pc->store(target, std::memory_order_release);
       }
       g_monitor_moves.fetch_add(1, std::memory_order_relaxed);
-      strikes[idx] = 0;
+      strikes[i] = 0;
       if (verbose)
-        fprintf(stderr, "[sage placement] helper %d: cpu %d crowded (run-queue delay %.1f ms, sibling load %.0f %%) -> cpu %d\n", idx, c,
-                dd * 1e-6, 100.0 * sib_busy, target);
+        fprintf(stderr, "[sage placement] %s %d: cpu %d crowded (run-queue delay %.1f ms, sibling load %.0f %%) -> cpu %d\n",
+                i < 3 ? "helper" : "pool worker", i < 3 ? i : i - 3, c, dd * 1e-6, 100.0 * sib_busy, target);
     }
     prev.swap(cur);
   }
@@ -3185,11 +3223,13 @@ static void place_pool(SepPool *q, int cpu, int mode, const std::vector<int> &B,
     for (size_t c = 1; c < n_ccx && (int)c <= chains_per_half && t < q->tids.size(); ++c, ++t, ++n0)
     {
       pin_one(q->tids[t], cores[c]);
+      q->cpu[t].store(cores[c], std::memory_order_release);
       q->dom[t] = 0;
     }
     for (size_t c = 2; c < B.size() && (int)c - 1 <= chains_per_half && t < q->tids.size(); ++c, ++t, ++n1)
     {
       pin_one(q->tids[t], B[c]);
+      q->cpu[t].store(B[c], std::memory_order_release);
       q->dom[t] = 1;
     }
     // the rest: the remaining cores of domain A, then of the node (short tasks, pair products, back substitution)
@@ -3197,6 +3237,7 @@ static void place_pool(SepPool *q, int cpu, int mode, const std::vector<int> &B,
     {
       if (std::find(B.begin(), B.end(), cores[c]) != B.end())
         continue;
+      q->cpu[t].store(cores[c], std::memory_order_release);
       pin_one(q->tids[t++], cores[c]);
     }
   }
@@ -3206,6 +3247,7 @@ static void place_pool(SepPool *q, int cpu, int mode, const std::vector<int> &B,
     for (size_t t = 0; t < q->tids.size() && t + off < cores.size(); ++t)
     {
       pin_one(q->tids[t], cores[t + off]);
+      q->cpu[t].store(cores[t + off], std::memory_order_release);
       q->dom[t] = t + off < n_ccx ? 0 : -1;
       n0 += q->dom[t] == 0 ? 1 : 0;
     }
