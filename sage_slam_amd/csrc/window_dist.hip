@@ -1,6 +1,7 @@
 // window_dist.hip -- sharded windows: one process per GPU (NUMA / CCX placement of the host threads), the all-reduce hook and
 // the native RCCL binding (librccl bound with dlopen; ncclAllReduce(double, sum) issued on the window's stream).
 #include "runtime_internal.h"
+#include <unistd.h>
 
 static bool device_local_cpulist(int device, char *buf, size_t n)
 {
@@ -150,7 +151,10 @@ extern "C" int sage_bind_thread_to_device(int device)
     if (on_node <= 1)
     {
       // L3 domains of the node: the one with the most quiet physical cores (ties: the first)
+      // (among the domains within one core of the best the process id decides: processes started together -- they cannot see
+      //  each other while all of them are looking -- spread out instead of landing on the same domain)
       std::vector<char> seen(CPU_SETSIZE, 0);
+      std::vector<std::pair<int, std::vector<int>>> doms;
       int best = -1;
       for (int c : cpus)
       {
@@ -167,12 +171,15 @@ extern "C" int sage_bind_thread_to_device(int device)
           if (std::find(cpus.begin(), cpus.end(), x) != cpus.end())
             in.push_back(x);
         const int q = quiet_cores_of(in);
-        if (q > best)
-        {
-          best = q;
-          pick = in;
-        }
+        best = std::max(best, q);
+        doms.emplace_back(q, std::move(in));
       }
+      std::vector<const std::vector<int> *> good;
+      for (const auto &d : doms)
+        if (d.first >= std::max(best - 1, 4))
+          good.push_back(&d.second);
+      if (!good.empty())
+        pick = *good[(size_t)getpid() % good.size()];
     }
     std::vector<int> quiet_pick;
     for (int c : pick)
