@@ -487,9 +487,11 @@ def main():
     from sage_slam_amd import capi, synth
     capi.lib()
     # one process per GPU: stay on the NUMA node the GPU hangs off (the window solve reads freshly DMA'd pinned memory)
+    full_affinity = os.sched_getaffinity(0)
     if os.environ.get("SAGE_BENCH_NO_BIND") != "1":
         capi.bind_thread_to_device(dev_index)
     if args.mode == "edge":
+        os.sched_setaffinity(0, full_affinity)     # (no host solve in this mode; its CPU leg wants its 16 threads on 16 cores)
         out = edge_mode(capi, synth, torch)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
         return
@@ -755,7 +757,21 @@ def main():
                                                  "value": residuals_per_step / (ms_c * 1e-3) / 1e6, "unit": "Mresiduals/s",
                                                  "note": "median of the iterations 2..3 after each restart (every timed iteration "
                                                          "accepted); a rejected iteration costs a linearize here instead of an error pass"}
+        # where the host side ran (the replicated solve is a fifth of the step and lives on host cores that a 1-GPU box
+        # shares with the node's other tenants: DESIGN s7 "what the slow processes are")
+        try:
+            import ctypes
+            out["host_placement"] = {"lm_thread_cpu": int(ctypes.CDLL(None).sched_getcpu()),
+                                     "lm_thread_mask_cpus": len(os.sched_getaffinity(0)),
+                                     "solver_helper_cpus": capi.solver_helper_cpus(),
+                                     "placement_monitor_moves": capi.solver_placement_moves(),
+                                     "loadavg_1min": float(open("/proc/loadavg").read().split()[0])}
+        except Exception as e:                                  # diagnostics only
+            out["host_placement"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
+            # the baseline's OpenMP team inherits the caller's mask: give it back every CPU the process started with (the
+            # binding above narrows the LM thread to one L3 domain)
+            os.sched_setaffinity(0, full_affinity)
             out["cpu_baseline"] = cpu_baseline(win_h)
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     win.close()
