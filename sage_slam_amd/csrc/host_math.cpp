@@ -1733,7 +1733,8 @@ static double mono_seconds()
 }
 // from_col: only the blocks (i, j >= from_col) -- the others have been consumed already (the arrow-row tasks take their
 // blocks one by one).  Structural fill blocks (E.fill) are zeroed here instead of waited for: this is their first touch.
-static __attribute__((noinline)) bool wait_row_tickets(const BlockEnvelope &E, int i, double *T, int from_col = 0)
+static __attribute__((noinline)) bool wait_row_tickets(const BlockEnvelope &E, int i, double *T, int from_col = 0,
+                                                       int skip_lo = 0, int skip_hi = 0)
 {
   const int na = E.a_cnt ? E.a_cnt[i] : 0;
   const int b0[2] = {na ? E.a_off[i] : 0, E.row_off[i]}, nb[2] = {na, i - E.row_first[i] + 1};
@@ -1742,8 +1743,8 @@ static __attribute__((noinline)) bool wait_row_tickets(const BlockEnvelope &E, i
   for (int rg = 0; rg < 2; ++rg)
     for (int q = 0; q < nb[rg]; ++q)
     {
-      if (c0[rg] + q < from_col)
-        continue;
+      if (c0[rg] + q < from_col || (c0[rg] + q >= skip_lo && c0[rg] + q < skip_hi))
+        continue; // (skip range: blocks the separator pre-pass has taken care of, tickets and fill included)
       if (E.fill && E.fill[b0[rg] + q])
       {
         std::memset(T + (size_t)(b0[rg] + q) * BB, 0, BB * sizeof(double));
@@ -1803,15 +1804,38 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
       }
       return true;
     };
+    if (role == 2 && E.sep_pre)
+      pipe->pre.store(1, std::memory_order_release); // (before this stage's first `early`: the chain thread cannot finish its half unseen)
     for (int i = lo; i < hi; ++i)
     {
       LAP(5);
       if (E.before_row && E.before_row(E.user, i))
         return -2;
-      if (role != 1 && E.ready && !wait_row_tickets(E, i, T))
+      // separator row of a plain split window: its blocks against a half's columns may have been formed already by that
+      // half's look-ahead thread (sep_pre) -- tickets, fill and arithmetic; they are skipped below
+      int pre_lo[2] = {0, 0}, pre_hi[2] = {0, 0};
+      if (role == 0 && E.sep_pre && E.pipe && i >= E.n1 + E.n2)
+      {
+        for (int hf = 0; hf < 2; ++hf)
+        {
+          int v;
+          while ((v = E.pipe[hf].pre.load(std::memory_order_acquire)) == 1)
+            __builtin_ia32_pause();
+          if (v < 0)
+            return -2;
+          if (v == 2)
+          {
+            pre_lo[hf] = hf == 0 ? afirst(i) : row_first[i];
+            pre_hi[hf] = hf == 0 ? afirst(i) + acnt(i) : std::min(E.n1 + E.n2, i);
+          }
+        }
+      }
+      if (role != 1 && E.ready && !wait_row_tickets(E, i, T, pre_hi[0] > pre_lo[0] ? pre_hi[0] : 0, pre_lo[1], pre_hi[1]))
       {
         if (pipe)
           pipe->early.store(-1, std::memory_order_release);
+        if (role == 2 && E.sep_pre)
+          pipe->pre.store(-1, std::memory_order_release);
         return -2;
       }
       LAP(0);
@@ -1830,7 +1854,11 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
       {
         // look-ahead: needs the rows <= i-2 complete (and its own earlier rows)
         if (!pipe_wait(pipe->late, i - 1 - lo))
+        {
+          if (E.sep_pre)
+            pipe->pre.store(-1, std::memory_order_release);
           return -2;
+        }
         for (int j = row_first[i]; j < i; ++j)
         {
           double *CT = blk(i, j);
@@ -1867,6 +1895,8 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
       for (int rg = 0; rg < 2; ++rg)
         for (int j = r0[rg]; j < r1[rg]; ++j)
         {
+          if ((j >= pre_lo[0] && j < pre_hi[0]) || (j >= pre_lo[1] && j < pre_hi[1]))
+            continue; // (formed by the half's look-ahead thread: same operations, same order)
           double *CT = blk(i, j);
           for (int rk = 0; rk <= rg; ++rk)
             for (int k = r0[rk]; k < std::min(r1[rk], j); ++k)
@@ -1922,6 +1952,86 @@ static inline __attribute__((always_inline)) int block_chol_pass(const BlockEnve
         pipe->late.store(i + 1 - lo, std::memory_order_release);
       if (E.progress && i < E.n1 + E.n2)
         E.progress[i >= E.n1 ? 1 : 0].store(i + 1, std::memory_order_release);
+    }
+    if (role == 2 && E.sep_pre)
+    {
+      // ---- separator pre-pass (r05): the blocks L_sj of the separator rows s against THIS half's columns j only need rows of
+      // this half -- L_sj = (A_sj - sum_{k < j, same range} L_jk L_sk) L_jj^-T -- and this thread has nothing left to do: it
+      // forms them right behind the chain thread's row j instead of the caller forming them after both halves have joined.
+      // Per block the same operations in the same order as in the separator pass (bit-identical factor).
+      const int sep0 = E.n1 + E.n2, half = lo >= E.n1 && E.n1 > 0 ? 1 : 0;
+      auto rng = [&](int srow, int &a, int &b) {
+        a = half == 0 ? afirst(srow) : (int)row_first[srow];
+        b = half == 0 ? afirst(srow) + acnt(srow) : std::min(sep0, srow);
+      };
+      int jlo = hi;
+      for (int srow = sep0; srow < K; ++srow)
+      {
+        int a, b;
+        rng(srow, a, b);
+        if (a < b)
+          jlo = std::min(jlo, a);
+      }
+      RowPrefetch pf0{nullptr, nullptr};
+      bool ok = true;
+      // the separator rows' blocks were written by the device's DMA and sit in no cache: ask for them now, while the chain
+      // thread still works on the rows this pass waits for
+      for (int srow = sep0; srow < K; ++srow)
+      {
+        int a, b;
+        rng(srow, a, b);
+        for (int j = std::max(a, lo); j < std::min(b, hi); ++j)
+        {
+          const char *pb = reinterpret_cast<const char *>(
+              T + (size_t)(j < row_first[srow] ? E.a_off[srow] + j - E.a_first[srow] : row_off[srow] + j - row_first[srow]) * BB);
+          for (size_t o = 0; o < (size_t)BB * sizeof(double); o += 64)
+            __builtin_prefetch(pb + o, 1, 3);
+        }
+      }
+      for (int j = std::max(jlo, lo); j < hi && ok; ++j)
+      {
+        if (!pipe_wait(pipe->late, j + 1 - lo)) // row j complete: its blocks and the inverse of its diagonal factor
+        {
+          ok = false;
+          break;
+        }
+        for (int srow = sep0; srow < K && ok; ++srow)
+        {
+          int a, b;
+          rng(srow, a, b);
+          if (j < a || j >= b)
+            continue;
+          const size_t idx = (size_t)(j < row_first[srow] ? E.a_off[srow] + j - E.a_first[srow] : row_off[srow] + j - row_first[srow]);
+          double *CT = T + idx * BB;
+          if (E.fill && E.fill[idx])
+            std::memset(CT, 0, (size_t)BB * sizeof(double)); // structural fill: first touch
+          else if (E.ready)
+          {
+            const volatile unsigned *f = E.ready + idx;
+            const double t0 = mono_seconds();
+            unsigned spins = 0;
+            while (*f != E.epoch)
+            {
+              __builtin_ia32_pause();
+              if ((++spins & 0xfff) == 0 && mono_seconds() - t0 > 2.0)
+              {
+                ok = false;
+                break;
+              }
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (!ok)
+              break;
+          }
+          for (int k = a; k < j; ++k)
+            if (has(j, k))
+              tn_sub<NV>(CT, blk(j, k), blk(srow, k), false, pf0);
+          apply_inverse<NV>(CT, X + (size_t)j * BB);
+        }
+      }
+      pipe->pre.store(ok ? 2 : -1, std::memory_order_release);
+      if (!ok)
+        return -2;
     }
     if (prof)
       fprintf(stderr, "[chol profile] rows %d..%d kcycles: wait %.0f gemm+syrk %.0f apply-inverse %.0f factor+inverse %.0f fwd-subst %.0f other %.0f\n",
@@ -3585,6 +3695,8 @@ int block_chol_solve_tr(const BlockEnvelope &E0, double *T, double *X, double *y
   }
   BlockEnvelope::RowPipe pipes[2];
   E.pipe = pipes;
+  static const bool no_sep_pre = sage::env_flag("SAGE_SOLVE_NO_SEP_PRE");
+  E.sep_pre = !arrow && !no_sep_pre && E.n1 > 0 && E.n2 > 0 && !E.before_row;
   CholHelper *h = chol_helper();
   bool shared = false;
   if (h && h->armed.load(std::memory_order_acquire))

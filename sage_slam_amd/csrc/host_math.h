@@ -85,8 +85,12 @@ struct BlockEnvelope
   {
     alignas(64) std::atomic<int> early{0};
     alignas(64) std::atomic<int> late{0};
+    // r05: the separator rows' blocks against this half's columns, formed by the half's look-ahead thread right behind the
+    // rows they depend on (sep_pre): 0 nobody does it (the separator pass forms them itself), 1 pending, 2 done, -1 given up
+    alignas(64) std::atomic<int> pre{0};
   };
   RowPipe *pipe = nullptr;
+  bool sep_pre = false; // plain split windows: the look-ahead threads pre-form the separator rows' half blocks
 };
 // In place: T becomes L^T blockwise, X (K*Bp*Bp) receives the inverses of the diagonal factors, y (K*Bp) the
 // right-hand side on entry and the solution on return.  Returns 0, or 1 + the block column of the first non-positive
