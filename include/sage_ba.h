@@ -69,10 +69,12 @@ typedef struct SagePyramid
 } SagePyramid;
 
 /* CameraPyramid ctor: level i = level i-1 resized to (size_t)(w/2),(size_t)(h/2). Host only. */
-/* (The photometric entry points and sage_window_create accept pyramids whose per-level focal ratios fx_l/fx_0, fy_l/fy_0 are
- * powers of two -- what this function and the reference's CameraPyramid build -- and return SAGE_E_UNSUPPORTED otherwise: the
- * kernels form a level's coordinate with the host-side quotient, which is only then bit-identical to the reference's
- * ((p + 0.5) * fx_l) / fx_0 - 0.5, photometric_factor_kernels.cpp:101-103.) */
+/* (Level coordinates: a pyramid whose per-level focal ratios fx_l/fx_0, fy_l/fy_0 are exact powers of two -- every pyramid
+ * this function / the reference's CameraPyramid builds while the level sizes stay even, i.e. the only sizes for which the
+ * reference's own conv / camera / mask pyramids agree -- is sampled with the host-side quotient (bit-identical to the
+ * reference's ((p + 0.5) * fx_l) / fx_0 - 0.5, photometric_factor_kernels.cpp:101-103, there).  r06: any other pyramid (an odd
+ * level size, w = 250 -> 125 -> 62, or hand-made focal lengths) is accepted too: the kernels then evaluate the reference's
+ * expression per pixel -- true multiplication, true division -- on the texture-path sampler; slower, same results.) */
 int sage_camera_pyramid(const SageCamera *base, int levels, SagePyramid *out);
 
 const char *sage_version(void);
@@ -179,10 +181,22 @@ int sage_gaussian_pyramid_with_grad(SageWorkspace *ws, float *pyr_dev, float *gr
 int sage_bind_thread_to_device(int device);
 /* Diagnostics of the hybrid solve's thread placement: the CPUs its (up to three) helper threads are pinned to (-1: not
  * placed yet; returns how many entries were written), and how often the placement monitor has moved a helper off a core
- * that another process crowded (a background thread looks at the helpers' run-queue delay and at the load on their cores'
- * other hardware threads every 250 ms; SAGE_PLACEMENT_MONITOR=0 turns it off). */
+ * that another process crowded.
+ * r06: the placement monitor -- a background thread that looks at the helpers' run-queue delay and at the load on their
+ * cores' other hardware threads every 250 ms and re-pins a crowded helper -- is OPT-IN: SAGE_PLACEMENT_MONITOR=1 in the
+ * environment or sage_placement_monitor(1) before the first solve (sage_placement_monitor(0) stops and joins it).  A
+ * drop-in library does not edit thread affinities from the background unless asked to. */
 int sage_solver_helper_cpus(int *cpus, int n);
 int sage_solver_placement_moves(void);
+int sage_placement_monitor(int enable);
+/* Host threads of the library (r06).  The window solve runs on up to 3 helper threads (+ up to 10 pool workers for
+ * loop-closure plans, + the opt-in monitor).  They are started by the first solve that wants them and are JOINABLE:
+ * the last sage_window_destroy of the process, sage_shutdown() and process exit (atexit) stop and join them -- nothing
+ * is detached, no thread of this library outlives its last window.  sage_shutdown() may be called at any time no
+ * solve is in flight (e.g. before dlclose); a later solve starts the threads again.
+ * sage_host_threads_running() = how many of them are alive (diagnostic). */
+void sage_shutdown(void);
+int sage_host_threads_running(void);
 
 /* se3_exp (core/mapping/mapping_utils.h:316-346): R[9], t[3] from omega[3], v[3]. */
 void sage_se3_exp(const float *omega, const float *v, float *R, float *t);

@@ -98,7 +98,7 @@ SYMBOLS = [
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_prepare_factors", "sage_factor_psd", "sage_factor_cut_blocks", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_get_phase_time", "sage_window_lm_step", "sage_window_lm_run", "sage_window_lm_run_timed", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_window_emulate_peers", "sage_sort_locations", "sage_bind_thread_to_device", "sage_solver_helper_cpus", "sage_solver_placement_moves",
+    "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_prepare_factors", "sage_factor_psd", "sage_factor_cut_blocks", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_get_phase_time", "sage_window_lm_step", "sage_window_lm_run", "sage_window_lm_run_timed", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_window_emulate_peers", "sage_sort_locations", "sage_bind_thread_to_device", "sage_solver_helper_cpus", "sage_solver_placement_moves", "sage_placement_monitor", "sage_shutdown", "sage_host_threads_running",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",
@@ -124,6 +124,7 @@ def lib():
         L.sage_version.restype = C.c_char_p
         L.sage_error_string.restype = C.c_char_p
         L.sage_window_packed_count.restype = C.c_size_t
+        L.sage_shutdown.restype = None
         L.sage_window_packed_dev.restype = C.c_void_p
         L.sage_window_error_dev.restype = C.c_void_p
         L.sage_window_residuals_per_linearize.restype = C.c_double
@@ -916,6 +917,21 @@ def solver_helper_cpus():
 def solver_placement_moves() -> int:
     """``sage_solver_placement_moves``: helpers the placement monitor has moved off crowded cores so far."""
     return int(lib().sage_solver_placement_moves())
+
+
+def placement_monitor(enable: bool) -> None:
+    """``sage_placement_monitor``: the background re-pinning of crowded helper threads is opt-in (r06)."""
+    lib().sage_placement_monitor(1 if enable else 0)
+
+
+def shutdown() -> None:
+    """``sage_shutdown``: stop and join every host thread the library started (they restart on demand)."""
+    lib().sage_shutdown()
+
+
+def host_threads_running() -> int:
+    """``sage_host_threads_running``: helper / pool / monitor threads of the library that are alive."""
+    return int(lib().sage_host_threads_running())
 
 
 def sort_locations(ws, loc1d, homo, H, W):

@@ -1426,6 +1426,7 @@ void EnvelopeMatrix::solve_inplace(std::vector<double> &b) const
 // ------------------------------------------------------------------------------------------------
 namespace sage
 {
+static void host_threads_atexit_once(); // (defined with host_threads_shutdown below)
 namespace
 {
 #define SAGE_STOREU(p, v) __builtin_memcpy((p), &(v), sizeof(v8d))
@@ -2638,22 +2639,28 @@ struct SepPool
   std::atomic<bool> busy{false};
   std::atomic<SepJob *> job{nullptr};
   std::vector<pthread_t> tids;
+  std::vector<std::thread> ths; // joinable: host_threads_shutdown() stops and joins them, block_chol_arm() starts them again
+  int n_workers = 0;
+  std::atomic<bool> quit{false}, running{false};
+  unsigned seen0 = 0;
   std::unique_ptr<std::atomic<int>[]> ktid, cpu; // per worker: kernel thread id, CPU it is pinned to (-1: none) -- placement monitor
   std::vector<int> dom; // per worker: 0 / 1 = pinned to a core of the first / second half's L3 domain, -1 elsewhere (place_pool)
-  int near_cpu = -1;
-  int near_mode = -1;
+  std::atomic<int> near_cpu{-1};
+  std::atomic<int> near_mode{-1};
   void loop(int idx)
   {
-    unsigned seen = posted.load(std::memory_order_acquire);
+    unsigned seen = seen0;
     for (;;)
     {
       {
         std::unique_lock<std::mutex> lk(mu);
-        cv.wait(lk, [&] { return armed.load(std::memory_order_acquire); });
+        cv.wait(lk, [&] { return armed.load(std::memory_order_acquire) || quit.load(std::memory_order_acquire); });
       }
+      if (quit.load(std::memory_order_acquire))
+        return;
       double t0 = mono_seconds();
       unsigned spins = 0;
-      while (armed.load(std::memory_order_acquire))
+      while (armed.load(std::memory_order_acquire) && !quit.load(std::memory_order_relaxed))
       {
         const unsigned p = posted.load(std::memory_order_acquire);
         if (p != seen)
@@ -2683,10 +2690,14 @@ struct SepPool
     }
   }
 };
+// ---- life cycle of the solver's host threads (r06).  The OBJECTS (CholHelper x 3, SepPool) are made once and never freed
+// -- a caller that lost a race with a shutdown still holds valid memory and, by the hand-over protocols' design, depends on
+// no thread that has not claimed its job -- but the THREADS are joinable: block_chol_arm() starts them on demand,
+// host_threads_shutdown() (sage_shutdown(), the last sage_window_destroy, atexit) stops and joins them.  Nothing is detached.
+static std::mutex g_threads_mu;
 static std::atomic<SepPool *> g_sep_pool_made{nullptr}; // (the placement monitor must not CREATE the pool by asking for it)
 static SepPool *sep_pool()
 {
-  // deliberately leaked, like the helper
   static SepPool *p = [] {
     const unsigned hw = std::thread::hardware_concurrency();
     // (r04: the halves run two threads each now, so the arrow-row tasks are what the halves wait for -- config 5 per LM
@@ -2696,6 +2707,7 @@ static SepPool *sep_pool()
     if (n < 1)
       return (SepPool *)nullptr;
     SepPool *q = new SepPool;
+    q->n_workers = n;
     q->ktid.reset(new std::atomic<int>[n]);
     q->cpu.reset(new std::atomic<int>[n]);
     for (int i = 0; i < n; ++i)
@@ -2703,19 +2715,34 @@ static SepPool *sep_pool()
       q->ktid[i].store(0);
       q->cpu[i].store(-1);
     }
-    for (int i = 0; i < n; ++i)
-    {
-      std::thread th([q, i] {
-        q->ktid[i].store((int)syscall(SYS_gettid), std::memory_order_release);
-        q->loop(i);
-      });
-      q->tids.push_back(th.native_handle());
-      th.detach();
-    }
     g_sep_pool_made.store(q, std::memory_order_release);
     return q;
   }();
   return p;
+}
+// (g_threads_mu held)
+static void sep_pool_start(SepPool *q)
+{
+  if (q->running.load(std::memory_order_acquire))
+    return;
+  host_threads_atexit_once();
+  q->quit.store(false, std::memory_order_release);
+  q->tids.clear();
+  q->ths.clear();
+  q->near_cpu.store(-1, std::memory_order_release); // new threads: not pinned yet, place_pool places them again
+  q->near_mode.store(-1, std::memory_order_release);
+  q->seen0 = q->posted.load(std::memory_order_acquire);
+  for (int i = 0; i < q->n_workers; ++i)
+  {
+    q->ktid[i].store(0);
+    q->cpu[i].store(-1);
+    q->ths.emplace_back([q, i] {
+      q->ktid[i].store((int)syscall(SYS_gettid), std::memory_order_release);
+      q->loop(i);
+    });
+    q->tids.push_back(q->ths.back().native_handle());
+  }
+  q->running.store(true, std::memory_order_release);
 }
 
 static int block_chol_range(const BlockEnvelope &E, double *T, double *X, double *y, int phase, int lo, int hi,
@@ -2748,14 +2775,15 @@ struct CholHelper
   pthread_t tid{};
   std::atomic<int> ktid{0};    // kernel thread id (its /proc/self/task entry: the placement monitor reads its run-queue delay)
   std::atomic<int> cpu{-1};    // the CPU it is pinned to (-1: not pinned)
-  int near_cpu = -1, near_mode = -1;
-  bool started = false;
+  std::atomic<int> near_cpu{-1}, near_mode{-1};
+  std::atomic<bool> quit{false}, running{false}; // joinable thread: started by block_chol_arm, stopped by host_threads_shutdown
+  unsigned seen0 = 0;
   static void cpu_relax() { __builtin_ia32_pause(); }
   void loop();
 };
 static CholHelper *chol_helper(int idx = 0)
 {
-  // deliberately leaked: the threads may still be parked on their condition variables when the process exits
+  // the objects live for the life of the process (see "life cycle" above); their threads come and go
   static CholHelper **hs = [] {
     CholHelper **v = new CholHelper *[3]{nullptr, nullptr, nullptr};
     const unsigned hc = std::thread::hardware_concurrency();
@@ -2765,17 +2793,30 @@ static CholHelper *chol_helper(int idx = 0)
         continue;
       CholHelper *p = new CholHelper;
       p->kind = i == 0 ? 0 : 1;
-      p->th = std::thread([p] {
-        p->ktid.store((int)syscall(SYS_gettid), std::memory_order_release);
-        p->loop();
-      });
-      p->tid = p->th.native_handle();
-      p->th.detach();
       v[i] = p;
     }
     return v;
   }();
   return hs[idx];
+}
+// (g_threads_mu held)
+static void chol_helper_start(CholHelper *p)
+{
+  if (p->running.load(std::memory_order_acquire))
+    return;
+  host_threads_atexit_once();
+  p->quit.store(false, std::memory_order_release);
+  p->ktid.store(0, std::memory_order_release);
+  p->cpu.store(-1, std::memory_order_release);
+  p->near_cpu.store(-1, std::memory_order_release);
+  p->near_mode.store(-1, std::memory_order_release);
+  p->seen0 = p->posted.load(std::memory_order_acquire);
+  p->th = std::thread([p] {
+    p->ktid.store((int)syscall(SYS_gettid), std::memory_order_release);
+    p->loop();
+  });
+  p->tid = p->th.native_handle();
+  p->running.store(true, std::memory_order_release);
 }
 
 static std::atomic<long long> g_lookahead_count{0};
@@ -2835,16 +2876,19 @@ static void lookahead_release(int idx)
 
 void CholHelper::loop()
 {
-  unsigned seen = 0;
+  unsigned seen = seen0; // (sampled by the thread that started this one, before it can post: a restarted thread does not
+                         //  answer posts from before its time and cannot miss the starter's first one)
   for (;;)
   {
     {
       std::unique_lock<std::mutex> lk(mu);
-      cv.wait(lk, [&] { return armed.load(std::memory_order_acquire); });
+      cv.wait(lk, [&] { return armed.load(std::memory_order_acquire) || quit.load(std::memory_order_acquire); });
     }
+    if (quit.load(std::memory_order_acquire))
+      return;
     const double t0 = mono_seconds();
     unsigned spins = 0;
-    while (armed.load(std::memory_order_acquire))
+    while (armed.load(std::memory_order_acquire) && !quit.load(std::memory_order_relaxed))
     {
       const unsigned p = posted.load(std::memory_order_acquire);
       if (p != seen)
@@ -2926,8 +2970,10 @@ static std::vector<int> read_cpu_list(const char *path)
 static std::mutex g_place_mu;
 static bool g_place_override = false;
 static cpu_set_t g_place_allowed;
-static std::map<std::pair<int, bool>, std::vector<int>> g_ccx_cache;
-static std::map<std::pair<int, size_t>, std::vector<int>> g_dom2_cache;
+// (heap-allocated and never destroyed: a thread of this library may still look at them while the process runs its static
+//  destructors)
+static std::map<std::pair<int, bool>, std::vector<int>> &g_ccx_cache = *new std::map<std::pair<int, bool>, std::vector<int>>;
+static std::map<std::pair<int, size_t>, std::vector<int>> &g_dom2_cache = *new std::map<std::pair<int, size_t>, std::vector<int>>;
 
 void placement_set_allowed(const cpu_set_t *allowed)
 {
@@ -3129,6 +3175,10 @@ static std::vector<int> second_domain_cores_uncached(int cpu, size_t want)
 static std::atomic<bool> g_monitor_started{false};
 static std::atomic<int> g_monitor_moves{0};
 static std::mutex g_pin_mu;
+static std::mutex g_monitor_mu;
+static std::condition_variable g_monitor_cv;
+static bool g_monitor_stop = false;           // (g_monitor_mu)
+static std::thread *g_monitor_thread = nullptr; // (g_threads_mu)
 
 static long long read_run_delay_ns(int ktid)
 {
@@ -3174,9 +3224,25 @@ static void placement_monitor_loop()
   std::vector<long long> prev_delay(3, -1);
   std::vector<int> strikes(3, 0);
   stat_snapshot(prev);
+  {
+    // its own affinity: the CPUs the placement may use (not the one-L3 mask inherited from the LM thread that started it,
+    // where it would compete with the thread that spins)
+    cpu_set_t allowed;
+    bool ok;
+    {
+      std::lock_guard<std::mutex> lk(g_place_mu);
+      ok = placement_allowed(&allowed);
+    }
+    if (ok)
+      (void)pthread_setaffinity_np(pthread_self(), sizeof(allowed), &allowed);
+  }
   for (;;)
   {
-    std::this_thread::sleep_for(std::chrono::milliseconds(250));
+    {
+      std::unique_lock<std::mutex> lm(g_monitor_mu);
+      if (g_monitor_cv.wait_for(lm, std::chrono::milliseconds(250), [] { return g_monitor_stop; }))
+        return;
+    }
     cur.clear();
     if (!stat_snapshot(cur))
       continue;
@@ -3189,13 +3255,16 @@ static void placement_monitor_loop()
     };
     CholHelper *hs[3] = {chol_helper(0), chol_helper(1), chol_helper(2)};
     SepPool *q = g_sep_pool_made.load(std::memory_order_acquire);
-    const int nq = q ? (int)q->tids.size() : 0;
+    const int nq = q ? q->n_workers : 0;
     prev_delay.resize(3 + nq, -1);
     strikes.resize(3 + nq, 0);
-    auto slot_cpu = [&](int i) -> std::atomic<int> * { return i < 3 ? (hs[i] ? &hs[i]->cpu : nullptr) : &q->cpu[i - 3]; };
+    auto slot_cpu = [&](int i) -> std::atomic<int> * {
+      return i < 3 ? ((hs[i] && hs[i]->running.load(std::memory_order_acquire)) ? &hs[i]->cpu : nullptr)
+                   : (q->running.load(std::memory_order_acquire) ? &q->cpu[i - 3] : nullptr);
+    };
     auto slot_ktid = [&](int i) { return i < 3 ? (hs[i] ? hs[i]->ktid.load(std::memory_order_acquire) : 0) : q->ktid[i - 3].load(std::memory_order_acquire); };
     auto slot_thread = [&](int i) { return i < 3 ? hs[i]->tid : q->tids[i - 3]; };
-    const int near = hs[0] ? hs[0]->near_cpu : (q ? q->near_cpu : -1);
+    const int near = hs[0] ? hs[0]->near_cpu.load(std::memory_order_acquire) : (q ? q->near_cpu.load(std::memory_order_acquire) : -1);
     for (int i = 0; i < 3 + nq; ++i)
     {
       std::atomic<int> *pc = slot_cpu(i);
@@ -3266,16 +3335,57 @@ static void placement_monitor_loop()
   }
 }
 
+
+// r06: OPT-IN (SAGE_PLACEMENT_MONITOR=1 or sage_placement_monitor(1)) -- a drop-in library does not edit thread affinities
+// from a background thread unless asked to.  Joinable: host_threads_shutdown() stops it.
+static std::atomic<int> g_monitor_wanted{-1}; // -1: ask the environment, 0 / 1: set through the API
 static void placement_monitor_start()
 {
+  int want = g_monitor_wanted.load(std::memory_order_acquire);
+  if (want < 0)
+  {
+    const char *e = getenv("SAGE_PLACEMENT_MONITOR");
+    want = (e && atoi(e) != 0) ? 1 : 0;
+    g_monitor_wanted.store(want, std::memory_order_release);
+  }
+  if (!want || g_monitor_started.load(std::memory_order_acquire))
+    return;
   bool expect = false;
   if (!g_monitor_started.compare_exchange_strong(expect, true))
     return;
-  if (const char *e = getenv("SAGE_PLACEMENT_MONITOR"))
-    if (atoi(e) == 0)
-      return;
-  std::thread(placement_monitor_loop).detach();
+  std::lock_guard<std::mutex> lk(g_threads_mu);
+  host_threads_atexit_once();
+  {
+    std::lock_guard<std::mutex> lm(g_monitor_mu);
+    g_monitor_stop = false;
+  }
+  g_monitor_thread = new std::thread(placement_monitor_loop);
 }
+// (g_threads_mu held)
+static void placement_monitor_stop()
+{
+  if (!g_monitor_thread)
+    return;
+  {
+    std::lock_guard<std::mutex> lm(g_monitor_mu);
+    g_monitor_stop = true;
+  }
+  g_monitor_cv.notify_all();
+  g_monitor_thread->join();
+  delete g_monitor_thread;
+  g_monitor_thread = nullptr;
+  g_monitor_started.store(false, std::memory_order_release);
+}
+void placement_monitor_enable(int on)
+{
+  g_monitor_wanted.store(on ? 1 : 0, std::memory_order_release);
+  if (!on)
+  {
+    std::lock_guard<std::mutex> lk(g_threads_mu);
+    placement_monitor_stop();
+  }
+}
+int placement_monitor_running() { return g_monitor_started.load(std::memory_order_acquire) ? 1 : 0; }
 
 int placement_helper_cpus(int *cpus, int n)
 {
@@ -3293,38 +3403,34 @@ int placement_monitor_moves() { return g_monitor_moves.load(std::memory_order_re
 //         B[0] second half, B[1] its look-ahead stage, pool workers for the second half's chains from B[2] on
 static void place_helper(CholHelper *h, int cpu, int idx, int mode, const std::vector<int> &B)
 {
-  if (cpu < 0 || (cpu == h->near_cpu && mode == h->near_mode))
+  if (cpu < 0 || (cpu == h->near_cpu.load(std::memory_order_acquire) && mode == h->near_mode.load(std::memory_order_acquire)))
     return;
-  h->near_cpu = cpu;
-  h->near_mode = mode;
+  h->near_cpu.store(cpu, std::memory_order_release);
+  h->near_mode.store(mode, std::memory_order_release);
   const std::vector<int> &A = ccx_cores_of(cpu, false);
+  int core = -1;
   if (mode == 2)
+    core = idx == 0 ? (B.size() > 0 ? B[0] : -1) : idx == 1 ? (A.size() > 0 ? A[0] : -1) : (B.size() > 1 ? B[1] : -1);
+  else if ((int)A.size() > idx)
+    core = A[idx];
+  if (core >= 0)
   {
-    const int core = idx == 0 ? (B.size() > 0 ? B[0] : -1) : idx == 1 ? (A.size() > 0 ? A[0] : -1) : (B.size() > 1 ? B[1] : -1);
-    if (core >= 0)
-    {
-      pin_one(h->tid, core);
-      h->cpu.store(core, std::memory_order_release);
-    }
-    placement_monitor_start();
-    return;
+    std::lock_guard<std::mutex> pin_lk(g_pin_mu); // (the placement monitor re-pins under the same lock: cpu and affinity stay in step)
+    pin_one(h->tid, core);
+    h->cpu.store(core, std::memory_order_release);
   }
-  if ((int)A.size() > idx)
-  {
-    pin_one(h->tid, A[idx]);
-    h->cpu.store(A[idx], std::memory_order_release);
-  }
-  placement_monitor_start();
+  placement_monitor_start(); // (opt-in; takes g_threads_mu -- not under g_pin_mu, which the monitor itself takes)
 }
 
 static void place_pool(SepPool *q, int cpu, int mode, const std::vector<int> &B, int chains_per_half)
 {
-  if (cpu < 0 || (cpu == q->near_cpu && mode == q->near_mode))
+  if (cpu < 0 || (cpu == q->near_cpu.load(std::memory_order_acquire) && mode == q->near_mode.load(std::memory_order_acquire)))
     return;
-  q->near_cpu = cpu;
-  q->near_mode = mode;
+  q->near_cpu.store(cpu, std::memory_order_release);
+  q->near_mode.store(mode, std::memory_order_release);
   const std::vector<int> &cores = ccx_cores_of(cpu, true); // domain A first, then the rest of the NUMA node
   const size_t n_ccx = ccx_cores_of(cpu, false).size();
+  std::lock_guard<std::mutex> pin_lk(g_pin_mu);
   q->dom.assign(q->tids.size(), -1);
   int n0 = 0, n1 = 0;
   if (mode == 2)
@@ -3396,6 +3502,11 @@ bool block_chol_arm(bool with_pool, int long_arrow_chains)
   for (int idx = 0; idx < (no_la ? 1 : 3); ++idx)
   {
     CholHelper *h = chol_helper(idx);
+    if (h && !h->running.load(std::memory_order_acquire))
+    {
+      std::lock_guard<std::mutex> lk(g_threads_mu);
+      chol_helper_start(h);
+    }
     if (h && !h->armed.load(std::memory_order_acquire))
     {
       place_helper(h, cpu, idx, mode, B);
@@ -3406,9 +3517,15 @@ bool block_chol_arm(bool with_pool, int long_arrow_chains)
       h->cv.notify_one();
     }
   }
+  placement_monitor_start(); // (opt-in: two relaxed loads when it is off or already running)
   if (!with_pool)
     return no_la;
   SepPool *q = sep_pool();
+  if (q && !q->running.load(std::memory_order_acquire))
+  {
+    std::lock_guard<std::mutex> lk(g_threads_mu);
+    sep_pool_start(q);
+  }
   if (q && !q->armed.load(std::memory_order_acquire))
   {
     place_pool(q, cpu, mode, B, per_half);
@@ -3419,6 +3536,60 @@ bool block_chol_arm(bool with_pool, int long_arrow_chains)
     q->cv.notify_all();
   }
   return no_la;
+}
+
+// Stop and join every host thread this library started (helpers, arrow-row pool, placement monitor).  Safe to call at any
+// time no solve is in flight; the next block_chol_arm() starts them again.  Called by sage_shutdown(), by the last
+// sage_window_destroy and at process exit.
+void host_threads_shutdown()
+{
+  std::lock_guard<std::mutex> lk(g_threads_mu);
+  placement_monitor_stop();
+  for (int idx = 0; idx < 3; ++idx)
+  {
+    CholHelper *h = chol_helper(idx);
+    if (!h || !h->running.load(std::memory_order_acquire))
+      continue;
+    {
+      std::lock_guard<std::mutex> lh(h->mu);
+      h->quit.store(true, std::memory_order_release);
+    }
+    h->cv.notify_all();
+    h->th.join();
+    h->armed.store(false, std::memory_order_release);
+    h->cpu.store(-1, std::memory_order_release);
+    h->running.store(false, std::memory_order_release);
+  }
+  if (SepPool *q = g_sep_pool_made.load(std::memory_order_acquire))
+    if (q->running.load(std::memory_order_acquire))
+    {
+      {
+        std::lock_guard<std::mutex> lq(q->mu);
+        q->quit.store(true, std::memory_order_release);
+      }
+      q->cv.notify_all();
+      for (std::thread &t : q->ths)
+        t.join();
+      q->ths.clear();
+      q->tids.clear();
+      q->armed.store(false, std::memory_order_release);
+      q->running.store(false, std::memory_order_release);
+    }
+}
+int host_threads_running()
+{
+  int n = placement_monitor_running();
+  for (int idx = 0; idx < 3; ++idx)
+    if (CholHelper *h = chol_helper(idx))
+      n += h->running.load(std::memory_order_acquire) ? 1 : 0;
+  if (SepPool *q = g_sep_pool_made.load(std::memory_order_acquire))
+    n += q->running.load(std::memory_order_acquire) ? q->n_workers : 0;
+  return n;
+}
+static void host_threads_atexit_once()
+{
+  static std::once_flag once;
+  std::call_once(once, [] { atexit(host_threads_shutdown); });
 }
 
 // rows of the separator part whose ranges run far along a half (> 16 columns): the chains the pool's fast threads carry

@@ -116,6 +116,13 @@ std::vector<int> placement_core_siblings(int cpu);
 std::vector<int> placement_l3_domain(int cpu);
 int placement_helper_cpus(int *cpus, int n); // CPUs the solve's (up to three) helper threads are pinned to
 int placement_monitor_moves();              // helpers moved off crowded cores so far (placement monitor)
+// r06: the placement monitor is OPT-IN (SAGE_PLACEMENT_MONITOR=1 or placement_monitor_enable(1)); every thread the solve
+// starts (helpers, arrow-row pool, monitor) is joinable: host_threads_shutdown() stops and joins them, the next
+// block_chol_arm() starts them again.  host_threads_running() = how many are alive.
+void placement_monitor_enable(int on);
+int placement_monitor_running();
+void host_threads_shutdown();
+int host_threads_running();
 int block_plan_long_arrow_chains(const BlockEnvelope &env);
 // true when the separator rows of the plan reach far into the halves (cover keyframes of loop closures): the
 // factorisation then wants the worker pool

@@ -160,7 +160,7 @@ extern "C" int sage_photometric_jac_error_calculate(
   if (!ws || !AtA_dev || !Atb_dev || !pyr || !weights_host || !R0 || !t0 || !R1 || !t1 || !bias0 || !basis0 ||
       !code0 || !mask1 || !loc1d || !homo || !feat0 || !feat1 || !grad1)
     return SAGE_E_INVALID;
-  if (!supported(CS, FS) || pyr->levels < 1 || pyr->levels > SAGE_MAX_LEVELS || !pyramid_is_dyadic(*pyr))
+  if (!supported(CS, FS) || pyr->levels < 1 || pyr->levels > SAGE_MAX_LEVELS)
     return SAGE_E_UNSUPPORTED;
   LaunchCommon lc;
   int rc = ws_prepare(ws, N, photo_partial_floats(CS), &lc);
@@ -189,7 +189,7 @@ extern "C" int sage_photometric_error_calculate(
   if (!ws || !pyr || !weights_host || !R10 || !t10 || !bias0 || !basis0 || !code0 || !mask1 || !loc1d || !homo ||
       !feat0 || !feat1)
     return SAGE_E_INVALID;
-  if (!supported(CS, FS) || pyr->levels < 1 || pyr->levels > SAGE_MAX_LEVELS || !pyramid_is_dyadic(*pyr))
+  if (!supported(CS, FS) || pyr->levels < 1 || pyr->levels > SAGE_MAX_LEVELS)
     return SAGE_E_UNSUPPORTED;
   LaunchCommon lc;
   int rc = ws_prepare(ws, N, 2, &lc);
@@ -216,7 +216,7 @@ static int track_common(SageWorkspace *ws, bool jac, int dof, float *AtA, float 
   if (!ws || !pyr || !R || !t || !mask1 || !dpts0 || !homo || !feat0s || !feat1 || !weights_dev ||
       (jac && (!grad1 || !AtA || !Atb)))
     return SAGE_E_INVALID;
-  if ((FS != 16 && FS != 32) || pyr->levels < 1 || pyr->levels > SAGE_MAX_LEVELS || !pyramid_is_dyadic(*pyr))
+  if ((FS != 16 && FS != 32) || pyr->levels < 1 || pyr->levels > SAGE_MAX_LEVELS)
     return SAGE_E_UNSUPPORTED;
   // tracker kernels process exactly one kTile per workgroup
   if (ws->cached_N != -(N + 2))

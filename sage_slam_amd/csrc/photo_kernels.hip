@@ -43,6 +43,10 @@ struct PhotoParams
   const int32_t *rec_first;
   int flush;
   float merge_w; // > 0: merged linearize (LaunchCommon::merge_geo_weight) -- the geometric factor weight w_g
+  // r06: a pyramid whose per-level focal ratios are not exact powers of two (pyramid_is_dyadic) -- the level coordinate is then
+  // formed per pixel exactly as the reference writes it, ((p + 0.5) * fx_l) / fx_0 - 0.5 (photometric_factor_kernels.cpp:101-103,
+  // :142-144), on the texture-path sampler; dyadic pyramids (every CameraPyramid of even level sizes) keep the host quotient
+  int exact_coord;
 };
 
 __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
@@ -65,6 +69,9 @@ __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
 #ifndef SAGE_PHOTO_PRIO_SAMPLING
 #define SAGE_PHOTO_PRIO_SAMPLING 3 // s_setprio of the linearize kernel's sampling phase (its contraction phases run at 0)
 #endif
+#ifndef SAGE_PHOTO_STAGGER_CUS
+#define SAGE_PHOTO_STAGGER_CUS 256
+#endif
 #ifndef SAGE_PHOTO_LIN_GUNROLL
 #define SAGE_PHOTO_LIN_GUNROLL 8
 #endif
@@ -82,6 +89,31 @@ __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
 #define SAGE_PHASE(name) \
   do                     \
   {                      \
+  } while (0)
+#endif
+
+// scripts/photo_trace.py builds a variant with -DSAGE_PHOTO_TRACE: lane 0 of every wave of the merged linearize stamps
+// s_memtime at the phase boundaries of every sub-tile into a static device array (+ a header: HW_ID, XCC_ID, s_memrealtime),
+// read back through sage_debug_photo_trace().  Diagnostic only -- never defined in the product build.
+#ifdef SAGE_PHOTO_TRACE
+constexpr int kTraceMaxWg = 3072, kTraceSubs = 9, kTraceMarks = 8; // [wg][wave][sub (8 = header)][mark]
+__device__ unsigned long long g_photo_trace[(size_t)kTraceMaxWg * 4 * kTraceSubs * kTraceMarks];
+#define SAGE_TMARK(m)                                                                                          \
+  do                                                                                                           \
+  {                                                                                                            \
+    if constexpr (JAC && MODE == 2)                                                                            \
+    {                                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+      const unsigned long long t_ = __builtin_readcyclecounter();                                              \
+      if (bid < kTraceMaxWg && sub < kTraceSubs - 1 && (threadIdx.x & 63) == 0)                                \
+        g_photo_trace[(((size_t)bid * 4 + (threadIdx.x >> 6)) * kTraceSubs + sub) * kTraceMarks + (m)] = t_;   \
+      __builtin_amdgcn_sched_barrier(0);                                                                       \
+    }                                                                                                          \
+  } while (0)
+#else
+#define SAGE_TMARK(m) \
+  do                  \
+  {                   \
   } while (0)
 #endif
 
@@ -231,6 +263,8 @@ __device__ __forceinline__ void sload_pose_pair(const float *R0, const float *t0
 // level-l pixel coordinate of a level-0 coordinate (:101-103, :142-144): ONE rounding sequence for the lanes and for the
 // bounding box (floor() of it is then monotone in p, so the box of [min p, max p] contains every lane's taps)
 __device__ __forceinline__ float level_coord(float p, float ratio) { return __builtin_fmaf(p + 0.5f, ratio, -0.5f); }
+// the reference's own expression (true multiplication, true division): non-dyadic pyramids
+__device__ __forceinline__ float level_coord_exact(float p05, float fl, float f0) { return (p05 * fl) / f0 - 0.5f; }
 
 // wave64 float min / max, returned wave-uniform.  The DPP ladder of wave_sum with the min / max fused into the DPP
 // instruction itself: v = op(dpp(v), v), a lane whose DPP source is masked or out of range keeps its value.  Written as
@@ -408,6 +442,34 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
                        //  array nothing in the program writes or reads is not allocated)
   __syncthreads(); // s_red zeroed
 
+#ifdef SAGE_PHOTO_STAGGER
+  // experiment: the first wave of workgroups -- three per CU, dispatched together -- starts a third of a
+  // sub-tile period apart, so that the co-resident workgroups are in different phases
+  if constexpr (JAC && PACKED)
+  {
+    const int slot = bid / SAGE_PHOTO_STAGGER_CUS;
+    if (slot < 3)
+      for (int i = 0; i < slot * SAGE_PHOTO_STAGGER; ++i)
+        __builtin_amdgcn_s_sleep(127);
+  }
+#endif
+
+#ifdef SAGE_PHOTO_TRACE
+  if constexpr (JAC && MODE == 2)
+  {
+    if (bid < kTraceMaxWg && lane == 0)
+    {
+      unsigned long long *h = g_photo_trace + (((size_t)bid * 4 + wave) * kTraceSubs + (kTraceSubs - 1)) * kTraceMarks;
+      h[0] = (unsigned)__builtin_amdgcn_s_getreg(4 | (31 << 11));  // HW_REG_HW_ID
+      h[1] = (unsigned)__builtin_amdgcn_s_getreg(20 | (31 << 11)); // HW_REG_XCC_ID
+      h[2] = __builtin_amdgcn_s_memrealtime();
+      h[3] = __builtin_readcyclecounter();
+      h[4] = (unsigned)wi.edge;
+      h[5] = (unsigned)wi.tile;
+    }
+  }
+#endif
+
   const int nsub = min(prm.tiles_per_block, (N + kTile - 1) / kTile - wi.tile);
   const int flush = JAC ? max(1, prm.flush) : 1;
   const int rec_base = (JAC && prm.rec_first) ? uni(prm.rec_first[wi.edge]) + wi.tile / flush : bid;
@@ -430,6 +492,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
   SAGE_PHASE("A_warp");
+  SAGE_TMARK(0);
   const int tile = wi.tile + sub;
   const int n = tile * kTile + tid;
   bool in_range = n < N;
@@ -543,6 +606,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   };
   bool slice_live = true; // linearize, engine layout: false when no pixel of this wave's slice is an inlier
   SAGE_PHASE("B_setup");
+  SAGE_TMARK(1);
   if (PACKED)
   {
     // wave priority: a wave in its sampling phase goes ahead of the waves of its SIMD that are in their VALU / MFMA
@@ -565,7 +629,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     // per level: box origin, width, first slot inside its staging region (wave-uniform)
     int bx0[kStageLevels] = {}, by0[kStageLevels] = {}, bwd[kStageLevels] = {}, bhd[kStageLevels] = {}, sb[kStageLevels] = {};
     int cnt0 = 0, cntC = 0;
-    if (slice_live && nlev == kStageLevels)
+    if (slice_live && nlev == kStageLevels && !prm.exact_coord)
     {
       // (floor coordinate of the first tap .. second tap, NOT clamped to the image: columns -1 / W_l and rows -1 / H_l
       //  are part of the box when an inlier's taps reach them -- those taps carry weight 0 and are filled with a
@@ -694,6 +758,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
         dma16<3u * kStageCap0 * 16u + 2u * kStageCapC * 16u>(r_f1, lds0, voC, soff + 2u * pyr_bytes);
       };
       SAGE_PHASE("B_taps");
+  SAGE_TMARK(2);
       lgkm_wait0(); // the stash reads of the previous sub-tile's contraction are done before the region is rewritten
       // the source quads of a channel group live in a ring of four registers quads: quad l is reloaded with the next
       // group's level l right after its use, a full group (~4 level steps) before it is needed
@@ -811,6 +876,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       v1 = Pv1[0] + Pv1[1];
       err = Pee[0] + Pee[1];
       SAGE_PHASE("B_end");
+  SAGE_TMARK(3);
       }
       else
       {
@@ -877,7 +943,11 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       for (int l = 0; l < nlev; ++l)
       {
         Taps td;
-        make_taps(td, level_coord(p, prm.rx[l]), level_coord(q, prm.ry[l]), prm.lw[l], prm.lh[l]);
+        if (prm.exact_coord) // (wave-uniform)
+          make_taps(td, level_coord_exact(p + 0.5f, pyr.cam[l].fx, fx0), level_coord_exact(q + 0.5f, pyr.cam[l].fy, fy0), prm.lw[l],
+                    prm.lh[l]);
+        else
+          make_taps(td, level_coord(p, prm.rx[l]), level_coord(q, prm.ry[l]), prm.lw[l], prm.lh[l]);
         const uint32_t lo = (uint32_t)pyr.level_offsets[l];
         uint32_t dof[4];
 #pragma unroll
@@ -928,8 +998,16 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       const int Wl = prm.lw[l], Hl = prm.lh[l];
       const float rx = prm.rx[l], ry = prm.ry[l];
       Taps ts, td;
-      make_taps(ts, su * rx - 0.5f, sv * ry - 0.5f, Wl, Hl);
-      make_taps(td, (p + 0.5f) * rx - 0.5f, (q + 0.5f) * ry - 0.5f, Wl, Hl);
+      if (prm.exact_coord) // (wave-uniform)
+      {
+        make_taps(ts, level_coord_exact(su, fxl, fx0), level_coord_exact(sv, fyl, fy0), Wl, Hl);
+        make_taps(td, level_coord_exact(p + 0.5f, fxl, fx0), level_coord_exact(q + 0.5f, fyl, fy0), Wl, Hl);
+      }
+      else
+      {
+        make_taps(ts, su * rx - 0.5f, sv * ry - 0.5f, Wl, Hl);
+        make_taps(td, (p + 0.5f) * rx - 0.5f, (q + 0.5f) * ry - 0.5f, Wl, Hl);
+      }
       const uint32_t lo = (uint32_t)pyr.level_offsets[l];
       uint32_t so[4], dof[4];
 #pragma unroll
@@ -1115,6 +1193,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   // ---- MFMA contractions over this wave's 64 pixels, 4 pixels (K) per instruction; basis rows streamed from
   //      global memory in operand layout, AHEAD groups in flight ----
   SAGE_PHASE("D_contract");
+  SAGE_TMARK(4);
   {
 #if SAGE_PHOTO_ALT_ACC
     // extra accumulator sets of the three noise-critical tiles (live in this phase only): pixel group g goes to set g mod
@@ -1227,6 +1306,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   }
   __builtin_amdgcn_wave_barrier(); // the stash is rewritten by the next sub-tile
   SAGE_PHASE("E_second_level_flush");
+  SAGE_TMARK(5);
   } // slice_live
   // ---- second level: the LM step's distance from the exact step is set by the fp32 accumulation chains of the two
   //      cross tiles (rows c, sigma d, u6: the code gradient and the pose-code blocks) and of the pose tile; the code-code
@@ -1344,6 +1424,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     }
   }
   SAGE_PHASE("loop_end");
+  SAGE_TMARK(6);
   } // sub-tile loop
 
   if (!JAC)
@@ -1438,6 +1519,7 @@ static PhotoParams make_params(const PhotoEdge *single, const PhotoEdge *table, 
   p.rec_first = lc.flush > 0 ? lc.edge_first : nullptr;
   p.flush = lc.flush > 0 ? lc.flush : lc.tiles_per_block;
   p.merge_w = lc.merge_geo_weight;
+  p.exact_coord = pyramid_is_dyadic(pyr) ? 0 : 1;
   for (int l = 0; l < pyr.levels; ++l)
   {
     p.rx[l] = pyr.cam[l].fx / pyr.cam[0].fx; // same fp32 quotient the kernels used to form per pixel
@@ -1541,3 +1623,20 @@ hipError_t launch_photo_error(hipStream_t s, int CS, int FS, const PhotoEdge *si
 }
 
 } // namespace sage
+
+#ifdef SAGE_PHOTO_TRACE
+extern "C" int sage_debug_photo_trace(void *dst, size_t bytes)
+{
+  const size_t all = sizeof(unsigned long long) * (size_t)sage::kTraceMaxWg * 4 * sage::kTraceSubs * sage::kTraceMarks;
+  if (bytes > all)
+    bytes = all;
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(sage::g_photo_trace), bytes, 0, hipMemcpyDeviceToHost);
+}
+extern "C" int sage_debug_photo_trace_clear()
+{
+  void *p = nullptr;
+  if (hipGetSymbolAddress(&p, HIP_SYMBOL(sage::g_photo_trace)) != hipSuccess)
+    return 1;
+  return (int)hipMemset(p, 0, sizeof(unsigned long long) * (size_t)sage::kTraceMaxWg * 4 * sage::kTraceSubs * sage::kTraceMarks);
+}
+#endif

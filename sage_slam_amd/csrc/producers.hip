@@ -160,7 +160,7 @@ hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev,
 // pixels, with the Jacobian kernel's source coordinates (photometric_factor_kernels.cpp:101-139) -- pose independent,
 // built once per keyframe (the tracker's cat_sampled_features_0, camera_tracker.cpp:1104-1123)
 __global__ void presample_source_kernel(float *__restrict__ f0s, const float *__restrict__ feat_pk,
-                                        const float *__restrict__ homo, int N, int G, const SagePyramid pyr)
+                                        const float *__restrict__ homo, int N, int G, const SagePyramid pyr, int exact_coord)
 {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   const int g = blockIdx.y, l = blockIdx.z;
@@ -171,7 +171,10 @@ __global__ void presample_source_kernel(float *__restrict__ f0s, const float *__
   const int Wl = (int)pyr.cam[l].w, Hl = (int)pyr.cam[l].h;
   const float su = homo[3 * n + 0] * fx0 + cx0 + 0.5f, sv = homo[3 * n + 1] * fy0 + cy0 + 0.5f;
   Taps ts;
-  make_taps(ts, su * (fxl / fx0) - 0.5f, sv * (fyl / fy0) - 0.5f, Wl, Hl);
+  if (exact_coord) // non-dyadic pyramid: the reference's own expression (photometric_factor_kernels.cpp:101-103)
+    make_taps(ts, (su * fxl) / fx0 - 0.5f, (sv * fyl) / fy0 - 0.5f, Wl, Hl);
+  else
+    make_taps(ts, su * (fxl / fx0) - 0.5f, sv * (fyl / fy0) - 0.5f, Wl, Hl);
   const f32x4 *src = reinterpret_cast<const f32x4 *>(feat_pk) + (size_t)g * pyr.P + pyr.level_offsets[l];
   f32x4 f = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -187,7 +190,7 @@ hipError_t launch_presample_source(hipStream_t s, float *f0s, const float *feat_
   if (N <= 0)
     return hipSuccess;
   hipLaunchKernelGGL(presample_source_kernel, dim3((N + 255) / 256, FS / 4, pyr.levels), dim3(256), 0, s, f0s, feat_pk,
-                     homo, N, FS / 4, pyr);
+                     homo, N, FS / 4, pyr, pyramid_is_dyadic(pyr) ? 0 : 1);
   return hipGetLastError();
 }
 

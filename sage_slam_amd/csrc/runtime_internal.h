@@ -166,23 +166,6 @@ static inline float *ws_stats(SageWorkspace *ws) { return ws->stats_ptr ? ws->st
 int ws_ticket_wait(SageWorkspace *ws);
 
 
-// The photometric kernels form a level's pixel coordinate as fma(p + 0.5, fx_l / fx_0, -0.5) with the quotient precomputed on
-// the host; the reference evaluates ((p + 0.5) * fx_l) / fx_0 - 0.5 per pixel (photometric_factor_kernels.cpp:101-103,
-// :142-144).  The two agree bit for bit when the quotient is a power of two -- every pyramid sage_camera_pyramid and the
-// reference's CameraPyramid build (halving per level) -- and can differ in floor() at texel boundaries otherwise: such
-// pyramids are refused (SAGE_E_UNSUPPORTED) instead of sampled one texel off.
-static inline bool pyramid_is_dyadic(const SagePyramid &pyr)
-{
-  for (int l = 0; l < pyr.levels && l < SAGE_MAX_LEVELS; ++l)
-  {
-    int e;
-    const float rx = pyr.cam[l].fx / pyr.cam[0].fx, ry = pyr.cam[l].fy / pyr.cam[0].fy;
-    if (!(rx > 0.f) || !(ry > 0.f) || std::frexp(rx, &e) != 0.5f || std::frexp(ry, &e) != 0.5f)
-      return false;
-  }
-  return true;
-}
-
 // instantiated (CS, FS) combinations of the factor kernels
 static inline bool supported(int CS, int FS)
 {

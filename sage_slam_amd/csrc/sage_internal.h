@@ -4,10 +4,31 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <cmath>
 #include <utility>
 #include <vector>
 
 #include "sage_ba.h"
+
+// The photometric kernels form a level's pixel coordinate as fma(p + 0.5, fx_l / fx_0, -0.5) with the quotient precomputed on
+// the host; the reference evaluates ((p + 0.5) * fx_l) / fx_0 - 0.5 per pixel (photometric_factor_kernels.cpp:101-103,
+// :142-144).  The two agree bit for bit when the quotient is a power of two -- every CameraPyramid whose level sizes stay
+// even (common/camera_pyramid.h:18-32; the only sizes for which the reference's conv / camera / mask pyramids agree) -- and
+// can differ in floor() at texel boundaries otherwise.  r06: such pyramids are no longer refused: the kernels then form the
+// coordinate with the reference's own expression (PhotoParams::exact_coord, TrackParams::exact_coord, the source pre-sampler)
+// on the texture-path sampler.
+static inline bool pyramid_is_dyadic(const SagePyramid &pyr)
+{
+  for (int l = 0; l < pyr.levels && l < SAGE_MAX_LEVELS; ++l)
+  {
+    int e;
+    const float rx = pyr.cam[l].fx / pyr.cam[0].fx, ry = pyr.cam[l].fy / pyr.cam[0].fy;
+    if (!(rx > 0.f) || !(ry > 0.f) || std::frexp(rx, &e) != 0.5f || std::frexp(ry, &e) != 0.5f)
+      return false;
+  }
+  return true;
+}
+
 
 namespace sage
 {

@@ -18,6 +18,7 @@ struct TrackParams
   SagePyramid pyr;
   float eps;
   int dof;
+  int exact_coord; // non-dyadic pyramid (pyramid_is_dyadic): the reference's own coordinate expression per pixel
 };
 
 __device__ __forceinline__ int sidx7(int i, int j) { return i * 7 - (i * (i - 1)) / 2 + (j - i); } // i<=j<7
@@ -36,6 +37,7 @@ __global__ __launch_bounds__(kBlock) void track_kernel(const TrackParams prm)
   const int nn = in_range ? n : 0;
   const Pose p10 = load_pose2(E.R, E.t);
   const SagePyramid &pyr = prm.pyr;
+  const int exact_coord = prm.exact_coord;
   const float fx0 = pyr.cam[0].fx, fy0 = pyr.cam[0].fy, cx0 = pyr.cam[0].cx, cy0 = pyr.cam[0].cy;
   const int W0 = (int)pyr.cam[0].w, H0 = (int)pyr.cam[0].h;
 
@@ -66,7 +68,10 @@ __global__ __launch_bounds__(kBlock) void track_kernel(const TrackParams prm)
     const float fxl = pyr.cam[l].fx, fyl = pyr.cam[l].fy;
     const int Wl = (int)pyr.cam[l].w, Hl = (int)pyr.cam[l].h;
     Taps td;
-    make_taps(td, (p + 0.5f) * (fxl / fx0) - 0.5f, (q + 0.5f) * (fyl / fy0) - 0.5f, Wl, Hl);
+    if (exact_coord) // (uniform) non-dyadic pyramid: the reference's own expression, photometric_factor_kernels.cpp:142-144
+      make_taps(td, ((p + 0.5f) * fxl) / fx0 - 0.5f, ((q + 0.5f) * fyl) / fy0 - 0.5f, Wl, Hl);
+    else
+      make_taps(td, (p + 0.5f) * (fxl / fx0) - 0.5f, (q + 0.5f) * (fyl / fy0) - 0.5f, Wl, Hl);
     const uint32_t lo = (uint32_t)pyr.level_offsets[l];
     uint32_t dof[4];
 #pragma unroll
@@ -239,6 +244,7 @@ static hipError_t track_impl(hipStream_t s, bool jac, int dof, const TrackEdge &
   p.pyr = pyr;
   p.eps = eps;
   p.dof = dof;
+  p.exact_coord = pyramid_is_dyadic(pyr) ? 0 : 1;
   if (jac)
     hipLaunchKernelGGL((track_kernel<FS, true>), dim3(lc.n_work), dim3(kBlock), 0, s, p);
   else

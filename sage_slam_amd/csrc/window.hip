@@ -1,5 +1,6 @@
 // window.hip -- the batched window engine: edge tables, work lists, deterministic assembly into block-sparse normal
 // equations, linearize / error pass / damped solve / LM iteration (no reference counterpart: SURVEY s8 "new").
+#include <atomic>
 #include "runtime_internal.h"
 #include "finalize_bodies.h"
 
@@ -463,11 +464,14 @@ int window_upload_vars(SageWindow *w, int set)
   return SAGE_OK;
 }
 
+// live windows of the process: the last sage_window_destroy stops the solver's host threads (host_math.cpp "life cycle")
+static std::atomic<int> g_live_windows{0};
+
 extern "C" int sage_window_create(const SageWindowConfig *cfg, void *hip_stream, SageWindow **out)
 {
   if (!cfg || !out || !cfg->mask_dev)
     return SAGE_E_INVALID;
-  if (!supported(cfg->CS, cfg->FS) || cfg->pyr.levels < 1 || cfg->pyr.levels > SAGE_MAX_LEVELS || !pyramid_is_dyadic(cfg->pyr))
+  if (!supported(cfg->CS, cfg->FS) || cfg->pyr.levels < 1 || cfg->pyr.levels > SAGE_MAX_LEVELS)
     return SAGE_E_UNSUPPORTED;
   int ndev = 0;
   SAGE_HIP(hipGetDeviceCount(&ndev));
@@ -479,6 +483,7 @@ extern "C" int sage_window_create(const SageWindowConfig *cfg, void *hip_stream,
   w->B = 7 + cfg->CS;
   w->VS = ((13 + cfg->CS + 3) / 4) * 4;
   *out = w;
+  g_live_windows.fetch_add(1, std::memory_order_acq_rel);
   return SAGE_OK;
 }
 
@@ -486,6 +491,16 @@ extern "C" void sage_window_destroy(SageWindow *w)
 {
   if (!w)
     return;
+  // no thread of this library outlives the last window (r06): helpers, arrow-row pool and the opt-in
+  // placement monitor are stopped and joined; the next window's first solve starts them again
+  struct LastOut
+  {
+    ~LastOut()
+    {
+      if (g_live_windows.fetch_sub(1, std::memory_order_acq_rel) == 1)
+        sage::host_threads_shutdown();
+    }
+  } last_out;
   DevBuf *bufs[] = {&w->packed_save, &w->packed_loc, &w->asm_blocks, &w->geo_px, &w->rec_first_p, &w->rec_count_p, &w->wide_p, &w->wide_g, &w->sorted_loc, &w->sorted_homo, &w->vars[0], &w->vars[1], &w->dpt, &w->dgrad, &w->depth_items[0], &w->depth_items[1],
                     &w->pk, &w->f0s, &w->ptab[0], &w->ptab[1], &w->gtab[0], &w->gtab[1], &w->work_p, &w->first_p, &w->tiles_p,
                     &w->work_g, &w->first_g, &w->tiles_g, &w->part_p, &w->part_g, &w->AtA_p, &w->Atb_p,
@@ -1372,9 +1387,11 @@ static int window_total_error(SageWindow *w, int from_linearize, double *err, bo
     return rcs;
   // a failed factorisation only invalidates the CANDIDATE: the error at the linearisation point is still served
   const int rc_out = from_linearize ? SAGE_OK : rcs;
-  if (w->world == 1 && w->h_err)
+  if (w->world == 1 && !w->allreduce && w->h_err)
   {
-    // single-rank window: the kernels mirrored the totals into pinned host memory
+    // single-rank window WITHOUT an all-reduce hook: the kernels mirrored the totals into pinned host memory (the same
+    // condition the writers use -- ap.tail_mirror, the error_totals mirror; a one-rank RCCL communicator or
+    // sage_window_set_allreduce leaves the mirror unwritten and takes the copies below: ADVICE r5)
     if (!stream_idle)
       SAGE_HIP(hipStreamSynchronize(w->stream));
     const double *m = w->h_err + (from_linearize ? 0 : 4);
@@ -1822,12 +1839,14 @@ static int lm_step_at_candidate(SageWindow *w, SageLmState *st, const SageLmConf
     if (rc && !not_psd)
       return rc;
     double cur_tot[4] = {0, 0, 0, 0};
+    bool have_cur_tot = false; // (a synchronous NOT_PSD of the solve leaves the mirror alone: nothing to put back)
     st->candidate_error = INFINITY;
     if (!not_psd)
     {
       const uint64_t lin_epoch = w->lin_epoch;
       const bool was_reduced = w->packed_reduced;
       std::memcpy(cur_tot, w->h_err, sizeof(cur_tot)); // (mirrored and seen at the end of the previous evaluation)
+      have_cur_tot = true;
       if ((rc = evaluate(1, w->packed_save.as<double>(), w->emu_cur + 1)))
         return rc;
       w->lin_epoch = lin_epoch; // (`packed` still is the current estimate's system; the candidate's sits in packed_save)
@@ -1858,7 +1877,8 @@ static int lm_step_at_candidate(SageWindow *w, SageLmState *st, const SageLmConf
       break;
     }
     // rejected: `packed` never left; the mirror goes back to the current estimate's totals
-    std::memcpy(w->h_err, cur_tot, sizeof(cur_tot));
+    if (have_cur_tot)
+      std::memcpy(w->h_err, cur_tot, sizeof(cur_tot));
     const bool give_up = st->damp >= cfg->max_damp || (cfg->max_inner_evals > 0 && evals >= cfg->max_inner_evals);
     st->damp = clampd(st->damp * cfg->damp_inc_factor);
     if (give_up)

@@ -203,6 +203,13 @@ extern "C" int sage_bind_thread_to_device(int device)
 
 extern "C" int sage_solver_helper_cpus(int *cpus, int n) { return cpus && n > 0 ? sage::placement_helper_cpus(cpus, n) : 0; }
 extern "C" int sage_solver_placement_moves(void) { return sage::placement_monitor_moves(); }
+extern "C" int sage_placement_monitor(int enable)
+{
+  sage::placement_monitor_enable(enable);
+  return SAGE_OK;
+}
+extern "C" int sage_host_threads_running(void) { return sage::host_threads_running(); }
+extern "C" void sage_shutdown(void) { sage::host_threads_shutdown(); }
 
 extern "C" int sage_window_set_allreduce(SageWindow *w, SageAllReduceFn fn, void *user)
 {

@@ -81,22 +81,26 @@ _G = (np.array([[1, 2, 1], [2, 4, 2], [1, 2, 1]], dtype=F32) / F32(16.0)).astype
 
 
 def _conv_s2(img: np.ndarray) -> np.ndarray:
-    """3x3 Gaussian, stride 2, zero pad 1 on [C,H,W] (H, W even)."""
+    """3x3 Gaussian, stride 2, zero pad 1 on [C,H,W] -> [C, H // 2, W // 2] (an odd last row / column is dropped: the size the
+    camera pyramid gives the level, ``common/camera_pyramid.h:26-27``)."""
     C, H, W = img.shape
     p = np.pad(img, ((0, 0), (1, 1), (1, 1)))
-    out = np.zeros((C, H // 2, W // 2), dtype=F32)
+    h2, w2 = H // 2, W // 2
+    out = np.zeros((C, h2, w2), dtype=F32)
     for dy in range(3):
         for dx in range(3):
-            out += _G[dy, dx] * p[:, dy:dy + H:2, dx:dx + W:2]
+            out += _G[dy, dx] * p[:, dy:dy + 2 * h2:2, dx:dx + 2 * w2:2]
     return out
 
 
-def gaussian_pyramid_with_grad(feat: np.ndarray, mask: np.ndarray, levels: int):
+def gaussian_pyramid_with_grad(feat: np.ndarray, mask: np.ndarray, levels: int, allow_odd: bool = False):
     """feat [FS,H,W], mask [H,W] -> (pyr [FS,P], grad [2,FS,P]).  Masked stride-2
     Gaussian: level k+1 = conv(level_k * mask_k) / (conv(mask_k) + 1e-8); the mask
     pyramid is nearest-neighbour decimation (source index 2i)."""
     FS, H, W = feat.shape
-    assert H % (1 << (levels - 1)) == 0 and W % (1 << (levels - 1)) == 0, \
+    # (allow_odd: test inputs with NON-DYADIC camera pyramids, w = 62 -> 31 -> 15 -- levels cropped to the camera pyramid's
+    #  floor sizes; the reference's own producer disagrees with its camera pyramid there, the factor kernels do not care)
+    assert allow_odd or (H % (1 << (levels - 1)) == 0 and W % (1 << (levels - 1)) == 0), \
         "level sizes must stay even (the reference's conv/camera/mask pyramids only agree then)"
     cur = feat.astype(F32)
     curm = mask.astype(F32)
@@ -110,7 +114,7 @@ def gaussian_pyramid_with_grad(feat: np.ndarray, mask: np.ndarray, levels: int):
         raw = _conv_s2(cur * curm[None])
         rm = _conv_s2(curm[None])
         cur = (raw / (rm + F32(1.0e-8))).astype(F32)
-        curm = curm[::2, ::2].copy()
+        curm = curm[::2, ::2][:cur.shape[1], :cur.shape[2]].copy()
     return np.ascontiguousarray(np.concatenate(pyr, 1)), np.ascontiguousarray(np.concatenate(grad, 2))
 
 
@@ -196,7 +200,7 @@ def _smooth_fields(rng, n, H, W, sigma, max_cycles=2.0, n_waves=4):
 def make_window(K: int, H: int, W: int, FS: int = 16, CS: int = 32, L: int = 4,
                 n_samples: int = 0, back_links: int = 3, seed: int = 0,
                 baseline: float = 0.025, pose_noise: float = 1.0, code_noise: float = 0.03,
-                border: int = 2, erode: int = 6, loop_radius: float = 0.0) -> Window:
+                border: int = 2, erode: int = 6, loop_radius: float = 0.0, allow_odd: bool = False) -> Window:
     """Build a K-keyframe window (SURVEY.md s8d "synthetic inputs").
 
     ``n_samples == 0`` -> dense sampling (all pixels of the eroded mask, row-major like
@@ -244,7 +248,7 @@ def make_window(K: int, H: int, W: int, FS: int = 16, CS: int = 32, L: int = 4,
         uv = np.stack([Xw @ e1, Xw @ e2], -1)                                   # [H,W,2]
         arg = 2 * np.pi * np.einsum("hwd,cjd->cjhw", uv, kvec) + phase[:, :, None, None]
         feat = (amp[:, :, None, None] * np.sin(arg)).sum(1).astype(F32)         # [FS,H,W] in [-1,1]
-        pyr, grad = gaussian_pyramid_with_grad(feat, mask, L)
+        pyr, grad = gaussian_pyramid_with_grad(feat, mask, L, allow_odd)
 
         krng = np.random.default_rng(seed * 100003 + k)                         # seed = kf id
         basis = _smooth_fields(krng, CS, H, W, 0.05).reshape(CS, -1).T          # [HW,CS]

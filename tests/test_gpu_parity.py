@@ -190,6 +190,76 @@ def test_tracker_linearize_and_error(capi, ws, orc, dof):
     assert hn == on and he == pytest.approx(oe, rel=1e-5)
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# non-dyadic camera pyramids (r06; VERDICT r5 missing 5 / ADVICE r5): w = 62 -> 31 -> 15, h = 50 -> 25 -> 12 -- the level-2
+# focal ratio 0.5 * 15 / 31 is not a power of two, the kernels form the level coordinate with the reference's own
+# ((p + 0.5) * fx_l) / fx_0 - 0.5 (photometric_factor_kernels.cpp:101-103, :142-144) instead of the host quotient.  The
+# oracle always evaluates that expression.  Bars as for the dyadic cases.
+# ---------------------------------------------------------------------------------------------------------------
+NON_DYADIC = dict(H=50, W=62, FS=16, CS=32, L=3, allow_odd=True, border=2, erode=3)
+
+
+def test_non_dyadic_pyramid_operators(capi, ws, orc):
+    import torch
+    w = synth.make_window(K=2, n_samples=0, seed=31, **NON_DYADIC)
+    assert [int(c.w) for c in w.cams] == [62, 31, 15] and float(w.cams[2].fx / w.cams[0].fx) not in (0.25,)
+    pyr, mask, kfs = dev_window(capi, w)
+    for k0, k1 in ((0, 1), (1, 0)):
+        o = oracle_photo(orc, w, k0, k1)
+        h = hip_photo(capi, ws, w, pyr, mask, kfs, k0, k1)
+        assert h["num_inliers"] == o["num_inliers"] and o["num_inliers"] > 0
+        assert h["error"] == pytest.approx(o["error"], rel=1e-5)
+        assert rel(h["AtA"], o["AtA"]) < TOL_H and rel(h["Atb"], o["Atb"]) < TOL_H
+        oe = oracle_photo(orc, w, k0, k1, jac=False)
+        he = hip_photo(capi, ws, w, pyr, mask, kfs, k0, k1, jac=False)
+        assert he["num_inliers"] == oe["num_inliers"] and he["error"] == pytest.approx(oe["error"], rel=1e-5)
+    # tracker trio on the same pyramid
+    a, b = w.keyframes[0], w.keyframes[1]
+    R10, t10 = synth.relative_pose(a.R, a.t, b.R, b.t)
+    feat0s = presample_source(orc, w, a)
+    dpts0 = (np.float32(a.scale) * (a.bias + a.basis @ a.code))[a.loc1d].astype(np.float32)
+    wd = torch.from_numpy(w.photo_weights).cuda()
+    f0 = torch.from_numpy(feat0s).cuda(); dp = torch.from_numpy(dpts0).cuda()
+    for dof in (6, 7):
+        o = orc.tracker_photo_jac_error(dof, R10, t10, w.mask, dpts0, a.homo, feat0s, b.feat_pyr, b.grad_pyr,
+                                        w.level_offsets, w.cams, w.eps, w.photo_weights, scale0=a.scale)
+        h = capi.tracker_photo_jac_error(ws, dof, R10, t10, mask, dp, kfs[0].homo, f0, kfs[1].feat_pyr,
+                                         kfs[1].grad_pyr, pyr, a.scale, w.eps, wd, w.FS)
+        assert h["num_inliers"] == o["num_inliers"] > 0 and h["error"] == pytest.approx(o["error"], rel=1e-5)
+        assert rel(h["AtA"], o["AtA"]) < TOL_H and rel(h["Atb"], o["Atb"]) < TOL_H
+
+
+def test_non_dyadic_pyramid_window(capi, orc):
+    """the window engine on a non-dyadic pyramid: engine-layout kernels (pre-sampled source features, texture-path sampler),
+    per-edge results and the packed system vs the oracle, then the LM iteration's MERGED linearize (photo_kernel<.., 2>) vs
+    the separate kernels' system at the accepted candidate"""
+    w = synth.make_window(K=4, n_samples=0, seed=32, back_links=2, **NON_DYADIC)
+    win = capi.Window(w)
+    win.linearize()
+    res = {}
+    for l, (a, b) in enumerate(w.links):
+        for d, (k0, k1) in enumerate(((a, b), (b, a))):
+            res[(0, l, d)] = oracle_photo(orc, w, k0, k1)
+            res[(1, l, d)] = oracle_geo(orc, w, k0, k1)
+            for t in (0, 1):
+                he = win.get_edge(t, 2 * l + d)
+                assert he["num_inliers"] == res[(t, l, d)]["num_inliers"] > 0
+                assert rel(he["AtA"], res[(t, l, d)]["AtA"]) < TOL_H and rel(he["Atb"], res[(t, l, d)]["Atb"]) < TOL_H
+                assert he["error"] == pytest.approx(res[(t, l, d)]["error"], rel=2e-5)
+    packed = win.packed_host().astype(np.float64)
+    ref = capi.assemble_packed(len(w.keyframes), w.links, w.CS, res)
+    assert rel(packed[:-4], ref[:-4]) < TOL_H and packed[-4:] == pytest.approx(ref[-4:], rel=2e-5)
+    # merged linearize of the LM iteration: one classic step, then the system at the new estimate both ways
+    st = capi.SageLmState(); cfg = capi.lm_config_default(); cfg.max_inner_evals = 1; cfg.linearize_at_candidate = 1
+    win.reset(); win.lm_step(st, cfg)
+    assert st.accepted == 1 and st.candidate_error < st.error
+    merged = win.packed_host().astype(np.float64)          # the candidate's system, merged kernels
+    win.linearize()                                        # separate kernels at the same (accepted) estimate
+    sep = win.packed_host().astype(np.float64)
+    assert rel(merged[:-4], sep[:-4]) < TOL_H and merged[-4:] == pytest.approx(sep[-4:], rel=2e-5)
+    win.close()
+
+
 def test_producers_match_oracle(capi, ws, orc):
     import torch
     w = synth.make_window(K=1, H=64, W=80, FS=16, CS=32, L=4, seed=13)
@@ -277,7 +347,8 @@ def test_window_step_noise_floor(capi, orc):
       (b) every seed: the engine's step is within 1e-4 of the exact step wherever the oracle's own is within 5.5e-5, and
           never more than 5e-5 farther from exact than the oracle's;
       (c) population: rms distance from exact <= 1e-4 / sqrt(2) (what two evaluations 1e-4 apart can share), rms distance
-          from the fp32 oracle's step <= 1e-4, and at most 3 of the 12 seeds above 1e-4 against the oracle's step."""
+          from the fp32 oracle's step <= 1e-4, and at most 2 of the 12 seeds above 1e-4 against the oracle's step;
+      (d) seeds 22, 23, 24 (the originally gated ones): hard 1e-4 against the fp32 oracle's step, seed by seed."""
     CS = 32
     rows = []
     for seed in range(22, 34):
@@ -324,7 +395,12 @@ def test_window_step_noise_floor(capi, orc):
         if oe < 5.5e-5:
             assert he < TOL_DELTA, (seed, he, oe)
     assert rms[0] <= TOL_DELTA / np.sqrt(2.0) and rms[2] <= TOL_DELTA                                      # (c)
-    assert int((a[:, 2] > TOL_DELTA).sum()) <= 3
+    assert int((a[:, 2] > TOL_DELTA).sum()) <= 2
+    # (d) the three seeds this test gated on before the sweep was widened keep their HARD per-seed bar against the fp32
+    #     oracle's step: a regression on one of them fails the suite whatever the population does
+    for seed, he, oe, ho in rows:
+        if seed in (22, 23, 24):
+            assert ho < TOL_DELTA, (seed, ho)
 
 
 def test_window_lm_reduces_error(capi):

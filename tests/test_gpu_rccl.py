@@ -69,6 +69,41 @@ def test_rccl_single_rank_lm_matches_plain_window():
     assert float(x.sum()) == 499500.0
 
 
+def test_rccl_single_rank_total_error_matches_plain_window():
+    """the pinned mirror of the totals is written only by windows WITHOUT an all-reduce hook; a one-rank window
+    that has one (native RCCL communicator) must serve sage_window_total_error from the reduced device buffers -- after
+    sage_window_linearize (0 = at the linearisation point), after solve + sage_window_error (1 = candidate), and through
+    the classic lm_step's rejection path."""
+    import torch
+    from sage_slam_amd import capi
+    comm = capi.rccl_comm_create(capi.rccl_unique_id(), 0, 1)
+    w = synth.make_window(K=5, H=48, W=64, FS=16, CS=32, L=3, n_samples=1500, seed=12)
+
+    def run(use_rccl):
+        win = capi.Window(w)
+        if use_rccl:
+            win.use_rccl(comm)
+        win.linearize()
+        e_lin = win.total_error(True)
+        win.solve(1e-4, want_norm=False)
+        win.error(1)
+        e_cand = win.total_error(False)
+        e_lin_again = win.total_error(True)
+        # a huge damping keeps the step tiny; a classic lm_step with max_inner_evals = 1 then reports both errors
+        st = capi.SageLmState(); cfg = capi.lm_config_default(); cfg.max_inner_evals = 1; cfg.linearize_at_candidate = -1
+        win.reset()
+        win.lm_step(st, cfg)
+        out = (e_lin, e_cand, e_lin_again, st.error, st.candidate_error)
+        win.close()
+        return out
+
+    a, b = run(False), run(True)
+    assert all(np.isfinite(a)) and a[0] > 0 and a[1] > 0
+    assert a[0] == a[2] and b[0] == b[2]                      # the linearisation point's error survives the candidate's pass
+    np.testing.assert_allclose(b, a, rtol=1e-12)               # (sum over one rank = identity)
+    capi.rccl_comm_destroy(comm)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # N > 1 ranks on the native RCCL path (one GPU per rank)
 # ---------------------------------------------------------------------------------------------------------------

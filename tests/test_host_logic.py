@@ -247,6 +247,7 @@ def solve_for(sec):
     t0 = time.time()
     while time.time() - t0 < sec:
         capi.block_solve(packed, K, links, B, 1e-4)
+capi.placement_monitor(True)   # r06: the monitor is opt-in
 solve_for(0.6)
 before = [c for c in capi.solver_helper_cpus() if c >= 0]
 hogs = [subprocess.Popen([sys.executable, "-c", "import os\nos.sched_setaffinity(0, {%d})\nwhile True: pass" % c]) for c in set(before)]
@@ -261,6 +262,51 @@ finally:
 after = [c for c in capi.solver_helper_cpus() if c >= 0]
 sys.stdout.write("%d %d %d" % (len(before), capi.solver_placement_moves(), len(set(before) & set(after))))
 """
+
+
+_LIFECYCLE_SNIPPET = _LOOKAHEAD_SNIPPET.split("ref = np.linalg.solve")[0] + r"""
+import os
+def n_tasks():
+    return len(os.listdir("/proc/self/task"))
+base = n_tasks()
+for _ in range(20):
+    capi.block_solve(packed, K, links, B, 1e-4)
+up = n_tasks(); running = capi.host_threads_running()
+first = capi.block_solve(packed, K, links, B, 1e-4)
+capi.shutdown()
+down = n_tasks(); running_down = capi.host_threads_running()
+# the threads come back on demand, with the same bits
+again = capi.block_solve(packed, K, links, B, 1e-4)
+for _ in range(5):
+    capi.block_solve(packed, K, links, B, 1e-4)
+up2 = capi.host_threads_running()
+capi.placement_monitor(True)
+for _ in range(5):
+    capi.block_solve(packed, K, links, B, 1e-4)
+mon = capi.host_threads_running()
+capi.shutdown()
+down2 = n_tasks()
+sys.stdout.write("%d %d %d %d %d %d %d %d %d" % (base, up, running, down, running_down, up2, mon, down2, int(np.array_equal(first, again))))
+"""
+
+
+def test_host_threads_are_joinable_and_monitor_is_opt_in():
+    """r06: nothing in the library is detached.  The solve's helper threads start on demand, the placement
+    monitor only when asked for (SAGE_PLACEMENT_MONITOR=1 / sage_placement_monitor(1)), sage_shutdown() stops and JOINS
+    all of them -- the process is back at its thread count from before the first solve -- and the next solve starts them
+    again with a bit-identical result."""
+    import subprocess, sys
+    if (os.cpu_count() or 1) < 4:
+        pytest.skip("no helper threads on < 4 CPUs")
+    env = {k: v for k, v in os.environ.items() if k != "SAGE_PLACEMENT_MONITOR"}
+    r = subprocess.run([sys.executable, "-c", _LIFECYCLE_SNIPPET], capture_output=True, text=True, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    base, up, running, down, running_down, up2, mon, down2, same = (int(v) for v in r.stdout.split())
+    assert running >= 1 and up == base + running, (base, up, running)       # helpers only: no monitor by default
+    assert down == base and running_down == 0, (base, down, running_down)   # joined, not merely asked to stop
+    assert up2 == running and mon == running + 1 and down2 == base, (up2, mon, down2)
+    assert same == 1
 
 
 def test_placement_monitor_moves_helpers_off_crowded_cores():
