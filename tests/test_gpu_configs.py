@@ -3,8 +3,8 @@
   config 1  2-keyframe tracker BA, 64x80x16, CS 32, N = 3072     -> test_gpu_parity.py (tracker tests) + test_gpu_tracker.py
   config 2  16-keyframe local-BA window, 128x160x16, CS 32, dense -> test_config2_window_k16
   config 3  64-keyframe global BA, 128x160x16, CS 32, dense       -> test_config3_window_k64   (the bench.py headline window)
-  config 4  16 keyframes, 256x320x32, CS 32, dense                -> test_config4_highres_k16
-  config 5  512-keyframe loop-closure refinement, 64x80x16        -> test_config5_loop_closure_k512
+  config 4  16 keyframes, 256x320x32, CS 32, dense                -> test_config4_highres_k16        (r06: LM delta vs the oracle
+  config 5  512-keyframe loop-closure refinement, 64x80x16        -> test_config5_loop_closure_k512   on every edge, committed fixtures)
 
 Bars (north_star: "pose/code deltas within 1e-4 rel-L2 of reference", fp32):
   * every per-edge AtA / Atb of the window vs the fp32 oracle           rel-L2 <= 2e-5, inlier counts exact
@@ -196,6 +196,21 @@ def window_vs_oracle(capi, orc, w, label, gold, live=("f32", "f64")):
     return r_h64, r_h32, r_3264
 
 
+def assert_delta_bars(label, dh, gold, what="LM delta"):
+    """the north_star bar on an LM step: hard 1e-4 against the fp64 solve of the fp32-ORACLE system; against the exact
+    (fp64-oracle) step 1e-4 wherever the fp32 oracle itself is < 7.5e-5 from exact, else not farther than it + 1e-4 -- the
+    rule of window_vs_oracle above.  Prints the three rel-L2 figures into the run's summary."""
+    d32, d64 = gold["d32"], gold["d64"]
+    r_h32, r_h64, r_3264 = rel(dh, d32), rel(dh, d64), rel(d32, d64)
+    summary_line(f"[{label}] {what} rel-L2: hip-fp32oracle {r_h32:.2e}  hip-exact {r_h64:.2e}  fp32oracle-exact {r_3264:.2e}")
+    assert r_h32 < TOL_DELTA, (label, what, r_h32)
+    if r_3264 < 0.75 * TOL_DELTA:
+        assert r_h64 < TOL_DELTA, (label, what, r_h64)
+    else:
+        assert r_h64 < r_3264 + TOL_DELTA, (label, what, r_h64, r_3264)
+    return r_h32, r_h64, r_3264
+
+
 @pytest.mark.parametrize("seed", [0, 1, 2, 3])
 def test_config2_window_k16(capi, orc, seed):
     """BASELINE config 2: 16-keyframe local-BA window, 128x160x16, 32-dim code, dense sampling (N = 16 128); four windows,
@@ -260,16 +275,30 @@ def test_config4_highres_k16(capi, orc):
             done += 1
     summary_line(f"[config4] K=16 256x320x32: {done} edges (one photometric + one geometric into every keyframe) vs the fp32 "
                  f"oracle: worst rel-L2 AtA {worst[0]:.1e} Atb {worst[1]:.1e}")
-    # solve through the engine == host block solve of the same packed system; the LM iteration descends
+    # solve through the engine == host block solve of the same packed system
     packed = win.packed_host().astype(np.float64)
     dadd, gadd = prior_vectors(w, CS)
     win.solve(DAMP)
+    dh = win.delta()
     dref = capi.block_solve(packed[:-4], len(w.keyframes), w.links, 7 + CS, DAMP, dadd, gadd)
-    assert rel(win.delta(), dref) < 1e-7
+    assert rel(dh, dref) < 1e-7
+    # r06: the LM delta of the WHOLE window against the oracle -- all 168 edges through oracle/sage_oracle.c
+    # in fp32 and fp64, offline (tests/golden/make_window_delta_golden.py cfg4: 8 min of host time), same bars as configs 2 / 3
+    gold = np.load(os.path.join(GOLDEN, "window_delta_cfg4_k16_seed41.npz"))
+    assert int(gold["n_links"]) == len(w.links) and int(gold["N"]) == N
+    assert_delta_bars("config4", dh, gold)
+    # the LM iteration descends; its MERGED linearize (photo_kernel<32,32,true,2>) leaves the system of the linearisation
+    # point in `packed`: same normal equations, same bars
     cfg = capi.lm_config_default(); cfg.max_inner_evals = 1
     st = capi.SageLmState()
-    errs = []
-    for _ in range(3):
+    win.lm_step(st, cfg)
+    assert st.accepted == 1 and st.candidate_error < st.error
+    pm = win.packed_host().astype(np.float64)
+    assert rel(pm[:-4], packed[:-4]) < 2e-6
+    Hm, gm = add_priors(*capi.unpack_dense(pm, len(w.keyframes), w.links, CS)[:2], w, CS)
+    assert_delta_bars("config4", damped_delta(Hm, gm, DAMP), gold, what="merged-linearize LM delta")
+    errs = [(st.error, st.candidate_error, st.accepted)]
+    for _ in range(2):
         win.lm_step(st, cfg)
         errs.append((st.error, st.candidate_error, st.accepted))
     assert errs[0][2] == 1 and errs[-1][1] < errs[0][0], errs
@@ -302,6 +331,12 @@ def test_config5_loop_closure_k512(capi, orc):
         print(f"[config5] {len(w.links)} links ({len(loops)} loop closures): engine solve vs host block solve "
               f"{rel(dh, dref):.2e}")
         assert rel(dh, dref) < 1e-7
+        # r06: the LM delta of the whole 512-keyframe window against the oracle -- all 6 120 / 6 140 edges
+        # through oracle/sage_oracle.c in fp32 and fp64 offline, the 19 968-unknown systems solved by a sparse LU in double
+        # (tests/golden/make_window_delta_golden.py cfg5: nothing of the engine's block solver in the fixture)
+        gold = np.load(os.path.join(GOLDEN, f"window_delta_cfg5_k512_seed7_{'loops' if loops else 'noloops'}.npz"))
+        assert int(gold["n_links"]) == len(w.links) and np.array_equal(gold["links"], np.array(w.links, np.int32))
+        assert_delta_bars(f"config5/{len(loops)} loop links", dh, gold)
         # sampled edges against the oracle: first / middle / last temporal link and every loop link
         for l in [0, n_temporal // 2, n_temporal - 1] + list(range(n_temporal, len(w.links))):
             a, b = w.links[l]
@@ -316,9 +351,16 @@ def test_config5_loop_closure_k512(capi, orc):
         cfg = capi.lm_config_default(); cfg.max_inner_evals = 1
         st = capi.SageLmState()
         errs = []
-        for _ in range(3):
+        for it in range(3):
             win.lm_step(st, cfg)
             errs.append((st.error, st.candidate_error, st.accepted))
+            if it == 0:
+                # the merged linearize of the LM iteration at the same linearisation point: same bars through the engine's own
+                # host block solve (checked against the sparse LU above)
+                pm = win.packed_host().astype(np.float64)
+                assert rel(pm[:-4], packed[:-4]) < 2e-6
+                assert_delta_bars(f"config5/{len(loops)} loop links", capi.block_solve(pm[:-4], K, w.links, B, DAMP, dadd, gadd),
+                                  gold, what="merged-linearize LM delta")
         print(f"[config5] LM trace {errs}")
         assert errs[0][2] == 1 and errs[-1][1] < errs[0][0], errs
         win.close()
