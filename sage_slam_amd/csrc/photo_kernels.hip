@@ -69,8 +69,12 @@ __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
 #ifndef SAGE_PHOTO_PRIO_SAMPLING
 #define SAGE_PHOTO_PRIO_SAMPLING 3 // s_setprio of the linearize kernel's sampling phase (its contraction phases run at 0)
 #endif
-#ifndef SAGE_PHOTO_STAGGER_CUS
-#define SAGE_PHOTO_STAGGER_CUS 256
+// r06: the next sub-tile's per-pixel inputs of phase A (location, homogeneous coordinates, depth: a chain of dependent global
+// loads, 3.3 k cycles of a wave's 36 k per sub-tile in the wave timeline) are asked for during the current sub-tile's phases
+// C / D: photometric linearize 0.622 -> 0.611 ms in the cold micro-bench (profiles/r06_kernel_ab_experiments.txt); +4 VGPRs.
+// 0 = off (A/B)
+#ifndef SAGE_PHOTO_PREFETCH_A
+#define SAGE_PHOTO_PREFETCH_A 1
 #endif
 #ifndef SAGE_PHOTO_LIN_GUNROLL
 #define SAGE_PHOTO_LIN_GUNROLL 8
@@ -442,17 +446,6 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
                        //  array nothing in the program writes or reads is not allocated)
   __syncthreads(); // s_red zeroed
 
-#ifdef SAGE_PHOTO_STAGGER
-  // experiment: the first wave of workgroups -- three per CU, dispatched together -- starts a third of a
-  // sub-tile period apart, so that the co-resident workgroups are in different phases
-  if constexpr (JAC && PACKED)
-  {
-    const int slot = bid / SAGE_PHOTO_STAGGER_CUS;
-    if (slot < 3)
-      for (int i = 0; i < slot * SAGE_PHOTO_STAGGER; ++i)
-        __builtin_amdgcn_s_sleep(127);
-  }
-#endif
 
 #ifdef SAGE_PHOTO_TRACE
   if constexpr (JAC && MODE == 2)
@@ -474,7 +467,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   const int flush = JAC ? max(1, prm.flush) : 1;
   const int rec_base = (JAC && prm.rec_first) ? uni(prm.rec_first[wi.edge]) + wi.tile / flush : bid;
   int run_pos = 0, rec_idx = 0; // sub-tiles since the last partial record, records written so far
-#ifdef SAGE_PHOTO_PREFETCH_A
+#if SAGE_PHOTO_PREFETCH_A
   // next sub-tile's per-pixel inputs of phase A, asked for during the contraction phase of the current one (linearize, engine layout)
   int pf_loc = 0;
   float pf_d = 1.0f, pf_hm0 = 0.f, pf_hm1 = 0.f, pf_hm2 = 1.f;
@@ -506,7 +499,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   int my_loc;
   float d;
   float hm[3] = {0.f, 0.f, 1.f};
-#ifdef SAGE_PHOTO_PREFETCH_A
+#if SAGE_PHOTO_PREFETCH_A
   if (JAC && PACKED && sub > 0)
   {
     in_range = pf_in;
@@ -625,13 +618,6 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     }
   };
   bool slice_live = true; // linearize, engine layout: false when no pixel of this wave's slice is an inlier
-#ifdef SAGE_PHOTO_GP_EARLY
-  // merged linearize: the geometric kernel's hand-over for this pixel is asked for BEFORE the sampling phase (a stream from
-  // HBM, 16 B per pixel, first used in phase C)
-  f32x4 gp_early = {0.f, 0.f, 0.f, 0.f};
-  if (MERGE)
-    gp_early = reinterpret_cast<const f32x4 *>(E.geo_px)[in_range ? n : 0];
-#endif
   SAGE_PHASE("B_setup");
   SAGE_TMARK(1);
   if (PACKED)
@@ -1096,7 +1082,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   // ---- per-pixel 7x7 reduced system ----
   SAGE_PHASE("C_rows");
   __builtin_amdgcn_s_setprio(0);
-#ifdef SAGE_PHOTO_PREFETCH_A
+#if SAGE_PHOTO_PREFETCH_A
   if (PACKED && sub + 1 < nsub)
   {
     const int n2 = n + kTile;
@@ -1111,136 +1097,14 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   const bool live = vm != 0.0f;
   // merged linearize (LaunchCommon::merge_geo_weight): the geometric kernel's hand-over for this pixel, asked for first
   f32x4 gp = {0.f, 0.f, 0.f, 0.f};
-#ifdef SAGE_PHOTO_GP_EARLY
-  gp = gp_early;
-#else
   if (MERGE)
     gp = reinterpret_cast<const f32x4 *>(E.geo_px)[in_range ? n : 0];
-#endif
   const float vm2 = vm * vm; // gradient and residual both carry m (:200, :234)
   G00 *= vm2;
   G01 *= vm2;
   G11 *= vm2;
   v0 *= vm2;
   v1 *= vm2;
-#ifdef SAGE_PHOTO_C_DOUBLE
-  // DIAGNOSTIC (r06 numerics probe, never in the product): the per-pixel reduced system of phase C in double
-#define CR double
-  CR Q[2][7];
-  CR dXz[6]; // z-row of dX/dT0 (merged linearize: the geometric edge's pose row starts from it)
-  {
-    // world-from-keyframe poses, re-read per sub-tile through the scalar cache: held across the sampling phase their 24 SGPRs
-    // were spilled to VGPR lanes and every use paid a v_readlane
-    Pose p0, p1;
-    if constexpr (FS >= 32)
-    {
-      // FS = 32 (BASELINE config 4) is bound by the memory side (fetch 1.58 x the algorithmic bytes, L2 hit rate 35 %): there
-      // the kernel runs 4 % FASTER with the per-lane loads the compiler makes of this (seven round trips in series that
-      // hold the wave back from its next burst of requests) than with the scalar loads -- measured, r05_kernel_ab_experiments
-      const float *R0p = E.R0, *R1p = E.R1;
-      asm volatile("" : "+s"(R0p), "+s"(R1p));
-      p0 = load_pose2(R0p, E.t0);
-      p1 = load_pose2(R1p, E.t1);
-    }
-    else
-      sload_pose_pair(E.R0, E.t0, E.R1, E.t1, p0, p1);
-    // (engine layout: the homogeneous coordinates are read again and the warp of phase A recomputed -- same operations,
-    //  same values -- instead of ten registers staying live across the sampling phase)
-    if (PACKED)
-    {
-      const float *hp = E.homo + 3 * (in_range ? n : 0);
-      hm[0] = in_range ? hp[0] : 0.f;
-      hm[1] = in_range ? hp[1] : 0.f;
-      hm[2] = in_range ? hp[2] : 1.f;
-#pragma unroll
-      for (int i = 0; i < 3; ++i)
-      {
-        rh[i] = p10.R[i * 3 + 0] * hm[0] + p10.R[i * 3 + 1] * hm[1] + p10.R[i * 3 + 2] * hm[2];
-        X[i] = d * rh[i] + p10.t[i];
-      }
-    }
-    const CR inv_z = (CR)1 / (CR)X[2];
-    CR Xw[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      Xw[i] = (CR)d * ((CR)p0.R[i * 3 + 0] * (CR)hm[0] + (CR)p0.R[i * 3 + 1] * (CR)hm[1] + (CR)p0.R[i * 3 + 2] * (CR)hm[2]) + (CR)p0.t[i];
-    CR dX[3][6];
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-    {
-      const CR r0 = p1.R[0 * 3 + i], r1 = p1.R[1 * 3 + i], r2 = p1.R[2 * 3 + i];
-      dX[i][0] = r0; dX[i][1] = r1; dX[i][2] = r2;
-      dX[i][3] = r2 * Xw[1] - r1 * Xw[2];
-      dX[i][4] = r0 * Xw[2] - r2 * Xw[0];
-      dX[i][5] = r1 * Xw[0] - r0 * Xw[1];
-    }
-    const CR jx = -(CR)X[0] * inv_z * inv_z, jy = -(CR)X[1] * inv_z * inv_z;
-#pragma unroll
-    for (int j = 0; j < 6; ++j)
-    {
-      Q[0][j] = inv_z * dX[0][j] + jx * dX[2][j];
-      Q[1][j] = inv_z * dX[1][j] + jy * dX[2][j];
-      dXz[j] = dX[2][j];
-    }
-    Q[0][6] = (CR)rh[0] * inv_z - (CR)X[0] * (CR)rh[2] * inv_z * inv_z; // :324-325 without fx, fy
-    Q[1][6] = (CR)rh[1] * inv_z - (CR)X[1] * (CR)rh[2] * inv_z * inv_z;
-  }
-  CR S6[7], u6;
-  {
-    CR GQ0[7], GQ1[7];
-#pragma unroll
-    for (int j = 0; j < 7; ++j)
-    {
-      // dead pixels: G and v are exactly zero (vm = 0), Q may hold inf/nan -> zero it so that every product vanishes
-      Q[0][j] = live ? Q[0][j] : (CR)0;
-      Q[1][j] = live ? Q[1][j] : (CR)0;
-      GQ0[j] = (CR)G00 * Q[0][j] + (CR)G01 * Q[1][j];
-      GQ1[j] = (CR)G01 * Q[0][j] + (CR)G11 * Q[1][j];
-    }
-#pragma unroll
-    for (int i = 0; i < 7; ++i)
-      S6[i] = Q[0][i] * GQ0[6] + Q[1][i] * GQ1[6];
-    u6 = Q[0][6] * (CR)v0 + Q[1][6] * (CR)v1;
-    sdd_acc += (float)(S6[6] * (CR)d * (CR)d); // (the photometric sigma only: the geometric edge keeps its own scale0-scale0 entry)
-    CR row8 = 0;
-    if (MERGE)
-    {
-      // merged linearize: the geometric edge of the same pair (geometric_factor_kernels.cpp:671-716) at the same pixel --
-      // {omega, D, grad D} from its kernel; a = dX_z/dT0 - gradD^T Jpi dX/dT0 and kappa = r_z - gradD^T dpi/dd in terms of
-      // this kernel's own Q (Jpi's unit-focal form: P = diag(fx, fy) Q).  Its code0 column is kappa s0 b_n, so every block it
-      // enters has the form of one the photometric contraction carries -- sigma b b^T, (c, sigma d, u6) b^T: the weights are
-      // added and contracted once.  With wk = w_g omega kappa and g = (fx dD/dx, fy dD/dy):
-      //   c_r  += wk a_r = wk dXz_r - Q0r (wk g_x) - Q1r (wk g_y)     (r < 6; the same form with dXz_6 := r_z gives sigma)
-      //   u6   += wk rho,   row 8 = wk D  (the scale1-code0 block, read by the geometric finalize)
-      // omega is zero for every pixel the geometric kernel found dead (the same pixels as here: same warp, same mask)
-      const CR om = in_range ? gp[0] : 0.f;
-      const CR gx = (CR)gp[2] * (CR)fx0, gy = (CR)gp[3] * (CR)fy0;
-      const CR kap = (CR)rh[2] - (gx * Q[0][6] + gy * Q[1][6]);
-      const CR wk = ((CR)prm.merge_w * om) * kap;
-      const CR wgx = wk * gx, wgy = wk * gy;
-#pragma unroll
-      for (int r = 0; r < 6; ++r)
-        S6[r] += wk * dXz[r] - (Q[0][r] * wgx + Q[1][r] * wgy);
-      S6[6] += wk * kap;
-      u6 += wk * ((CR)gp[1] - (CR)X[2]);
-      row8 = wk * (CR)gp[1];
-    }
-    // stash: the rows that multiply b_n (c (6), sigma*d, u6), sigma and the byte offset of the basis row, then the
-    // operands of the pose tile
-    f32x4 *st = reinterpret_cast<f32x4 *>(st_w + lane * kPhotoStashLD);
-    st[0] = f32x4{(float)(S6[0]), (float)(S6[1]), (float)(S6[2]), (float)(S6[3])};
-    st[1] = f32x4{(float)(S6[4]), (float)(S6[5]), (float)(S6[6] * d), (float)(u6)};
-    st[2] = f32x4{(float)(S6[6]), __int_as_float(my_loc * (CS * 4)), (float)(GQ0[0]), (float)(GQ0[1])};
-    st[3] = f32x4{(float)(GQ0[2]), (float)(GQ0[3]), (float)(GQ0[4]), (float)(GQ0[5])};
-    st[4] = f32x4{(float)(GQ1[0]), (float)(GQ1[1]), (float)(GQ1[2]), (float)(GQ1[3])};
-    st[5] = f32x4{(float)(GQ1[4]), (float)(GQ1[5]), (float)(v0), (float)(v1)};
-    st[6] = f32x4{(float)(Q[0][0]), (float)(Q[0][1]), (float)(Q[0][2]), (float)(Q[0][3])};
-    st[7] = f32x4{(float)(Q[0][4]), (float)(Q[0][5]), (float)(Q[1][0]), (float)(Q[1][1])};
-    st[8] = f32x4{(float)(Q[1][2]), (float)(Q[1][3]), (float)(Q[1][4]), (float)(Q[1][5])};
-    st[9] = f32x4{(float)(Q[0][6] * d), (float)(Q[1][6] * d), (float)(row8), (float)(0.f)};
-  }
-#undef CR
-#else
   float Q[2][7];
   float dXz[6]; // z-row of dX/dT0 (merged linearize: the geometric edge's pose row starts from it)
   {
@@ -1346,7 +1210,6 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     st[8] = f32x4{Q[1][2], Q[1][3], Q[1][4], Q[1][5]};
     st[9] = f32x4{Q[0][6] * d, Q[1][6] * d, row8, 0.f};
   }
-#endif
   __builtin_amdgcn_wave_barrier(); // same-wave LDS hand-over (in-order LDS pipe): no workgroup barrier needed
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 
@@ -1468,7 +1331,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   SAGE_PHASE("E_second_level_flush");
   SAGE_TMARK(5);
   } // slice_live
-#ifdef SAGE_PHOTO_PREFETCH_A
+#if SAGE_PHOTO_PREFETCH_A
   if (PACKED && sub + 1 < nsub)
   {
     pf_in = pf_in && (unsigned)pf_loc < (unsigned)(W0 * H0);

@@ -908,6 +908,10 @@ extern "C" int sage_window_finalize(SageWindow *w)
     int flush = tpb >= 8 ? 4 : 0;
     if (const char *e = getenv("SAGE_PHOTO_FLUSH"))
       flush = std::max(0, atoi(e));
+    // (r06, VERDICT r5 item 4 -- measured and dropped: the runs of an edge dealt to the XCDs in contiguous BANDS of image strips
+    //  (workgroup b runs on XCD b % 8; band x = runs [x R / 8, (x + 1) R / 8), all XCDs on the same edge at the same time), so that
+    //  vertically adjacent strips share their destination halo in ONE L2: config 4 photometric linearize 1.202 -> 1.191 ms, error
+    //  pass 0.638 -> 0.624, K = 64 unchanged (0.622 / 0.623) -- profiles/r06_kernel_ab_experiments.txt)
     wp.build(Nedge, tpb, nullptr, flush);
     // (r05, VERDICT r4 item 6 -- measured and dropped: the linearize's work items in destination-keyframe-major order, the
     //  runs of the <= 6 edges that sample one keyframe interleaved strip by strip, so that the workgroups in flight want ONE
