@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 # Counter constants of the K = 64 headline window (rocprofv3 --pmc, separate passes, scripts/pmc_run.sh ->
-# profiles/r05_v3_pmc_summary.txt; bench.py cannot collect PMC counters itself, null for any other workload).  They are
+# profiles/r06_v1_pmc_summary.txt; bench.py cannot collect PMC counters itself, null for any other workload).  They are
 # per-launch INSTRUCTION / BYTE counts of one build on one workload -- fixed by the code, not by the box -- and are combined
 # below with the launch durations measured live in this run.  They belong to ONE build of the kernel sources: the summary
 # records sage_slam_amd.build.kernel_source_sha16() of the tree it was taken from, and the constants are quoted only while
@@ -43,11 +43,15 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s ac
 #   kernels: the LM iteration's merged pair -- photo_kernel<32,16,true,2> and geo_kernel<32,true,true>
 #   traffic: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane reads on gfx950, + WRITE_SIZE
 PMC_K64 = {
-    "source": "profiles/r05_v4_pmc_summary.txt",
-    "kernel_source_sha16": "9b78637bed7944dc",
-    "photo": {"fetch_size_kb": 853490.0, "write_size_kb": 44262.2, "insts_vmem_rd": 7.41147e6, "insts_valu": 1.48417e8,
-              "insts_mfma": 8.96938e6, "lds_idx_active": 1.36843e8, "lds_bank_conflict": 3.54242e7},
-    "geo": {"insts_vmem_rd": 9.07898e6, "insts_valu": 6.70424e7, "insts_mfma": 1.4949e7, "lds_idx_active": 3.31144e7},
+    "source": "profiles/r06_v1_pmc_summary.txt",
+    "kernel_source_sha16": "a8ef1b80b4db13e5",
+    # grbm_gui_active / pmc_pass_avg_us: the engine clock of the counter pass itself (r06: issue fractions at the measured
+    # clock -- 1.06996e7 / 8 / 595.08 us = 2.25 GHz -- not at the 2.4 GHz spec clock)
+    "photo": {"fetch_size_kb": 917356.0, "write_size_kb": 44477.2, "insts_vmem_rd": 7.41147e6, "insts_valu": 1.51657e8,
+              "insts_mfma": 8.96938e6, "mfma_busy_cycles": 2.8702e8, "lds_idx_active": 1.36861e8, "lds_bank_conflict": 3.54242e7,
+              "grbm_gui_active": 1.06996e7, "pmc_pass_avg_us": 595.082},
+    "geo": {"insts_vmem_rd": 9.07898e6, "insts_valu": 6.70424e7, "insts_mfma": 1.4949e7, "mfma_busy_cycles": 4.78367e8,
+            "lds_idx_active": 3.31144e7, "grbm_gui_active": 6.87343e6, "pmc_pass_avg_us": 374.375},
 }
 PMC_TRAFFIC_BYTES_K64 = {"hbm_bytes_per_launch": (2 * PMC_K64["photo"]["fetch_size_kb"] + PMC_K64["photo"]["write_size_kb"]) * 1024.0}
 
@@ -66,19 +70,40 @@ L1_PEAK_GBS = N_CU * 64 * CLK_HZ / 1e9         # CU texture path: 64 B / clk / C
 MFMA_F32_PEAK_TFLOPS = 157.3                    # dense f32 matrix peak (= the f32 vector peak on this part)
 
 
+def measured_clock_hz(pmc):
+    """engine clock of the counter pass itself: GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the kernel's average duration
+    in the same rocprofv3 pass (MI355X_MICROARCH.md "DVFS give-back")"""
+    if pmc.get("grbm_gui_active") and pmc.get("pmc_pass_avg_us"):
+        return pmc["grbm_gui_active"] / 8.0 / (pmc["pmc_pass_avg_us"] * 1e-6)
+    return CLK_HZ
+
+
+def roofs(pmc, ms, ach_gbs):
+    clk = measured_clock_hz(pmc)
+    t = ms * 1e-3
+    valu_s = pmc["insts_valu"] * 4.0 / N_SIMD / clk          # one quad-cycle issue slot per wave instruction (SQ_ACTIVE_INST_VALU == SQ_INSTS_VALU)
+    mfma_s = pmc["mfma_busy_cycles"] / N_SIMD / clk if pmc.get("mfma_busy_cycles") else pmc["insts_mfma"] * 32.0 / N_SIMD / clk
+    lds_s = pmc["lds_idx_active"] / N_CU / clk
+    return {"hbm_algorithmic": {"achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach_gbs / HBM_PEAK_GBS},
+            "issue_serialised": {"valu_ms": 1e3 * valu_s, "mfma_ms": 1e3 * mfma_s, "lds_ms": 1e3 * lds_s, "launch_ms": ms,
+                                 "frac": (valu_s + mfma_s + lds_s) / t, "clock_ghz": clk / 1e9,
+                                 "note": "busy-sum / wall of the VALU issue port, the MFMA pipe (per SIMD) and the LDS array (per CU)"}}
+
+
 def issue_roofline(pmc, ms):
     """Per-pipe utilisation of one launch from its instruction counts (committed PMC constants) and its duration measured
     in this run.  l1: wave-loads x 1 KiB (16 B / lane, the dwordx4 taps / staging loads) against the CUs' texture-path
     rate; lds: LDS-array busy cycles per CU; valu: one issue slot (4 cycles per SIMD) per wave instruction; mfma: FLOP of
-    the 16x16x4 f32 instructions against the dense f32 matrix peak.  The peak clock is assumed (the part runs ~2.0-2.1 GHz
-    under this load: fractions are lower bounds of the pipes' busy time)."""
+    the 16x16x4 f32 instructions against the dense f32 matrix peak.  r06: peaks at the clock the counter pass measured
+    (GRBM_GUI_ACTIVE / 8 / kernel duration), not at the 2.4 GHz spec clock."""
     if not pmc or ms <= 0:
         return None
     t = ms * 1e-3
-    out = {"l1": {"achieved": pmc["insts_vmem_rd"] * 1024.0 / t / 1e9, "peak": L1_PEAK_GBS, "unit": "GB/s"},
-           "valu": {"achieved": pmc["insts_valu"] * 4.0 / N_SIMD / t / 1e9, "peak": CLK_HZ / 1e9, "unit": "Gcycles/s per SIMD"},
-           "mfma": {"achieved": pmc["insts_mfma"] * 2048.0 / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s"},
-           "lds": {"achieved": pmc["lds_idx_active"] / N_CU / t / 1e9, "peak": CLK_HZ / 1e9, "unit": "Gcycles/s per CU"}}
+    clk = measured_clock_hz(pmc)   # r06: the clock of the counter pass (GRBM_GUI_ACTIVE / 8 / duration), not the 2.4 GHz peak
+    out = {"l1": {"achieved": pmc["insts_vmem_rd"] * 1024.0 / t / 1e9, "peak": N_CU * 64 * clk / 1e9, "unit": "GB/s"},
+           "valu": {"achieved": pmc["insts_valu"] * 4.0 / N_SIMD / t / 1e9, "peak": clk / 1e9, "unit": "Gcycles/s per SIMD"},
+           "mfma": {"achieved": pmc["insts_mfma"] * 2048.0 / t / 1e12, "peak": MFMA_F32_PEAK_TFLOPS * clk / CLK_HZ, "unit": "TFLOP/s"},
+           "lds": {"achieved": pmc["lds_idx_active"] / N_CU / t / 1e9, "peak": clk / 1e9, "unit": "Gcycles/s per CU"}}
     for v in out.values():
         v["frac"] = v["achieved"] / v["peak"]
     return out
@@ -659,6 +684,22 @@ def main():
         dist.all_gather(allr, mine)
         per_rank_ms = [{"rank": r, "photo_linearize": float(v[0]), "geo_linearize": float(v[1]),
                         "error_pass": float(v[2])} for r, v in enumerate(allr)]
+        # r06: the first SCALE run verifies itself -- what each rank's COMMUNICATOR says about the job
+        # (ncclCommCount / ncclCommUserRank) and how many directed edges the rank's window actually linearizes
+        seen = (-1, -1)
+        if rccl_comm is not None:
+            try:
+                seen = capi.rccl_comm_info(rccl_comm)
+            except Exception:
+                pass
+        schur_r = os.environ.get("SAGE_SHARD_SCHUR", "1" if args.keyframes >= 256 else "0") not in ("0", "")
+        n_loc = (2 * len(capi.shard_links(len(win_h.links), rank, world)) if schur_r else
+                 len(capi.shard_edges(len(win_h.links), rank, world)))
+        mine2 = torch.tensor([seen[0], seen[1], n_loc], dtype=torch.int64, device="cpu" if one_dev else "cuda")
+        all2 = [torch.zeros_like(mine2) for _ in range(world)]
+        dist.all_gather(all2, mine2)
+        for r, v in enumerate(all2):
+            per_rank_ms[r].update({"rccl_ranks_seen": int(v[0]), "rccl_rank": int(v[1]), "local_directed_edges": int(v[2])})
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -708,6 +749,12 @@ def main():
                        "accepted_steps": n_acc,
                        "error_first_last": [hist[0][0], hist[-1][1]]},
             "roofline": {"bound": "hbm",
+                         # r06: BOTH roofs in the parsed line.  hbm_algorithmic = SURVEY s8(d)'s bytes over the
+                         # launch time (the contract's `frac`); issue_serialised = (VALU + MFMA issue time per SIMD + LDS-array
+                         # time per CU) / launch time at the MEASURED engine clock -- ~1 means the three pipes run one after the
+                         # other, which is what binds this kernel (profiles/r06_photo_wave_timeline.txt), not HBM
+                         "roofs": roofs(PMC_K64["photo"], ms_photo, ach) if pmc_ok else
+                                  {"hbm_algorithmic": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS}},
                          "kernel": "photo_kernel<CS,FS,true,2> (fused photometric linearize of the LM iteration; since r05 it also "
                                    "contracts the geometric edge's code0 blocks of the same pair -- the merged linearize)",
                          "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
@@ -748,6 +795,16 @@ def main():
             except Exception as exc:            # the headline line must not depend on the emulation
                 out["shard_emulation"] = {"error": repr(exc)}
             se = out["shard_emulation"]
+            if isinstance(se, dict) and "speedup_vs_one_gpu_classic" in se:
+                # r06: the ceiling belongs in the line, not only in DESIGN.md
+                sp = se["speedup_vs_one_gpu_classic"]
+                se["ceiling_note"] = (
+                    f"one rank of {ew} measured on this device runs an LM iteration {sp:.1f}x faster than the one-GPU step BEFORE any "
+                    "xGMI transfer: the >= 6x strong-scaling target is out of reach at this window size by design -- the "
+                    "replicated host factorisation (a chain of K/2 block rows per half, ~0.2 ms) does not shard.  The four-chain "
+                    "elimination was costed again in r06 (DESIGN s7): two of its four chains sit between two separators and drag "
+                    "3-row arrow chains of the same length behind them -- ~2x the multiply-adds, ~14 host threads per rank for "
+                    "~30 us of critical path; not built")
             if classic_seq and se.get("one_gpu_ms_per_step_same_sequence", 0) == se.get("one_gpu_ms_per_step_same_sequence", float("nan")):
                 # the same window with the engine's other LM sequence (SageLmConfig.linearize_at_candidate = 1: the candidate is
                 # evaluated by the linearize kernels, an accepted iteration has no separate error pass; identical iterates and
@@ -765,6 +822,8 @@ def main():
                                      "lm_thread_mask_cpus": len(os.sched_getaffinity(0)),
                                      "solver_helper_cpus": capi.solver_helper_cpus(),
                                      "placement_monitor_moves": capi.solver_placement_moves(),
+                                     "placement_monitor": "opt-in (SAGE_PLACEMENT_MONITOR=1); off" if os.environ.get("SAGE_PLACEMENT_MONITOR", "0") in ("", "0") else "on",
+                                     "host_threads_running": capi.host_threads_running(),
                                      "loadavg_1min": float(open("/proc/loadavg").read().split()[0])}
         except Exception as e:                                  # diagnostics only
             out["host_placement"] = {"error": str(e)}

@@ -613,6 +613,9 @@ int sage_window_emulate_peers(SageWindow *w, const double *rest_dev, int n_itera
 int sage_rccl_unique_id(unsigned char *id128);
 int sage_rccl_comm_create(const unsigned char *id128, int rank, int world, void **comm_out);
 void sage_rccl_comm_destroy(void *comm);
+/* what the communicator itself reports (ncclCommCount / ncclCommUserRank): bench.py prints it so that the first multi-GPU
+ * line is self-verifying (r06) */
+int sage_rccl_comm_info(void *comm, int *ranks_out, int *rank_out);
 int sage_window_use_rccl(SageWindow *w, void *nccl_comm);
 
 /* one full LM iteration: linearize -> (all-reduce) -> solve -> error at candidate -> (all-reduce) -> accept/reject

@@ -794,6 +794,13 @@ def rccl_comm_destroy(comm: int):
     lib().sage_rccl_comm_destroy(C.c_void_p(comm))
 
 
+def rccl_comm_info(comm: int):
+    """(ranks, rank) as the communicator itself reports them (``ncclCommCount`` / ``ncclCommUserRank``)."""
+    n, r = C.c_int(), C.c_int()
+    _chk(lib().sage_rccl_comm_info(C.c_void_p(comm), C.byref(n), C.byref(r)), "sage_rccl_comm_info")
+    return n.value, r.value
+
+
 def shard_links(nlinks: int, rank: int, world: int) -> List[int]:
     """link ownership rule of windows that use the domain-decomposed solve (``SAGE_SHARD_SCHUR`` / K >= 256) and of
     ``sage_shard_plan_create``: rank r owns the contiguous range [r*n/world, (r+1)*n/world) of the link list."""

@@ -236,6 +236,8 @@ struct RcclApi
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
   bool ok = false;
 };
 
@@ -258,6 +260,8 @@ RcclApi &rccl()
     a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.handle, "ncclCommDestroy"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.handle, "ncclAllReduce"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.handle, "ncclGetErrorString"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(a.handle, "ncclCommCount"));
+    a.CommUserRank = reinterpret_cast<decltype(a.CommUserRank)>(dlsym(a.handle, "ncclCommUserRank"));
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce;
     return a;
   }();
@@ -324,6 +328,23 @@ extern "C" int sage_rccl_comm_create(const unsigned char *id128, int rank, int w
     return SAGE_E_STATE;
   }
   *comm_out = c;
+  return SAGE_OK;
+}
+
+extern "C" int sage_rccl_comm_info(void *comm, int *ranks_out, int *rank_out)
+{
+  if (!comm)
+    return SAGE_E_INVALID;
+  if (!rccl().ok || !rccl().CommCount || !rccl().CommUserRank)
+    return SAGE_E_UNSUPPORTED;
+  int n = 0, r = 0;
+  if (rccl().CommCount(static_cast<ncclComm_t>(comm), &n) != ncclSuccess ||
+      rccl().CommUserRank(static_cast<ncclComm_t>(comm), &r) != ncclSuccess)
+    return SAGE_E_STATE;
+  if (ranks_out)
+    *ranks_out = n;
+  if (rank_out)
+    *rank_out = r;
   return SAGE_OK;
 }
 

@@ -32,6 +32,7 @@ def test_rccl_single_rank_lm_matches_plain_window():
     assert len(uid) == 128 and any(uid)
     comm = capi.rccl_comm_create(uid, 0, 1)
     assert comm
+    assert capi.rccl_comm_info(comm) == (1, 0)          # what bench.py prints as rccl_ranks_seen
     w = synth.make_window(K=6, H=48, W=64, FS=16, CS=32, L=3, n_samples=1500, seed=9)
 
     def run(use_rccl, variant=-1):
@@ -142,6 +143,7 @@ def _rccl_worker(rank, world, port, out_dir, schur):
     uid = [capi.rccl_unique_id() if rank == 0 else None]
     dist.broadcast_object_list(uid, 0)
     comm = capi.rccl_comm_create(uid[0], rank, world)
+    assert capi.rccl_comm_info(comm) == (world, rank)
     w = _make_multi()
     win = capi.Window(w, rank=rank, world=world)
     win.use_rccl(comm)
