@@ -98,7 +98,7 @@ SYMBOLS = [
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
     "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
-    "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_prepare_factors", "sage_factor_psd", "sage_factor_cut_blocks", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_get_phase_time", "sage_window_lm_step", "sage_window_lm_run", "sage_window_lm_run_timed", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_window_use_rccl", "sage_window_emulate_peers", "sage_sort_locations", "sage_bind_thread_to_device", "sage_solver_helper_cpus", "sage_solver_placement_moves", "sage_placement_monitor", "sage_shutdown", "sage_host_threads_running",
+    "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_prepare_factors", "sage_factor_psd", "sage_factor_cut_blocks", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_get_phase_time", "sage_window_lm_step", "sage_window_lm_run", "sage_window_lm_run_timed", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_rccl_comm_info", "sage_window_use_rccl", "sage_window_emulate_peers", "sage_sort_locations", "sage_bind_thread_to_device", "sage_solver_helper_cpus", "sage_solver_placement_moves", "sage_placement_monitor", "sage_shutdown", "sage_host_threads_running",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
     "sage_reprojection_jac_error_calculate", "sage_reprojection_error_calculate",
     "sage_tracker_reproj_jac_error_calculate", "sage_tracker_reproj_error_calculate",

@@ -361,6 +361,9 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
   __shared__ __attribute__((aligned(16))) float s_estage[(!JAC && PACKED) ? kWaves * kErrStageGroups * kErrStageGroupBytes / 4 : 4];
 
   const int tid_wg = threadIdx.x, tid = tid_wg, lane = tid & 63, wave = tid_wg >> 6;
+#ifdef SAGE_PHOTO_TRACE
+  const unsigned long long t_entry_ = __builtin_readcyclecounter(); // first instruction of the wave: dispatch vs prologue
+#endif
   const int bid = (int)blockIdx.x;
   WorkItem wi = prm.work[bid];
   wi.edge = uni(wi.edge);
@@ -459,6 +462,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       h[3] = __builtin_readcyclecounter();
       h[4] = (unsigned)wi.edge;
       h[5] = (unsigned)wi.tile;
+      h[6] = t_entry_;
     }
   }
 #endif

@@ -85,7 +85,8 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         out = os.path.join(td, "photo.s")
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
-                               "-I" + os.path.dirname(SRC), "-x", "hip", "--cuda-device-only", "-S", SRC, "-o", out],
+                               "-I" + os.path.dirname(SRC), "-x", "hip", "--cuda-device-only", "-S", SRC, "-o", out] +
+                              [a for a in sys.argv[1:] if a.startswith("-D")],   # (variant builds: -DSAGE_...)
                               stderr=subprocess.DEVNULL)
         n, problems = check(open(out).read())
     print(f"{n} hand-tracked loads checked, {len(problems)} problems")

@@ -76,6 +76,23 @@ def analyse(path, verbose=True):
     wg_start = hdr[:, :, 3].min(axis=1)
     last = np.where(ran, t0[..., 6], 0).max(axis=(1, 2))
     res["wg_cycles_mean"] = round(float((last - wg_start).mean()), 0)
+    # prologue (kernel entry -> first sub-tile: work item, edge table, poses, s_red barrier) per wave, and -- per CU slot -- the
+    # time between a workgroup's last stamp and its successor's ENTRY (the hardware's dispatch) when the entry stamp exists
+    entry = hdr[:, :, 6]
+    if (entry > 0).all():
+        res["prologue_cycles_p10_p50_p90"] = [int(np.percentile((hdr[:, :, 3] - entry).reshape(-1), q)) for q in (10, 50, 90)]
+        cu_key = ((xcc[:, 0] * 8 + se[:, 0]) * 2 + sh[:, 0]) * 16 + cu[:, 0]
+        gaps_d, gaps_t = [], []
+        for k in np.unique(cu_key):
+            m = np.nonzero(cu_key == k)[0]
+            for slot in np.unique(waveslot[m, 0]):
+                mm = m[waveslot[m, 0] == slot]
+                o = mm[np.argsort(entry[mm].min(axis=1))]
+                for a_, b_ in zip(o[:-1], o[1:]):
+                    gaps_d.append(int(entry[b_].min() - last[a_]))
+                    gaps_t.append(int(hdr[b_, :, 3].min() - last[a_]))
+        res["dispatch_gap_cycles_p10_p50_p90"] = [int(np.percentile(gaps_d, q)) for q in (10, 50, 90)]
+        res["end_to_first_subtile_cycles_p10_p50_p90"] = [int(np.percentile(gaps_t, q)) for q in (10, 50, 90)]
     spans = []
     for x in range(8):
         m = xcc[:, 0] == x
