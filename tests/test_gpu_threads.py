@@ -162,3 +162,46 @@ def test_operators_and_windows_are_reentrant_across_host_threads():
         win.close()
     for sc in scenes:
         sc.close()
+
+
+_LIFECYCLE_SNIPPET = r"""
+import os, sys
+sys.path.insert(0, %(root)r)
+from sage_slam_amd import capi, synth
+def n_tasks():
+    return len(os.listdir("/proc/self/task"))
+import torch
+torch.zeros(1, device="cuda"); torch.cuda.synchronize()          # runtime threads exist before the baseline is taken
+w = synth.make_window(K=24, H=32, W=40, FS=16, CS=32, L=3, seed=3)     # long enough for the two-ended elimination order
+a = capi.Window(w); b = capi.Window(w)
+st = capi.SageLmState(); cfg = capi.lm_config_default()
+base = n_tasks() - capi.host_threads_running()
+a.lm_step(st, cfg); b.lm_step(capi.SageLmState(), cfg)
+up = capi.host_threads_running()
+a.close()
+mid = capi.host_threads_running()                                 # one window is still alive: the helpers stay
+b.close()
+down, tasks = capi.host_threads_running(), n_tasks()
+c = capi.Window(w); c.lm_step(capi.SageLmState(), cfg)            # ... and come back for the next window
+again = capi.host_threads_running()
+e0 = st.candidate_error
+c.close()
+sys.stdout.write("%%d %%d %%d %%d %%d %%d %%d" %% (base, up, mid, down, tasks, again, capi.host_threads_running()))
+"""
+
+
+def test_no_library_thread_outlives_the_last_window():
+    """r06: the solve's helper threads are started by the first solve, survive while any window is alive and are
+    stopped AND joined by the last sage_window_destroy of the process (no detached thread, no monitor by default); the next window
+    starts them again."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "SAGE_PLACEMENT_MONITOR"}
+    r = subprocess.run([sys.executable, "-c", _LIFECYCLE_SNIPPET % {"root": root}], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    base, up, mid, down, tasks, again, end = (int(v) for v in r.stdout.split())
+    assert up >= 1 and mid == up, (up, mid)
+    assert down == 0 and end == 0 and again == up, (down, again, end)
+    assert tasks == base, (tasks, base)          # joined: the process is back at its thread count from before the first solve
