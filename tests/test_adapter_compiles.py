@@ -43,6 +43,40 @@ def test_adapter_compiles_against_reference_headers_and_libtorch():
             assert l.split()[-1] in capi.SYMBOLS, l
 
 
+EXPECTED_KP = ["tracker_reproj_jac_error_calculate", "tracker_reproj_error_calculate", "reprojection_jac_error_calculate<32>",
+               "reprojection_error_calculate<32>", "tracker_match_geom_error_calculate", "tracker_match_geom_jac_error_calculate",
+               "tracker_match_geom_jac_error_calculate_with_scale", "match_geometry_error_calculate<32>",
+               "match_geometry_jac_error_calculate<32>", "loop_mg_error_calculate", "loop_mg_jac_error_calculate"]
+
+
+@pytest.mark.skipif(not (os.path.isdir(REF) and os.path.exists(HIPCC)), reason="needs the reference tree and hipcc")
+def test_keypoint_adapter_compiles_against_reference_headers_and_libtorch():
+    """r06: integration/sage_adapter_keypoints.cpp -- the replacement TU for cuda/{reprojection,match_geometry}_factor_kernels.cpp --
+    against the reference's real headers (reprojection_factor_kernels.h:10-38, match_geometry_factor_kernels.h:9-66): all eleven
+    `df::` entry points defined, every C-ABI function it calls declared and exported.  (Executed on the GPU by
+    tests/test_gpu_adapter_run.py through integration/compile_check/_bin/adapter_run.)"""
+    import torch
+    T = os.path.dirname(torch.__file__)
+    with tempfile.TemporaryDirectory() as tmp:
+        obj = os.path.join(tmp, "sage_adapter_keypoints.o")
+        cmd = [HIPCC, "-x", "c++", "-std=c++17", "-c", "-fPIC", "-w", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
+               "-DDF_CODE_SIZE=32", "-DDF_FEAT_SIZE=16",
+               "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "integration", "compile_check"),
+               "-I" + REF + "/sources/cuda", "-I" + REF + "/sources/common", "-I" + REF + "/thirdparty/eigen",
+               "-I" + T + "/include", "-I" + T + "/include/torch/csrc/api/include", "-I/opt/rocm/include",
+               os.path.join(ROOT, "integration", "sage_adapter_keypoints.cpp"), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        syms = subprocess.run(["nm", "-C", obj], capture_output=True, text=True).stdout
+    defined = [l for l in syms.splitlines() if " W " in l or " T " in l]
+    for name in EXPECTED_KP:
+        assert any(("df::" + name + "(") in l for l in defined), name
+    from sage_slam_amd import capi
+    for l in syms.splitlines():
+        if " U sage_" in l:
+            assert l.split()[-1] in capi.SYMBOLS, l
+
+
 @pytest.mark.skipif(not (os.path.isdir(REF) and os.path.exists(HIPCC)), reason="needs the reference tree and hipcc")
 def test_gtsam_prepass_header_is_valid_cxx():
     """integration/sage_gtsam_prepass.h (f2: the gtsam-side type conversion around sage_window_prepass / _factor) goes
