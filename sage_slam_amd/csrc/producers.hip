@@ -462,9 +462,18 @@ __device__ __forceinline__ int walk_to_pixel(int c, int W, int H, int TW, int TH
   return (x < W && y < H) ? y * W + x : -1;
 }
 
+// r06 -- tile-padded order (pad_flags[k] != 0, 8 x 8 tiles only: a wave of the walk IS a tile).  The compaction above drops the
+// empty pixels of a partially sampled tile, so every sample behind the first partial tile sits at a shifted position: a wave's 64
+// consecutive samples then straddle two tiles, their warped footprint is twice as wide, the LDS-staged sampler of the photometric
+// kernels refuses it and the whole keyframe goes through the texture path (measured: a 148 x 116 sample rectangle that starts at
+// x = 6 instead of x = 8 runs the linearize 1.67 x slower than the aligned 144 x 112 one; any irregular mask -- an endoscope's
+// circle -- does the same).  Padded: every tile that holds a sample keeps all 64 slots, a slot without a sample carries location -1
+// (the kernels drop it like any out-of-image location) and the ray (0, 0, 1); waves and tiles coincide whatever the mask.
+// tiles_out[k] (optional) = tiles with at least one sample, so that the host can price the padding before it asks for it.
 __global__ __launch_bounds__(1024) void order_locations_kernel(const SortItem *__restrict__ items, int HW, int W, int TW,
                                                                int TH, const int *__restrict__ mark,
-                                                               int *__restrict__ status)
+                                                               int *__restrict__ status, const int *__restrict__ pad_flags,
+                                                               int *__restrict__ tiles_out)
 {
   __shared__ int s_wave[16];
   __shared__ int s_base;
@@ -473,8 +482,13 @@ __global__ __launch_bounds__(1024) void order_locations_kernel(const SortItem *_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int H = HW / W;
   const int n_walk = TW > 0 ? ((W + TW - 1) / TW) * ((H + TH - 1) / TH) * TW * TH : HW;
+  const bool pad = pad_flags && pad_flags[k] != 0 && TW * TH == 64;
+  __shared__ int s_tiles;
   if (tid == 0)
+  {
     s_base = 0;
+    s_tiles = 0;
+  }
   __syncthreads();
   for (int c0 = 0; c0 < n_walk; c0 += 1024)
   {
@@ -483,9 +497,13 @@ __global__ __launch_bounds__(1024) void order_locations_kernel(const SortItem *_
     const int src = i >= 0 ? mark[(size_t)k * HW + i] : -1;
     const bool v = src >= 0;
     const unsigned long long b = __ballot(v);
-    const int before = __popcll(b & ((1ull << lane) - 1ull));
+    const int before = pad ? lane : __popcll(b & ((1ull << lane) - 1ull));
     if (lane == 0)
-      s_wave[wave] = __popcll(b);
+    {
+      s_wave[wave] = pad ? (b != 0ull ? 64 : 0) : __popcll(b);
+      if (b != 0ull && TW * TH == 64)
+        atomicAdd(&s_tiles, 1);
+    }
     __syncthreads();
     int off = s_base;
     for (int w = 0; w < wave; ++w)
@@ -498,6 +516,14 @@ __global__ __launch_bounds__(1024) void order_locations_kernel(const SortItem *_
       it.homo_out[3 * n + 1] = it.homo[3 * src + 1];
       it.homo_out[3 * n + 2] = it.homo[3 * src + 2];
     }
+    else if (pad && b != 0ull)
+    {
+      const int n = off + before; // a hole of a kept tile
+      it.loc_out[n] = -1;
+      it.homo_out[3 * n + 0] = 0.f;
+      it.homo_out[3 * n + 1] = 0.f;
+      it.homo_out[3 * n + 2] = 1.f;
+    }
     __syncthreads();
     if (tid == 0)
     {
@@ -509,11 +535,16 @@ __global__ __launch_bounds__(1024) void order_locations_kernel(const SortItem *_
     __syncthreads();
   }
   if (tid == 0)
-    status[2 * k + 1] = s_base;
+  {
+    status[2 * k + 1] = s_base; // samples written (compact order) / slots written (padded order)
+    if (tiles_out)
+      tiles_out[k] = s_tiles;
+  }
 }
 
 hipError_t launch_sort_locations(hipStream_t s, const SortItem *items_dev, int K, int max_n, int HW, int *mark_dev,
-                                 int *status_dev, int W, int tile_w, int tile_h)
+                                 int *status_dev, int W, int tile_w, int tile_h, const int *pad_flags_dev, int *tiles_out_dev,
+                                 bool keep_marks)
 {
   if (W <= 0 || HW % W != 0 || tile_w <= 0 || tile_h <= 0)
   {
@@ -521,13 +552,17 @@ hipError_t launch_sort_locations(hipStream_t s, const SortItem *items_dev, int K
     tile_w = tile_h = 0;
   }
   hipError_t e;
-  if ((e = hipMemsetAsync(mark_dev, 0xff, (size_t)K * HW * sizeof(int), s)) != hipSuccess ||
-      (e = hipMemsetAsync(status_dev, 0, (size_t)2 * K * sizeof(int), s)) != hipSuccess)
-    return e;
-  if (max_n > 0)
-    hipLaunchKernelGGL(mark_locations_kernel, dim3((max_n + 255) / 256, K), dim3(256), 0, s, items_dev, HW, mark_dev,
-                       status_dev);
-  hipLaunchKernelGGL(order_locations_kernel, dim3(K), dim3(1024), 0, s, items_dev, HW, W, tile_w, tile_h, mark_dev, status_dev);
+  if (!keep_marks) // (keep_marks: a second ordering pass over the mark planes of the first -- the padded order)
+  {
+    if ((e = hipMemsetAsync(mark_dev, 0xff, (size_t)K * HW * sizeof(int), s)) != hipSuccess ||
+        (e = hipMemsetAsync(status_dev, 0, (size_t)2 * K * sizeof(int), s)) != hipSuccess)
+      return e;
+    if (max_n > 0)
+      hipLaunchKernelGGL(mark_locations_kernel, dim3((max_n + 255) / 256, K), dim3(256), 0, s, items_dev, HW, mark_dev,
+                         status_dev);
+  }
+  hipLaunchKernelGGL(order_locations_kernel, dim3(K), dim3(1024), 0, s, items_dev, HW, W, tile_w, tile_h, mark_dev, status_dev,
+                     pad_flags_dev, tiles_out_dev);
   return hipGetLastError();
 }
 

@@ -237,6 +237,7 @@ struct SageWindow
   DevBuf wide_p, wide_g;                // per-edge results before their fp32 rounding (EdgeOut::wide)
   DevBuf sorted_loc, sorted_homo;       // raster-ordered copies of the keyframes' sampled locations
   std::vector<std::pair<const int64_t *, const float *>> user_samples; // the caller's arrays
+  std::vector<int> user_n; // ... and their lengths (views[k].N becomes the tile-padded slot count for keyframes relaid with holes)
   DevBuf dpt, dgrad, depth_items[2];    // per-keyframe depth maps of the set being evaluated
   int n_depth = 0;                      // keyframes this rank's edges touch (= entries of depth_items)
   int dpt_set = -1;                     // variable set the depth maps currently hold (-1: none) ...

@@ -235,7 +235,8 @@ struct SortItem
   int n;
 };
 hipError_t launch_sort_locations(hipStream_t s, const SortItem *items_dev, int K, int max_n, int HW, int *mark_dev,
-                                 int *status_dev, int W = 0, int tile_w = 0, int tile_h = 0);
+                                 int *status_dev, int W = 0, int tile_w = 0, int tile_h = 0, const int *pad_flags_dev = nullptr,
+                                 int *tiles_out_dev = nullptr, bool keep_marks = false);
 // depth maps (and, for the Jacobian pass, their central-difference gradients) of all keyframes of a window
 hipError_t launch_depth_batch(hipStream_t s, int CS, const DepthItem *items_dev, int K, int H, int W, bool with_depth,
                               bool with_grad);

@@ -683,33 +683,43 @@ extern "C" int sage_window_finalize(SageWindow *w)
   // ---- sampled locations: validated (the kernels index depth maps / basis rows with them unchecked) and relaid in
   //      raster order (engine-owned copies; see producers.hip: the sums are order independent, the L1 is not)
   {
+    if ((int)w->user_samples.size() != K) // (a retried finalize must not sort the sorted copies onto themselves)
+    {
+      w->user_samples.resize(K);
+      w->user_n.resize(K);
+      for (int k = 0; k < K; ++k)
+      {
+        w->user_samples[k] = {w->views[k].loc1d, w->views[k].homo};
+        w->user_n[k] = w->views[k].N;
+      }
+    }
+    for (int k = 0; k < K; ++k)
+      w->views[k].N = w->user_n[k];
+    // (capacity per keyframe: its samples, or -- tile-padded order -- every 8 x 8 tile of the image with all 64 slots)
+    const size_t cap_tiles = (size_t)(((int)c.pyr.cam[0].w + 7) / 8) * (size_t)(((int)c.pyr.cam[0].h + 7) / 8) * 64;
     std::vector<size_t> soff(K + 1, 0);
     int max_n = 0;
     for (int k = 0; k < K; ++k)
     {
-      soff[k + 1] = soff[k] + (size_t)std::max(1, w->views[k].N);
+      soff[k + 1] = soff[k] + std::max<size_t>(std::max(1, w->views[k].N), cap_tiles);
       max_n = std::max(max_n, w->views[k].N);
     }
     if ((rc = w->sorted_loc.reserve(soff[K] * sizeof(int64_t))) || (rc = w->sorted_homo.reserve(soff[K] * 3 * sizeof(float))))
       return rc;
-    if ((int)w->user_samples.size() != K) // (a retried finalize must not sort the sorted copies onto themselves)
-    {
-      w->user_samples.resize(K);
-      for (int k = 0; k < K; ++k)
-        w->user_samples[k] = {w->views[k].loc1d, w->views[k].homo};
-    }
     std::vector<SortItem> items(K);
     for (int k = 0; k < K; ++k)
       items[k] = SortItem{reinterpret_cast<const long long *>(w->user_samples[k].first), w->user_samples[k].second,
                           w->sorted_loc.as<long long>() + soff[k], w->sorted_homo.as<float>() + 3 * soff[k],
                           w->views[k].N};
-    DevBuf d_items, d_mark, d_status;
-    std::vector<int> status((size_t)2 * K, 0);
+    DevBuf d_items, d_mark, d_status, d_tiles, d_pad;
+    std::vector<int> status((size_t)2 * K, 0), tiles_nonempty(K, 0), pad_flags(K, 0);
     rc = upload(d_items, items, w->stream);
     if (!rc)
       rc = d_mark.reserve((size_t)K * HW * sizeof(int));
     if (!rc)
       rc = d_status.reserve((size_t)2 * K * sizeof(int));
+    if (!rc)
+      rc = d_tiles.reserve((size_t)K * sizeof(int));
     hipError_t he = hipSuccess;
     {
       // walk order of the samples: image tiles of 8 x 8 pixels -- a wave's 64 consecutive samples then warp to a compact
@@ -724,15 +734,54 @@ extern "C" int sage_window_finalize(SageWindow *w)
       }();
       if (!rc)
         he = launch_sort_locations(w->stream, d_items.as<SortItem>(), K, max_n, HW, d_mark.as<int>(), d_status.as<int>(),
-                                   (int)c.pyr.cam[0].w, tile.first, tile.second);
+                                   (int)c.pyr.cam[0].w, tile.first, tile.second, nullptr, d_tiles.as<int>());
+      if (!rc && he == hipSuccess)
+        he = hipMemcpyAsync(status.data(), d_status.p, status.size() * sizeof(int), hipMemcpyDeviceToHost, w->stream);
+      if (!rc && he == hipSuccess)
+        he = hipMemcpyAsync(tiles_nonempty.data(), d_tiles.p, (size_t)K * sizeof(int), hipMemcpyDeviceToHost, w->stream);
+      if (!rc && he == hipSuccess)
+        he = hipStreamSynchronize(w->stream);
+      // r06 -- tile-padded order (producers.hip, order_locations_kernel): keyframes whose sampled tiles are not all full are relaid
+      // with every sampled tile's 64 slots (holes = location -1), so that a wave of the kernels is one tile whatever the mask looks
+      // like.  Only where it is cheap: slots <= 1.25 x samples (a dense mask with a ragged edge: a few percent; a sparse random
+      // sample set would grow several-fold and keeps the compact order).  SAGE_SAMPLE_PAD=0 turns it off.
+      bool any_pad = false;
+      if (!rc && he == hipSuccess && tile.first * tile.second == 64 && !(getenv("SAGE_SAMPLE_PAD") && atoi(getenv("SAGE_SAMPLE_PAD")) == 0))
+        for (int k = 0; k < K; ++k)
+        {
+          const long long slots = 64ll * tiles_nonempty[k];
+          if (status[2 * k] == 0 && status[2 * k + 1] == w->views[k].N && slots > w->views[k].N && 4 * slots <= 5ll * w->views[k].N)
+          {
+            pad_flags[k] = 1;
+            any_pad = true;
+          }
+        }
+      if (any_pad)
+      {
+        std::vector<int> status2((size_t)2 * K, 0);
+        rc = upload(d_pad, pad_flags, w->stream);
+        if (!rc)
+          he = launch_sort_locations(w->stream, d_items.as<SortItem>(), K, max_n, HW, d_mark.as<int>(), d_status.as<int>(),
+                                     (int)c.pyr.cam[0].w, tile.first, tile.second, d_pad.as<int>(), nullptr, true);
+        if (!rc && he == hipSuccess)
+          he = hipMemcpyAsync(status2.data(), d_status.p, status2.size() * sizeof(int), hipMemcpyDeviceToHost, w->stream);
+        if (!rc && he == hipSuccess)
+          he = hipStreamSynchronize(w->stream);
+        for (int k = 0; k < K && !rc && he == hipSuccess; ++k)
+          if (pad_flags[k])
+          {
+            if (status2[2 * k + 1] != 64 * tiles_nonempty[k])
+              rc = SAGE_E_STATE;
+            else
+              w->views[k].N = status2[2 * k + 1]; // slots, holes included
+          }
+      }
     }
-    if (!rc && he == hipSuccess)
-      he = hipMemcpyAsync(status.data(), d_status.p, status.size() * sizeof(int), hipMemcpyDeviceToHost, w->stream);
-    if (!rc && he == hipSuccess)
-      he = hipStreamSynchronize(w->stream);
     d_items.release();
     d_mark.release();
     d_status.release();
+    d_tiles.release();
+    d_pad.release();
     if (rc)
       return rc;
     if (he != hipSuccess)
@@ -741,7 +790,7 @@ extern "C" int sage_window_finalize(SageWindow *w)
     {
       if (status[2 * k] > 0)
         return SAGE_E_INVALID; // a location outside the image
-      if (status[2 * k + 1] != w->views[k].N)
+      if (status[2 * k + 1] != w->user_n[k])
         continue; // (a pixel sampled twice: the compaction dropped a sample -> keep the caller's order)
       w->views[k].loc1d = reinterpret_cast<const int64_t *>(items[k].loc_out);
       w->views[k].homo = items[k].homo_out;
@@ -823,15 +872,15 @@ extern "C" int sage_window_finalize(SageWindow *w)
           {
             adjv[k0].push_back(AdjEntry{0, e, 0});
             adjv[k1].push_back(AdjEntry{0, e, 1});
-            residuals += (double)c.pyr.levels * v0.N * FS;
-            bytes += (double)v0.N * 4.0 * (4.0 * FS * rho + CS + 6.0);
+            residuals += (double)c.pyr.levels * w->user_n[k0] * FS; // (the caller's samples: holes of a padded order do not count)
+            bytes += (double)w->user_n[k0] * 4.0 * (4.0 * FS * rho + CS + 6.0);
           }
           if (c.use_geo)
           {
             adjv[k0].push_back(AdjEntry{1, e, 0});
             adjv[k1].push_back(AdjEntry{1, e, 1});
-            residuals += (double)v0.N;
-            bytes += (double)v0.N * 4.0 * (2.0 * CS + 9.0);
+            residuals += (double)w->user_n[k0];
+            bytes += (double)w->user_n[k0] * 4.0 * (2.0 * CS + 9.0);
           }
         }
       }
@@ -900,12 +949,38 @@ extern "C" int sage_window_finalize(SageWindow *w)
           tpb = (T + nwg - 1) / nwg;       //  9 x 7 measured 5-7 % slower on the headline window)
       }
     }
+    {
+      // r06 -- runs per edge a multiple of 8.  Workgroup b runs on XCD b % 8 and every XCD has its own L2: with 8 m runs per edge,
+      // run j of EVERY edge lands on XCD j % 8 -- the same band of the image, whose destination texels the XCD's L2 then serves to
+      // the next edges that share the keyframe.  The BASELINE sizes have it by luck (63 sub-tiles = 8 runs of 8, config 4: 32
+      // runs); on the same window 13 / 11 / 7 runs per edge (SAGE_PHOTO_TPB = 5 / 6 / 10) cost the photometric linearize 20-30 %
+      // and the error pass 50 % (profiles/r06_kernel_ab_experiments.txt s11).  Padding an edge to 8 m runs with empty work items
+      // is no way out (the XCDs that get the real runs then carry twice the load: +60 %): the run LENGTH is chosen instead,
+      // among lengths that leave a record cadence of 3-5 sub-tiles.
+      std::vector<int> tiles;
+      for (int n : Nedge)
+        tiles.push_back((n + kTile - 1) / kTile);
+      if (!tiles.empty())
+      {
+        std::nth_element(tiles.begin(), tiles.begin() + tiles.size() / 2, tiles.end());
+        const int T = std::max(1, tiles[tiles.size() / 2]);
+        if (T >= 48 && ((T + tpb - 1) / tpb) % 8 != 0)
+          for (int t : {8, 9, 10, 12, 6, 15, 16, 20})
+            if (((T + t - 1) / t) % 8 == 0)
+            {
+              tpb = t;
+              break;
+            }
+      }
+    }
     if (const char *e = getenv("SAGE_PHOTO_TPB"))
       tpb = std::max(1, atoi(e));
     // a partial record every 4 sub-tiles of a run of 8 (0 = one per workgroup): with the second level of the
     // noise-critical tiles and their split accumulators in the kernel this puts the K = 64 LM step 7.0-8.2e-5 from the fp32
     // oracle's on four windows (r03: tests/tools/delta_probe.py; one record per workgroup: 8.8-9.8e-5) for +2 % of the kernel
-    int flush = tpb >= 8 ? 4 : 0;
+    int flush = 0;
+    if (tpb >= 8)
+      flush = tpb % 4 == 0 ? 4 : (tpb % 5 == 0 ? 5 : (tpb % 3 == 0 ? 3 : 0)); // (r06: run lengths 9, 10, 15 -- see above)
     if (const char *e = getenv("SAGE_PHOTO_FLUSH"))
       flush = std::max(0, atoi(e));
     // (r06, VERDICT r5 item 4 -- measured and dropped: the runs of an edge dealt to the XCDs in contiguous BANDS of image strips

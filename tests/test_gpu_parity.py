@@ -260,6 +260,45 @@ def test_non_dyadic_pyramid_window(capi, orc):
     win.close()
 
 
+def test_ragged_mask_takes_the_tile_padded_sample_order(capi, orc):
+    """r06: a sample rectangle that does not start on the 8 x 8 tile grid (erode = 3: x from 5, 17 700 samples).  The engine relays
+    such a keyframe with every sampled tile's 64 slots (holes carry location -1: dead lanes), so that a wave of the kernels is one
+    tile and the LDS-staged sampler keeps working (compact order: 0.51 ms photometric linearize at K = 32, padded: 0.37;
+    profiles/r06_kernel_ab_experiments.txt s11).  Same factor values: per edge vs the oracle, inlier counts exact (the holes count
+    nowhere), and against the compact order (SAGE_SAMPLE_PAD=0) to fp32 summation order -- not bit-identical, which shows the other
+    order was taken."""
+    w = synth.make_window(K=3, H=128, W=160, FS=16, CS=32, L=4, seed=33, erode=3)
+    assert w.keyframes[0].homo.shape[0] == (128 - 10) * (160 - 10)
+    packed = {}
+    for pad in ("1", "0"):
+        os.environ["SAGE_SAMPLE_PAD"] = pad
+        try:
+            win = capi.Window(w)
+        finally:
+            os.environ.pop("SAGE_SAMPLE_PAD", None)
+        win.linearize()
+        packed[pad] = win.packed_host().astype(np.float64)
+        if pad == "1":
+            for l, (a, b) in enumerate(w.links):
+                for d, (k0, k1) in enumerate(((a, b), (b, a))):
+                    for t, fn in ((0, oracle_photo), (1, oracle_geo)):
+                        o = fn(orc, w, k0, k1)
+                        h = win.get_edge(t, 2 * l + d)
+                        assert h["num_inliers"] == o["num_inliers"] > 0, (t, l, d)
+                        assert rel(h["AtA"], o["AtA"]) < TOL_H and rel(h["Atb"], o["Atb"]) < TOL_H, (t, l, d)
+                        assert h["error"] == pytest.approx(o["error"], rel=2e-5)
+            # the LM iteration (merged linearize + error pass) on the padded order: same system, descends
+            st = capi.SageLmState(); cfg = capi.lm_config_default(); cfg.max_inner_evals = 1
+            win.lm_step(st, cfg)
+            assert st.accepted == 1 and st.candidate_error < st.error
+            pm = win.packed_host().astype(np.float64)
+            assert rel(pm[:-4], packed["1"][:-4]) < 2e-6 and np.array_equal(pm[-2:], packed["1"][-2:])
+        win.close()
+    assert np.array_equal(packed["1"][-2:], packed["0"][-2:])                      # inlier totals: exact
+    assert rel(packed["1"][:-4], packed["0"][:-4]) < 1e-6
+    assert not np.array_equal(packed["1"][:-4], packed["0"][:-4])                   # (another summation order was taken)
+
+
 def test_producers_match_oracle(capi, ws, orc):
     import torch
     w = synth.make_window(K=1, H=64, W=80, FS=16, CS=32, L=4, seed=13)
