@@ -76,6 +76,16 @@ __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
 #ifndef SAGE_PHOTO_PREFETCH_A
 #define SAGE_PHOTO_PREFETCH_A 1
 #endif
+#ifndef SAGE_PHOTO_LOCKSTEP
+// r06: the four waves of a workgroup issue every staging fill TOGETHER (one s_barrier ahead of each fill; a wave on the
+// texture path or with a dead slice executes the same number of barriers).  The waves' tiles are x-neighbours: a box row
+// of 11 texels spans 2.4 cache lines of which 1.3 also belong to the neighbour's box -- issued within a few hundred
+// cycles of each other the second request hits the CU's L1 instead of going to the L2 (which holds ~5 us of this
+// kernel's stream and never caught it).  Config 4 (FS = 32): L1 -> L2 requests 9.5e7 -> 7.7e7, memory-side fetch
+// -8 %, linearize 1.20 -> 1.105 ms, error pass 0.625 -> 0.528 ms; K = 64 (FS = 16): -1 % on all three kernels
+// (profiles/r06_kernel_ab_experiments.txt s12).  Bit mask: 1 linearize FS >= 32, 2 linearize FS = 16, 4 / 8 error pass.
+#define SAGE_PHOTO_LOCKSTEP 15
+#endif
 #ifndef SAGE_PHOTO_LIN_GUNROLL
 #define SAGE_PHOTO_LIN_GUNROLL 8
 #endif
@@ -683,9 +693,14 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       }
       staged = cnt0 <= kStageCap0 && cntC <= kStageCapC; // (6 x 6 + 4 x 4 + 3 x 3 = 61 coarse texels, one more row / column at an image border)
     }
+    constexpr bool LOCKSTEP = ((SAGE_PHOTO_LOCKSTEP) >> ((JAC ? 0 : 2) + (FS >= 32 ? 0 : 1))) & 1;
+    constexpr int NBAR = JAC ? NG : (NG + kErrStageGroups - 1) / kErrStageGroups; // staging fills per slice
     if (!slice_live)
     {
       // nothing to sample
+      if constexpr (LOCKSTEP)
+        for (int g = 0; g < NBAR; ++g)
+          __builtin_amdgcn_s_barrier();
     }
     else if (staged)
     {
@@ -783,6 +798,8 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
 #pragma unroll
       for (int l = 0; l < kStageLevels; ++l)
         f0q[l] = gload16(f0_base(l, 0), f0_vo);
+      if constexpr (LOCKSTEP)
+        __builtin_amdgcn_s_barrier();
       stage0(0u);
       stageC(0u);
       // running sums of the slice as channel PAIRS (one v_pk_fma_f32 per sum and step; the halves meet once, below)
@@ -854,6 +871,8 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
         {
           f0q[0] = gload16(f0_base(0, g + 1), f0_vo);
           lgkm_wait0(); // level-0 taps have been read: the region takes the next group
+          if constexpr (LOCKSTEP)
+            __builtin_amdgcn_s_barrier();
           stage0(soffn);
           vm_wait_keep<7>(f0q[1]);
         }
@@ -905,6 +924,8 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       for (int g0 = 0; g0 < NG; g0 += kErrStageGroups)
       {
         lgkm_wait0(); // (the previous batch's taps / the previous sub-tile's have been read)
+        if constexpr (LOCKSTEP)
+          __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int j = 0; j < kErrStageGroups; ++j)
         {
@@ -956,6 +977,9 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
       // ================= texture-path sampler: (level, channel group) steps, the 13 dwordx4 loads of a step issued
       // together, then reduced =================
       SAGE_PHASE("B_texture_path");
+      if constexpr (LOCKSTEP)
+        for (int g = 0; g < NBAR; ++g)
+          __builtin_amdgcn_s_barrier();
       const f32x4 *f0s = reinterpret_cast<const f32x4 *>(E.f0s) + (in_range ? n : 0);
       for (int l = 0; l < nlev; ++l)
       {
