@@ -1,10 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for i in 1 2 3; do
- for v in "20:def" "20:27" "20:60" "40:def"; do
-  st=${v%%:*}; ins=${v#*:}
-  if [ $ins = def ]; then unset SAGE_BENCH_INSTR_STEPS; else export SAGE_BENCH_INSTR_STEPS=$ins; fi
-  echo "steps $st instr $ins: $(timeout 300 python bench.py --gpus 1 --steps $st --warmup 5 --no-cpu-baseline --emulate-shard off 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],4), d['phase_ms']['solve'], d['roofline']['avg_launch_ms'])")"
- done
-done
-unset SAGE_BENCH_INSTR_STEPS
-timeout 600 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06_final_bench.json 2>/dev/null; tail -c 300 gpurun_out/r06_final_bench.json
+bash scripts/ab_env_kbench.sh "flush4: flush3:SAGE_PHOTO_FLUSH=3 flush0:SAGE_PHOTO_FLUSH=0 flush5:SAGE_PHOTO_FLUSH=5 flush6:SAGE_PHOTO_FLUSH=6 flush1:SAGE_PHOTO_FLUSH=1" "64 5" 2
+for f in 3; do echo "== FLUSH $f"; SAGE_PHOTO_FLUSH=$f timeout 600 python tests/tools/delta_probe.py 64 2>&1 | tail -3 | cut -c1-420; done
+echo "== config4"; bash scripts/ab_env_kbench.sh "flush4: flush3:SAGE_PHOTO_FLUSH=3" "16 3 256 320 32 32" 2
+echo "== config2"; bash scripts/ab_env_kbench.sh "flush4: flush3:SAGE_PHOTO_FLUSH=3" "16 5 128 160 16 32" 2
