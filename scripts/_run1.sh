@@ -1,5 +1,7 @@
 cd $GRAFT_REPO_ROOT
-bash scripts/ab_env_kbench.sh "flush4: flush3:SAGE_PHOTO_FLUSH=3 flush0:SAGE_PHOTO_FLUSH=0 flush5:SAGE_PHOTO_FLUSH=5 flush6:SAGE_PHOTO_FLUSH=6 flush1:SAGE_PHOTO_FLUSH=1" "64 5" 2
-for f in 3; do echo "== FLUSH $f"; SAGE_PHOTO_FLUSH=$f timeout 600 python tests/tools/delta_probe.py 64 2>&1 | tail -3 | cut -c1-420; done
-echo "== config4"; bash scripts/ab_env_kbench.sh "flush4: flush3:SAGE_PHOTO_FLUSH=3" "16 3 256 320 32 32" 2
-echo "== config2"; bash scripts/ab_env_kbench.sh "flush4: flush3:SAGE_PHOTO_FLUSH=3" "16 5 128 160 16 32" 2
+for i in 1 2 3 4 5; do
+ for v in off on; do
+  if [ $v = on ]; then export SAGE_PLACEMENT_MONITOR=1; else unset SAGE_PLACEMENT_MONITOR; fi
+  echo "monitor $v: $(timeout 300 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --emulate-shard off 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['ms_per_step'],4), round(d['phase_ms']['solve'],4), d['host_placement'].get('placement_monitor_moves'), d['host_placement'].get('loadavg_1min'))")"
+ done
+done

@@ -15,6 +15,7 @@ import sys
 import tempfile
 from collections import OrderedDict, Counter
 
+JACB = 0 if os.environ.get("CENSUS_ERROR_PASS") == "1" else 1   # CENSUS_ERROR_PASS=1: photo_kernel<CS,FS,false,MODE>
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SRC = os.path.join(ROOT, "sage_slam_amd", "csrc", "photo_kernels.hip")
 
@@ -58,7 +59,7 @@ def classify(op):
 
 
 def kernel_body(asm, CS, FS, MODE=1):
-    key = f"photo_kernelILi{CS}ELi{FS}ELb1ELi{MODE}EE"
+    key = f"photo_kernelILi{CS}ELi{FS}ELb{JACB}ELi{MODE}EE"
     lines = asm.split("\n")
     start = next(i for i, l in enumerate(lines) if re.match(r"^_Z\w*" + key + r"\w*:", l))
     end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
@@ -88,7 +89,7 @@ def census(body):
 
 def vgprs(lines, CS, FS, MODE=1):
     """(VGPRs, VGPR spills, SGPR spills) from the kernel's metadata record"""
-    key = f"photo_kernelILi{CS}ELi{FS}ELb1ELi{MODE}EE"
+    key = f"photo_kernelILi{CS}ELi{FS}ELb{JACB}ELi{MODE}EE"
     txt = "\n".join(lines)
     i = txt.find(".name:", txt.find("amdhsa.kernels"))
     m = re.search(r"\.name:\s+_Z\w*" + key + r"\w*\n([\s\S]*?)\.wavefront_size", txt)
