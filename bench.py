@@ -409,6 +409,7 @@ def main():
     ap.add_argument("--fs", type=int, default=16)
     ap.add_argument("--cs", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-tune", action="store_true", help="keep the static rule's photometric run length (no sage_window_tune_runs)")
     ap.add_argument("--config", type=int, default=0,
                     help="BASELINE.json configuration 1..5 (1 = tracker frame -> --mode edge; 3 = the headline window = default)")
     ap.add_argument("--lm-variant", choices=["auto", "classic", "candidate"], default="auto",
@@ -525,6 +526,15 @@ def main():
     for lk in loops:
         win_h.links.append(lk)
     win = capi.Window(win_h, rank=rank, world=world)
+    # r06: the run length of the photometric workgroups measured on the window itself (sage_window_tune_runs: opt-in set-up step of
+    # the engine, ~20-40 ms, single-rank windows; --no-tune / SAGE_PHOTO_TPB keep the static rule's choice).  The headline window
+    # keeps the rule's 8; BASELINE config 4 moves 9 -> 12 (-7 % linearize + error pass)
+    photo_runs = {"tuned": False}
+    if world == 1 and not args.no_tune and os.environ.get("SAGE_BENCH_FORCE_DIST") != "1":
+        t_tune = time.perf_counter()
+        photo_runs = dict(win.tune_runs(), tuned=True)
+        photo_runs["tune_ms"] = round(1e3 * (time.perf_counter() - t_tune), 1)
+        win.reset()
     packed = win.packed_tensor()
     errt = win.error_tensor()
     cfg = capi.lm_config_default()
@@ -739,6 +749,7 @@ def main():
                                    f"pyramids (L=4), {args.cs}-dim depth code, dense sampling N={N}, "
                                    f"{len(win_h.links)} links = {n_dir} photometric + {n_dir} geometric directed edges",
                        "residuals_per_step": residuals_per_step,
+                       "photo_runs": photo_runs,
                        "parallelism": f"edge-shard x{world}" if world > 1 else "single GPU",
                        "collective": collective,
                        **({"per_rank_kernel_ms": per_rank_ms} if per_rank_ms else {}),

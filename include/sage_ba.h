@@ -385,6 +385,15 @@ int sage_window_linearize(SageWindow *w);
 /* total error of every local edge at the CANDIDATE (or current, which = 0/1) variables -> 4-double device
  * buffer [err_photo err_geo n_photo n_geo]; async. */
 int sage_window_error(SageWindow *w, int which);
+/* (no reference counterpart) run-length tuning of the photometric kernels on the window's own data: times the photometric
+ * linearize + error pass with workgroup runs of 4 ... 16 sub-tiles at the current estimate (three timed evaluations per candidate) and keeps
+ * the fastest when it beats the static rule's choice by >= 4 %.  Opt-in -- call it once after sage_window_finalize (or set
+ * SAGE_AUTOTUNE=1, then finalize calls it); SAGE_PHOTO_TPB pins the run length and turns this into a no-op, as does a sharded
+ * window.  Results are bit-reproducible for a given run length, not across run lengths (different fp32 summation order).
+ * Outputs (any may be NULL): the run length now in use, the rule's, and the two timings in ms (0 when nothing was measured). */
+int sage_window_tune_runs(SageWindow *w, int *tpb_out, int *tpb_rule_out, float *ms_rule_out, float *ms_best_out);
+/* re-apply a run length found by sage_window_tune_runs on an earlier window of the same geometry (1 <= tpb <= 64). */
+int sage_window_set_runs(SageWindow *w, int tpb);
 double *sage_window_error_dev(SageWindow *w);
 /* after (optional) all-reduce of the packed buffer: add priors, D2H, damped solve in double on the host,
  * write the candidate variables (retracted) and upload them.  Returns the predicted step norm. */

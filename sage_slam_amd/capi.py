@@ -96,7 +96,7 @@ SYMBOLS = [
     "sage_window_set_shard", "sage_window_finalize", "sage_window_num_keyframes", "sage_window_num_links",
     "sage_window_block_size", "sage_window_packed_count", "sage_window_packed_dev",
     "sage_window_residuals_per_linearize", "sage_window_bytes_per_linearize", "sage_window_linearize",
-    "sage_window_error", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
+    "sage_window_error", "sage_window_tune_runs", "sage_window_set_runs", "sage_window_error_dev", "sage_window_solve", "sage_window_total_error",
     "sage_window_accept", "sage_window_reset", "sage_window_get_keyframe", "sage_window_set_keyframe", "sage_window_get_delta",
     "sage_window_get_edge", "sage_window_prepass", "sage_window_factor", "sage_window_factor_error", "sage_window_prepare_factors", "sage_factor_psd", "sage_factor_cut_blocks", "sage_window_set_profiling", "sage_window_get_kernel_time", "sage_window_get_phase_time", "sage_window_lm_step", "sage_window_lm_run", "sage_window_lm_run_timed", "sage_window_sync_variables", "sage_window_set_allreduce", "sage_shard_plan_create", "sage_shard_plan_create_domains", "sage_block_solve_domains", "sage_shard_plan_destroy", "sage_shard_sep_count", "sage_shard_num_separators", "sage_shard_num_interior", "sage_shard_keyframe_owner", "sage_shard_keyframe_is_local", "sage_shard_eliminate", "sage_shard_solve", "sage_rccl_unique_id", "sage_rccl_comm_create", "sage_rccl_comm_destroy", "sage_rccl_comm_info", "sage_window_use_rccl", "sage_window_emulate_peers", "sage_sort_locations", "sage_bind_thread_to_device", "sage_solver_helper_cpus", "sage_solver_placement_moves", "sage_placement_monitor", "sage_shutdown", "sage_host_threads_running",
     "sage_valid_locations", "sage_shuffle_indices", "sage_sample_locations",
@@ -546,6 +546,18 @@ class Window:
 
     def error(self, which=1):
         _chk(lib().sage_window_error(self.h, which), "sage_window_error")
+
+    def tune_runs(self):
+        """``sage_window_tune_runs``: measure the photometric kernels' run lengths on this window, keep the fastest ->
+        dict(tpb, tpb_rule, ms_rule, ms_best)."""
+        tpb, rule = C.c_int(0), C.c_int(0)
+        ms_rule, ms_best = C.c_float(0), C.c_float(0)
+        _chk(lib().sage_window_tune_runs(self.h, C.byref(tpb), C.byref(rule), C.byref(ms_rule), C.byref(ms_best)),
+             "sage_window_tune_runs")
+        return dict(tpb=tpb.value, tpb_rule=rule.value, ms_rule=ms_rule.value, ms_best=ms_best.value)
+
+    def set_runs(self, tpb):
+        _chk(lib().sage_window_set_runs(self.h, int(tpb)), "sage_window_set_runs")
 
     def solve(self, damp, want_norm=True):
         """Damped step + candidate variables.  With ``want_norm=False`` the device solver is only enqueued (no

@@ -86,6 +86,15 @@ __device__ __forceinline__ int load_loc(const void *loc, int is64, int n)
 // (profiles/r06_kernel_ab_experiments.txt s12).  Bit mask: 1 linearize FS >= 32, 2 linearize FS = 16, 4 / 8 error pass.
 #define SAGE_PHOTO_LOCKSTEP 15
 #endif
+#ifndef SAGE_PHOTO_FS32_SLOAD
+// FS >= 32 (BASELINE config 4): r05 kept the per-lane pose loads of phase C and one group of basis prefetch there -- bound by its memory
+// side (fetch 1.58 x algorithmic), that kernel lost 4 % with the scalar loads + six groups in flight that FS = 16 runs with.  With the
+// lockstep fills (fetch 1.38 x) the order is reversed: scalar loads + six groups -1.7 % (profiles/r06_kernel_ab_experiments.txt s16).
+#define SAGE_PHOTO_FS32_SLOAD 1 // FS >= 32: poses of phase C by per-lane loads (0, r05) or scalar loads (1)
+#endif
+#ifndef SAGE_PHOTO_FS32_AHEAD
+#define SAGE_PHOTO_FS32_AHEAD 6 // FS >= 32: pixel groups of basis rows in flight ahead of the contraction (r05: 1)
+#endif
 #ifndef SAGE_PHOTO_LIN_GUNROLL
 #define SAGE_PHOTO_LIN_GUNROLL 8
 #endif
@@ -1139,11 +1148,10 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
     // world-from-keyframe poses, re-read per sub-tile through the scalar cache: held across the sampling phase their 24 SGPRs
     // were spilled to VGPR lanes and every use paid a v_readlane
     Pose p0, p1;
-    if constexpr (FS >= 32)
+    if constexpr (FS >= 32 && !SAGE_PHOTO_FS32_SLOAD)
     {
-      // FS = 32 (BASELINE config 4) is bound by the memory side (fetch 1.58 x the algorithmic bytes, L2 hit rate 35 %): there
-      // the kernel runs 4 % FASTER with the per-lane loads the compiler makes of this (seven round trips in series that
-      // hold the wave back from its next burst of requests) than with the scalar loads -- measured, r05_kernel_ab_experiments
+      // (r05, FS = 32 while its fetch was 1.58 x the algorithmic bytes: 4 % faster with the per-lane loads the compiler makes of this --
+      //  seven round trips in series that hold the wave back from its next burst of requests; off since the lockstep fills)
       const float *R0p = E.R0, *R1p = E.R1;
       asm volatile("" : "+s"(R0p), "+s"(R1p));
       p0 = load_pose2(R0p, E.t0);
@@ -1262,8 +1270,7 @@ __global__ __launch_bounds__(kBlock, !JAC ? (FS == 16 ? SAGE_PHOTO_ERR_WAVES : 3
 #ifndef SAGE_PHOTO_AHEAD
 #define SAGE_PHOTO_AHEAD 6
 #endif
-    // (FS = 32: one group ahead -- the memory-side-bound configuration loses 4 % with six, see phase C)
-    constexpr int G = 16, AHEAD = FS >= 32 ? 1 : SAGE_PHOTO_AHEAD;
+    constexpr int G = 16, AHEAD = FS >= 32 ? SAGE_PHOTO_FS32_AHEAD : SAGE_PHOTO_AHEAD;
     float bl[G], bh[G], ai[G], sg[G], ya[G], yb[G];
     f32x2 vb[G]; // the loaded pairs stay whole until their wait (a half copied out earlier would be read before it landed)
     int locp[G];

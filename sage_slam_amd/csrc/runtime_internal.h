@@ -267,6 +267,8 @@ struct SageWindow
   DevBuf work_p, first_p, tiles_p, work_g, first_g, tiles_g;
   DevBuf rec_first_p, rec_count_p;      // photometric linearize: partial RECORDS per edge (flush_p sub-tiles each)
   int flush_p = 0, n_rec_p = 0;
+  std::vector<int> Nedge;               // samples (slots) per local directed edge: what the photometric run plan is built from
+  int tpb_heur = 1;                     // run length the static rule chose (sage_window_tune_runs measures alternatives)
   DevBuf part_p, part_g;
   DevBuf AtA_p, Atb_p, stats_p, AtA_g, Atb_g, stats_g;
   DevBuf adj_start, adj, link_edges, packed, errbuf;

@@ -583,6 +583,38 @@ extern "C" double sage_window_residuals_per_linearize(const SageWindow *w) { ret
 extern "C" double sage_window_bytes_per_linearize(const SageWindow *w) { return w ? w->bytes_per_lin : 0; }
 
 
+// ---- photometric run plan (work list of the photometric linearize / error pass) ------------------------------------------------
+// record cadence of a run length: a partial record every 3-5 sub-tiles (0 = one record per workgroup).  With the second level of
+// the noise-critical tiles and their split accumulators in the kernel this puts the K = 64 LM step 7.0-8.2e-5 from the fp32
+// oracle's on four windows (r03: tests/tools/delta_probe.py; one record per workgroup: 8.8-9.8e-5) for +2 % of the kernel
+static int photo_flush_for_runs(int tpb)
+{
+  int flush = 0;
+  if (tpb >= 6)
+    flush = tpb % 4 == 0 ? 4 : (tpb % 5 == 0 ? 5 : (tpb % 3 == 0 ? 3 : 0)); // (r06: run lengths 6, 9, 10, 15)
+  if (const char *e = getenv("SAGE_PHOTO_FLUSH"))
+    flush = std::max(0, atoi(e));
+  return flush;
+}
+
+// (re)build the photometric work list for runs of `tpb` sub-tiles and upload it; the partial-record buffer grows to fit
+static int window_plan_photo_runs(SageWindow *w, int tpb, int flush)
+{
+  WorkList wp;
+  wp.build(w->Nedge, tpb, nullptr, flush);
+  int rc;
+  w->n_work_p = (int)wp.work.size();
+  w->tpb_p = wp.tiles_per_block;
+  w->flush_p = wp.flush;
+  w->n_rec_p = wp.n_records;
+  if ((rc = upload(w->work_p, wp.work, w->stream)) || (rc = upload(w->first_p, wp.edge_first, w->stream)) ||
+      (rc = upload(w->tiles_p, wp.edge_tiles, w->stream)) || (rc = upload(w->rec_first_p, wp.rec_first, w->stream)) ||
+      (rc = upload(w->rec_count_p, wp.rec_count, w->stream)))
+    return rc;
+  SAGE_HIP(hipStreamSynchronize(w->stream)); // (the host vectors go out of scope)
+  return w->part_p.reserve(std::max<size_t>(1, std::max(w->n_work_p, w->n_rec_p)) * photo_partial_floats(w->cfg.CS) * sizeof(float));
+}
+
 extern "C" int sage_window_finalize(SageWindow *w)
 {
   if (!w || w->finalized || w->K < 1)
@@ -916,7 +948,6 @@ extern "C" int sage_window_finalize(SageWindow *w)
   SAGE_HIP(hipStreamSynchronize(w->stream));
   {
     // photometric work list: its own sub-tile run length
-    WorkList wp;
     long long total = 0;
     for (int n : Nedge)
       total += (n + kTile - 1) / kTile;
@@ -975,31 +1006,19 @@ extern "C" int sage_window_finalize(SageWindow *w)
     }
     if (const char *e = getenv("SAGE_PHOTO_TPB"))
       tpb = std::max(1, atoi(e));
-    // a partial record every 4 sub-tiles of a run of 8 (0 = one per workgroup): with the second level of the
-    // noise-critical tiles and their split accumulators in the kernel this puts the K = 64 LM step 7.0-8.2e-5 from the fp32
-    // oracle's on four windows (r03: tests/tools/delta_probe.py; one record per workgroup: 8.8-9.8e-5) for +2 % of the kernel
-    int flush = 0;
-    if (tpb >= 8)
-      flush = tpb % 4 == 0 ? 4 : (tpb % 5 == 0 ? 5 : (tpb % 3 == 0 ? 3 : 0)); // (r06: run lengths 9, 10, 15 -- see above)
-    if (const char *e = getenv("SAGE_PHOTO_FLUSH"))
-      flush = std::max(0, atoi(e));
+    const int flush = photo_flush_for_runs(tpb);
     // (r06, VERDICT r5 item 4 -- measured and dropped: the runs of an edge dealt to the XCDs in contiguous BANDS of image strips
     //  (workgroup b runs on XCD b % 8; band x = runs [x R / 8, (x + 1) R / 8), all XCDs on the same edge at the same time), so that
     //  vertically adjacent strips share their destination halo in ONE L2: config 4 photometric linearize 1.202 -> 1.191 ms, error
     //  pass 0.638 -> 0.624, K = 64 unchanged (0.622 / 0.623) -- profiles/r06_kernel_ab_experiments.txt)
-    wp.build(Nedge, tpb, nullptr, flush);
     // (r05, VERDICT r4 item 6 -- measured and dropped: the linearize's work items in destination-keyframe-major order, the
     //  runs of the <= 6 edges that sample one keyframe interleaved strip by strip, so that the workgroups in flight want ONE
     //  packed pyramid at a time: config 4 photometric linearize 1.195 -> 1.356 ms, K = 64 0.677 -> 0.820 ms, config 2 0.157 ->
     //  0.192 ms.  Consecutive runs of ONE edge share their source streams and overlap in the destination; the link order
     //  (i-1,i) (i-2,i) (i-3,i), both directions adjacent, already keeps keyframe i in three of six consecutive edges.)
-    w->n_work_p = (int)wp.work.size();
-    w->tpb_p = wp.tiles_per_block;
-    w->flush_p = wp.flush;
-    w->n_rec_p = wp.n_records;
-    if ((rc = upload(w->work_p, wp.work, w->stream)) || (rc = upload(w->first_p, wp.edge_first, w->stream)) ||
-        (rc = upload(w->tiles_p, wp.edge_tiles, w->stream)) || (rc = upload(w->rec_first_p, wp.rec_first, w->stream)) ||
-        (rc = upload(w->rec_count_p, wp.rec_count, w->stream)))
+    w->Nedge = Nedge;
+    w->tpb_heur = tpb;
+    if ((rc = window_plan_photo_runs(w, tpb, flush)))
       return rc;
   }
   SAGE_HIP(hipStreamSynchronize(w->stream));
@@ -1080,6 +1099,13 @@ extern "C" int sage_window_finalize(SageWindow *w)
     }
   }
   w->finalized = true;
+  if (const char *e = getenv("SAGE_AUTOTUNE"))
+    if (atoi(e) != 0)
+    {
+      const int rct = sage_window_tune_runs(w, nullptr, nullptr, nullptr, nullptr);
+      if (rct)
+        return rct;
+    }
   return SAGE_OK;
 }
 
@@ -1235,6 +1261,117 @@ extern "C" int sage_window_linearize(SageWindow *w)
 
 static int window_error_pass(SageWindow *w, int which, bool speculate_gradients);
 extern "C" int sage_window_error(SageWindow *w, int which) { return window_error_pass(w, which, false); }
+
+// the run length a previous sage_window_tune_runs found for this window geometry (an embedder tunes once per image size / mask / window
+// length and re-applies the result to the windows it builds afterwards: the tuning costs 20-40 ms, a window lives for a few LM steps)
+extern "C" int sage_window_set_runs(SageWindow *w, int tpb)
+{
+  if (!w || !w->finalized)
+    return SAGE_E_STATE;
+  if (tpb < 1 || tpb > 64)
+    return SAGE_E_INVALID;
+  return window_plan_photo_runs(w, tpb, photo_flush_for_runs(tpb));
+}
+
+// r06 -- run-length tuning of the photometric kernels, measured on the window itself.  The time of the photometric linearize
+// and of the error pass depends on the run length of a workgroup in a way no static rule captured (profiles/
+// r06_kernel_ab_experiments.txt s16): which runs share an XCD's L2 with which, how run boundaries fall on image strips, how the
+// workgroups fill the 768 slots.  On BASELINE config 4 runs of 12 are 6 % faster than the rule's 8 while 11 and 13 are 14 % slower; on
+// a 192 x 256 window the rule's 8 is strip-aligned and 18 % (error pass: 27 %) slower than 6.  This call times the candidates on
+// the window's own data -- three timed linearize + error-pass evaluations each at the current estimate, the rule measured first and last -- and keeps the fastest if it beats
+// the rule's choice by >= 4 % (so that equal candidates do not flip between calls: results are bit-reproducible for a given run
+// length, not across run lengths).  Opt-in: an explicit call, or SAGE_AUTOTUNE=1 at sage_window_finalize; SAGE_PHOTO_TPB pins
+// the run length and disables it.  Single-rank windows only (a sharded window's linearize contains a collective).
+extern "C" int sage_window_tune_runs(SageWindow *w, int *tpb_out, int *tpb_rule_out, float *ms_rule_out, float *ms_best_out)
+{
+  if (!w || !w->finalized)
+    return SAGE_E_STATE;
+  const int rule = w->tpb_heur;
+  if (tpb_out)
+    *tpb_out = w->tpb_p;
+  if (tpb_rule_out)
+    *tpb_rule_out = rule;
+  if (ms_rule_out)
+    *ms_rule_out = 0.f;
+  if (ms_best_out)
+    *ms_best_out = 0.f;
+  if (getenv("SAGE_PHOTO_TPB") || w->world > 1 || w->allreduce || w->n_edges == 0 || !(w->cfg.use_photo))
+    return SAGE_OK;
+  int typical = 1;
+  {
+    std::vector<int> tiles;
+    for (int n : w->Nedge)
+      tiles.push_back((n + kTile - 1) / kTile);
+    std::nth_element(tiles.begin(), tiles.begin() + tiles.size() / 2, tiles.end());
+    typical = std::max(1, tiles[tiles.size() / 2]);
+  }
+  std::vector<int> cand{rule};
+  for (int t : {4, 6, 8, 9, 10, 12, 16})
+    if (t != rule && t <= typical && 2 * t >= std::min(rule, 8)) // (shorter than half the rule's runs: prologue-bound, not tried)
+      cand.push_back(t);
+  const bool prof_was = w->profiling;
+  const int level_was = w->prof_level;
+  int rc = sage_window_set_profiling(w, 1);
+  double best_ms = 0.0, rule_ms = 0.0;
+  int best = rule;
+  // one plan's time: an untimed evaluation (its caches), then the fastest of three
+  auto measure = [&](int t, double &ms) -> int {
+    int r = window_plan_photo_runs(w, t, photo_flush_for_runs(t));
+    for (int rep = 0; rep < 4 && !r; ++rep)
+    {
+      if ((r = sage_window_linearize(w)) || (r = sage_window_error(w, 1)))
+        break;
+      double lin = 0.0, err = 0.0;
+      int nl = 0, ne = 0;
+      if ((r = sage_window_get_kernel_time(w, 0, &lin, &nl)) || (r = sage_window_get_kernel_time(w, 2, &err, &ne)))
+        break;
+      const double tt = lin / std::max(1, nl) + err / std::max(1, ne);
+      if (rep > 0)
+        ms = rep == 1 ? tt : std::min(ms, tt);
+    }
+    return r;
+  };
+  // the device's clocks and caches settle over the first ~25 evaluations of a process (profiles/r04_step_series.txt): the rule's plan
+  // is measured first AND last, so that whoever comes first is not charged for the warm-up
+  for (int i = 0; i < 8 && !rc; ++i)
+    if ((rc = sage_window_linearize(w)) || (rc = sage_window_error(w, 1)))
+      break;
+  (void)sage_window_get_kernel_time(w, 0, nullptr, nullptr);
+  (void)sage_window_get_kernel_time(w, 2, nullptr, nullptr);
+  if (!rc)
+    rc = measure(rule, rule_ms);
+  best_ms = rule_ms;
+  for (size_t c = 1; c < cand.size() && !rc; ++c)
+  {
+    double ms = 0.0;
+    if ((rc = measure(cand[c], ms)))
+      break;
+    if (ms < best_ms)
+    {
+      best_ms = ms;
+      best = cand[c];
+    }
+  }
+  if (!rc && best != rule)
+  {
+    double again = 0.0;
+    if (!(rc = measure(rule, again)))
+      rule_ms = std::min(rule_ms, again);
+  }
+  (void)sage_window_get_kernel_time(w, 1, nullptr, nullptr); // (drop the geometric kernels' records of these evaluations)
+  (void)sage_window_get_kernel_time(w, 3, nullptr, nullptr);
+  (void)sage_window_set_profiling(w, prof_was ? level_was : 0);
+  if (!rc && !(best_ms < 0.96 * rule_ms))
+    best = rule;
+  const int rc2 = window_plan_photo_runs(w, rc ? rule : best, photo_flush_for_runs(rc ? rule : best));
+  if (tpb_out)
+    *tpb_out = w->tpb_p;
+  if (ms_rule_out)
+    *ms_rule_out = (float)rule_ms;
+  if (ms_best_out)
+    *ms_best_out = (float)(best == rule ? rule_ms : best_ms);
+  return rc ? rc : rc2;
+}
 
 // speculate_gradients (the LM iteration's candidate evaluation, one GPU): the depth-map gradients of the evaluated set are
 // launched right behind the totals -- the stream is idle while the host takes the accept / reject decision, and an accepted
