@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s achievable
 
 # Counter constants of the K = 64 headline window (rocprofv3 --pmc, separate passes, scripts/pmc_run.sh ->
-# profiles/r06_v4_pmc_summary.txt; bench.py cannot collect PMC counters itself, null for any other workload).  They are
+# profiles/r06_v5_pmc_summary.txt; bench.py cannot collect PMC counters itself, null for any other workload).  They are
 # per-launch INSTRUCTION / BYTE counts of one build on one workload -- fixed by the code, not by the box -- and are combined
 # below with the launch durations measured live in this run.  They belong to ONE build of the kernel sources: the summary
 # records sage_slam_amd.build.kernel_source_sha16() of the tree it was taken from, and the constants are quoted only while
@@ -43,15 +43,15 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 GB/s ac
 #   kernels: the LM iteration's merged pair -- photo_kernel<32,16,true,2> and geo_kernel<32,true,true>
 #   traffic: FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16 B/lane reads on gfx950, + WRITE_SIZE
 PMC_K64 = {
-    "source": "profiles/r06_v4_pmc_summary.txt",
-    "kernel_source_sha16": "c194a56abb0736e5",
+    "source": "profiles/r06_v5_pmc_summary.txt",
+    "kernel_source_sha16": "3f7e88daa2f13aac",
     # grbm_gui_active / pmc_pass_avg_us: the engine clock of the counter pass itself (r06: issue fractions at the measured
-    # clock -- 1.04336e7 / 8 / 598.78 us = 2.18 GHz -- not at the 2.4 GHz spec clock)
-    "photo": {"fetch_size_kb": 865446.0, "write_size_kb": 44146.9, "insts_vmem_rd": 7.41147e6, "insts_valu": 1.50417e8,
+    # clock -- 1.04469e7 / 8 / 577.46 us = 2.26 GHz -- not at the 2.4 GHz spec clock)
+    "photo": {"fetch_size_kb": 863517.0, "write_size_kb": 44167.9, "insts_vmem_rd": 7.41147e6, "insts_valu": 1.50417e8,
               "insts_mfma": 8.96938e6, "mfma_busy_cycles": 2.8702e8, "lds_idx_active": 1.36861e8, "lds_bank_conflict": 3.54242e7,
-              "grbm_gui_active": 1.04336e7, "pmc_pass_avg_us": 598.777},
+              "grbm_gui_active": 1.04469e7, "pmc_pass_avg_us": 577.459},
     "geo": {"insts_vmem_rd": 9.07898e6, "insts_valu": 6.70424e7, "insts_mfma": 1.4949e7, "mfma_busy_cycles": 4.78367e8,
-            "lds_idx_active": 3.31144e7, "grbm_gui_active": 6.85518e6, "pmc_pass_avg_us": 387.909},
+            "lds_idx_active": 3.31144e7, "grbm_gui_active": 6.95112e6, "pmc_pass_avg_us": 373.603},
 }
 PMC_TRAFFIC_BYTES_K64 = {"hbm_bytes_per_launch": (2 * PMC_K64["photo"]["fetch_size_kb"] + PMC_K64["photo"]["write_size_kb"]) * 1024.0}
 

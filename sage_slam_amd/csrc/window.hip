@@ -995,13 +995,26 @@ extern "C" int sage_window_finalize(SageWindow *w)
       {
         std::nth_element(tiles.begin(), tiles.begin() + tiles.size() / 2, tiles.end());
         const int T = std::max(1, tiles[tiles.size() / 2]);
+        // (r06, later: the edges that share a keyframe -- as destination or as source -- are TWO apart in the launch order, so a run
+        //  count of 0 mod 4 already aligns them: taken when no candidate gives 0 mod 8 -- a 192 x 256 window, 165 sub-tiles per
+        //  edge: runs of 8 = 21 per edge, runs of 6 = 28: linearize -18 %, error pass -27 %.  sage_window_tune_runs measures.)
         if (T >= 48 && ((T + tpb - 1) / tpb) % 8 != 0)
-          for (int t : {8, 9, 10, 12, 6, 15, 16, 20})
-            if (((T + t - 1) / t) % 8 == 0)
-            {
-              tpb = t;
+        {
+          int pick = 0;
+          for (int mod : {8, 4})
+          {
+            for (int t : {8, 9, 10, 12, 6, 15, 16, 20})
+              if (((T + t - 1) / t) % mod == 0)
+              {
+                pick = t;
+                break;
+              }
+            if (pick)
               break;
-            }
+          }
+          if (pick)
+            tpb = pick;
+        }
       }
     }
     if (const char *e = getenv("SAGE_PHOTO_TPB"))

@@ -14,6 +14,10 @@ if [ -n "$CFG" ]; then BARGS="--config $CFG"; fi
 if [ "$CFG" = "4" ]; then export KBENCH_ARGS="16 3 256 320 32 32"; fi
 if [ "$CFG" = "2" ]; then export KBENCH_ARGS="16 3 128 160 16 32"; fi
 timeout 900 python bench.py $BARGS --steps 40 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err
+# r06: bench.py tunes the photometric run length on the window (sage_window_tune_runs); the trace and counter passes below pin the
+# run length it found instead of tuning again, so that their per-kernel averages hold the timed plan's launches only
+TPB=$(python -c "import json,sys; print(json.loads(open('$OUT/bench.json').read().strip().splitlines()[-1])['config']['photo_runs'].get('tpb', 0))" 2>/dev/null)
+if [ -n "$TPB" ] && [ "$TPB" != "0" ]; then export SAGE_PHOTO_TPB=$TPB; echo "photometric run length pinned to $TPB for the trace / counter passes" > $OUT/pinned_runs.txt; fi
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o $TAG -- python $R/bench.py $BARGS --steps 20 --warmup 3 --no-cpu-baseline --emulate-shard off > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 DB=$(find $OUT/trace -name "*.db" | head -1)
