@@ -1,6 +1,5 @@
 cd $GRAFT_REPO_ROOT
-SAGE_EDGE_ORDER=1 timeout 600 python -m pytest tests/test_gpu_parity.py -q -m gpu -x 2>&1 | tail -2
-echo k64
-bash scripts/ab_env_kbench.sh "base: order:SAGE_EDGE_ORDER=1" "64 5" 3
-echo c4
-bash scripts/ab_env_kbench.sh "base:SAGE_PHOTO_TPB=12 order:SAGE_PHOTO_TPB=12,SAGE_EDGE_ORDER=1 o9:SAGE_PHOTO_TPB=9,SAGE_EDGE_ORDER=1 o8:SAGE_PHOTO_TPB=8,SAGE_EDGE_ORDER=1" "16 3 256 320 32 32" 2
+for t in 6 3 4 12 2; do
+  SAGE_PHOTO_TPB=$t timeout 600 python bench.py --config 5 --steps 12 --warmup 3 --no-cpu-baseline --emulate-shard off --no-tune 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; print('tpb $t', round(d['ms_per_step'],4), 'photo', round(r['avg_launch_ms'],4), 'err', r.get('error_pass_ms'), {k:round(v,3) for k,v in d['phase_ms'].items() if isinstance(v,float)})"
+done
