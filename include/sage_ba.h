@@ -390,6 +390,8 @@ int sage_window_error(SageWindow *w, int which);
  * the fastest when it beats the static rule's choice by >= 4 %.  Opt-in -- call it once after sage_window_finalize (or set
  * SAGE_AUTOTUNE=1, then finalize calls it); SAGE_PHOTO_TPB pins the run length and turns this into a no-op, as does a sharded
  * window.  Results are bit-reproducible for a given run length, not across run lengths (different fp32 summation order).
+ * Side effects: the window is left linearized and error-evaluated at its current variables, and the kernel-time records of
+ * sage_window_set_profiling are consumed (the profiling switch itself is restored).
  * Outputs (any may be NULL): the run length now in use, the rule's, and the two timings in ms (0 when nothing was measured). */
 int sage_window_tune_runs(SageWindow *w, int *tpb_out, int *tpb_rule_out, float *ms_rule_out, float *ms_best_out);
 /* re-apply a run length found by sage_window_tune_runs on an earlier window of the same geometry (1 <= tpb <= 64). */
