@@ -56,3 +56,23 @@ def test_checker_flags_a_use_before_the_wait():
 """
     n, problems = c.check(branchy)
     assert n == 1 and problems
+
+
+def test_makefile_builds_the_same_translation_units_as_build_py():
+    """The root Makefile (the no-Python build for a C++ maintainer) and sage_slam_amd/build.py must not drift apart: same
+    sources, same headers in the dependency list, and `make -n` resolves every rule."""
+    import re
+    from sage_slam_amd import build as b
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "Makefile")).read().replace("\\\n", " ")
+    hip = re.search(r"^HIP_SRC\s*:=\s*(.*)$", text, re.M).group(1).split()
+    host = re.search(r"^HOST_SRC\s*:=\s*(.*)$", text, re.M).group(1).split()
+    assert sorted(hip + host) == sorted(b.SOURCES)
+    hdr = re.search(r"^HEADERS\s*:=\s*(.*)$", text, re.M).group(1)
+    for h in b.HEADERS:
+        assert os.path.basename(h) in hdr, h
+    out = subprocess.run(["make", "-n", "-B", "OBJ=/tmp/_sage_mk_dry", "LIB=/tmp/_sage_mk_dry.so"], cwd=root,
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.count("--offload-arch=gfx950") == len(hip) + 1      # every .hip + the link line
+    assert out.stdout.count("clang++") == len(host)
