@@ -76,3 +76,17 @@ def test_makefile_builds_the_same_translation_units_as_build_py():
     assert out.returncode == 0, out.stderr
     assert out.stdout.count("--offload-arch=gfx950") == len(hip) + 1      # every .hip + the link line
     assert out.stdout.count("clang++") == len(host)
+
+
+@pytest.mark.parametrize("cc,std,lang", [("gcc", "-std=c99", "c"), ("g++", "-std=c++11", "c++")])
+def test_public_header_is_plain_c_abi(tmp_path, cc, std, lang):
+    """include/sage_ba.h is the drop-in boundary: it must compile on its own as strict C99 (a cgo / ctypes / C caller) and as
+    C++11 (the reference's translation units), warnings as errors, with nothing but the standard headers."""
+    import shutil
+    if not shutil.which(cc):
+        pytest.skip(f"{cc} not installed")
+    src = tmp_path / "hdr_only.c"
+    src.write_text('#include "sage_ba.h"\nint main(void) { return (int)sizeof(SageCamera) == 0; }\n')
+    r = subprocess.run([cc, std, "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT, "include"), "-x", lang,
+                        "-c", str(src), "-o", str(tmp_path / "hdr_only.o")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
