@@ -296,7 +296,8 @@ def test_ragged_mask_takes_the_tile_padded_sample_order(capi, orc):
         win.close()
     assert np.array_equal(packed["1"][-2:], packed["0"][-2:])                      # inlier totals: exact
     assert rel(packed["1"][:-4], packed["0"][:-4]) < 1e-6
-    assert not np.array_equal(packed["1"][:-4], packed["0"][:-4])                   # (another summation order was taken)
+    if os.environ.get("SAGE_SAMPLE_TILE", "8x8") != "0x0":                          # (raster order forced: there is no tile order to pad)
+        assert not np.array_equal(packed["1"][:-4], packed["0"][:-4])               # (another summation order was taken)
 
 
 def test_producers_match_oracle(capi, ws, orc):
@@ -1002,6 +1003,9 @@ def test_merged_linearize_pairs_match_the_oracle(capi, orc):
                         worst = max(worst, r)
                         assert r < 1e-5, (l, d, n1, n2, r)        # (measured 4.7e-7)
             # the mixture itself: the geometric edge's code0 blocks read zero, but for scale1-code0
+            # (SAGE_NO_MERGE=1 keeps the separate kernels in the LM iteration too: the sums above still hold, nothing is mixed)
+            if os.environ.get("SAGE_NO_MERGE", "0") not in ("", "0"):
+                continue
             Ag = np.asarray(hg["AtA"], np.float64)
             c0 = blocks["code0"]
             assert not Ag[np.ix_(c0, c0)].any() and not Ag[np.ix_(blocks["pose"], c0)].any() and not Ag[np.ix_(blocks["s0"], c0)].any()
