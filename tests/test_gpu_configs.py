@@ -364,3 +364,48 @@ def test_config5_loop_closure_k512(capi, orc):
         print(f"[config5] LM trace {errs}")
         assert errs[0][2] == 1 and errs[-1][1] < errs[0][0], errs
         win.close()
+
+
+def test_large_image_window_512x640(capi, orc):
+    """Beyond the BASELINE sizes: 512 x 640 x 32 feature maps (4x config 4's pixels per keyframe: 309 k samples per edge, 168 MB of
+    packed pyramids and 42 MB of basis per keyframe), K = 3.  Nothing in the kernels' 32-bit byte offsets, staging boxes, work
+    lists or record counts may depend on the BASELINE geometry: both directed edges of one link through the fp32 oracle, the
+    size-independent properties on every edge, the engine's solve against the host block solve, and the LM iteration (merged
+    linearize) reproduces the separate kernels' system and descends."""
+    CS = 32
+    w = synth.make_window(K=3, H=512, W=640, FS=32, CS=CS, L=4, seed=5)
+    N = w.keyframes[0].homo.shape[0]
+    assert N == (512 - 16) * (640 - 16)
+    win = capi.Window(w)
+    win.linearize()
+    packed = win.packed_host().astype(np.float64)
+    tot = np.zeros(2)
+    for e in range(2 * len(w.links)):
+        ph, ge = win.get_edge(0, e), win.get_edge(1, e)
+        A, b = ph["AtA"].astype(np.float64), ph["Atb"].astype(np.float64)
+        assert np.array_equal(A, A.T) and np.array_equal(A[0:6, 6:12], -A[0:6, 0:6]) and np.array_equal(b[6:12], -b[0:6])
+        assert ph["num_inliers"] > 0.5 * N and ge["num_inliers"] == ph["num_inliers"]
+        tot += [ph["error"], ge["error"]]
+    assert packed[-4] == pytest.approx(tot[0], rel=1e-6) and packed[-3] == pytest.approx(tot[1], rel=1e-6)
+    worst = [0.0, 0.0]
+    li = max(range(len(w.links)), key=lambda i: abs(w.links[i][1] - w.links[i][0]))   # the link with the largest baseline
+    a, b = w.links[li]
+    for d, (k0, k1) in enumerate(((a, b), (b, a))):
+        for t, fn in ((0, oracle_photo), (1, oracle_geo)):
+            o = fn(orc, w, k0, k1)
+            h = win.get_edge(t, 2 * li + d)
+            ra, rb = rel(h["AtA"], o["AtA"]), rel(h["Atb"], o["Atb"])
+            worst = [max(worst[0], ra), max(worst[1], rb)]
+            assert ra < TOL_H and rb < TOL_H, (t, d, ra, rb)
+            assert h["num_inliers"] == o["num_inliers"]
+            assert h["error"] == pytest.approx(o["error"], rel=1e-5)
+    summary_line(f"[512x640x32, K=3] N = {N} per edge: 4 edges vs the fp32 oracle, worst rel-L2 AtA {worst[0]:.1e} Atb {worst[1]:.1e}")
+    dadd, gadd = prior_vectors(w, CS)
+    win.solve(DAMP)
+    assert rel(win.delta(), capi.block_solve(packed[:-4], len(w.keyframes), w.links, 7 + CS, DAMP, dadd, gadd)) < 1e-7
+    cfg = capi.lm_config_default(); cfg.max_inner_evals = 1
+    st = capi.SageLmState()
+    win.lm_step(st, cfg)
+    assert st.accepted == 1 and st.candidate_error < st.error
+    assert rel(win.packed_host().astype(np.float64)[:-4], packed[:-4]) < 2e-6
+    win.close()
