@@ -198,7 +198,9 @@ int sage_placement_monitor(int enable);
 void sage_shutdown(void);
 int sage_host_threads_running(void);
 
-/* se3_exp (core/mapping/mapping_utils.h:316-346): R[9], t[3] from omega[3], v[3]. */
+/* se3_exp (core/mapping/mapping_utils.h:316-346): R[9], t[3] from omega[3], v[3].  (The void helpers -- this one,
+ * sage_pose_retract, sage_lm_config_default -- treat a null argument as a no-op; every int entry point answers a null /
+ * out-of-range argument with a status code: tests/test_host_logic.py calls all of them with NULL / 0.) */
 void sage_se3_exp(const float *omega, const float *v, float *R, float *t);
 /* left retraction T <- exp([v,w]) T (core/gtsam/gtsam_traits.h:45-70; camera_tracker.cpp:491-512);
  * pose/out are 12 floats (R then t), delta = [v(3), w(3)]. */

@@ -101,6 +101,8 @@ extern "C" int sage_shuffle_indices(int64_t seed, int64_t n, int64_t *idx)
 
 extern "C" void sage_se3_exp(const float *omega, const float *v, float *R, float *t)
 {
+  if (!omega || !v || !R || !t) // (void helpers: a null argument is a no-op, never a fault)
+    return;
   float theta = std::sqrt(omega[0] * omega[0] + omega[1] * omega[1] + omega[2] * omega[2]);
   float n[3] = {1.f, 0.f, 0.f}; // "a casual rotation direction vector" when theta == 0
   if (theta > 0)
@@ -132,6 +134,8 @@ extern "C" void sage_se3_exp(const float *omega, const float *v, float *R, float
 
 extern "C" void sage_pose_retract(const float *pose, const float *d, float *out)
 {
+  if (!pose || !d || !out)
+    return;
   float dR[9], dt[3];
   sage_se3_exp(d + 3, d, dR, dt); // delta = [v, omega]
   float R[9], t[3];
@@ -875,6 +879,8 @@ extern "C" int sage_damped_solve_qr_f32(const float *A, const float *b, int n, f
 // ---------------------------------------------------------------- tracker LM policy
 extern "C" void sage_lm_config_default(SageLmConfig *c)
 {
+  if (!c)
+    return;
   // system/configs/slam_run.flags:17-23
   c->max_num_iters = 40;
   c->min_grad_thresh = 1.0e-4f;

@@ -6,6 +6,8 @@
 """
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -685,3 +687,55 @@ def test_non_dyadic_pyramids_are_accepted():
     p2 = capi.make_pyramid(capi.SageCamera(55.8, 55.8, 31.0, 25.0, 62.0, 50.0), 3)
     assert [(int(p2.cam[l].w), int(p2.cam[l].h)) for l in range(3)] == [(62, 50), (31, 25), (15, 12)]
     assert p2.cam[2].fx / p2.cam[0].fx != 0.25
+
+
+_NULL_PROBE = r"""
+import ctypes, os, re, sys
+root = sys.argv[1]
+hdr = open(os.path.join(root, "include", "sage_ba.h")).read()
+protos = re.findall(r"^\s*([A-Za-z_][\w \*]*?)\s*\b(sage_\w+)\s*\(([^;]*?)\)\s*;", hdr, re.M | re.S)
+L = ctypes.CDLL(os.path.join(root, "sage_slam_amd", "libsage_ba.so"))
+crashed, called = [], 0
+for ret, name, args in protos:
+    parts = [a.strip() for a in re.split(r",(?![^()]*\))", args) if a.strip() and a.strip() != "void"]
+    argv = []
+    for a in parts:
+        if "*" in a or "Fn" in a:
+            argv.append(ctypes.c_void_p(0))
+        elif re.match(r"(const\s+)?double\b", a):
+            argv.append(ctypes.c_double(0))
+        elif re.match(r"(const\s+)?float\b", a):
+            argv.append(ctypes.c_float(0))
+        elif re.match(r"(const\s+)?(int|unsigned|int32_t|int64_t|size_t|uint32_t)\b", a):
+            argv.append(ctypes.c_long(0))
+        else:
+            argv = None            # a struct passed by value: not part of this probe
+            break
+    if argv is None:
+        continue
+    called += 1
+    pid = os.fork()                # (this interpreter is single-threaded: the library has started no thread yet)
+    if pid == 0:
+        try:
+            f = getattr(L, name)
+            f.restype = ctypes.c_int if ret.strip() == "int" else None
+            f(*argv)
+            os._exit(0)
+        except BaseException:
+            os._exit(3)
+    _, st = os.waitpid(pid, 0)
+    if os.WIFSIGNALED(st) or os.WEXITSTATUS(st) != 0:
+        crashed.append(name)
+print(len(protos), called, ",".join(crashed))
+"""
+
+
+def test_every_entry_point_survives_null_and_zero_arguments():
+    """Drop-in robustness: every function include/sage_ba.h declares is called with NULL for every pointer and 0 for every
+    scalar, each in a forked child of a fresh interpreter (a fault must not take the test process down, and a fork of THIS
+    process would leave the solver's helper threads behind).  None may crash: the `int` entry points answer with a status
+    code, the `void` helpers and destroy calls are no-ops.  (No GPU needed: argument validation comes first.)"""
+    r = subprocess.run([sys.executable, "-c", _NULL_PROBE, ROOT], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    n_protos, called, crashed = (r.stdout.strip().split(" ") + [""])[:3]
+    assert int(n_protos) > 90 and int(called) > 90 and crashed == "", r.stdout
