@@ -735,9 +735,12 @@ extern "C" int sage_block_solve_domains(const double *packed, int K, int nlinks,
           sep[0][i] += sep[d][i];
       std::fill(delta, delta + (size_t)K * B, 0.0);
       th.clear();
+      // every domain solves into a buffer of its own: a separator keyframe next to two domains is written by both (the same
+      // values, but two threads storing to one address is still a data race -- found with ThreadSanitizer); merged below
+      std::vector<std::vector<double>> dd((size_t)ndomains, std::vector<double>((size_t)K * B, 0.0));
       for (int d = 0; d < ndomains; ++d)
       {
-        auto job = [&, d] { rcs[d] = sage_shard_solve(plans[d], sep[0].data(), delta); };
+        auto job = [&, d] { rcs[d] = sage_shard_solve(plans[d], sep[0].data(), dd[d].data()); };
         if (d + 1 < ndomains)
           th.emplace_back(job);
         else
@@ -748,6 +751,11 @@ extern "C" int sage_block_solve_domains(const double *packed, int K, int nlinks,
       for (int d = 0; d < ndomains; ++d)
         if (rcs[d])
           rc = rcs[d];
+      // (an interior keyframe has one owner, a separator's rows are identical in every domain that holds it)
+      for (int d = 0; d < ndomains; ++d)
+        for (size_t i = 0; i < (size_t)K * B; ++i)
+          if (dd[d][i] != 0.0)
+            delta[i] = dd[d][i];
     }
   }
   for (SageShardPlan *p : plans)
