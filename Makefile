@@ -19,6 +19,13 @@ HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-functio
 # pure host translation units: ROCm's clang++ without offload (function multiversioning for AVX2 / AVX-512 inside)
 HOSTFLAGS := -O3 -std=c++17 -fPIC -Wall $(INC)
 
+# make CHECK=1 OBJ=/tmp/chk_obj LIB=/tmp/libsage_ba_chk.so : libstdc++'s bounds-checked containers in all host code (the `-m gpu`
+# suite runs green on such a build: DESIGN s1 "Sanitizer passes"); point the harness at it with SAGE_BA_LIB=<LIB>
+ifdef CHECK
+HIPFLAGS  += -D_GLIBCXX_ASSERTIONS
+HOSTFLAGS += -D_GLIBCXX_ASSERTIONS
+endif
+
 OBJS := $(addprefix $(OBJ)/,$(HIP_SRC:.hip=.o) $(HOST_SRC:.cpp=.o))
 
 .PHONY: lib oracle clean
